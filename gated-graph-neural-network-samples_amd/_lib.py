@@ -1,0 +1,72 @@
+"""ctypes binding of libggnn_hip.so (the C ABI declared in include/ggnn_hip.h).
+
+The library is built in-tree by build.py (hipcc --offload-arch=gfx950) and sits next to this file.
+There is NO fallback: if the shared object is missing or a symbol is absent, importing an op fails
+loudly -- the product path never routes through a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libggnn_hip.so")
+ABI_VERSION = 1
+
+# every symbol include/ggnn_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "ggnn_abi_version": (c_int, []),
+    "ggnn_last_error": (c_char_p, []),
+    "ggnn_csr_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "ggnn_build_target_csr": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int, c_int64, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ggnn_msg_transform_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ggnn_gather_segment_sum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                            c_int, c_int, c_int, c_void_p]),
+    "ggnn_unsorted_segment_sum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "ggnn_gru_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "ggnn_gru_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ggnn_gru_gates_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_int, c_void_p]),
+    "ggnn_gru_candidate_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ggnn_gemm_f32": (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                              c_void_p]),
+}
+
+_lib = None
+
+
+class GGNNError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libggnn_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library once and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libggnn_hip.so not found at %s -- run `python __graft_entry__.py build` (hipcc, gfx950). "
+            "There is no CPU fallback for the GGNN hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)        # AttributeError if the symbol is missing: loud by design
+        fn.restype = restype
+        fn.argtypes = argtypes
+    ver = lib.ggnn_abi_version()
+    if ver != ABI_VERSION:
+        raise ImportError("libggnn_hip.so ABI version %d != expected %d; rebuild" % (ver, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().ggnn_last_error()
+        raise GGNNError(rc, msg.decode("utf-8", "replace") if msg else "")

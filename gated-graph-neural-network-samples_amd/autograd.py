@@ -1,0 +1,47 @@
+"""One propagation timestep as a unit (forward on the HIP kernels; backward added for training), plus
+the per-graph segment sum of the readout.
+
+propagation_step == chem_tensorflow_sparse.py:153-216 for one timestep:
+    H        = h @ [W_0 | W_1 | .. | W_{T-1}]                    (msg_transform,      :160-164)
+    incoming = segment_sum(H rows) [+ nin @ b] [/ (deg + 1e-7)]   (gather_segment_sum, :198-209)
+    h'       = GRU([residuals.. | incoming], h)                   (gru,                :211-216)
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tensor, edge_weights: torch.Tensor,
+                     edge_biases: Optional[torch.Tensor], use_avg: bool, residual_states: Sequence[torch.Tensor],
+                     cell, activation: str, need_grad: bool = False) -> torch.Tensor:
+    if need_grad:
+        from .backward import PropagationStepFn
+        return PropagationStepFn.apply(h, index, nin, edge_weights, edge_biases, use_avg, activation,
+                                       cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias,
+                                       *residual_states)
+    H = ops.msg_transform(h, edge_weights.contiguous())
+    incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
+    return ops.gru(list(residual_states) + [incoming], h, cell.gates_kernel, cell.gates_bias,
+                   cell.candidate_kernel, cell.candidate_bias, activation)
+
+
+class _SegmentSumRows(torch.autograd.Function):
+    """tf.unsorted_segment_sum for the readout (chem_tensorflow_sparse.py:226-228); backward = gather."""
+
+    @staticmethod
+    def forward(ctx, data, ids, num_segments):
+        ctx.save_for_backward(ids)
+        return ops.unsorted_segment_sum(data.contiguous(), ids, int(num_segments))
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (ids,) = ctx.saved_tensors
+        return grad_out.index_select(0, ids.long()), None, None
+
+
+def segment_sum_rows(data: torch.Tensor, ids: torch.Tensor, num_segments: int) -> torch.Tensor:
+    return _SegmentSumRows.apply(data, ids, num_segments)

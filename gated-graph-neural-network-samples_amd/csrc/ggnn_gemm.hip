@@ -1,0 +1,165 @@
+// Launchers + C-ABI entry points for the FP32-MFMA GEMM family:
+//   ggnn_msg_transform_f32  (K1, chem_tensorflow_sparse.py:160-164)
+//   ggnn_gru_f32            (K3, chem_tensorflow_sparse.py:211-216 / TF-1.3 GRUCell)
+//   ggnn_gemm_f32           (plain C = [A0|A1|..] x B, used by the host layer's backward pass)
+#include "ggnn_gemm.hpp"
+
+namespace ggnn {
+
+static inline int round_up8(int x) { return (x + 7) / 8 * 8; }
+
+// Resident workgroups per CU targeted by the persistent (single-stage) variant.
+constexpr int kPersistBlocksPerCU = 2;
+
+template <int KC, int MT, int NT, int NW, class Epi>
+static int launch_gemm(const GemmOperands& g, const Epi& epi, hipStream_t st) {
+    using Cfg = GemmCfg<KC, MT, NT, NW>;
+    const int ncg = (g.N + Cfg::BN - 1) / Cfg::BN;
+    const int row_tiles = (g.M + Cfg::BM - 1) / Cfg::BM;
+    if (row_tiles == 0 || ncg == 0) return GGNN_OK;
+    const int nstages = g.nseg * (g.D / KC);
+    int workers = round_up8(row_tiles);
+    if (nstages == 1) {
+        int target = num_cus() * kPersistBlocksPerCU / ncg;
+        target = target / 8 * 8;
+        if (target < 8) target = 8;
+        if (workers > target) workers = target;
+    }
+    const dim3 grid((unsigned)(ncg * workers));
+    hipLaunchKernelGGL((ggnn_gemm_kernel<KC, MT, NT, NW, Epi>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                       g, epi, ncg, row_tiles, workers);
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+// padded column count if N is covered by groups of nt*16 columns
+static inline int padded_cols(int N, int nt) { const int bn = nt * 16; return (N + bn - 1) / bn * bn; }
+
+template <class Epi>
+static int dispatch_gemm(const GemmOperands& g, const Epi& epi, hipStream_t st) {
+    constexpr int MT = 1, NW = 8;
+    const int D = g.D, N = g.N;
+    if (D % 100 == 0) {
+        if (padded_cols(N, 5) <= padded_cols(N, 7)) return launch_gemm<100, MT, 5, NW>(g, epi, st);
+        return launch_gemm<100, MT, 7, NW>(g, epi, st);
+    }
+    if (D % 64 == 0) {
+        if (padded_cols(N, 8) <= padded_cols(N, 4)) return launch_gemm<64, MT, 8, NW>(g, epi, st);
+        return launch_gemm<64, MT, 4, NW>(g, epi, st);
+    }
+    if (D % 32 == 0) {
+        const int p8 = padded_cols(N, 8), p4 = padded_cols(N, 4), p2 = padded_cols(N, 2);
+        if (p8 <= p4 && p8 <= p2) return launch_gemm<32, MT, 8, NW>(g, epi, st);
+        if (p4 <= p2) return launch_gemm<32, MT, 4, NW>(g, epi, st);
+        return launch_gemm<32, MT, 2, NW>(g, epi, st);
+    }
+    return fail(GGNN_E_UNSUPPORTED, "hidden size %d unsupported (need a multiple of 100, 64 or 32)", D);
+}
+
+static int check_common(int V, int D) {
+    GGNN_CHECK_ARG(V >= 0, "negative node count %d", V);
+    GGNN_CHECK_ARG(D > 0 && D % 4 == 0, "hidden size %d must be a positive multiple of 4", D);
+    return GGNN_OK;
+}
+
+}  // namespace ggnn
+
+using namespace ggnn;
+
+extern "C" int ggnn_msg_transform_f32(const float* h, int ldh, const float* W, float* H, int V, int D, int T,
+                                      ggnn_stream_t stream) {
+    if (int rc = check_common(V, D)) return rc;
+    GGNN_CHECK_ARG(T > 0, "num_edge_types %d must be positive", T);
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(h && W && H, "null pointer");
+    GGNN_CHECK_ARG(ldh >= D && ldh % 4 == 0, "ldh %d must be >= D and a multiple of 4", ldh);
+    GGNN_CHECK_ARG(aligned16(h) && aligned16(W) && aligned16(H), "pointers must be 16-byte aligned");
+    GemmOperands g{};
+    g.A[0] = h; g.lda[0] = ldh; g.nseg = 1; g.D = D;
+    g.B = W; g.ldb = D; g.b_blk_cols = D; g.b_blk_stride = (long)D * D;   // [T,D,D]: column block t is W[t]
+    g.M = V; g.N = T * D;
+    EpiStore epi{H, T * D};
+    return dispatch_gemm(g, epi, (hipStream_t)stream);
+}
+
+extern "C" int ggnn_gemm_f32(const float* const* a_segs, int nseg, int D, const float* B, int ldb, float* C,
+                             int ldc, int M, int N, ggnn_stream_t stream) {
+    if (int rc = check_common(M, D)) return rc;
+    GGNN_CHECK_ARG(nseg >= 1 && nseg <= 4, "nseg %d outside 1..4", nseg);
+    GGNN_CHECK_ARG(N > 0 && N % 4 == 0 && ldb >= N && ldb % 4 == 0 && ldc >= N && ldc % 4 == 0,
+                   "N/ldb/ldc must be multiples of 4 with ldb,ldc >= N");
+    if (M == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(a_segs && B && C, "null pointer");
+    GemmOperands g{};
+    for (int s = 0; s < nseg; ++s) {
+        GGNN_CHECK_ARG(a_segs[s] && aligned16(a_segs[s]), "segment %d null or misaligned", s);
+        g.A[s] = a_segs[s]; g.lda[s] = D;
+    }
+    g.nseg = nseg; g.D = D; g.B = B; g.ldb = ldb; g.b_blk_cols = N; g.b_blk_stride = 0; g.M = M; g.N = N;
+    EpiStore epi{C, ldc};
+    return dispatch_gemm(g, epi, (hipStream_t)stream);
+}
+
+extern "C" size_t ggnn_gru_workspace_bytes(int V, int D) {
+    if (V < 0 || D <= 0) return 0;
+    return (size_t)2 * (size_t)V * (size_t)D * sizeof(float);   // r*h and u
+}
+
+static int gru_args_check(const float* const* x_segs, int nx, const float* h, int V, int D) {
+    if (int rc = check_common(V, D)) return rc;
+    GGNN_CHECK_ARG(nx >= 1 && nx <= 3, "nx %d outside 1..3 (residual inputs + aggregated messages)", nx);
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(x_segs && h && aligned16(h), "null or misaligned pointer");
+    for (int s = 0; s < nx; ++s) GGNN_CHECK_ARG(x_segs[s] && aligned16(x_segs[s]), "x segment %d null or misaligned", s);
+    return GGNN_OK;
+}
+
+extern "C" int ggnn_gru_gates_f32(const float* const* x_segs, int nx, const float* h, const float* Wg, const float* bg,
+                                  float* rh, float* u, float* save_r, int V, int D, ggnn_stream_t stream) {
+    if (int rc = gru_args_check(x_segs, nx, h, V, D)) return rc;
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(Wg && bg && rh && u, "null pointer");
+    GGNN_CHECK_ARG(aligned16(Wg) && aligned16(bg) && aligned16(rh) && aligned16(u) && (!save_r || aligned16(save_r)),
+                   "pointers must be 16-byte aligned");
+    GemmOperands g{};
+    for (int s = 0; s < nx; ++s) { g.A[s] = x_segs[s]; g.lda[s] = D; }
+    g.A[nx] = h; g.lda[nx] = D;
+    g.nseg = nx + 1; g.D = D; g.M = V;
+    g.B = Wg; g.ldb = 2 * D; g.b_blk_cols = 2 * D; g.b_blk_stride = 0; g.N = 2 * D;
+    EpiGruGates eg{bg, h, rh, u, save_r, D};
+    return dispatch_gemm(g, eg, (hipStream_t)stream);
+}
+
+extern "C" int ggnn_gru_candidate_f32(const float* const* x_segs, int nx, const float* rh, const float* h,
+                                      const float* u, const float* Wc, const float* bc, float* h_out, float* save_c,
+                                      int V, int D, int act, ggnn_stream_t stream) {
+    if (int rc = gru_args_check(x_segs, nx, h, V, D)) return rc;
+    GGNN_CHECK_ARG(act == GGNN_ACT_TANH || act == GGNN_ACT_RELU, "unknown activation %d", act);
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(rh && u && Wc && bc && h_out, "null pointer");
+    GGNN_CHECK_ARG(h_out != h && h_out != rh && h_out != u, "h_out must not alias h, r*h or u");
+    GGNN_CHECK_ARG(aligned16(rh) && aligned16(u) && aligned16(Wc) && aligned16(bc) && aligned16(h_out) &&
+                   (!save_c || aligned16(save_c)), "pointers must be 16-byte aligned");
+    GemmOperands g{};
+    for (int s = 0; s < nx; ++s) { g.A[s] = x_segs[s]; g.lda[s] = D; }
+    g.A[nx] = rh; g.lda[nx] = D;
+    g.nseg = nx + 1; g.D = D; g.M = V;
+    g.B = Wc; g.ldb = D; g.b_blk_cols = D; g.b_blk_stride = 0; g.N = D;
+    EpiGruCand ec{bc, h, u, h_out, save_c, D, act};
+    return dispatch_gemm(g, ec, (hipStream_t)stream);
+}
+
+extern "C" int ggnn_gru_f32(const float* const* x_segs, int nx, const float* h, const float* Wg, const float* bg,
+                            const float* Wc, const float* bc, float* h_out, void* ws, size_t ws_bytes,
+                            float* save_r, float* save_u, float* save_c, int V, int D, int act,
+                            ggnn_stream_t stream) {
+    if (int rc = gru_args_check(x_segs, nx, h, V, D)) return rc;
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(ws && aligned16(ws), "workspace null or misaligned");
+    if (ws_bytes < ggnn_gru_workspace_bytes(V, D))
+        return fail(GGNN_E_WORKSPACE, "GRU workspace too small: %zu < %zu", ws_bytes, ggnn_gru_workspace_bytes(V, D));
+    float* rh = static_cast<float*>(ws);
+    float* u = save_u ? save_u : rh + (size_t)V * D;
+    if (int rc = ggnn_gru_gates_f32(x_segs, nx, h, Wg, bg, rh, u, save_r, V, D, stream)) return rc;
+    return ggnn_gru_candidate_f32(x_segs, nx, rh, h, u, Wc, bc, h_out, save_c, V, D, act, stream);
+}

@@ -1,0 +1,231 @@
+// K2: edge-indexed gather + segment sum (tf.unsorted_segment_sum of the per-edge messages,
+// chem_tensorflow_sparse.py:160-162,168,198-209) and its index prep (:120-129).
+//
+// HBM-bound.  Design (DESIGN.md "K2"):
+//   * the M messages are bucketed by TARGET once per batch with a stable radix sort (rocPRIM via
+//     hipcub): inside a node the slots keep the reference's accumulation order (type ascending,
+//     then list order), the sum needs no atomics and is bit-reproducible.
+//   * one sub-wave (16/32/64 lanes, 16 B per lane) owns one target node: it loads up to LPR slot
+//     indices with ONE coalesced read, broadcasts them with __shfl, and streams the gathered
+//     D-float source rows (each a contiguous, 16-byte aligned 4*D-byte read) with 4 rows in flight
+//     per lane, accumulating in registers in slot order.
+//   * bias (:202-204), mean normalisation (:206-209) and the single coalesced row store are the
+//     epilogue; [M,D] messages are never materialised (the reference materialises them twice,
+//     :161-168).
+#include "ggnn_common.h"
+#include <hipcub/hipcub.hpp>
+
+namespace ggnn {
+
+constexpr int kMaxTypes = 64;
+struct TypeOffsets { long long off[kMaxTypes + 1]; int T; };
+
+static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+// ---- index prep -----------------------------------------------------------------------------------
+__global__ void csr_prep_kernel(const int* __restrict__ adj, long long M, int V, int* keys, int* vals, int* err_flag) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int src = adj[2 * m], dst = adj[2 * m + 1];
+    if ((unsigned)src >= (unsigned)V || (unsigned)dst >= (unsigned)V) {
+        if (err_flag) *err_flag = 1;
+    }
+    keys[m] = min(max(dst, 0), V - 1);
+    vals[m] = (int)m;
+}
+
+__global__ void csr_finalize_kernel(const int* __restrict__ adj, const int* __restrict__ vals_sorted, TypeOffsets to,
+                                    long long M, int V, int* gather_row, int* msg_perm) {
+    const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= M) return;
+    const int m = vals_sorted[slot];
+    int t = 0;
+    while (t + 1 < to.T && (long long)m >= to.off[t + 1]) ++t;
+    const int src = min(max(adj[2 * (long long)m], 0), V - 1);
+    gather_row[slot] = src * to.T + t;
+    if (msg_perm) msg_perm[slot] = m;
+}
+
+__global__ void csr_rowptr_kernel(const int* __restrict__ keys_sorted, long long M, int V, int* row_ptr) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > V) return;
+    long long lo = 0, hi = M;          // first slot with key >= v
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (keys_sorted[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    row_ptr[v] = (int)lo;
+}
+
+static size_t cub_temp_bytes(long long M, int end_bit) {
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (const int*)nullptr,
+                                       (int*)nullptr, (int)M, 0, end_bit, (hipStream_t)0);
+    return bytes;
+}
+
+static int key_bits(int V) {
+    int bits = 1;
+    while (bits < 31 && (1LL << bits) < (long long)V) ++bits;
+    return bits;
+}
+
+// ---- gather + segment sum ---------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void gather_segment_sum_kernel(
+        const float* __restrict__ H, const int* __restrict__ row_ptr, const int* __restrict__ gidx,
+        const float* __restrict__ nin, const float* __restrict__ bias, int use_avg, float* __restrict__ out,
+        int V, int D, int T) {
+    constexpr int NODES = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    int v = blockIdx.x * NODES + threadIdx.x / LPR;
+    const bool live = v < V;
+    v = live ? v : V - 1;                       // keep the sub-wave convergent for __shfl
+    const int beg = row_ptr[v], end = live ? row_ptr[v + 1] : beg;
+    const int D4 = D >> 2;
+
+    float deg = 0.f;
+    if (use_avg && nin)
+        for (int t = 0; t < T; ++t) deg += nin[(size_t)v * T + t];
+    const float den = deg + 1e-7f;              // utils.py:8 SMALL_NUMBER, fp32 like the reference
+
+    for (int c0 = 0; c0 < D4; c0 += LPR) {      // one pass for D <= 4*LPR
+        const int c4 = c0 + l;
+        const bool col_ok = c4 < D4;
+        const float* hcol = H + 4 * (col_ok ? c4 : 0);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int e0 = beg; e0 < end; e0 += LPR) {
+            const int cnt = min(LPR, end - e0);
+            const int my = (l < cnt) ? gidx[e0 + l] : 0;     // one coalesced read of <= LPR slot indices
+            int j = 0;
+            for (; j + 4 <= cnt; j += 4) {                   // 4 gathered rows in flight per lane
+                const int i0 = __shfl(my, j, LPR), i1 = __shfl(my, j + 1, LPR);
+                const int i2 = __shfl(my, j + 2, LPR), i3 = __shfl(my, j + 3, LPR);
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(hcol + (size_t)i0 * D);
+                const f32x4 r1 = *reinterpret_cast<const f32x4*>(hcol + (size_t)i1 * D);
+                const f32x4 r2 = *reinterpret_cast<const f32x4*>(hcol + (size_t)i2 * D);
+                const f32x4 r3 = *reinterpret_cast<const f32x4*>(hcol + (size_t)i3 * D);
+                acc += r0; acc += r1; acc += r2; acc += r3;  // slot order = reference accumulation order
+            }
+            for (; j < cnt; ++j) {
+                const int i0 = __shfl(my, j, LPR);
+                acc += *reinterpret_cast<const f32x4*>(hcol + (size_t)i0 * D);
+            }
+        }
+        if (col_ok && live) {
+            if (bias) {                                       // :202-204  incoming += nin @ edge_biases
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < T; ++t)
+                    b += nin[(size_t)v * T + t] * *reinterpret_cast<const f32x4*>(bias + (size_t)t * D + 4 * c4);
+                acc += b;
+            }
+            if (use_avg) acc = acc / den;                     // :206-209
+            *reinterpret_cast<f32x4*>(out + (size_t)v * D + 4 * c4) = acc;
+        }
+    }
+}
+
+__global__ void unsorted_segment_sum_kernel(const float* __restrict__ data, const int* __restrict__ ids,
+                                            float* out, long long total, int D, int num_segments) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const long long m = e / D;
+    const int d = (int)(e - m * D);
+    const int id = ids[m];
+    if ((unsigned)id < (unsigned)num_segments) unsafeAtomicAdd(out + (size_t)id * D + d, data[e]);
+}
+
+}  // namespace ggnn
+
+using namespace ggnn;
+
+extern "C" size_t ggnn_csr_workspace_bytes(int64_t M, int V) {
+    if (M <= 0 || V <= 0) return 256;
+    return 4 * align256((size_t)M * sizeof(int)) + align256(cub_temp_bytes(M, key_bits(V))) + 256;
+}
+
+extern "C" int ggnn_build_target_csr(const int32_t* adj, const int64_t* type_off, int T, int V, int64_t M,
+                                     int32_t* row_ptr, int32_t* gather_row, int32_t* msg_perm, int32_t* err_flag,
+                                     void* ws, size_t ws_bytes, ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(T > 0 && T <= kMaxTypes, "num_edge_types %d outside 1..%d", T, kMaxTypes);
+    GGNN_CHECK_ARG(V >= 0 && M >= 0 && M < (1LL << 31), "bad sizes V=%d M=%lld", V, (long long)M);
+    GGNN_CHECK_ARG((long long)V * T < (1LL << 31), "V*T overflows int32");
+    GGNN_CHECK_ARG(type_off && row_ptr, "null pointer");
+    GGNN_CHECK_ARG(type_off[0] == 0 && type_off[T] == M, "type_off must start at 0 and end at M");
+    for (int t = 0; t < T; ++t) GGNN_CHECK_ARG(type_off[t] <= type_off[t + 1], "type_off not monotone");
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0 || V == 0) {
+        GGNN_CHECK_HIP(hipMemsetAsync(row_ptr, 0, sizeof(int) * ((size_t)V + 1), st));
+        return GGNN_OK;
+    }
+    GGNN_CHECK_ARG(adj && gather_row && ws, "null pointer");
+    if (ws_bytes < ggnn_csr_workspace_bytes(M, V))
+        return fail(GGNN_E_WORKSPACE, "CSR workspace too small: %zu < %zu", ws_bytes, ggnn_csr_workspace_bytes(M, V));
+    const size_t arr = align256((size_t)M * sizeof(int));
+    char* p = static_cast<char*>(ws);
+    p = reinterpret_cast<char*>(align256(reinterpret_cast<size_t>(p)));
+    int* keys_in = reinterpret_cast<int*>(p);
+    int* vals_in = reinterpret_cast<int*>(p + arr);
+    int* keys_out = reinterpret_cast<int*>(p + 2 * arr);
+    int* vals_out = reinterpret_cast<int*>(p + 3 * arr);
+    void* cub_ws = p + 4 * arr;
+    const int bits = key_bits(V);
+    size_t cub_bytes = cub_temp_bytes(M, bits);
+
+    const int threads = 256;
+    const unsigned blocks_m = (unsigned)((M + threads - 1) / threads);
+    hipLaunchKernelGGL(csr_prep_kernel, dim3(blocks_m), dim3(threads), 0, st, adj, (long long)M, V, keys_in, vals_in, err_flag);
+    GGNN_CHECK_HIP(hipGetLastError());
+    GGNN_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(cub_ws, cub_bytes, (const int*)keys_in, keys_out,
+                                                      (const int*)vals_in, vals_out, (int)M, 0, bits, st));
+    TypeOffsets to;
+    to.T = T;
+    for (int t = 0; t <= T; ++t) to.off[t] = type_off[t];
+    hipLaunchKernelGGL(csr_finalize_kernel, dim3(blocks_m), dim3(threads), 0, st, adj, (const int*)vals_out, to,
+                       (long long)M, V, gather_row, msg_perm);
+    GGNN_CHECK_HIP(hipGetLastError());
+    const unsigned blocks_v = (unsigned)(((long long)V + 1 + threads - 1) / threads);
+    hipLaunchKernelGGL(csr_rowptr_kernel, dim3(blocks_v), dim3(threads), 0, st, (const int*)keys_out, (long long)M, V, row_ptr);
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+extern "C" int ggnn_gather_segment_sum_f32(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row,
+                                           const float* nin, const float* bias, int use_avg, float* out, int V,
+                                           int D, int T, ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(V >= 0 && D > 0 && D % 4 == 0 && T > 0, "bad sizes V=%d D=%d T=%d", V, D, T);
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(Hrows && row_ptr && out, "null pointer");
+    GGNN_CHECK_ARG(!(bias || use_avg) || nin, "nin is required with bias or mean aggregation");
+    GGNN_CHECK_ARG(aligned16(Hrows) && aligned16(out) && (!bias || aligned16(bias)), "pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int D4 = D / 4;
+    if (D4 <= 16) {
+        hipLaunchKernelGGL(gather_segment_sum_kernel<16>, dim3((V + 15) / 16), dim3(256), 0, st, Hrows, row_ptr,
+                           gather_row, nin, bias, use_avg, out, V, D, T);
+    } else if (D4 <= 32) {
+        hipLaunchKernelGGL(gather_segment_sum_kernel<32>, dim3((V + 7) / 8), dim3(256), 0, st, Hrows, row_ptr,
+                           gather_row, nin, bias, use_avg, out, V, D, T);
+    } else {
+        hipLaunchKernelGGL(gather_segment_sum_kernel<64>, dim3((V + 3) / 4), dim3(256), 0, st, Hrows, row_ptr,
+                           gather_row, nin, bias, use_avg, out, V, D, T);
+    }
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+extern "C" int ggnn_unsorted_segment_sum_f32(const float* data, const int32_t* ids, float* out, int64_t M, int D,
+                                             int num_segments, ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(M >= 0 && D > 0 && num_segments >= 0, "bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    if (num_segments == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(out, "null pointer");
+    GGNN_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)num_segments * D, st));
+    if (M == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(data && ids, "null pointer");
+    const long long total = (long long)M * D;
+    hipLaunchKernelGGL(unsorted_segment_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, data,
+                       ids, out, total, D, num_segments);
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}

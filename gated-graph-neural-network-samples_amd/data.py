@@ -1,0 +1,330 @@
+"""Molecule-graph data handling for the sparse/dense GGNN hot path.
+
+Two jobs, both on the host, both off the timed path:
+
+1. `MoleculeSet` -- a tensorised (structure-of-arrays) container for a list of graphs in the
+   reference's on-disk schema ``{'targets': [[y],..], 'graph': [[src, bond, dst],..],
+   'node_features': [[one-hot],..]}`` (reference get_data.py:82-86), plus a vectorised generator of
+   synthetic QM9-shaped molecules (there is no network / no RDKit / no QM9 here).
+
+2. `pack_batches` -- the vectorised twin of the reference's pure-Python packer
+   (chem_tensorflow_sparse.py:254-350): graphs are concatenated into one disconnected super-graph
+   while ``node_offset + n < batch_size`` (strict, :297); with `tie_fwd_bkwd` every bond yields both
+   directions under the same type (:259-263); per type the list is sorted by (src,dst) per graph and
+   graphs are concatenated in order (:265, :307, :345) -- which is a global lexsort on the offset
+   node ids; `num_incoming_edges_per_type` counts incoming edges per (node,type) (:260-263, :310-313);
+   node features are zero-padded to `hidden_size` (:300-302).  Output arrays are float32/int32
+   directly (the reference feeds float64/int64 and lets TF cast).
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+
+@dataclass
+class MoleculeSet:
+    """Structure-of-arrays view of a list of molecule graphs.
+
+    node_ptr   int64 [G+1]   node range of graph g is node_ptr[g]:node_ptr[g+1]
+    node_feat  float32 [N,A] per-node annotation (A = annotation_size, 5 for QM9: H,C,N,O,F)
+    bond_ptr   int64 [G+1]   bond range of graph g
+    bonds      int32 [B,3]   (src_local, bond_type in 1..F, dst_local)   (get_data.py:70-71)
+    targets    float32 [G,K] targets[g,k] = d['targets'][k][0]
+    """
+    node_ptr: np.ndarray
+    node_feat: np.ndarray
+    bond_ptr: np.ndarray
+    bonds: np.ndarray
+    targets: np.ndarray
+
+    @property
+    def num_graphs(self) -> int:
+        return len(self.node_ptr) - 1
+
+    @property
+    def annotation_size(self) -> int:
+        return self.node_feat.shape[1]
+
+    @property
+    def num_fwd_edge_types(self) -> int:
+        """max bond id seen (chem_tensorflow.py:116-119)."""
+        return int(self.bonds[:, 1].max()) if len(self.bonds) else 0
+
+    def nodes_per_graph(self) -> np.ndarray:
+        return np.diff(self.node_ptr)
+
+    # ---- reference JSON schema <-> arrays -------------------------------------------------
+    @classmethod
+    def from_json(cls, raw: Sequence[dict]) -> "MoleculeSet":
+        n = np.array([len(d["node_features"]) for d in raw], dtype=np.int64)
+        b = np.array([len(d["graph"]) for d in raw], dtype=np.int64)
+        node_ptr = np.concatenate([[0], np.cumsum(n)])
+        bond_ptr = np.concatenate([[0], np.cumsum(b)])
+        A = len(raw[0]["node_features"][0]) if len(raw) else 0   # chem_tensorflow.py:121
+        feat = np.zeros((int(node_ptr[-1]), A), np.float32)
+        bonds = np.zeros((int(bond_ptr[-1]), 3), np.int32)
+        K = len(raw[0]["targets"]) if len(raw) else 0
+        targets = np.zeros((len(raw), K), np.float32)
+        for g, d in enumerate(raw):
+            feat[node_ptr[g]:node_ptr[g + 1]] = np.asarray(d["node_features"], np.float32)
+            if b[g]:
+                bonds[bond_ptr[g]:bond_ptr[g + 1]] = np.asarray(d["graph"], np.int32)
+            targets[g] = [t[0] for t in d["targets"]]
+        return cls(node_ptr, feat, bond_ptr, bonds, targets)
+
+    @classmethod
+    def load(cls, path: str) -> "MoleculeSet":
+        with open(path, "r") as f:
+            return cls.from_json(json.load(f))
+
+    def to_json(self) -> List[dict]:
+        out = []
+        for g in range(self.num_graphs):
+            out.append({
+                "targets": [[float(t)] for t in self.targets[g]],
+                "graph": [[int(s), int(e), int(d)] for s, e, d in self.bonds[self.bond_ptr[g]:self.bond_ptr[g + 1]]],
+                "node_features": self.node_feat[self.node_ptr[g]:self.node_ptr[g + 1]].astype(int).tolist(),
+            })
+        return out
+
+    def subset(self, idx: np.ndarray) -> "MoleculeSet":
+        idx = np.asarray(idx, dtype=np.int64)
+        n = np.diff(self.node_ptr)[idx]
+        b = np.diff(self.bond_ptr)[idx]
+        node_ptr = np.concatenate([[0], np.cumsum(n)])
+        bond_ptr = np.concatenate([[0], np.cumsum(b)])
+        nsel = _ranges(self.node_ptr[idx], n)
+        bsel = _ranges(self.bond_ptr[idx], b)
+        return MoleculeSet(node_ptr, self.node_feat[nsel], bond_ptr, self.bonds[bsel], self.targets[idx])
+
+
+def _ranges(starts: np.ndarray, lengths: np.ndarray) -> np.ndarray:
+    """Concatenation of arange(starts[i], starts[i]+lengths[i]) without a Python loop."""
+    total = int(lengths.sum())
+    if total == 0:
+        return np.zeros(0, np.int64)
+    ends = np.cumsum(lengths)
+    base = np.repeat(starts - (ends - lengths), lengths)
+    return base + np.arange(total, dtype=np.int64)
+
+
+def synthetic_qm9(num_graphs: int, mean_nodes: float = 18.0, seed: int = 0, num_bond_types: int = 4,
+                  annotation_size: int = 5, num_tasks: int = 1) -> MoleculeSet:
+    """Synthetic QM9-shaped molecules.
+
+    n ~ clip(round(N(mean_nodes,3)), 3, 29) atoms (29 = the dense model's largest bucket,
+    chem_tensorflow_dense.py:134); a random spanning tree plus 0-2 ring-closure bonds; bond type ~
+    Categorical(0.85, 0.07, 0.03, 0.05) over {1..4} (get_data.py:62); one-hot atom annotation
+    uniform over `annotation_size`; z-scored scalar targets.  mean_nodes = 18 is QM9 with hydrogens
+    (get_data.py:66 AddHs); BASELINE.json's "~9 nodes" is the heavy-atom count.
+    All four bond types are guaranteed to appear (num_edge_types is data-derived,
+    chem_tensorflow.py:116-120).
+    """
+    rng = np.random.default_rng(seed)
+    n = np.clip(np.rint(rng.normal(mean_nodes, 3.0, num_graphs)), 3, 29).astype(np.int64)
+    node_ptr = np.concatenate([[0], np.cumsum(n)])
+    N = int(node_ptr[-1])
+    local = np.arange(N, dtype=np.int64) - np.repeat(node_ptr[:-1], n)
+    graph_of = np.repeat(np.arange(num_graphs, dtype=np.int64), n)
+    # spanning tree: node i>=1 bonds to a uniformly random earlier node of its graph
+    nonroot = local > 0
+    parent = np.floor(rng.random(N) * np.maximum(local, 1)).astype(np.int64)
+    t_src = parent[nonroot]
+    t_dst = local[nonroot]
+    t_g = graph_of[nonroot]
+    # 0-2 ring closures per graph between distinct nodes that are not already bonded
+    k = rng.integers(0, 3, num_graphs)
+    r_g = np.repeat(np.arange(num_graphs, dtype=np.int64), k)
+    a = np.floor(rng.random(len(r_g)) * n[r_g]).astype(np.int64)
+    b = np.floor(rng.random(len(r_g)) * n[r_g]).astype(np.int64)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    ok = (lo != hi) & (parent[node_ptr[r_g] + hi] != lo)
+    r_g, lo, hi = r_g[ok], lo[ok], hi[ok]
+    key = (r_g * 32 + lo) * 32 + hi
+    _, first = np.unique(key, return_index=True)
+    r_g, lo, hi = r_g[first], lo[first], hi[first]
+    g_all = np.concatenate([t_g, r_g])
+    s_all = np.concatenate([t_src, lo])
+    d_all = np.concatenate([t_dst, hi])
+    order = np.argsort(g_all, kind="stable")
+    g_all, s_all, d_all = g_all[order], s_all[order], d_all[order]
+    probs = np.array([0.85, 0.07, 0.03, 0.05][:num_bond_types], dtype=np.float64)
+    probs = probs / probs.sum()
+    btype = rng.choice(np.arange(1, num_bond_types + 1), size=len(g_all), p=probs).astype(np.int64)
+    if len(btype) >= num_bond_types:
+        btype[:num_bond_types] = np.arange(1, num_bond_types + 1)
+    bonds = np.stack([s_all, btype, d_all], axis=1).astype(np.int32)
+    bond_ptr = np.concatenate([[0], np.cumsum(np.bincount(g_all, minlength=num_graphs))]).astype(np.int64)
+    feat = np.zeros((N, annotation_size), np.float32)
+    feat[np.arange(N), rng.integers(0, annotation_size, N)] = 1.0
+    targets = rng.normal(0, 1, (num_graphs, num_tasks)).astype(np.float32)
+    return MoleculeSet(node_ptr, feat, bond_ptr, bonds, targets)
+
+
+@dataclass
+class SparseBatch:
+    """One minibatch in the reference feed layout (chem_tensorflow_sparse.py:331-350), as NumPy
+    float32/int32 arrays.  Keys mirror the reference placeholder names."""
+    node_features: np.ndarray                    # [V,A] f32 (un-padded annotations)
+    hidden_size: int
+    adjacency_lists: List[np.ndarray]            # T x [E_t,2] i32 (src,dst)
+    num_incoming_edges_per_type: np.ndarray      # [V,T] f32
+    graph_nodes_list: np.ndarray                 # [V] i32
+    target_values: np.ndarray                    # [tasks,G] f32
+    target_mask: np.ndarray                      # [tasks,G] f32
+    num_graphs: int
+    extras: Dict[str, object] = field(default_factory=dict)
+
+    @property
+    def initial_node_representation(self) -> np.ndarray:
+        """[V,D] f32: annotations zero-padded to hidden_size (chem_tensorflow_sparse.py:300-302).  Built
+        on demand; the device upload pads on the GPU instead of touching 4*V*D host bytes per batch."""
+        V, A = self.node_features.shape
+        h0 = np.zeros((V, self.hidden_size), np.float32)
+        h0[:, :A] = self.node_features
+        return h0
+
+    @property
+    def num_nodes(self) -> int:
+        return self.node_features.shape[0]
+
+    @property
+    def num_messages(self) -> int:
+        return int(sum(len(a) for a in self.adjacency_lists))
+
+
+def batch_boundaries(nodes_per_graph: np.ndarray, batch_size: int) -> List[int]:
+    """Greedy packing of chem_tensorflow_sparse.py:287-297: a batch keeps taking the next graph
+    while node_offset + n < batch_size (strict).  Returns graph-index boundaries [0, ..., G].
+    A graph with n >= batch_size would make the reference loop forever (an empty batch is yielded
+    and num_graphs never advances); that is reported as an error here."""
+    if (nodes_per_graph >= batch_size).any():
+        raise ValueError("a graph has >= batch_size nodes; the reference packer cannot place it")
+    csum = np.concatenate([[0], np.cumsum(nodes_per_graph)])
+    bounds = [0]
+    G = len(nodes_per_graph)
+    while bounds[-1] < G:
+        s = bounds[-1]
+        # largest e with csum[e] - csum[s] < batch_size
+        e = int(np.searchsorted(csum, csum[s] + batch_size, side="left")) - 1
+        bounds.append(min(max(e, s + 1), G))
+    return bounds
+
+
+def pack_batch(ms: MoleculeSet, graph_ids: np.ndarray, num_edge_types: int, hidden_size: int,
+               tie_fwd_bkwd: bool = True, task_ids: Sequence[int] = (0,),
+               label_mask: Optional[np.ndarray] = None) -> SparseBatch:
+    """Build ONE batch from graphs `graph_ids` (in this order).  Vectorised restatement of
+    chem_tensorflow_sparse.py:254-276 + :298-348.
+
+    For tie_fwd_bkwd=False the reference code is broken; the intended semantics are
+    implemented: forward types 0..F-1, backward types F..2F-1 with F = num_edge_types//2, the
+    reversed edge (dst,src) counted as incoming at src.
+    """
+    graph_ids = np.asarray(graph_ids, dtype=np.int64)
+    n = np.diff(ms.node_ptr)[graph_ids]
+    G = len(graph_ids)
+    offs = np.concatenate([[0], np.cumsum(n)])
+    V = int(offs[-1])
+    nsel = _ranges(ms.node_ptr[graph_ids], n)
+    if ms.annotation_size > hidden_size:
+        raise ValueError("annotation_size %d exceeds hidden_size %d" % (ms.annotation_size, hidden_size))
+    feats = ms.node_feat[nsel]                                                   # padded to D lazily (:300-302)
+    gnl = np.repeat(np.arange(G, dtype=np.int32), n)                             # :304
+    nb = np.diff(ms.bond_ptr)[graph_ids]
+    bsel = _ranges(ms.bond_ptr[graph_ids], nb)
+    bonds = ms.bonds[bsel].astype(np.int64)
+    boff = np.repeat(offs[:-1], nb)
+    src = bonds[:, 0] + boff                                                     # :307 (+ node_offset)
+    dst = bonds[:, 2] + boff
+    typ = bonds[:, 1] - 1                                                        # :258
+    if tie_fwd_bkwd:
+        s_all = np.concatenate([src, dst]); d_all = np.concatenate([dst, src])   # :259-263
+        t_all = np.concatenate([typ, typ])
+    else:
+        F = num_edge_types // 2
+        s_all = np.concatenate([src, dst]); d_all = np.concatenate([dst, src])
+        t_all = np.concatenate([typ, typ + F])
+    if len(t_all) and (t_all.min() < 0 or t_all.max() >= num_edge_types):
+        raise IndexError("edge type outside [0, num_edge_types)")
+    order = np.lexsort((d_all, s_all, t_all))                                    # :265 sorted((src,dst)) per type
+    s_all, d_all, t_all = s_all[order], d_all[order], t_all[order]
+    cnt = np.bincount(t_all, minlength=num_edge_types)
+    tptr = np.concatenate([[0], np.cumsum(cnt)])
+    adjacency = [np.stack([s_all[tptr[t]:tptr[t + 1]], d_all[tptr[t]:tptr[t + 1]]], axis=1).astype(np.int32)
+                 if cnt[t] else np.zeros((0, 2), np.int32) for t in range(num_edge_types)]   # :343-348
+    nin = np.bincount(d_all * num_edge_types + t_all, minlength=V * num_edge_types)
+    nin = nin.reshape(V, num_edge_types).astype(np.float32)                      # :310-313
+    task_ids = list(task_ids)
+    tv = ms.targets[graph_ids][:, task_ids].T.astype(np.float32).copy()          # :335
+    tm = np.ones_like(tv) if label_mask is None else label_mask[graph_ids][:, task_ids].T.astype(np.float32)
+    tv = tv * tm                                                                 # masked labels feed 0. (:319-321)
+    return SparseBatch(feats, hidden_size, adjacency, nin, gnl, tv, tm, G)
+
+
+def pack_batches(ms: MoleculeSet, params: dict, num_edge_types: int, order: Optional[np.ndarray] = None,
+                 label_mask: Optional[np.ndarray] = None, rank: int = 0, world_size: int = 1) -> List[SparseBatch]:
+    """All minibatches of one epoch (chem_tensorflow_sparse.py:278-350) for graph order `order`.
+
+    Data parallel (world_size > 1): the epoch's batches are formed exactly as on one device and batch i
+    goes to rank i % world_size; every rank gets the same number of batches (ceil(B/world_size)), the
+    tail is padded with EMPTY batches (no graphs) so the per-step gradient all-reduce stays matched."""
+    G = ms.num_graphs
+    order = np.arange(G, dtype=np.int64) if order is None else np.asarray(order, np.int64)
+    bounds = batch_boundaries(np.diff(ms.node_ptr)[order], params["batch_size"])
+    nb = len(bounds) - 1
+    steps = (nb + world_size - 1) // world_size
+    out = []
+    for s in range(steps):
+        i = s * world_size + rank
+        ids = order[bounds[i]:bounds[i + 1]] if i < nb else np.zeros(0, np.int64)
+        out.append(pack_batch(ms, ids, num_edge_types, params["hidden_size"], params.get("tie_fwd_bkwd", True),
+                              params.get("task_ids", [0]), label_mask))
+    return out
+
+
+# ---- dense layout (chem_tensorflow_dense.py:30-36, 132-228) ----------------------------------
+@dataclass
+class DenseBatch:
+    initial_node_representation: np.ndarray      # [b,v,D] f32
+    adjacency_matrix: np.ndarray                 # [b,e,v,v] f32, A[b,e,dst,src]
+    node_mask: np.ndarray                        # [b,v] f32
+    num_vertices: int
+    target_values: np.ndarray                    # [tasks,b]
+    target_mask: np.ndarray                      # [tasks,b]
+    num_graphs: int
+
+
+DENSE_BUCKET_SIZES = np.array(list(range(4, 28, 2)) + [29])   # chem_tensorflow_dense.py:134
+
+
+def pack_dense_batch(ms: MoleculeSet, graph_ids: np.ndarray, num_vertices: int, num_edge_types: int,
+                     hidden_size: int, tie_fwd_bkwd: bool = True, task_ids: Sequence[int] = (0,)) -> DenseBatch:
+    """chem_tensorflow_dense.py:30-36 (graph_to_adj_mat), :143-153 (pad_annotations + mask)."""
+    graph_ids = np.asarray(graph_ids, np.int64)
+    b = len(graph_ids)
+    v = num_vertices
+    n = np.diff(ms.node_ptr)[graph_ids]
+    if (n > v).any():
+        raise ValueError("graph larger than bucket size")
+    h0 = np.zeros((b, v, hidden_size), np.float32)
+    mask = np.zeros((b, v), np.float32)
+    A = np.zeros((b, num_edge_types, v, v), np.float32)
+    gi = np.repeat(np.arange(b), n)
+    li = _ranges(np.zeros(b, np.int64), n)
+    nsel = _ranges(ms.node_ptr[graph_ids], n)
+    h0[gi, li, :ms.annotation_size] = ms.node_feat[nsel]
+    mask[gi, li] = 1.0
+    nb = np.diff(ms.bond_ptr)[graph_ids]
+    bsel = _ranges(ms.bond_ptr[graph_ids], nb)
+    bonds = ms.bonds[bsel].astype(np.int64)
+    bg = np.repeat(np.arange(b), nb)
+    bwd = 0 if tie_fwd_bkwd else num_edge_types // 2
+    A[bg, bonds[:, 1] - 1, bonds[:, 2], bonds[:, 0]] = 1.0            # amat[e-1, dest, src] = 1
+    A[bg, bonds[:, 1] - 1 + bwd, bonds[:, 0], bonds[:, 2]] = 1.0      # amat[e-1+off, src, dest] = 1
+    tv = ms.targets[graph_ids][:, list(task_ids)].T.astype(np.float32).copy()
+    return DenseBatch(h0, A, mask, v, tv, np.ones_like(tv), b)

@@ -1,0 +1,264 @@
+"""Operator layer: torch-ROCm tensors in, libggnn_hip.so HIP kernels underneath (via ctypes).
+
+One function per TF op call site of the reference's sparse hot path
+(chem_tensorflow_sparse.py:117-218):
+
+    build_message_index   S1 (+ our bucketing by target)     :120-129
+    msg_transform         S3 (transform-first)                :160-164
+    gather_segment_sum    S2,S4,S5,S6,S7                      :160-162,168,198-209
+    gru                   S8,S9                               :211-216
+    unsorted_segment_sum  general tf.unsorted_segment_sum     :198-200, :226-228
+
+PyTorch is plumbing only (device memory + streams).  Every function requires CUDA(HIP) tensors and
+raises if the extension is missing -- there is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+ACT_IDS = {"tanh": 0, "relu": 1}
+
+
+# ---- optional per-launch timing (bench.py's roofline leg) ---------------------------------------------
+_timing = None
+
+
+class kernel_timing:
+    """Context manager: while active every op brackets its launch(es) with HIP events recorded on the
+    stream the kernel is launched on (torch's current stream == the stream handed to the C ABI) and the
+    GRU is issued as its two separately addressable launches.  `.results()` -> {name: [ms, ...]}."""
+
+    def __enter__(self):
+        global _timing
+        self.records = _timing = []
+        return self
+
+    def __exit__(self, *exc):
+        global _timing
+        _timing = None
+
+    def results(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e in self.records:
+            out.setdefault(name, []).append(s.elapsed_time(e))
+        return out
+
+
+def _launch(name: str, fn):
+    if _timing is None:
+        return check(fn())
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = fn()
+    e.record()
+    _timing.append((name, s, e))
+    check(rc)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA/HIP tensor (the GGNN hot path has no CPU implementation)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+@dataclass
+class MessageIndex:
+    """Per-batch message index (built once, reused by all propagation steps and epochs).
+
+    adj         [M,2] int32  concatenated adjacency lists (type-major)   (:124-129)
+    type_off    list[T+1]    host offsets of each type in adj
+    row_ptr     [V+1] int32  slots of the messages INTO node v
+    gather_row  [M]   int32  slot -> src*T + type
+    msg_perm    [M]   int32  slot -> original message index
+    """
+    adj: torch.Tensor
+    type_off: List[int]
+    row_ptr: torch.Tensor
+    gather_row: torch.Tensor
+    msg_perm: torch.Tensor
+    num_nodes: int
+    num_edge_types: int
+
+    @property
+    def num_messages(self) -> int:
+        return int(self.type_off[-1])
+
+
+def build_message_index(adjacency_lists: Sequence[torch.Tensor], num_nodes: int,
+                        validate: bool = True) -> MessageIndex:
+    """chem_tensorflow_sparse.py:120-129 plus the stable bucketing by target that makes the segment
+    sum atomics-free.  adjacency_lists: T tensors int32 [E_t,2] (src,dst) on the GPU; E_t may be 0
+    (:346-347).  With validate=True an out-of-range src/dst raises IndexError (TF-CPU raises
+    InvalidArgument at the gather / segment_sum); this costs one device->host sync, once per batch."""
+    lib = _lib.load()
+    T = len(adjacency_lists)
+    if T == 0:
+        raise ValueError("need at least one edge type")
+    lists = [_req(a.reshape(-1, 2), torch.int32, "adjacency_lists[%d]" % i) for i, a in enumerate(adjacency_lists)]
+    dev = lists[0].device
+    type_off = [0]
+    for a in lists:
+        type_off.append(type_off[-1] + a.shape[0])
+    M = type_off[-1]
+    adj = torch.cat(lists, dim=0).contiguous() if M else torch.zeros((0, 2), dtype=torch.int32, device=dev)
+    row_ptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    gather_row = torch.empty(M, dtype=torch.int32, device=dev)
+    msg_perm = torch.empty(M, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.ggnn_csr_workspace_bytes(M, num_nodes)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    off = (ctypes.c_int64 * (T + 1))(*type_off)
+    check(lib.ggnn_build_target_csr(_ptr(adj), off, T, num_nodes, M, _ptr(row_ptr), _ptr(gather_row),
+                                    _ptr(msg_perm), _ptr(err), _ptr(ws), ws_bytes, _stream()))
+    if validate and M and int(err.item()) != 0:
+        raise IndexError("adjacency list holds a node id outside [0, %d)" % num_nodes)
+    return MessageIndex(adj, type_off, row_ptr, gather_row, msg_perm, num_nodes, T)
+
+
+def msg_transform(h: torch.Tensor, edge_weights: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """H[v, t*D:(t+1)*D] = h[v] @ edge_weights[t]   (chem_tensorflow_sparse.py:160-164, all types
+    in one FP32-MFMA GEMM).  h [V,D], edge_weights [T,D,D] -> H [V, T*D]."""
+    lib = _lib.load()
+    _req(h, torch.float32, "h"); _req(edge_weights, torch.float32, "edge_weights")
+    V, D = h.shape
+    T = edge_weights.shape[0]
+    if edge_weights.shape != (T, D, D):
+        raise ValueError("edge_weights must be [T,D,D]")
+    if out is None:
+        out = torch.empty((V, T * D), dtype=torch.float32, device=h.device)
+    else:
+        _req(out, torch.float32, "out")
+        if out.shape != (V, T * D):
+            raise ValueError("out must be [V, T*D]")
+    _launch("msg_transform", lambda: lib.ggnn_msg_transform_f32(_ptr(h), D, _ptr(edge_weights), _ptr(out), V, D, T, _stream()))
+    return out
+
+
+def gather_segment_sum(H: torch.Tensor, index: MessageIndex, num_incoming_edges_per_type: Optional[torch.Tensor],
+                       edge_biases: Optional[torch.Tensor], use_avg: bool,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """incoming[v] = (sum of H rows of the messages into v [+ nin[v] @ edge_biases]) [/ (sum_t nin[v,t] + 1e-7)]
+    (chem_tensorflow_sparse.py:160-162,168,198-209).  H [V, T*D] from msg_transform."""
+    lib = _lib.load()
+    _req(H, torch.float32, "H")
+    V, T = index.num_nodes, index.num_edge_types
+    if H.shape[0] != V or H.shape[1] % T:
+        raise ValueError("H must be [V, T*D]")
+    D = H.shape[1] // T
+    nin = num_incoming_edges_per_type
+    if nin is not None:
+        _req(nin, torch.float32, "num_incoming_edges_per_type")
+        if nin.shape != (V, T):
+            raise ValueError("num_incoming_edges_per_type must be [V,T]")
+    if edge_biases is not None:
+        _req(edge_biases, torch.float32, "edge_biases")
+        if edge_biases.shape != (T, D):
+            raise ValueError("edge_biases must be [T,D]")
+    if out is None:
+        out = torch.empty((V, D), dtype=torch.float32, device=H.device)
+    else:
+        _req(out, torch.float32, "out")
+    _launch("gather_segment_sum", lambda: lib.ggnn_gather_segment_sum_f32(
+        _ptr(H), _ptr(index.row_ptr), _ptr(index.gather_row), _ptr(nin), _ptr(edge_biases), 1 if use_avg else 0,
+        _ptr(out), V, D, T, _stream()))
+    return out
+
+
+def gru_workspace(V: int, D: int, device) -> torch.Tensor:
+    lib = _lib.load()
+    return torch.empty(lib.ggnn_gru_workspace_bytes(V, D) // 4, dtype=torch.float32, device=device)
+
+
+def gru(x_segs: Sequence[torch.Tensor], h: torch.Tensor, Wg: torch.Tensor, bg: torch.Tensor, Wc: torch.Tensor,
+        bc: torch.Tensor, activation: str = "tanh", out: Optional[torch.Tensor] = None,
+        ws: Optional[torch.Tensor] = None, save: Optional[dict] = None) -> torch.Tensor:
+    """TF-1.3 GRUCell on x = concat(x_segs) without materialising the concat
+    (chem_tensorflow_sparse.py:211-216).  save: optional dict receiving 'r','u','c' [V,D] tensors."""
+    lib = _lib.load()
+    _req(h, torch.float32, "h")
+    V, D = h.shape
+    nx = len(x_segs)
+    for i, x in enumerate(x_segs):
+        _req(x, torch.float32, "x_segs[%d]" % i)
+        if x.shape != (V, D):
+            raise ValueError("x_segs[%d] must be [V,D]" % i)
+    for n, w, shp in (("Wg", Wg, ((nx + 1) * D, 2 * D)), ("bg", bg, (2 * D,)), ("Wc", Wc, ((nx + 1) * D, D)), ("bc", bc, (D,))):
+        _req(w, torch.float32, n)
+        if tuple(w.shape) != shp:
+            raise ValueError("%s must have shape %s, got %s" % (n, shp, tuple(w.shape)))
+    act = ACT_IDS.get(activation.lower())
+    if act is None:
+        raise Exception("Unknown activation function type '%s'." % activation)
+    if out is None:
+        out = torch.empty_like(h)
+    if ws is None:
+        ws = gru_workspace(V, D, h.device)
+    sr = su = sc = None
+    if save is not None:
+        sr = save["r"] = torch.empty_like(h)
+        su = save["u"] = torch.empty_like(h)
+        sc = save["c"] = torch.empty_like(h)
+    segs = (ctypes.c_void_p * nx)(*[x.data_ptr() for x in x_segs])
+    if _timing is None:
+        check(lib.ggnn_gru_f32(segs, nx, _ptr(h), _ptr(Wg), _ptr(bg), _ptr(Wc), _ptr(bc), _ptr(out), _ptr(ws),
+                               ws.numel() * 4, _ptr(sr), _ptr(su), _ptr(sc), V, D, act, _stream()))
+    else:   # same two launches, individually bracketed by events
+        if ws.numel() < 2 * V * D:
+            raise ValueError("GRU workspace too small")
+        rh = ws[:V * D]
+        u = su if su is not None else ws[V * D:2 * V * D]
+        _launch("gru_gates[nx=%d]" % nx, lambda: lib.ggnn_gru_gates_f32(segs, nx, _ptr(h), _ptr(Wg), _ptr(bg), _ptr(rh),
+                                                                         _ptr(u), _ptr(sr), V, D, _stream()))
+        _launch("gru_candidate[nx=%d]" % nx, lambda: lib.ggnn_gru_candidate_f32(
+            segs, nx, _ptr(rh), _ptr(h), _ptr(u), _ptr(Wc), _ptr(bc), _ptr(out), _ptr(sc), V, D, act, _stream()))
+    return out
+
+
+def gemm(a_segs: Sequence[torch.Tensor], B: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = concat(a_segs, dim=1) @ B on the FP32-MFMA kernel (no concat materialised)."""
+    lib = _lib.load()
+    M, D = a_segs[0].shape
+    for i, a in enumerate(a_segs):
+        _req(a, torch.float32, "a_segs[%d]" % i)
+        if a.shape != (M, D):
+            raise ValueError("all segments must be [M,D]")
+    _req(B, torch.float32, "B")
+    K, N = B.shape
+    if K != len(a_segs) * D:
+        raise ValueError("B must be [nseg*D, N]")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=B.device)
+    segs = (ctypes.c_void_p * len(a_segs))(*[a.data_ptr() for a in a_segs])
+    check(lib.ggnn_gemm_f32(segs, len(a_segs), D, _ptr(B), N, _ptr(out), N, M, N, _stream()))
+    return out
+
+
+def unsorted_segment_sum(data: torch.Tensor, segment_ids: torch.Tensor, num_segments: int) -> torch.Tensor:
+    """tf.unsorted_segment_sum (fp32 atomics; any id order).  data [M,D] or [M], ids [M] int32."""
+    lib = _lib.load()
+    _req(data, torch.float32, "data"); _req(segment_ids, torch.int32, "segment_ids")
+    M = data.shape[0]
+    D = 1 if data.dim() == 1 else data.shape[1]
+    out = torch.empty((num_segments,) if data.dim() == 1 else (num_segments, D), dtype=torch.float32, device=data.device)
+    check(lib.ggnn_unsorted_segment_sum_f32(_ptr(data), _ptr(segment_ids), _ptr(out), M, D, num_segments, _stream()))
+    return out

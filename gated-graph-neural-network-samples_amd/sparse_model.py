@@ -1,0 +1,269 @@
+"""SparseGGNNChemModel -- host-side mirror of chem_tensorflow_sparse.py:36-376 on PyTorch-ROCm tensors,
+with compute_final_node_representations() running on the hand-written gfx950 kernels of
+libggnn_hip.so (msg_transform -> gather_segment_sum -> gru per timestep).
+
+Per timestep the reference executes (chem_tensorflow_sparse.py:153-216)
+    T gathers + T [E_t,D]x[D,D] matmuls + concat + unsorted_segment_sum (+ bias) (/ degree) + concat + GRUCell;
+here it is three launches (one FP32-MFMA GEMM [V,D]x[D,T*D], one gather/segment-sum with the
+bias/mean epilogue, one fused GRU = two MFMA GEMMs with sigmoid/tanh/blend epilogues) and no [M,D]
+or concat temporaries.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from .chem_model import ChemModel
+from .data import MoleculeSet, SparseBatch, pack_batches
+from .utils import glorot_init, SMALL_NUMBER, tf_dropout
+
+GGNNWeights = namedtuple('GGNNWeights', ['edge_weights',
+                                         'edge_biases',
+                                         'edge_type_attention_weights',
+                                         'rnn_cells', ])
+
+GRUCellWeights = namedtuple('GRUCellWeights', ['gates_kernel', 'gates_bias', 'candidate_kernel', 'candidate_bias'])
+
+
+class SparseGGNNChemModel(ChemModel):
+    def __init__(self, args):
+        super().__init__(args)
+
+    @classmethod
+    def default_params(cls):
+        # chem_tensorflow_sparse.py:40-61
+        params = dict(super().default_params())
+        params.update({
+            'batch_size': 100000,
+            'use_edge_bias': False,
+            'use_propagation_attention': False,
+            'use_edge_msg_avg_aggregation': True,
+            'residual_connections': {  # For layer i, specify list of layers whose output is added as an input
+                                     "2": [0],
+                                     "4": [0, 2]
+                                    },
+
+            'layer_timesteps': [2, 2, 1, 2, 1],  # number of layers & propagation steps per layer
+
+            'graph_rnn_cell': 'GRU',  # GRU, CudnnCompatibleGRUCell, or RNN
+            'graph_rnn_activation': 'tanh',  # tanh, ReLU
+            'graph_state_dropout_keep_prob': 1.,
+            'task_sample_ratios': {},
+            'edge_weight_dropout_keep_prob': .8
+        })
+        return params
+
+    # ---- weights ------------------------------------------------------------------------------------
+    def prepare_specific_graph_model(self) -> None:
+        """chem_tensorflow_sparse.py:63-115.  Placeholders become dict slots filled by feed(); the
+        variables are created here with the reference's shapes and initialisers."""
+        h_dim = self.params['hidden_size']
+        for name in ('initial_node_representation', 'adjacency_lists', 'num_incoming_edges_per_type',
+                     'graph_nodes_list', 'message_index'):
+            self.placeholders[name] = None
+        self.placeholders['graph_state_keep_prob'] = 1.0
+        self.placeholders['edge_weight_dropout_keep_prob'] = 1.0
+
+        activation_name = self.params['graph_rnn_activation'].lower()
+        if activation_name not in ('tanh', 'relu'):
+            raise Exception("Unknown activation function type '%s'." % activation_name)
+        if self.params['use_propagation_attention']:
+            raise NotImplementedError("use_propagation_attention (chem_tensorflow_sparse.py:170-196) is a "
+                                      "'next' row of the scope table (SURVEY 8f-4); default is off")
+        cell_type = self.params['graph_rnn_cell'].lower()
+        if cell_type != 'gru':
+            if cell_type in ('cudnncompatiblegrucell', 'rnn'):
+                raise NotImplementedError("graph_rnn_cell '%s' is a 'next' row of the scope table "
+                                          "(SURVEY 8f-4); default is GRU" % cell_type)
+            raise Exception("Unknown RNN cell type '%s'." % cell_type)
+
+        # Generate per-layer values for edge weights, biases and gated units:
+        self.gnn_weights = GGNNWeights([], [], [], [])
+        self._edge_weight_vars: List[torch.Tensor] = []
+        dev = self.device
+        for layer_idx in range(len(self.params['layer_timesteps'])):
+            # :88-90 glorot over [T*D, D], then viewed as [T,D,D]
+            ew = torch.from_numpy(glorot_init([self.num_edge_types * h_dim, h_dim])).to(dev)
+            self._edge_weight_vars.append(ew)
+            self.gnn_weights.edge_weights.append(ew.view(self.num_edge_types, h_dim, h_dim))
+            if self.params['use_edge_bias']:
+                self.gnn_weights.edge_biases.append(torch.zeros([self.num_edge_types, h_dim], dtype=torch.float32, device=dev))
+            res = self.params['residual_connections'].get(str(layer_idx)) or []
+            in_dim = h_dim * (len(res) + 1)
+            # TF-1.3 GRUCell: gates/kernel [(in+D),2D] glorot_uniform (the scope's default initializer),
+            # gates/bias = 1.0, candidate/kernel [(in+D),D], candidate/bias = 0
+            cell = GRUCellWeights(torch.from_numpy(glorot_init([in_dim + h_dim, 2 * h_dim])).to(dev),
+                                  torch.ones(2 * h_dim, dtype=torch.float32, device=dev),
+                                  torch.from_numpy(glorot_init([in_dim + h_dim, h_dim])).to(dev),
+                                  torch.zeros(h_dim, dtype=torch.float32, device=dev))
+            self.gnn_weights.rnn_cells.append(cell)
+
+    def graph_model_variables(self) -> Dict[str, torch.Tensor]:
+        """graph_model/* variables under the names TF-1.3 gives them (used by the pickle checkpoints,
+        chem_tensorflow.py:309-359)."""
+        out = {}
+        for l in range(len(self.params['layer_timesteps'])):
+            scope = "graph_model/gnn_layer_%i" % l
+            out["%s/gnn_edge_weights_%i:0" % (scope, l)] = self._edge_weight_vars[l]
+            if self.params['use_edge_bias']:
+                out["%s/gnn_edge_biases_%i:0" % (scope, l)] = self.gnn_weights.edge_biases[l]
+            cell = self.gnn_weights.rnn_cells[l]
+            base = "%s/timestep_0/gru_cell" % scope
+            out[base + "/gates/kernel:0"] = cell.gates_kernel
+            out[base + "/gates/bias:0"] = cell.gates_bias
+            out[base + "/candidate/kernel:0"] = cell.candidate_kernel
+            out[base + "/candidate/bias:0"] = cell.candidate_bias
+        return out
+
+    def set_graph_weights(self, layers: Sequence[dict]) -> None:
+        """Inject explicit weights (oracle layout: 'edge_weights' [T,D,D], optional 'edge_biases' [T,D],
+        'Wg','bg','Wc','bc') -- parity tests need this because TF's RNG is not reproducible."""
+        with torch.no_grad():
+            for l, L in enumerate(layers):
+                as_t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device)
+                self._edge_weight_vars[l].copy_(as_t(L['edge_weights']).reshape(self._edge_weight_vars[l].shape))
+                if self.params['use_edge_bias']:
+                    self.gnn_weights.edge_biases[l].copy_(as_t(L['edge_biases']))
+                cell = self.gnn_weights.rnn_cells[l]
+                cell.gates_kernel.copy_(as_t(L['Wg'])); cell.gates_bias.copy_(as_t(L['bg']))
+                cell.candidate_kernel.copy_(as_t(L['Wc'])); cell.candidate_bias.copy_(as_t(L['bc']))
+
+    # ---- the hot path -----------------------------------------------------------------------------------
+    def compute_final_node_representations(self) -> torch.Tensor:
+        """chem_tensorflow_sparse.py:117-218."""
+        from .autograd import propagation_step
+        ph = self.placeholders
+        h0 = ph['initial_node_representation']
+        node_states_per_layer = [h0]                                              # :118-119
+        index = ph.get('message_index')
+        if index is None:                                                         # :120-129
+            index = ops.build_message_index(ph['adjacency_lists'], h0.shape[0])
+            ph['message_index'] = index
+        nin = ph['num_incoming_edges_per_type']
+        use_avg = bool(self.params['use_edge_msg_avg_aggregation'])
+        act = self.params['graph_rnn_activation']
+        ew_keep = float(ph.get('edge_weight_dropout_keep_prob', 1.0))
+        st_keep = float(ph.get('graph_state_keep_prob', 1.0))
+        need_grad = self.training and torch.is_grad_enabled()
+
+        for (layer_idx, num_timesteps) in enumerate(self.params['layer_timesteps']):   # :131
+            layer_residual_connections = self.params['residual_connections'].get(str(layer_idx))   # :140
+            if layer_residual_connections is None:
+                layer_residual_states = []
+            else:
+                layer_residual_states = [node_states_per_layer[residual_layer_idx]
+                                         for residual_layer_idx in layer_residual_connections]
+            # :91 one weight-dropout mask per layer per run, shared by the layer's timesteps
+            edge_weights = tf_dropout(self.gnn_weights.edge_weights[layer_idx], ew_keep)
+            edge_biases = self.gnn_weights.edge_biases[layer_idx] if self.params['use_edge_bias'] else None
+            cell = self.gnn_weights.rnn_cells[layer_idx]
+            cur = node_states_per_layer[-1]                                        # :152
+            for step in range(num_timesteps):                                      # :153
+                cur = propagation_step(cur, index, nin, edge_weights, edge_biases, use_avg,
+                                       layer_residual_states, cell, act, need_grad)
+                cur = tf_dropout(cur, st_keep)                                     # :113-114 DropoutWrapper(state)
+            node_states_per_layer.append(cur)
+        return node_states_per_layer[-1]                                           # :218
+
+    def gated_regression(self, last_h, regression_gate, regression_transform):
+        """chem_tensorflow_sparse.py:220-231."""
+        from .autograd import segment_sum_rows
+        gate_input = torch.cat([last_h, self.placeholders['initial_node_representation']], dim=-1)   # [v x 2h]
+        gated_outputs = torch.sigmoid(regression_gate(gate_input)) * regression_transform(last_h)    # [v x 1]
+        # Sum up all nodes per-graph
+        graph_representations = segment_sum_rows(gated_outputs, self.placeholders['graph_nodes_list'],
+                                                 self.placeholders['num_graphs'])                    # [g x 1]
+        output = graph_representations.squeeze(-1)                                                   # [g]
+        self.output = output
+        return output
+
+    # ---- data preprocessing and chunking into minibatches ------------------------------------------------
+    def process_raw_graphs(self, raw_data, is_training_data: bool) -> Any:
+        """chem_tensorflow_sparse.py:234-252.  Keeps the data tensorised (MoleculeSet) instead of a list
+        of per-graph dicts; the adjacency lists / in-degree tables of :254-276 are built per batch by
+        data.pack_batch.  Training data are shuffled once here (:243-244) and labels beyond
+        task_sample_ratios are masked (:245-250)."""
+        ms = raw_data if isinstance(raw_data, MoleculeSet) else MoleculeSet.from_json(raw_data)
+        label_mask = np.ones((ms.num_graphs, ms.targets.shape[1]), dtype=np.float32)
+        if is_training_data:
+            perm = np.random.permutation(ms.num_graphs)
+            ms = ms.subset(perm)
+            for task_id in self.params['task_ids']:
+                task_sample_ratio = self.params['task_sample_ratios'].get(str(task_id))
+                if task_sample_ratio is not None:
+                    ex_to_sample = int(ms.num_graphs * task_sample_ratio)
+                    label_mask[ex_to_sample:, task_id] = 0.0
+        return {"molecules": ms, "label_mask": label_mask, "device_batches": None}
+
+    def to_device_batch(self, b: SparseBatch) -> Dict[str, Any]:
+        """Upload one packed batch and build its message index (once; reused every epoch)."""
+        dev = self.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        adjacency = [t(a) for a in b.adjacency_lists]
+        V, A = b.node_features.shape
+        h0 = torch.zeros((V, b.hidden_size), dtype=torch.float32, device=dev)     # :300-302 zero-pad to D
+        if V:
+            h0[:, :A] = t(b.node_features)
+        return {
+            'initial_node_representation': h0,
+            'adjacency_lists': adjacency,
+            'num_incoming_edges_per_type': t(b.num_incoming_edges_per_type),
+            'graph_nodes_list': t(b.graph_nodes_list),
+            'target_values': t(b.target_values),
+            'target_mask': t(b.target_mask),
+            'num_graphs': b.num_graphs,
+            'message_index': ops.build_message_index(adjacency, V),
+        }
+
+    def make_minibatch_iterator(self, data: Any, is_training: bool):
+        """chem_tensorflow_sparse.py:278-350: minibatches as one disconnected super-graph each.
+        Packing is vectorised (data.pack_batches); validation batches are packed and uploaded once and
+        stay resident in HBM; training batches are re-packed per epoch after the shuffle (:281-282)."""
+        ms: MoleculeSet = data["molecules"]
+        state_dropout_keep_prob = self.params['graph_state_dropout_keep_prob'] if is_training else 1.
+        edge_weights_dropout_keep_prob = self.params['edge_weight_dropout_keep_prob'] if is_training else 1.
+        rank = self.dist.rank if self.dist is not None else 0
+        world = self.dist.world_size if self.dist is not None else 1
+        if is_training:
+            order = np.random.permutation(ms.num_graphs)      # same seed on every rank -> same order
+            batches = pack_batches(ms, self.params, self.num_edge_types, order, data["label_mask"], rank, world)
+            device_batches = (self.to_device_batch(b) for b in batches)
+        else:
+            if data["device_batches"] is None:
+                data["device_batches"] = [self.to_device_batch(b) for b in
+                                          pack_batches(ms, self.params, self.num_edge_types, None,
+                                                       data["label_mask"], rank, world)]
+            device_batches = data["device_batches"]
+        for db in device_batches:
+            feed = dict(db)
+            feed['graph_state_keep_prob'] = state_dropout_keep_prob
+            feed['edge_weight_dropout_keep_prob'] = edge_weights_dropout_keep_prob
+            yield feed
+
+    def evaluate_one_batch(self, data):
+        """chem_tensorflow_sparse.py:352-362."""
+        outs = []
+        for item in self.make_minibatch_iterator(data, is_training=False):
+            item['graph_state_keep_prob'] = 1.0
+            item['edge_weight_dropout_keep_prob'] = 1.0
+            item['out_layer_dropout_keep_prob'] = 1.0
+            with torch.no_grad():
+                self.forward_batch(item)
+            outs.append(self.output.detach().cpu().numpy())
+            print(outs[-1])
+        return outs
+
+    def example_evaluation(self, molecules_file: str = 'molecules_valid.json'):
+        """chem_tensorflow_sparse.py:364-376: first 10 validation molecules, predictions next to targets."""
+        import json
+        n_example_molecules = 10
+        with open(molecules_file, 'r') as valid_file:
+            example_molecules = json.load(valid_file)[:n_example_molecules]
+        for mol in example_molecules:
+            print(mol['targets'])
+        example_molecules = self.process_raw_graphs(example_molecules, is_training_data=False)
+        return self.evaluate_one_batch(example_molecules)

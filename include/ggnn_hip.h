@@ -1,0 +1,126 @@
+/* ggnn_hip.h -- C ABI of libggnn_hip.so: the MI355X (gfx950) GGNN propagation engine.
+ *
+ * This is the drop-in boundary for the hot path of microsoft/gated-graph-neural-network-samples:
+ * SparseGGNNChemModel.compute_final_node_representations() (chem_tensorflow_sparse.py:117-218) and
+ * its dense twin (chem_tensorflow_dense.py:93-117).  The reference has no FFI of its own (it is
+ * pure Python on tensorflow==1.3.0); each entry point below replaces the TF op call sites cited
+ * next to it.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every pointer is a DEVICE pointer unless the
+ *     parameter is documented "host".  The caller owns every buffer; the library allocates nothing.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no device
+ *     synchronisation, no allocation, and is safe inside hipGraph capture.
+ *   - return 0 on success, <0 on error (GGNN_E_*); ggnn_last_error() gives a thread-local message.
+ *     Nothing throws or aborts across the ABI.
+ *   - fp32 data, int32 indices (chem_tensorflow_sparse.py:65-71), row-major, rows 16-byte aligned,
+ *     D % 4 == 0.  Supported hidden sizes D: multiples of 100, 64 or 32 (GGNN_E_UNSUPPORTED else).
+ *   - E_t = 0 and nodes with zero in-degree are valid (chem_tensorflow_sparse.py:346-347).
+ */
+#ifndef GGNN_HIP_H
+#define GGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGNN_ABI_VERSION 1
+
+#define GGNN_OK 0
+#define GGNN_E_INVALID (-1)      /* bad argument (null pointer, negative size, misalignment) */
+#define GGNN_E_UNSUPPORTED (-2)  /* shape outside the supported set */
+#define GGNN_E_WORKSPACE (-3)    /* workspace too small */
+#define GGNN_E_HIP (-4)          /* a HIP runtime call failed */
+#define GGNN_E_INDEX (-5)        /* index out of range (validated entry points only) */
+
+#define GGNN_ACT_TANH 0          /* chem_tensorflow_sparse.py:75-81 */
+#define GGNN_ACT_RELU 1
+
+typedef void* ggnn_stream_t;     /* hipStream_t */
+
+int ggnn_abi_version(void);
+const char* ggnn_last_error(void);
+
+/* ---- (a-1) message index prep: chem_tensorflow_sparse.py:120-129 -------------------------------
+ * The reference concatenates the per-type target columns into message_targets[M] (type ascending,
+ * list order).  We additionally bucket the M messages by target with a STABLE sort, so that the
+ * segment sum can be done atomics-free with the reference's accumulation order inside each node.
+ *
+ *   adj        [M,2] int32  the T adjacency lists concatenated in type order, rows (src,dst)
+ *   type_off   HOST [T+1]   type t owns rows type_off[t] .. type_off[t+1]-1 ; type_off[T] == M
+ *   row_ptr    [V+1] int32  out: messages into node v are slots row_ptr[v] .. row_ptr[v+1]-1
+ *   gather_row [M]   int32  out: slot -> src*T + type (row of the [V*T, D] transformed-state matrix)
+ *   msg_perm   [M]   int32  out (may be NULL): slot -> original message index
+ *   ws         scratch of at least ggnn_csr_workspace_bytes(M, V) bytes
+ * Indices are validated on the device: out-of-range src/dst set *err_flag (device int32, may be
+ * NULL) to 1 and are clamped, instead of faulting (TF-CPU raises InvalidArgument there).
+ */
+size_t ggnn_csr_workspace_bytes(int64_t M, int V);
+int ggnn_build_target_csr(const int32_t* adj, const int64_t* type_off, int T, int V, int64_t M,
+                          int32_t* row_ptr, int32_t* gather_row, int32_t* msg_perm, int32_t* err_flag,
+                          void* ws, size_t ws_bytes, ggnn_stream_t stream);
+
+/* ---- (a-3) per-edge-type message transform: chem_tensorflow_sparse.py:160-164 -------------------
+ * H[v, t*D:(t+1)*D] = h[v,:] @ W[t]  for all nodes and types in ONE [V,D]x[D,T*D] FP32-MFMA GEMM
+ * (transform-first: (h[src]) W == (h W)[src]).
+ *   h [V,D] (row stride ldh floats), W [T,D,D] (the reference's reshaped edge_weights, :90),
+ *   H [V,T*D] out.
+ */
+int ggnn_msg_transform_f32(const float* h, int ldh, const float* W, float* H, int V, int D, int T,
+                           ggnn_stream_t stream);
+
+/* ---- (a-2,a-4..a-7) gather + segment sum + bias + mean: chem_tensorflow_sparse.py:160-162,168,
+ *      198-209 ------------------------------------------------------------------------------------
+ * out[v,:] = ( sum_{slot in row_ptr[v]..row_ptr[v+1]} Hrows[gather_row[slot], :]
+ *              + sum_t nin[v,t]*bias[t,:] )  /  ( sum_t nin[v,t] + 1e-7 )
+ * with the bias term only if bias != NULL (:202-204) and the division only if use_avg (:206-209).
+ * Nodes without incoming messages get the zero row (tf.unsorted_segment_sum semantics).
+ *   Hrows  rows of D floats (H of ggnn_msg_transform_f32 viewed as [V*T, D])
+ *   nin    [V,T] fp32 incoming-edge counts (required if bias or use_avg), out [V,D].
+ */
+int ggnn_gather_segment_sum_f32(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row,
+                                const float* nin, const float* bias, int use_avg, float* out,
+                                int V, int D, int T, ggnn_stream_t stream);
+
+/* tf.unsorted_segment_sum in its general form (chem_tensorflow_sparse.py:198-200, 226-228):
+ * out[ids[m],:] += data[m,:] with out zero-filled first; fp32 atomics, any id order.  Used for the
+ * readout's per-graph sum and available for un-bucketed message lists. */
+int ggnn_unsorted_segment_sum_f32(const float* data, const int32_t* ids, float* out, int64_t M, int D,
+                                  int num_segments, ggnn_stream_t stream);
+
+/* ---- (a-8, a-G) residual concat + GRU node update: chem_tensorflow_sparse.py:211-216 -----------
+ * TF-1.3 GRUCell: [r|u] = sigmoid([x|h] Wg + bg); c = act([x | r*h] Wc + bc); h' = u*h + (1-u)*c
+ * with x = [x_segs[0] | ... | x_segs[nx-1]] read through nx pointers (no concat is materialised;
+ * residual states first, aggregated messages last, :211-212).
+ *   x_segs HOST array of nx (1..3) device pointers to [V,D]; h [V,D]; Wg [(nx+1)D, 2D]; bg [2D];
+ *   Wc [(nx+1)D, D]; bc [D]; h_out [V,D] (must not alias h);
+ *   ws: ggnn_gru_workspace_bytes(V,D) bytes of scratch (r*h and u);
+ *   save_r/save_u/save_c: optional [V,D] outputs for a backward pass (NULL to skip).
+ */
+size_t ggnn_gru_workspace_bytes(int V, int D);
+int ggnn_gru_f32(const float* const* x_segs, int nx, const float* h, const float* Wg, const float* bg,
+                 const float* Wc, const float* bc, float* h_out, void* ws, size_t ws_bytes,
+                 float* save_r, float* save_u, float* save_c, int V, int D, int act,
+                 ggnn_stream_t stream);
+
+/* The two launches of ggnn_gru_f32, separately addressable (profiling, fusion experiments):
+ *   gates:     [r|u] = sigmoid([x|h] Wg + bg) -> rh = r*h [V,D], u [V,D] (save_r optional)
+ *   candidate: c = act([x|rh] Wc + bc); h_out = u*h + (1-u)*c            (save_c optional) */
+int ggnn_gru_gates_f32(const float* const* x_segs, int nx, const float* h, const float* Wg, const float* bg,
+                       float* rh, float* u, float* save_r, int V, int D, ggnn_stream_t stream);
+int ggnn_gru_candidate_f32(const float* const* x_segs, int nx, const float* rh, const float* h, const float* u,
+                           const float* Wc, const float* bc, float* h_out, float* save_c, int V, int D, int act,
+                           ggnn_stream_t stream);
+
+/* Generic FP32-MFMA GEMM used by the above and by the host layer for the backward pass:
+ * C[M,N] = [A0 | A1 | ...] (nseg segments of width D each, K = nseg*D) x B[K,N]. */
+int ggnn_gemm_f32(const float* const* a_segs, int nseg, int D, const float* B, int ldb, float* C, int ldc,
+                  int M, int N, ggnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGNN_HIP_H */

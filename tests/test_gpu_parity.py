@@ -1,0 +1,218 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances (SURVEY 8c / BASELINE.md 4): per kernel atol 1e-6 / rtol 1e-5 against the fp64 oracle;
+final node states after 8 steps atol 1e-5 / rtol 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import random_graph_batch
+
+pytestmark = pytest.mark.gpu
+
+KERNEL_TOL = dict(atol=1e-6, rtol=1e-5)
+MODEL_TOL = dict(atol=1e-5, rtol=1e-4)
+
+
+def dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def test_library_loaded(pkg, cuda):
+    lib = pkg._lib.load()
+    assert lib.ggnn_abi_version() == 1
+
+
+@pytest.mark.parametrize("V,D,T", [(1, 100, 4), (17, 100, 4), (1000, 100, 4), (4097, 100, 4), (513, 64, 4),
+                                   (300, 32, 3), (2049, 256, 4), (700, 200, 2), (129, 128, 8)])
+def test_msg_transform(pkg, cuda, V, D, T):
+    rng = np.random.default_rng(V + D)
+    h = rng.uniform(-1, 1, (V, D)).astype(np.float32)
+    W = rng.uniform(-0.3, 0.3, (T, D, D)).astype(np.float32)
+    got = pkg.ops.msg_transform(dev(h, cuda), dev(W, cuda)).cpu().numpy()
+    want = np.concatenate([h.astype(np.float64) @ W[t].astype(np.float64) for t in range(T)], axis=1)
+    np.testing.assert_allclose(got, want, atol=2e-6, rtol=1e-5)
+
+
+def test_msg_transform_is_transpose_safe(pkg, cuda):
+    """A = I-like probe with an ASYMMETRIC weight catches a swapped operand / output layout."""
+    D, T, V = 100, 4, 100
+    h = np.eye(V, D, dtype=np.float32)
+    W = (np.arange(T * D * D, dtype=np.float32).reshape(T, D, D) % 977) / 977.0
+    got = pkg.ops.msg_transform(dev(h, cuda), dev(W, cuda)).cpu().numpy()
+    want = np.concatenate([W[t] for t in range(T)], axis=1)
+    np.testing.assert_allclose(got, want, atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("V,M,D,T,avg,bias", [
+    (50, 200, 100, 4, True, False), (50, 200, 100, 4, False, True), (1000, 5000, 100, 4, True, True),
+    (1000, 0, 100, 4, True, False), (333, 4000, 256, 4, True, False), (64, 5000, 32, 2, False, False),
+    (1, 7, 100, 4, True, False), (500, 700, 64, 3, True, True), (257, 3000, 200, 1, True, False)])
+def test_gather_segment_sum(pkg, oracle, cuda, V, M, D, T, avg, bias):
+    rng = np.random.default_rng(V * 7 + M)
+    _, adj, nin = random_graph_batch(rng, V, M, T, D)
+    H = rng.uniform(-1, 1, (V, T * D)).astype(np.float32)
+    b = rng.uniform(-1, 1, (T, D)).astype(np.float32) if bias else None
+    index = pkg.ops.build_message_index([dev(a, cuda) for a in adj], V)
+    got = pkg.ops.gather_segment_sum(dev(H, cuda), index, dev(nin, cuda), None if b is None else dev(b, cuda), avg).cpu().numpy()
+    # oracle: messages = H[src, type block], reference accumulation order
+    H64 = H.astype(np.float64).reshape(V, T, D)
+    msgs = np.concatenate([H64[adj[t][:, 0], t] for t in range(T)], axis=0).reshape(-1, D)
+    tg = np.concatenate([a[:, 1] for a in adj])
+    want = oracle.unsorted_segment_sum(msgs, tg, V)
+    if bias:
+        want = want + nin.astype(np.float64) @ b.astype(np.float64)
+    if avg:
+        want = want / (nin.astype(np.float64).sum(-1, keepdims=True) + 1e-7)
+    np.testing.assert_allclose(got, want, atol=5e-6, rtol=1e-5)
+    # nodes without incoming messages must be exactly zero when no bias (unsorted_segment_sum zero fill)
+    if not bias:
+        assert np.all(got[nin.sum(-1) == 0] == 0)
+
+
+def test_message_index_order_and_validation(pkg, cuda):
+    """Slots of a node keep the reference's accumulation order (type asc, then list order)."""
+    rng = np.random.default_rng(5)
+    V, M, T = 40, 400, 4
+    _, adj, _ = random_graph_batch(rng, V, M, T, 4)
+    index = pkg.ops.build_message_index([dev(a, cuda) for a in adj], V)
+    row_ptr = index.row_ptr.cpu().numpy(); perm = index.msg_perm.cpu().numpy(); g = index.gather_row.cpu().numpy()
+    tg = np.concatenate([a[:, 1] for a in adj]); sr = np.concatenate([a[:, 0] for a in adj])
+    ty = np.concatenate([np.full(len(a), t) for t, a in enumerate(adj)])
+    assert row_ptr[0] == 0 and row_ptr[-1] == M
+    for v in range(V):
+        seg = perm[row_ptr[v]:row_ptr[v + 1]]
+        assert np.all(tg[seg] == v)
+        assert np.all(np.diff(seg) > 0)          # stable: ascending original message index
+    assert np.array_equal(g, sr[perm] * T + ty[perm])
+    bad = [a.copy() for a in adj]
+    bad[1][0, 1] = V + 3
+    with pytest.raises(IndexError):
+        pkg.ops.build_message_index([dev(a, cuda) for a in bad], V)
+
+
+@pytest.mark.parametrize("V,D,R,act", [(1, 100, 0, "tanh"), (200, 100, 0, "tanh"), (1000, 100, 1, "tanh"),
+                                       (513, 100, 2, "relu"), (300, 64, 0, "tanh"), (1025, 256, 0, "tanh"),
+                                       (77, 32, 2, "tanh")])
+def test_gru(pkg, oracle, cuda, V, D, R, act):
+    rng = np.random.default_rng(V + D + R)
+    xs = [rng.uniform(-1, 1, (V, D)).astype(np.float32) for _ in range(R + 1)]
+    h = rng.uniform(-1, 1, (V, D)).astype(np.float32)
+    K = (R + 2) * D
+    Wg = rng.uniform(-0.2, 0.2, (K, 2 * D)).astype(np.float32); bg = rng.uniform(0.5, 1.5, 2 * D).astype(np.float32)
+    Wc = rng.uniform(-0.2, 0.2, (K, D)).astype(np.float32); bc = rng.uniform(-0.5, 0.5, D).astype(np.float32)
+    save = {}
+    got = pkg.ops.gru([dev(x, cuda) for x in xs], dev(h, cuda), dev(Wg, cuda), dev(bg, cuda), dev(Wc, cuda),
+                      dev(bc, cuda), act, save=save).cpu().numpy()
+    f = lambda a: a.astype(np.float64)
+    want, r, u, c = oracle.gru_cell(np.concatenate([f(x) for x in xs], 1), f(h), f(Wg), f(bg), f(Wc), f(bc),
+                                    oracle.activation(act))
+    np.testing.assert_allclose(got, want, atol=3e-6, rtol=1e-5)
+    np.testing.assert_allclose(save["r"].cpu().numpy(), r, atol=3e-6, rtol=1e-5)
+    np.testing.assert_allclose(save["u"].cpu().numpy(), u, atol=3e-6, rtol=1e-5)
+    np.testing.assert_allclose(save["c"].cpu().numpy(), c, atol=3e-6, rtol=1e-5)
+
+
+def test_unsorted_segment_sum(pkg, oracle, cuda):
+    rng = np.random.default_rng(11)
+    data = rng.uniform(-1, 1, (5000, 1)).astype(np.float32)
+    ids = rng.integers(0, 300, 5000).astype(np.int32)
+    got = pkg.ops.unsorted_segment_sum(dev(data, cuda), dev(ids, cuda), 300).cpu().numpy()
+    want = oracle.unsorted_segment_sum(data.astype(np.float64), ids, 300)
+    np.testing.assert_allclose(got, want, atol=1e-5, rtol=1e-5)
+
+
+def _model_and_feed(pkg, oracle, ms, config=None, seed=0):
+    args = {"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms, "--config": config or {}}
+    model = pkg.SparseGGNNChemModel(args)
+    layers = oracle.make_sparse_layers(np.random.default_rng(seed), model.params, model.num_edge_types, random_bias=True)
+    model.set_graph_weights(layers)
+    feeds = list(model.make_minibatch_iterator(model.valid_data, is_training=False))
+    return model, layers, feeds
+
+
+def _oracle_states(oracle, feed, layers, params, dtype=np.float64):
+    adj = [a.cpu().numpy() for a in feed["adjacency_lists"]]
+    return oracle.sparse_propagate(feed["initial_node_representation"].cpu().numpy(), adj,
+                                   feed["num_incoming_edges_per_type"].cpu().numpy(), layers, params, dtype=dtype)
+
+
+@pytest.mark.parametrize("config", [
+    {},                                                                  # reference defaults: 5 layers / 8 steps / residuals
+    {"use_edge_bias": True},
+    {"use_edge_msg_avg_aggregation": False, "use_edge_bias": True},
+    {"graph_rnn_activation": "ReLU"},
+    {"hidden_size": 64, "layer_timesteps": [3], "residual_connections": {}},
+    {"tie_fwd_bkwd": False},
+])
+def test_sparse_model_matches_oracle(pkg, oracle, cuda, config):
+    ms = pkg.synthetic_qm9(200, mean_nodes=14, seed=1)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms, config)
+    assert len(feeds) == 1
+    with torch.no_grad():
+        model.feed(feeds[0])
+        got = model.compute_final_node_representations().cpu().numpy()
+    want = _oracle_states(oracle, feeds[0], layers, model.params)
+    np.testing.assert_allclose(got, want, **MODEL_TOL)
+
+
+def test_sparse_model_graph_disjointness(pkg, oracle, cuda):
+    """A batch of G graphs == G single-graph runs (no cross-graph leakage)."""
+    ms = pkg.synthetic_qm9(12, mean_nodes=9, seed=2)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms)
+    with torch.no_grad():
+        model.feed(feeds[0])
+        full = model.compute_final_node_representations().cpu().numpy()
+    off = 0
+    for g in range(ms.num_graphs):
+        sub = ms.subset(np.array([g]))
+        b = pkg.data.pack_batch(sub, np.array([0]), model.num_edge_types, model.params["hidden_size"])
+        feed = model.to_device_batch(b)
+        with torch.no_grad():
+            model.feed(feed)
+            part = model.compute_final_node_representations().cpu().numpy()
+        n = part.shape[0]
+        np.testing.assert_allclose(full[off:off + n], part, atol=1e-6, rtol=1e-5)
+        off += n
+
+
+def test_forward_batch_loss_matches_oracle(pkg, oracle, cuda):
+    ms = pkg.synthetic_qm9(150, mean_nodes=12, seed=4)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms)
+    feed = feeds[0]
+    with torch.no_grad():
+        loss = float(model.forward_batch(feed))
+    last = _oracle_states(oracle, feed, layers, model.params)
+    g = model.weights['regression_gate_task0']; t = model.weights['regression_transform_task0']
+    f = lambda x: x.cpu().numpy().astype(np.float64)
+    pred = oracle.gated_regression(last, f(feed["initial_node_representation"]), feed["graph_nodes_list"].cpu().numpy(),
+                                   feed["num_graphs"], f(g.params["weights"][0]), f(g.params["biases"][0]),
+                                   f(t.params["weights"][0]), f(t.params["biases"][0]))
+    want, mae = oracle.task_loss(pred, f(feed["target_values"])[0], f(feed["target_mask"])[0])
+    assert abs(loss - want) < 1e-5 * max(1.0, abs(want))
+    assert abs(float(model.ops['accuracy_task0']) - mae) < 1e-5 * max(1.0, mae)
+
+
+def test_full_size_batch_properties(pkg, oracle, cuda):
+    """BASELINE config-2 sized batch (~100k nodes): size-independent checks -- finite, bounded by the GRU's
+    convex blend (|h| <= 1 for tanh with |h0| <= 1), bit-reproducible across runs, and equal to the
+    fp32 oracle on a sampled set of whole graphs re-run in isolation."""
+    ms = pkg.synthetic_qm9(6000, mean_nodes=18, seed=0)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms)
+    feed = feeds[0]
+    assert feed["initial_node_representation"].shape[0] > 90000
+    with torch.no_grad():
+        model.feed(feed); a = model.compute_final_node_representations().clone()
+        model.feed(feed); b = model.compute_final_node_representations().clone()
+    assert torch.equal(a, b)                       # atomics-free => deterministic
+    a = a.cpu().numpy()
+    assert np.isfinite(a).all() and np.abs(a).max() <= 1.0 + 1e-6
+    gnl = feed["graph_nodes_list"].cpu().numpy()
+    for g in (0, 17, 2500, feed["num_graphs"] - 1):
+        rows = np.nonzero(gnl == g)[0]
+        # graph ids inside the batch follow ms order for validation data
+        b1 = pkg.data.pack_batch(ms, np.array([g]), model.num_edge_types, model.params["hidden_size"])
+        want = oracle.sparse_propagate(b1.initial_node_representation, b1.adjacency_lists,
+                                       b1.num_incoming_edges_per_type, layers, model.params)
+        np.testing.assert_allclose(a[rows], want, **MODEL_TOL)
