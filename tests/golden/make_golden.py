@@ -1,0 +1,47 @@
+"""Generates tests/golden/*.npz from the fp64 NumPy oracle (oracle/ggnn_oracle.py).
+
+The reference cannot run here (tensorflow==1.3.0 is not installable) and ships no vectors of its own, so
+these fixtures pin the ORACLE against silent drift and give the GPU tests a committed target; they are
+not outputs of the reference (PARITY UNPINNED, see oracle/ggnn_oracle.py).
+
+    python tests/golden/make_golden.py
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ggnn_oracle as O  # noqa: E402
+
+pkg = importlib.import_module("gated-graph-neural-network-samples_amd")
+
+
+def sparse_small():
+    """24 QM9-shaped molecules, D=100, T=4, two layers ([2,1] timesteps, layer 1 sees h0 as a residual
+    input) with edge biases: every feature of the default model at a third of its weight bytes."""
+    params = {"use_edge_bias": True, "layer_timesteps": [2, 1], "residual_connections": {"1": [0]}}
+    p = O.default_sparse_params(); p.update(params)
+    ms = pkg.synthetic_qm9(24, mean_nodes=9, seed=7)
+    T, D = 4, p["hidden_size"]
+    b = pkg.data.pack_batch(ms, np.arange(ms.num_graphs), T, D)
+    layers = O.make_sparse_layers(np.random.default_rng(7), p, T, random_bias=True)
+    h0 = b.initial_node_representation
+    states = O.sparse_propagate(h0, b.adjacency_lists, b.num_incoming_edges_per_type, layers, p, return_all_layers=True)
+    out = {"params": np.array(params, dtype=object), "layers": np.array(layers, dtype=object), "T": T,
+           "h0": h0, "nin": b.num_incoming_edges_per_type, "graph_nodes_list": b.graph_nodes_list,
+           "molecules": np.array(ms.to_json(), dtype=object)}
+    for t, a in enumerate(b.adjacency_lists):
+        out["adj_%d" % t] = a
+    for i, s in enumerate(states):
+        out["state_%d" % i] = s
+    np.savez_compressed(os.path.join(HERE, "sparse_small.npz"), **out)
+    print("sparse_small: V=%d M=%d" % (b.num_nodes, b.num_messages))
+
+
+if __name__ == "__main__":
+    sparse_small()

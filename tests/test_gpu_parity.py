@@ -32,7 +32,10 @@ def test_msg_transform(pkg, cuda, V, D, T):
     W = rng.uniform(-0.3, 0.3, (T, D, D)).astype(np.float32)
     got = pkg.ops.msg_transform(dev(h, cuda), dev(W, cuda)).cpu().numpy()
     want = np.concatenate([h.astype(np.float64) @ W[t].astype(np.float64) for t in range(T)], axis=1)
-    np.testing.assert_allclose(got, want, atol=2e-6, rtol=1e-5)
+    # fp32 fmaf-chain error bound: ~1.5e-7 * sum_k |a_k b_k| (cdna guide, FP32 MFMA numerics); for |msg| <= 1
+    # (the GGNN regime: states in (-1,1), glorot weights) this is the per-kernel atol 1e-6 of SURVEY 8c
+    bound = 4e-7 * np.concatenate([np.abs(h).astype(np.float64) @ np.abs(W[t]).astype(np.float64) for t in range(T)], axis=1)
+    assert np.all(np.abs(got - want) <= bound + 1e-7)
 
 
 def test_msg_transform_is_transpose_safe(pkg, cuda):
@@ -216,3 +219,22 @@ def test_full_size_batch_properties(pkg, oracle, cuda):
         want = oracle.sparse_propagate(b1.initial_node_representation, b1.adjacency_lists,
                                        b1.num_incoming_edges_per_type, layers, model.params)
         np.testing.assert_allclose(a[rows], want, **MODEL_TOL)
+
+
+def test_golden_fixture_on_gpu(pkg, oracle, cuda):
+    """The committed fixture (tests/golden/make_golden.py) through the HIP path, layer by layer."""
+    import os
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sparse_small.npz"), allow_pickle=True)
+    raw = g["molecules"].tolist()
+    args = {"--quiet": True, "--device": "cuda:0", "train_data": raw, "valid_data": raw, "--config": g["params"].item()}
+    model = pkg.SparseGGNNChemModel(args)
+    model.set_graph_weights(g["layers"].tolist())
+    feed = next(iter(model.make_minibatch_iterator(model.valid_data, is_training=False)))
+    assert np.array_equal(feed["initial_node_representation"].cpu().numpy(), g["h0"])
+    for t in range(int(g["T"])):
+        assert np.array_equal(feed["adjacency_lists"][t].cpu().numpy(), g["adj_%d" % t])
+    with torch.no_grad():
+        model.feed(feed)
+        got = model.compute_final_node_representations().cpu().numpy()
+    np.testing.assert_allclose(got, g["state_2"], **MODEL_TOL)
