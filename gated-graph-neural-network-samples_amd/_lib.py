@@ -21,6 +21,8 @@ SYMBOLS = {
     "ggnn_csr_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "ggnn_build_target_csr": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int, c_int64, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ggnn_build_source_csr": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int, c_int64, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ggnn_msg_transform_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ggnn_gather_segment_sum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                             c_int, c_int, c_int, c_void_p]),
@@ -32,7 +34,7 @@ SYMBOLS = {
                                    c_int, c_int, c_void_p]),
     "ggnn_gru_candidate_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "ggnn_gemm_f32": (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+    "ggnn_gemm_f32": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_void_p]),
 }
 

@@ -82,10 +82,11 @@ extern "C" int ggnn_msg_transform_f32(const float* h, int ldh, const float* W, f
     return dispatch_gemm(g, epi, (hipStream_t)stream);
 }
 
-extern "C" int ggnn_gemm_f32(const float* const* a_segs, int nseg, int D, const float* B, int ldb, float* C,
+extern "C" int ggnn_gemm_f32(const float* const* a_segs, int nseg, int D, int lda, const float* B, int ldb, float* C,
                              int ldc, int M, int N, ggnn_stream_t stream) {
     if (int rc = check_common(M, D)) return rc;
     GGNN_CHECK_ARG(nseg >= 1 && nseg <= 4, "nseg %d outside 1..4", nseg);
+    GGNN_CHECK_ARG(lda >= D && lda % 4 == 0, "lda %d must be >= D and a multiple of 4", lda);
     GGNN_CHECK_ARG(N > 0 && N % 4 == 0 && ldb >= N && ldb % 4 == 0 && ldc >= N && ldc % 4 == 0,
                    "N/ldb/ldc must be multiples of 4 with ldb,ldc >= N");
     if (M == 0) return GGNN_OK;
@@ -93,7 +94,7 @@ extern "C" int ggnn_gemm_f32(const float* const* a_segs, int nseg, int D, const 
     GemmOperands g{};
     for (int s = 0; s < nseg; ++s) {
         GGNN_CHECK_ARG(a_segs[s] && aligned16(a_segs[s]), "segment %d null or misaligned", s);
-        g.A[s] = a_segs[s]; g.lda[s] = D;
+        g.A[s] = a_segs[s]; g.lda[s] = lda;
     }
     g.nseg = nseg; g.D = D; g.B = B; g.ldb = ldb; g.b_blk_cols = N; g.b_blk_stride = 0; g.M = M; g.N = N;
     EpiStore epi{C, ldc};

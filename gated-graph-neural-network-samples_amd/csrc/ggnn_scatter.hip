@@ -23,26 +23,35 @@ struct TypeOffsets { long long off[kMaxTypes + 1]; int T; };
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 // ---- index prep -----------------------------------------------------------------------------------
-__global__ void csr_prep_kernel(const int* __restrict__ adj, long long M, int V, int* keys, int* vals, int* err_flag) {
+// by_source == 0: key = dst           (V segments),   gathered row = src*T + type   (forward)
+// by_source == 1: key = src*T + type  (V*T segments), gathered row = dst            (backward: the transpose)
+__device__ __forceinline__ int type_of(const TypeOffsets& to, long long m) {
+    int t = 0;
+    while (t + 1 < to.T && m >= to.off[t + 1]) ++t;
+    return t;
+}
+
+__global__ void csr_prep_kernel(const int* __restrict__ adj, TypeOffsets to, long long M, int V, int by_source,
+                                int* keys, int* vals, int* err_flag) {
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const int src = adj[2 * m], dst = adj[2 * m + 1];
     if ((unsigned)src >= (unsigned)V || (unsigned)dst >= (unsigned)V) {
         if (err_flag) *err_flag = 1;
     }
-    keys[m] = min(max(dst, 0), V - 1);
+    const int s = min(max(src, 0), V - 1), d = min(max(dst, 0), V - 1);
+    keys[m] = by_source ? s * to.T + type_of(to, m) : d;
     vals[m] = (int)m;
 }
 
 __global__ void csr_finalize_kernel(const int* __restrict__ adj, const int* __restrict__ vals_sorted, TypeOffsets to,
-                                    long long M, int V, int* gather_row, int* msg_perm) {
+                                    long long M, int V, int by_source, int* gather_row, int* msg_perm) {
     const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= M) return;
     const int m = vals_sorted[slot];
-    int t = 0;
-    while (t + 1 < to.T && (long long)m >= to.off[t + 1]) ++t;
     const int src = min(max(adj[2 * (long long)m], 0), V - 1);
-    gather_row[slot] = src * to.T + t;
+    const int dst = min(max(adj[2 * (long long)m + 1], 0), V - 1);
+    gather_row[slot] = by_source ? dst : src * to.T + type_of(to, m);
     if (msg_perm) msg_perm[slot] = m;
 }
 
@@ -141,12 +150,13 @@ using namespace ggnn;
 
 extern "C" size_t ggnn_csr_workspace_bytes(int64_t M, int V) {
     if (M <= 0 || V <= 0) return 256;
-    return 4 * align256((size_t)M * sizeof(int)) + align256(cub_temp_bytes(M, key_bits(V))) + 256;
+    // sized for the larger (by-source, V*T <= 2^31 keys) variant: 31 key bits
+    return 4 * align256((size_t)M * sizeof(int)) + align256(cub_temp_bytes(M, 31)) + 256;
 }
 
-extern "C" int ggnn_build_target_csr(const int32_t* adj, const int64_t* type_off, int T, int V, int64_t M,
-                                     int32_t* row_ptr, int32_t* gather_row, int32_t* msg_perm, int32_t* err_flag,
-                                     void* ws, size_t ws_bytes, ggnn_stream_t stream) {
+static int build_csr(const int32_t* adj, const int64_t* type_off, int T, int V, int64_t M, int by_source,
+                     int32_t* row_ptr, int32_t* gather_row, int32_t* msg_perm, int32_t* err_flag, void* ws,
+                     size_t ws_bytes, ggnn_stream_t stream) {
     GGNN_CHECK_ARG(T > 0 && T <= kMaxTypes, "num_edge_types %d outside 1..%d", T, kMaxTypes);
     GGNN_CHECK_ARG(V >= 0 && M >= 0 && M < (1LL << 31), "bad sizes V=%d M=%lld", V, (long long)M);
     GGNN_CHECK_ARG((long long)V * T < (1LL << 31), "V*T overflows int32");
@@ -154,8 +164,9 @@ extern "C" int ggnn_build_target_csr(const int32_t* adj, const int64_t* type_off
     GGNN_CHECK_ARG(type_off[0] == 0 && type_off[T] == M, "type_off must start at 0 and end at M");
     for (int t = 0; t < T; ++t) GGNN_CHECK_ARG(type_off[t] <= type_off[t + 1], "type_off not monotone");
     hipStream_t st = (hipStream_t)stream;
+    const int nseg = by_source ? V * T : V;
     if (M == 0 || V == 0) {
-        GGNN_CHECK_HIP(hipMemsetAsync(row_ptr, 0, sizeof(int) * ((size_t)V + 1), st));
+        GGNN_CHECK_HIP(hipMemsetAsync(row_ptr, 0, sizeof(int) * ((size_t)nseg + 1), st));
         return GGNN_OK;
     }
     GGNN_CHECK_ARG(adj && gather_row && ws, "null pointer");
@@ -169,25 +180,39 @@ extern "C" int ggnn_build_target_csr(const int32_t* adj, const int64_t* type_off
     int* keys_out = reinterpret_cast<int*>(p + 2 * arr);
     int* vals_out = reinterpret_cast<int*>(p + 3 * arr);
     void* cub_ws = p + 4 * arr;
-    const int bits = key_bits(V);
+    const int bits = key_bits(nseg);
     size_t cub_bytes = cub_temp_bytes(M, bits);
-
-    const int threads = 256;
-    const unsigned blocks_m = (unsigned)((M + threads - 1) / threads);
-    hipLaunchKernelGGL(csr_prep_kernel, dim3(blocks_m), dim3(threads), 0, st, adj, (long long)M, V, keys_in, vals_in, err_flag);
-    GGNN_CHECK_HIP(hipGetLastError());
-    GGNN_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(cub_ws, cub_bytes, (const int*)keys_in, keys_out,
-                                                      (const int*)vals_in, vals_out, (int)M, 0, bits, st));
     TypeOffsets to;
     to.T = T;
     for (int t = 0; t <= T; ++t) to.off[t] = type_off[t];
-    hipLaunchKernelGGL(csr_finalize_kernel, dim3(blocks_m), dim3(threads), 0, st, adj, (const int*)vals_out, to,
-                       (long long)M, V, gather_row, msg_perm);
+
+    const int threads = 256;
+    const unsigned blocks_m = (unsigned)((M + threads - 1) / threads);
+    hipLaunchKernelGGL(csr_prep_kernel, dim3(blocks_m), dim3(threads), 0, st, adj, to, (long long)M, V, by_source,
+                       keys_in, vals_in, err_flag);
     GGNN_CHECK_HIP(hipGetLastError());
-    const unsigned blocks_v = (unsigned)(((long long)V + 1 + threads - 1) / threads);
-    hipLaunchKernelGGL(csr_rowptr_kernel, dim3(blocks_v), dim3(threads), 0, st, (const int*)keys_out, (long long)M, V, row_ptr);
+    GGNN_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(cub_ws, cub_bytes, (const int*)keys_in, keys_out,
+                                                      (const int*)vals_in, vals_out, (int)M, 0, bits, st));
+    hipLaunchKernelGGL(csr_finalize_kernel, dim3(blocks_m), dim3(threads), 0, st, adj, (const int*)vals_out, to,
+                       (long long)M, V, by_source, gather_row, msg_perm);
+    GGNN_CHECK_HIP(hipGetLastError());
+    const unsigned blocks_v = (unsigned)(((long long)nseg + 1 + threads - 1) / threads);
+    hipLaunchKernelGGL(csr_rowptr_kernel, dim3(blocks_v), dim3(threads), 0, st, (const int*)keys_out, (long long)M,
+                       nseg, row_ptr);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
+}
+
+extern "C" int ggnn_build_target_csr(const int32_t* adj, const int64_t* type_off, int T, int V, int64_t M,
+                                     int32_t* row_ptr, int32_t* gather_row, int32_t* msg_perm, int32_t* err_flag,
+                                     void* ws, size_t ws_bytes, ggnn_stream_t stream) {
+    return build_csr(adj, type_off, T, V, M, 0, row_ptr, gather_row, msg_perm, err_flag, ws, ws_bytes, stream);
+}
+
+extern "C" int ggnn_build_source_csr(const int32_t* adj, const int64_t* type_off, int T, int V, int64_t M,
+                                     int32_t* row_ptr, int32_t* gather_row, int32_t* msg_perm, int32_t* err_flag,
+                                     void* ws, size_t ws_bytes, ggnn_stream_t stream) {
+    return build_csr(adj, type_off, T, V, M, 1, row_ptr, gather_row, msg_perm, err_flag, ws, ws_bytes, stream);
 }
 
 extern "C" int ggnn_gather_segment_sum_f32(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row,

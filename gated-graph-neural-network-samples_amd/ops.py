@@ -104,12 +104,7 @@ class MessageIndex:
         return int(self.type_off[-1])
 
 
-def build_message_index(adjacency_lists: Sequence[torch.Tensor], num_nodes: int,
-                        validate: bool = True) -> MessageIndex:
-    """chem_tensorflow_sparse.py:120-129 plus the stable bucketing by target that makes the segment
-    sum atomics-free.  adjacency_lists: T tensors int32 [E_t,2] (src,dst) on the GPU; E_t may be 0
-    (:346-347).  With validate=True an out-of-range src/dst raises IndexError (TF-CPU raises
-    InvalidArgument at the gather / segment_sum); this costs one device->host sync, once per batch."""
+def _build_index(adjacency_lists: Sequence[torch.Tensor], num_nodes: int, validate: bool, by_source: bool) -> MessageIndex:
     lib = _lib.load()
     T = len(adjacency_lists)
     if T == 0:
@@ -121,18 +116,34 @@ def build_message_index(adjacency_lists: Sequence[torch.Tensor], num_nodes: int,
         type_off.append(type_off[-1] + a.shape[0])
     M = type_off[-1]
     adj = torch.cat(lists, dim=0).contiguous() if M else torch.zeros((0, 2), dtype=torch.int32, device=dev)
-    row_ptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    nseg = num_nodes * T if by_source else num_nodes
+    row_ptr = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
     gather_row = torch.empty(M, dtype=torch.int32, device=dev)
     msg_perm = torch.empty(M, dtype=torch.int32, device=dev)
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     ws_bytes = lib.ggnn_csr_workspace_bytes(M, num_nodes)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     off = (ctypes.c_int64 * (T + 1))(*type_off)
-    check(lib.ggnn_build_target_csr(_ptr(adj), off, T, num_nodes, M, _ptr(row_ptr), _ptr(gather_row),
-                                    _ptr(msg_perm), _ptr(err), _ptr(ws), ws_bytes, _stream()))
+    fn = lib.ggnn_build_source_csr if by_source else lib.ggnn_build_target_csr
+    check(fn(_ptr(adj), off, T, num_nodes, M, _ptr(row_ptr), _ptr(gather_row), _ptr(msg_perm), _ptr(err), _ptr(ws),
+             ws_bytes, _stream()))
     if validate and M and int(err.item()) != 0:
         raise IndexError("adjacency list holds a node id outside [0, %d)" % num_nodes)
-    return MessageIndex(adj, type_off, row_ptr, gather_row, msg_perm, num_nodes, T)
+    return MessageIndex(adj, type_off, row_ptr, gather_row, msg_perm, nseg, T)
+
+
+def build_message_index(adjacency_lists: Sequence[torch.Tensor], num_nodes: int,
+                        validate: bool = True) -> MessageIndex:
+    """chem_tensorflow_sparse.py:120-129 plus the stable bucketing by target that makes the segment
+    sum atomics-free.  adjacency_lists: T tensors int32 [E_t,2] (src,dst) on the GPU; E_t may be 0
+    (:346-347).  With validate=True an out-of-range src/dst raises IndexError (TF-CPU raises
+    InvalidArgument at the gather / segment_sum); this costs one device->host sync, once per batch."""
+    return _build_index(adjacency_lists, num_nodes, validate, by_source=False)
+
+
+def build_source_index(adjacency_lists: Sequence[torch.Tensor], num_nodes: int) -> MessageIndex:
+    """The transpose index for the backward pass: V*T segments keyed by (src*T + type), gathering dst rows."""
+    return _build_index(adjacency_lists, num_nodes, False, by_source=True)
 
 
 def msg_transform(h: torch.Tensor, edge_weights: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -235,13 +246,16 @@ def gru(x_segs: Sequence[torch.Tensor], h: torch.Tensor, Wg: torch.Tensor, bg: t
 
 
 def gemm(a_segs: Sequence[torch.Tensor], B: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """C = concat(a_segs, dim=1) @ B on the FP32-MFMA kernel (no concat materialised)."""
+    """C = concat(a_segs, dim=1) @ B on the FP32-MFMA kernel (no concat materialised).  Segments are
+    [M,D] tensors (contiguous, or equal-stride column slices of one wider row-major matrix)."""
     lib = _lib.load()
     M, D = a_segs[0].shape
+    lda = a_segs[0].stride(0) if M > 1 else D
     for i, a in enumerate(a_segs):
-        _req(a, torch.float32, "a_segs[%d]" % i)
-        if a.shape != (M, D):
-            raise ValueError("all segments must be [M,D]")
+        if not a.is_cuda or a.dtype != torch.float32:
+            raise TypeError("a_segs[%d] must be a float32 CUDA/HIP tensor" % i)
+        if a.shape != (M, D) or a.stride(1) != 1 or (M > 1 and a.stride(0) != lda):
+            raise ValueError("all segments must be [M,D] row-major with one common row stride")
     _req(B, torch.float32, "B")
     K, N = B.shape
     if K != len(a_segs) * D:
@@ -249,7 +263,7 @@ def gemm(a_segs: Sequence[torch.Tensor], B: torch.Tensor, out: Optional[torch.Te
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=B.device)
     segs = (ctypes.c_void_p * len(a_segs))(*[a.data_ptr() for a in a_segs])
-    check(lib.ggnn_gemm_f32(segs, len(a_segs), D, _ptr(B), N, _ptr(out), N, M, N, _stream()))
+    _launch("gemm[K=%d,N=%d]" % (K, N), lambda: lib.ggnn_gemm_f32(segs, len(a_segs), D, lda, _ptr(B), N, _ptr(out), N, M, N, _stream()))
     return out
 
 
@@ -261,4 +275,19 @@ def unsorted_segment_sum(data: torch.Tensor, segment_ids: torch.Tensor, num_segm
     D = 1 if data.dim() == 1 else data.shape[1]
     out = torch.empty((num_segments,) if data.dim() == 1 else (num_segments, D), dtype=torch.float32, device=data.device)
     check(lib.ggnn_unsorted_segment_sum_f32(_ptr(data), _ptr(segment_ids), _ptr(out), M, D, num_segments, _stream()))
+    return out
+
+
+def segment_sum_rows_by_index(rows: torch.Tensor, index: MessageIndex, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[s,:] = sum of rows[index.gather_row[slot],:] over the slots of segment s -- the plain
+    gather/segment-sum kernel without epilogue.  With a source index (build_source_index) and
+    rows = d_incoming [V,D] this is the backward of the forward gather: out = dH viewed as [V*T, D]."""
+    lib = _lib.load()
+    _req(rows, torch.float32, "rows")
+    D = rows.shape[1]
+    nseg = index.num_nodes
+    if out is None:
+        out = torch.empty((nseg, D), dtype=torch.float32, device=rows.device)
+    _launch("gather_segment_sum_bwd", lambda: lib.ggnn_gather_segment_sum_f32(
+        _ptr(rows), _ptr(index.row_ptr), _ptr(index.gather_row), None, None, 0, _ptr(out), nseg, D, 1, _stream()))
     return out

@@ -158,7 +158,9 @@ class SparseGGNNChemModel(ChemModel):
                 layer_residual_states = [node_states_per_layer[residual_layer_idx]
                                          for residual_layer_idx in layer_residual_connections]
             # :91 one weight-dropout mask per layer per run, shared by the layer's timesteps
-            edge_weights = tf_dropout(self.gnn_weights.edge_weights[layer_idx], ew_keep)
+            # (a fresh view of the [T*D, D] variable, :90, so autograd sees the variable when training)
+            h_dim = self.params['hidden_size']
+            edge_weights = tf_dropout(self._edge_weight_vars[layer_idx].view(self.num_edge_types, h_dim, h_dim), ew_keep)
             edge_biases = self.gnn_weights.edge_biases[layer_idx] if self.params['use_edge_bias'] else None
             cell = self.gnn_weights.rnn_cells[layer_idx]
             cur = node_states_per_layer[-1]                                        # :152

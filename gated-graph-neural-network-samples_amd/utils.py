@@ -44,7 +44,9 @@ class MLP(object):
         return {"weights": weights, "biases": biases}
 
     def init_weights(self, shape):
-        return np.sqrt(6.0 / (shape[-2] + shape[-1])) * (2 * np.random.rand(*shape).astype(np.float32) - 1)
+        # numpy 1.13 (the reference's pin) keeps float32 here (value-based scalar casting); numpy 2 would
+        # promote to float64 through the np.float64 scalar, so cast explicitly
+        return (np.sqrt(6.0 / (shape[-2] + shape[-1])) * (2 * np.random.rand(*shape).astype(np.float32) - 1)).astype(np.float32)
 
     def __call__(self, inputs):
         acts = inputs

@@ -63,6 +63,15 @@ int ggnn_build_target_csr(const int32_t* adj, const int64_t* type_off, int T, in
                           int32_t* row_ptr, int32_t* gather_row, int32_t* msg_perm, int32_t* err_flag,
                           void* ws, size_t ws_bytes, ggnn_stream_t stream);
 
+/* The transpose index for the backward pass (a-B): messages bucketed by (src*T + type) -- V*T segments,
+ * row_ptr [V*T+1] -- with gather_row[slot] = dst, so that
+ *   dH[src*T+type, :] = sum over the messages leaving (src,type) of d_incoming[dst, :]
+ * is the SAME gather/segment-sum kernel as the forward pass (ggnn_gather_segment_sum_f32 with V*T
+ * segments).  Same workspace size and argument meaning as ggnn_build_target_csr. */
+int ggnn_build_source_csr(const int32_t* adj, const int64_t* type_off, int T, int V, int64_t M,
+                          int32_t* row_ptr, int32_t* gather_row, int32_t* msg_perm, int32_t* err_flag,
+                          void* ws, size_t ws_bytes, ggnn_stream_t stream);
+
 /* ---- (a-3) per-edge-type message transform: chem_tensorflow_sparse.py:160-164 -------------------
  * H[v, t*D:(t+1)*D] = h[v,:] @ W[t]  for all nodes and types in ONE [V,D]x[D,T*D] FP32-MFMA GEMM
  * (transform-first: (h[src]) W == (h W)[src]).
@@ -116,8 +125,9 @@ int ggnn_gru_candidate_f32(const float* const* x_segs, int nx, const float* rh, 
                            ggnn_stream_t stream);
 
 /* Generic FP32-MFMA GEMM used by the above and by the host layer for the backward pass:
- * C[M,N] = [A0 | A1 | ...] (nseg segments of width D each, K = nseg*D) x B[K,N]. */
-int ggnn_gemm_f32(const float* const* a_segs, int nseg, int D, const float* B, int ldb, float* C, int ldc,
+ * C[M,N] = [A0 | A1 | ...] (nseg <= 4 segments of width D each, row stride lda floats, K = nseg*D) x B[K,N].
+ * a_segs is a HOST array of device pointers. */
+int ggnn_gemm_f32(const float* const* a_segs, int nseg, int D, int lda, const float* B, int ldb, float* C, int ldc,
                   int M, int N, ggnn_stream_t stream);
 
 #ifdef __cplusplus

@@ -1,0 +1,104 @@
+"""GPU tests of the training path: gradients of the HIP forward + hand-written backward against torch
+autograd of the CPU oracle (float64), one optimisation step against a restated TF-1.3 Adam with
+per-variable clipping, and loss descent."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(pkg, oracle, config, n=60, seed=0):
+    ms = pkg.synthetic_qm9(n, mean_nodes=10, seed=seed)
+    cfg = {"edge_weight_dropout_keep_prob": 1.0}
+    cfg.update(config)
+    model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms, "--config": cfg})
+    layers = oracle.make_sparse_layers(np.random.default_rng(seed), model.params, model.num_edge_types, random_bias=True)
+    model.set_graph_weights(layers)
+    feed = next(iter(model.make_minibatch_iterator(model.valid_data, is_training=False)))
+    return model, layers, feed
+
+
+def _oracle_loss_and_grads(oracle_torch, model, layers, feed):
+    """float64 torch-CPU autograd of the oracle: loss and d loss / d (every variable)."""
+    p = model.params
+    dd = lambda t: t.detach().cpu().double()
+    tl = []
+    for L in layers:
+        tl.append({k: torch.from_numpy(np.asarray(v)).double().requires_grad_(True) for k, v in L.items()})
+    g = model.weights['regression_gate_task0']; t = model.weights['regression_transform_task0']
+    ro = [dd(g.params["weights"][0]).requires_grad_(True), dd(g.params["biases"][0]).requires_grad_(True),
+          dd(t.params["weights"][0]).requires_grad_(True), dd(t.params["biases"][0]).requires_grad_(True)]
+    h0 = dd(feed["initial_node_representation"])
+    adj = [a.cpu() for a in feed["adjacency_lists"]]
+    last = oracle_torch.sparse_propagate(h0, adj, dd(feed["num_incoming_edges_per_type"]), tl, p)
+    pred = oracle_torch.gated_regression(last, h0, feed["graph_nodes_list"].cpu(), feed["num_graphs"], *ro)
+    loss, _ = oracle_torch.task_loss(pred, dd(feed["target_values"])[0], dd(feed["target_mask"])[0])
+    loss.backward()
+    grads = {}
+    for l, L in enumerate(tl):
+        scope = "graph_model/gnn_layer_%i" % l
+        grads["%s/gnn_edge_weights_%i:0" % (scope, l)] = L["edge_weights"].grad.reshape(-1, L["edge_weights"].shape[-1])
+        if "edge_biases" in L and p["use_edge_bias"]:
+            grads["%s/gnn_edge_biases_%i:0" % (scope, l)] = L["edge_biases"].grad
+        base = "%s/timestep_0/gru_cell" % scope
+        grads[base + "/gates/kernel:0"] = L["Wg"].grad; grads[base + "/gates/bias:0"] = L["bg"].grad
+        grads[base + "/candidate/kernel:0"] = L["Wc"].grad; grads[base + "/candidate/bias:0"] = L["bc"].grad
+    grads["out_layer_task0/regression_gate/MLP_W_layer0:0"] = ro[0].grad
+    grads["out_layer_task0/regression_gate/MLP_b_layer0:0"] = ro[1].grad
+    grads["out_layer_task0/regression/MLP_W_layer0:0"] = ro[2].grad
+    grads["out_layer_task0/regression/MLP_b_layer0:0"] = ro[3].grad
+    return float(loss), grads
+
+
+@pytest.mark.parametrize("config", [{}, {"use_edge_bias": True, "graph_rnn_activation": "relu"},
+                                    {"use_edge_msg_avg_aggregation": False, "hidden_size": 64,
+                                     "layer_timesteps": [2, 1], "residual_connections": {"1": [0]}}])
+def test_gradients_match_oracle_autograd(pkg, oracle, oracle_torch, cuda, config):
+    model, layers, feed = _setup(pkg, oracle, config)
+    want_loss, want = _oracle_loss_and_grads(oracle_torch, model, layers, feed)
+    variables = model.trainable_variables
+    for v in variables.values():
+        v.requires_grad_(True); v.grad = None
+    model.training = True
+    loss = model.forward_batch(feed)
+    loss.backward()
+    model.training = False
+    assert abs(float(loss) - want_loss) < 1e-5 * max(1.0, abs(want_loss))
+    assert set(want) == set(variables)
+    for name, v in variables.items():
+        got = v.grad.detach().cpu().double().reshape(want[name].shape)
+        scale = float(want[name].abs().max()) + 1e-12
+        err = float((got - want[name]).abs().max())
+        assert err <= 2e-4 * scale + 1e-7, (name, err, scale)
+        v.requires_grad_(False); v.grad = None
+
+
+def test_train_step_matches_restated_tf_adam(pkg, oracle, oracle_torch, cuda):
+    """One train step == oracle grads -> per-variable clip_by_norm (chem_tensorflow.py:186-190) -> TF-1.3 Adam."""
+    model, layers, feed = _setup(pkg, oracle, {})
+    _, grads = _oracle_loss_and_grads(oracle_torch, model, layers, feed)
+    before = {k: v.detach().cpu().double().clone() for k, v in model.trainable_variables.items()}
+    feed = dict(feed); feed["out_layer_dropout_keep_prob"] = 1.0
+    model.train_batch(feed)
+    lr, b1, b2, eps, clip = 1e-3, 0.9, 0.999, 1e-8, model.params["clamp_gradient_norm"]
+    for name, v in model.trainable_variables.items():
+        g = grads[name].reshape(before[name].shape)
+        g = g * clip / max(float(g.norm()), clip)
+        m = (1 - b1) * g; vv = (1 - b2) * g * g
+        lr_t = lr * np.sqrt(1 - b2) / (1 - b1)
+        want = before[name] - lr_t * m / (vv.sqrt() + eps)
+        got = v.detach().cpu().double()
+        assert float((got - want).abs().max()) < 2e-6, name
+
+
+def test_training_reduces_loss(pkg, oracle, cuda):
+    ms = pkg.synthetic_qm9(400, mean_nodes=9, seed=3)
+    model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms,
+                                     "--config": {"batch_size": 2000, "layer_timesteps": [2, 1],
+                                                  "residual_connections": {"1": [0]}, "learning_rate": 3e-3}})
+    l0 = model.run_epoch("valid", model.valid_data, False)[0]
+    for _ in range(6):
+        model.run_epoch("train", model.train_data, True)
+    l1 = model.run_epoch("valid", model.valid_data, False)[0]
+    assert np.isfinite(l1) and l1 < l0
