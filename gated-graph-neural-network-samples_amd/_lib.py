@@ -34,6 +34,7 @@ SYMBOLS = {
                                    c_int, c_int, c_void_p]),
     "ggnn_gru_candidate_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ggnn_dense_aggregate_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ggnn_gemm_f32": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_void_p]),
 }

@@ -1,9 +1,188 @@
-"""DenseGGNNChemModel placeholder (chem_tensorflow_dense.py) -- built in the dense milestone."""
+"""DenseGGNNChemModel -- host-side mirror of chem_tensorflow_dense.py:51-265 on PyTorch-ROCm tensors.
+
+Per timestep (chem_tensorflow_dense.py:100-115):
+    m_e  = h W_e (+ b_e)          for all e: ONE FP32-MFMA GEMM [b*v,D]x[D,e*D]  (ggnn_msg_transform_f32)
+    acts = sum_e A_e m_e          batched [v,v]x[v,D] from LDS                   (ggnn_dense_aggregate_f32)
+    h    = GRU(acts, h)           one GRU shared by all timesteps (:101-102)     (ggnn_gru_f32)
+Forward (inference / validation) path; the dense training path is not built (the sparse model is the
+north-star path).
+"""
 from __future__ import annotations
 
+from collections import defaultdict
+from typing import Any, Dict, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
 from .chem_model import ChemModel
+from .data import DENSE_BUCKET_SIZES, MoleculeSet, pack_dense_batch
+from .sparse_model import GRUCellWeights
+from .utils import glorot_init, tf_dropout
 
 
 class DenseGGNNChemModel(ChemModel):
     def __init__(self, args):
-        raise NotImplementedError("dense path not built yet")
+        super().__init__(args)
+
+    @classmethod
+    def default_params(cls):
+        # chem_tensorflow_dense.py:57-66
+        params = dict(super().default_params())
+        params.update({
+            'batch_size': 256,
+            'graph_state_dropout_keep_prob': 1.,
+            'task_sample_ratios': {},
+            'use_edge_bias': True,
+            'edge_weight_dropout_keep_prob': 1
+        })
+        return params
+
+    def prepare_specific_graph_model(self) -> None:
+        """chem_tensorflow_dense.py:68-91."""
+        h_dim = self.params['hidden_size']
+        for name in ('initial_node_representation', 'node_mask', 'num_vertices', 'adjacency_matrix'):
+            self.placeholders[name] = None
+        self.placeholders['graph_state_keep_prob'] = 1.0
+        self.placeholders['edge_weight_dropout_keep_prob'] = 1.0
+        dev = self.device
+        # :84 glorot over the last two dims of [e,h,h]
+        self.weights['edge_weights'] = torch.from_numpy(glorot_init([self.num_edge_types, h_dim, h_dim])).to(dev)
+        if self.params['use_edge_bias']:
+            self.weights['edge_biases'] = torch.zeros([self.num_edge_types, 1, h_dim], dtype=torch.float32, device=dev)
+        # :87-90 tf.contrib.rnn.GRUCell(h_dim) (tanh), gate bias 1, candidate bias 0
+        self.weights['node_gru'] = GRUCellWeights(torch.from_numpy(glorot_init([2 * h_dim, 2 * h_dim])).to(dev),
+                                                  torch.ones(2 * h_dim, dtype=torch.float32, device=dev),
+                                                  torch.from_numpy(glorot_init([2 * h_dim, h_dim])).to(dev),
+                                                  torch.zeros(h_dim, dtype=torch.float32, device=dev))
+
+    def graph_model_variables(self) -> Dict[str, torch.Tensor]:
+        out = {"graph_model/Variable:0": self.weights['edge_weights']}
+        if self.params['use_edge_bias']:
+            out["graph_model/Variable_1:0"] = self.weights['edge_biases']
+        cell = self.weights['node_gru']
+        base = "graph_model/gru_scope/gru_cell"
+        out[base + "/gates/kernel:0"] = cell.gates_kernel; out[base + "/gates/bias:0"] = cell.gates_bias
+        out[base + "/candidate/kernel:0"] = cell.candidate_kernel; out[base + "/candidate/bias:0"] = cell.candidate_bias
+        return out
+
+    def set_graph_weights(self, edge_weights, edge_biases, gru: dict) -> None:
+        with torch.no_grad():
+            as_t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device)
+            self.weights['edge_weights'].copy_(as_t(edge_weights))
+            if self.params['use_edge_bias']:
+                self.weights['edge_biases'].copy_(as_t(edge_biases).reshape(self.weights['edge_biases'].shape))
+            c = self.weights['node_gru']
+            c.gates_kernel.copy_(as_t(gru['Wg'])); c.gates_bias.copy_(as_t(gru['bg']))
+            c.candidate_kernel.copy_(as_t(gru['Wc'])); c.candidate_bias.copy_(as_t(gru['bc']))
+
+    def compute_final_node_representations(self) -> torch.Tensor:
+        """chem_tensorflow_dense.py:93-117."""
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("dense training path is not built; train with SparseGGNNChemModel")
+        ph = self.placeholders
+        v = ph['num_vertices']
+        h_dim = self.params['hidden_size']
+        h = ph['initial_node_representation']                          # [b, v, h]
+        b = h.shape[0]
+        h = h.reshape(-1, h_dim).contiguous()                          # :97
+        A = ph['adjacency_matrix']                                     # [b, e, v, v]; the :80 transpose is an indexing choice
+        keep_w = float(ph.get('edge_weight_dropout_keep_prob', 1.0))
+        keep_s = float(ph.get('graph_state_keep_prob', 1.0))
+        bias = self.weights['edge_biases'].reshape(self.num_edge_types, h_dim) if self.params['use_edge_bias'] else None
+        cell = self.weights['node_gru']
+        for i in range(self.params['num_timesteps']):                  # :100
+            # :104 a fresh weight-dropout mask per (timestep, edge type)
+            W = tf_dropout(self.weights['edge_weights'], keep_w).contiguous()
+            Hm = ops.msg_transform(h, W)                               # :104-106 for all edge types
+            acts = ops.dense_aggregate(A, Hm, bias)                    # :107-112
+            h = ops.gru([acts], h, cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias,
+                        "tanh")                                        # :115
+            h = tf_dropout(h, keep_s)
+        return h.reshape(b, v, h_dim)                                  # :116
+
+    def gated_regression(self, last_h, regression_gate, regression_transform):
+        """chem_tensorflow_dense.py:119-129."""
+        ph = self.placeholders
+        h_dim = self.params['hidden_size']
+        gate_input = torch.cat([last_h, ph['initial_node_representation']], dim=2).reshape(-1, 2 * h_dim)
+        last = last_h.reshape(-1, h_dim)
+        gated_outputs = torch.sigmoid(regression_gate(gate_input)) * regression_transform(last)     # [b*v, 1]
+        gated_outputs = gated_outputs.reshape(-1, ph['num_vertices'])                                # [b, v]
+        masked_gated_outputs = gated_outputs * ph['node_mask']
+        output = masked_gated_outputs.sum(dim=1)                                                     # [b]
+        self.output = output
+        return output
+
+    # ----- Data preprocessing and chunking into minibatches:
+    def process_raw_graphs(self, raw_data, is_training_data: bool, bucket_sizes=None) -> Any:
+        """chem_tensorflow_dense.py:132-164: bucket graphs by padded size; a bucket holds graph ids."""
+        ms = raw_data if isinstance(raw_data, MoleculeSet) else MoleculeSet.from_json(raw_data)
+        if bucket_sizes is None:
+            bucket_sizes = DENSE_BUCKET_SIZES
+        n = ms.nodes_per_graph()
+        # :138 argmax(bucket_sizes > max vertex index mentioned by an edge); graphs without bonds (the
+        # reference would fail on max([])) fall back to their node count
+        max_idx = n - 1
+        nb = np.diff(ms.bond_ptr)
+        has = nb > 0
+        if has.any():
+            ends = np.maximum(ms.bonds[:, 0], ms.bonds[:, 2]).astype(np.int64)
+            max_idx = max_idx.copy()
+            max_idx[has] = np.maximum.reduceat(ends, ms.bond_ptr[:-1][has])
+        if (max_idx >= n).any():
+            raise IndexError("a bond mentions a vertex outside its graph")
+        chosen = np.searchsorted(bucket_sizes, np.maximum(max_idx, n - 1), side='right')
+        if (chosen >= len(bucket_sizes)).any():
+            raise ValueError("graph larger than the largest bucket size")
+        bucketed = defaultdict(list)
+        for g, bi in enumerate(chosen):
+            bucketed[int(bi)].append(g)
+        if is_training_data:
+            for bucket_list in bucketed.values():
+                np.random.shuffle(bucket_list)
+        # :160-162 one entry per full batch of a bucket (remainder graphs are dropped)
+        bucket_at_step = [[bucket_idx for _ in range(len(bucket_data) // self.params['batch_size'])]
+                          for bucket_idx, bucket_data in bucketed.items()]
+        bucket_at_step = [x for y in bucket_at_step for x in y]
+        return {"molecules": ms, "bucketed": dict(bucketed), "bucket_sizes": np.asarray(bucket_sizes),
+                "bucket_at_step": bucket_at_step, "device_batches": {}}
+
+    def to_device_batch(self, db) -> Dict[str, Any]:
+        dev = self.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        return {'initial_node_representation': t(db.initial_node_representation), 'adjacency_matrix': t(db.adjacency_matrix),
+                'node_mask': t(db.node_mask), 'num_vertices': db.num_vertices, 'target_values': t(db.target_values),
+                'target_mask': t(db.target_mask), 'num_graphs': db.num_graphs}
+
+    def make_minibatch_iterator(self, data, is_training: bool):
+        """chem_tensorflow_dense.py:195-228."""
+        ms: MoleculeSet = data["molecules"]
+        bucketed, bucket_sizes, bucket_at_step = data["bucketed"], data["bucket_sizes"], list(data["bucket_at_step"])
+        if is_training:
+            np.random.shuffle(bucket_at_step)
+            for bucket in bucketed.values():
+                np.random.shuffle(bucket)
+        bucket_counters = defaultdict(int)
+        dropout_keep_prob = self.params['graph_state_dropout_keep_prob'] if is_training else 1.
+        bs = self.params['batch_size']
+        for step in range(len(bucket_at_step)):
+            bucket = bucket_at_step[step]
+            start_idx = bucket_counters[bucket] * bs
+            ids = np.asarray(bucketed[bucket][start_idx:start_idx + bs])
+            key = (bucket, bucket_counters[bucket])
+            if is_training or key not in data["device_batches"]:
+                db = pack_dense_batch(ms, ids, int(bucket_sizes[bucket]), self.num_edge_types,
+                                      self.params['hidden_size'], self.params['tie_fwd_bkwd'], self.params['task_ids'])
+                feed = self.to_device_batch(db)
+                if not is_training:
+                    data["device_batches"][key] = feed
+            else:
+                feed = data["device_batches"][key]
+            feed = dict(feed)
+            # :222-223 the dense model feeds graph_state_dropout_keep_prob into BOTH keep-prob placeholders
+            feed['graph_state_keep_prob'] = dropout_keep_prob
+            feed['edge_weight_dropout_keep_prob'] = dropout_keep_prob
+            bucket_counters[bucket] += 1
+            yield feed

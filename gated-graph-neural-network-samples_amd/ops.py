@@ -291,3 +291,24 @@ def segment_sum_rows_by_index(rows: torch.Tensor, index: MessageIndex, out: Opti
     _launch("gather_segment_sum_bwd", lambda: lib.ggnn_gather_segment_sum_f32(
         _ptr(rows), _ptr(index.row_ptr), _ptr(index.gather_row), None, None, 0, _ptr(out), nseg, D, 1, _stream()))
     return out
+
+
+def dense_aggregate(adjacency: torch.Tensor, Hm: torch.Tensor, edge_biases: Optional[torch.Tensor],
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """acts = sum_e A_e (h W_e + b_e)  (chem_tensorflow_dense.py:103-112).
+    adjacency [b,e,v,v] f32, Hm [b*v, e*D] (msg_transform output), edge_biases [e,D] or None -> [b*v, D]."""
+    lib = _lib.load()
+    _req(adjacency, torch.float32, "adjacency"); _req(Hm, torch.float32, "Hm")
+    b, E, v, v2 = adjacency.shape
+    if v != v2 or Hm.shape[0] != b * v or Hm.shape[1] % E:
+        raise ValueError("shape mismatch between adjacency [b,e,v,v] and Hm [b*v, e*D]")
+    D = Hm.shape[1] // E
+    if edge_biases is not None:
+        _req(edge_biases, torch.float32, "edge_biases")
+        if edge_biases.shape != (E, D):
+            raise ValueError("edge_biases must be [e,D]")
+    if out is None:
+        out = torch.empty((b * v, D), dtype=torch.float32, device=Hm.device)
+    _launch("dense_aggregate", lambda: lib.ggnn_dense_aggregate_f32(_ptr(adjacency), _ptr(Hm), _ptr(edge_biases), _ptr(out),
+                                                                   b, v, E, D, _stream()))
+    return out

@@ -124,6 +124,14 @@ int ggnn_gru_candidate_f32(const float* const* x_segs, int nx, const float* rh, 
                            const float* Wc, const float* bc, float* h_out, float* save_c, int V, int D, int act,
                            ggnn_stream_t stream);
 
+/* ---- (a-D) dense-adjacency aggregation: chem_tensorflow_dense.py:103-112 ---------------------------
+ * acts[g,i,:] = sum_e sum_j A[g,e,i,j] * ( Hm[g*v+j, e*D:(e+1)*D] + bias[e,:] )
+ *   A [b,e,v,v] fp32 (A[g,e,dst,src], chem_tensorflow_dense.py:30-36), Hm [b*v, e*D] = h W_e for all e
+ *   (ggnn_msg_transform_f32 output), bias [e,D] or NULL (:107-108), acts [b*v, D] out.
+ * The dense step is ggnn_msg_transform_f32 -> ggnn_dense_aggregate_f32 -> ggnn_gru_f32 (nx = 1). */
+int ggnn_dense_aggregate_f32(const float* A, const float* Hm, const float* bias, float* acts, int b, int v,
+                             int e, int D, ggnn_stream_t stream);
+
 /* Generic FP32-MFMA GEMM used by the above and by the host layer for the backward pass:
  * C[M,N] = [A0 | A1 | ...] (nseg <= 4 segments of width D each, row stride lda floats, K = nseg*D) x B[K,N].
  * a_segs is a HOST array of device pointers. */
