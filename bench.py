@@ -59,6 +59,9 @@ def kernel_model(name, V, M, D, T):
         return "mfma", 2.0 * V * D * T * D
     if name == "gather_segment_sum":
         return "hbm", float(M * D * 4 + M * 8 + V * D * 4)
+    if name.startswith("gru_fused"):
+        nx = int(name.split("nx=")[1].rstrip("]"))
+        return "mfma", 6.0 * V * (nx + 1) * D * D
     if name.startswith("gru_gates"):
         nx = int(name.split("nx=")[1].rstrip("]"))
         return "mfma", 2.0 * V * (nx + 1) * D * 2 * D

@@ -159,6 +159,17 @@ extern "C" int ggnn_gru_f32(const float* const* x_segs, int nx, const float* h, 
     GGNN_CHECK_ARG(ws && aligned16(ws), "workspace null or misaligned");
     if (ws_bytes < ggnn_gru_workspace_bytes(V, D))
         return fail(GGNN_E_WORKSPACE, "GRU workspace too small: %zu < %zu", ws_bytes, ggnn_gru_workspace_bytes(V, D));
+    GGNN_CHECK_ARG(act == GGNN_ACT_TANH || act == GGNN_ACT_RELU, "unknown activation %d", act);
+    GGNN_CHECK_ARG(Wg && bg && Wc && bc && h_out && h_out != h, "null pointer or h_out aliases h");
+    if (gru_fused_supported(D)) {     // one launch: gates -> r*h -> candidate -> blend chained in registers
+        GGNN_CHECK_ARG(aligned16(Wg) && aligned16(bg) && aligned16(Wc) && aligned16(bc) && aligned16(h_out),
+                       "pointers must be 16-byte aligned");
+        GruFusedArgs a{};
+        for (int s = 0; s < nx; ++s) { a.x[s] = x_segs[s]; GGNN_CHECK_ARG(x_segs[s] != h_out, "h_out aliases an input"); }
+        a.nx = nx; a.h = h; a.Wg = Wg; a.bg = bg; a.Wc = Wc; a.bc = bc; a.h_out = h_out;
+        a.save_r = save_r; a.save_u = save_u; a.save_c = save_c; a.V = V; a.act = act;
+        return gru_fused_dispatch(a, D, (hipStream_t)stream);
+    }
     float* rh = static_cast<float*>(ws);
     float* u = save_u ? save_u : rh + (size_t)V * D;
     if (int rc = ggnn_gru_gates_f32(x_segs, nx, h, Wg, bg, rh, u, save_r, V, D, stream)) return rc;

@@ -87,6 +87,18 @@ struct EpiGruCand {
     }
 };
 
+struct GruFusedArgs {
+    const float* x[3];
+    int nx;
+    const float* h;
+    const float* Wg; const float* bg; const float* Wc; const float* bc;
+    float* h_out; float* save_r; float* save_u; float* save_c;
+    int V; int act;
+};
+
+int gru_fused_supported(int D);
+int gru_fused_dispatch(const GruFusedArgs& a, int D, hipStream_t st);
+
 // ---- the kernel ---------------------------------------------------------------------------------
 // KC: K-slice per stage (D % KC == 0, KC % 4 == 0).  MT: 16-row tiles per wave.  NT: 16-column tiles
 // per workgroup column group (all waves share the columns).  NW: waves per workgroup.

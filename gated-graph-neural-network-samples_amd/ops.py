@@ -202,9 +202,10 @@ def gru_workspace(V: int, D: int, device) -> torch.Tensor:
 
 def gru(x_segs: Sequence[torch.Tensor], h: torch.Tensor, Wg: torch.Tensor, bg: torch.Tensor, Wc: torch.Tensor,
         bc: torch.Tensor, activation: str = "tanh", out: Optional[torch.Tensor] = None,
-        ws: Optional[torch.Tensor] = None, save: Optional[dict] = None) -> torch.Tensor:
+        ws: Optional[torch.Tensor] = None, save: Optional[dict] = None, two_launch: bool = False) -> torch.Tensor:
     """TF-1.3 GRUCell on x = concat(x_segs) without materialising the concat
-    (chem_tensorflow_sparse.py:211-216).  save: optional dict receiving 'r','u','c' [V,D] tensors."""
+    (chem_tensorflow_sparse.py:211-216).  save: optional dict receiving 'r','u','c' [V,D] tensors.
+    two_launch=True forces the un-fused gates + candidate kernels (the path large D takes)."""
     lib = _lib.load()
     _req(h, torch.float32, "h")
     V, D = h.shape
@@ -230,10 +231,11 @@ def gru(x_segs: Sequence[torch.Tensor], h: torch.Tensor, Wg: torch.Tensor, bg: t
         su = save["u"] = torch.empty_like(h)
         sc = save["c"] = torch.empty_like(h)
     segs = (ctypes.c_void_p * nx)(*[x.data_ptr() for x in x_segs])
-    if _timing is None:
-        check(lib.ggnn_gru_f32(segs, nx, _ptr(h), _ptr(Wg), _ptr(bg), _ptr(Wc), _ptr(bc), _ptr(out), _ptr(ws),
-                               ws.numel() * 4, _ptr(sr), _ptr(su), _ptr(sc), V, D, act, _stream()))
-    else:   # same two launches, individually bracketed by events
+    if not two_launch and (_timing is None or lib.ggnn_gru_is_fused(D)):
+        _launch("gru_fused[nx=%d]" % nx, lambda: lib.ggnn_gru_f32(
+            segs, nx, _ptr(h), _ptr(Wg), _ptr(bg), _ptr(Wc), _ptr(bc), _ptr(out), _ptr(ws), ws.numel() * 4,
+            _ptr(sr), _ptr(su), _ptr(sc), V, D, act, _stream()))
+    else:   # un-fused sizes: the same two launches, individually bracketed by events
         if ws.numel() < 2 * V * D:
             raise ValueError("GRU workspace too small")
         rh = ws[:V * D]

@@ -115,7 +115,11 @@ int ggnn_gru_f32(const float* const* x_segs, int nx, const float* h, const float
                  float* save_r, float* save_u, float* save_c, int V, int D, int act,
                  ggnn_stream_t stream);
 
-/* The two launches of ggnn_gru_f32, separately addressable (profiling, fusion experiments):
+/* 1 if ggnn_gru_f32 runs as ONE fused launch for this hidden size (gates -> r*h -> candidate -> blend
+ * chained in registers; D in {32, 64, 100}); 0 if it runs as the two launches below (ws is then used). */
+int ggnn_gru_is_fused(int D);
+
+/* The two launches of the un-fused ggnn_gru_f32, separately addressable (profiling, large D):
  *   gates:     [r|u] = sigmoid([x|h] Wg + bg) -> rh = r*h [V,D], u [V,D] (save_r optional)
  *   candidate: c = act([x|rh] Wc + bc); h_out = u*h + (1-u)*c            (save_c optional) */
 int ggnn_gru_gates_f32(const float* const* x_segs, int nx, const float* h, const float* Wg, const float* bg,

@@ -95,10 +95,11 @@ def test_message_index_order_and_validation(pkg, cuda):
         pkg.ops.build_message_index([dev(a, cuda) for a in bad], V)
 
 
-@pytest.mark.parametrize("V,D,R,act", [(1, 100, 0, "tanh"), (200, 100, 0, "tanh"), (1000, 100, 1, "tanh"),
+@pytest.mark.parametrize("V,D,R,act", [(1, 100, 0, "tanh"), (200, 100, 0, "tanh"), (33000, 100, 1, "tanh"), (4099, 64, 1, "relu"), (1000, 100, 1, "tanh"),
                                        (513, 100, 2, "relu"), (300, 64, 0, "tanh"), (1025, 256, 0, "tanh"),
                                        (77, 32, 2, "tanh")])
-def test_gru(pkg, oracle, cuda, V, D, R, act):
+@pytest.mark.parametrize("two_launch", [False, True])
+def test_gru(pkg, oracle, cuda, V, D, R, act, two_launch):
     rng = np.random.default_rng(V + D + R)
     xs = [rng.uniform(-1, 1, (V, D)).astype(np.float32) for _ in range(R + 1)]
     h = rng.uniform(-1, 1, (V, D)).astype(np.float32)
@@ -107,7 +108,7 @@ def test_gru(pkg, oracle, cuda, V, D, R, act):
     Wc = rng.uniform(-0.2, 0.2, (K, D)).astype(np.float32); bc = rng.uniform(-0.5, 0.5, D).astype(np.float32)
     save = {}
     got = pkg.ops.gru([dev(x, cuda) for x in xs], dev(h, cuda), dev(Wg, cuda), dev(bg, cuda), dev(Wc, cuda),
-                      dev(bc, cuda), act, save=save).cpu().numpy()
+                      dev(bc, cuda), act, save=save, two_launch=two_launch).cpu().numpy()
     f = lambda a: a.astype(np.float64)
     want, r, u, c = oracle.gru_cell(np.concatenate([f(x) for x in xs], 1), f(h), f(Wg), f(bg), f(Wc), f(bc),
                                     oracle.activation(act))
