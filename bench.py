@@ -53,10 +53,12 @@ def parse_args():
     return ap.parse_args()
 
 
-def kernel_model(name, V, M, D, T):
-    """Algorithmic flops / bytes per launch -> (bound, work, unit_work)."""
+def kernel_model(name, V, M, D, T, R=None):
+    """Algorithmic flops / bytes per launch -> (bound, work).  R = active (node,type) pairs."""
     if name == "msg_transform":
         return "mfma", 2.0 * V * D * T * D
+    if name == "msg_transform_compact":
+        return "mfma", 2.0 * R * D * D
     if name == "gather_segment_sum":
         return "hbm", float(M * D * 4 + M * 8 + V * D * 4)
     if name.startswith("gru_fused"):
@@ -133,6 +135,7 @@ def main():
                    "layer_timesteps": params["layer_timesteps"], "residual_connections": params["residual_connections"],
                    "nodes_per_batch": int(np.mean(nodes)), "messages_per_batch": int(np.mean(msgs)),
                    "graphs_per_batch": int(np.mean(graphs)), "mean_nodes_per_graph": args.mean_nodes,
+                   "active_source_type_pairs_per_batch": None,
                    "batch_size_param": params["batch_size"], "parallelism": "dp%d (independent graph batches)" % world},
         "graphs_per_sec": total_graphs / elapsed,
     }
@@ -145,9 +148,11 @@ def main():
                 step(i)
         res = kt.results()
         Vb, Mb = float(np.mean([nodes[i % len(feeds)] for i in range(reps)])), float(np.mean([msgs[i % len(feeds)] for i in range(reps)]))
+        comps = [getattr(f["message_index"], "_compact", None) for f in feeds]
+        Rb = float(np.mean([c.num_rows for c in comps])) if all(c is not None for c in comps) else None
         kernels = {}
         for name, times in res.items():
-            bound, work = kernel_model(name, Vb, Mb, D, T)
+            bound, work = kernel_model(name, Vb, Mb, D, T, Rb)
             avg_ms = float(np.mean(times))
             if bound == "mfma":
                 ach, peak, unit = work / (avg_ms * 1e-3) / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
@@ -161,6 +166,7 @@ def main():
             kernels[name]["time_share"] = float(np.sum(times)) / tot_ms
         dom = max(kernels, key=lambda k: kernels[k]["time_share"])
         out["roofline"] = dict(kernels[dom], kernel=dom)
+        out["config"]["active_source_type_pairs_per_batch"] = None if Rb is None else int(Rb)
         out["kernels"] = kernels
         out["kernel_time_ms_per_step"] = tot_ms / reps
 

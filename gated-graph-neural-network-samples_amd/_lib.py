@@ -24,6 +24,13 @@ SYMBOLS = {
     "ggnn_build_source_csr": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int, c_int64, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ggnn_msg_transform_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ggnn_msg_transform_compact_supported": (c_int, [c_int]),
+    "ggnn_compact_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "ggnn_build_compact_sources": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ggnn_remap_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "ggnn_msg_transform_compact_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "ggnn_msg_transform_compact_f32": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_size_t,
+                                               c_int, c_int, c_int, c_void_p]),
     "ggnn_gather_segment_sum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                             c_int, c_int, c_int, c_void_p]),
     "ggnn_unsorted_segment_sum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

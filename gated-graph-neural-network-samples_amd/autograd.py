@@ -15,6 +15,11 @@ import torch
 from . import ops
 
 
+# Inference path: source-compacted message transform (ops.msg_transform_compact) where the hidden size
+# supports it; set False to force the dense [V,D]x[D,T*D] form (the form the training path uses).
+USE_COMPACT_TRANSFORM = True
+
+
 def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tensor, edge_weights: torch.Tensor,
                      edge_biases: Optional[torch.Tensor], use_avg: bool, residual_states: Sequence[torch.Tensor],
                      cell, activation: str, need_grad: bool = False) -> torch.Tensor:
@@ -23,8 +28,17 @@ def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tens
         return PropagationStepFn.apply(h, index, nin, edge_weights, edge_biases, use_avg, activation,
                                        cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias,
                                        *residual_states)
-    H = ops.msg_transform(h, edge_weights.contiguous())
-    incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
+    D = h.shape[1]
+    if USE_COMPACT_TRANSFORM and ops.compact_supported(D):
+        # transform only the (node, type) pairs that emit a message; the pair list is built once per batch
+        comp = getattr(index, "_compact", None)
+        if comp is None:
+            comp = index._compact = ops.build_compact_sources(index)
+        Hc = ops.msg_transform_compact(h, edge_weights.contiguous(), comp)
+        incoming = ops.gather_segment_sum_compact(Hc, index, comp, nin, edge_biases, use_avg)
+    else:
+        H = ops.msg_transform(h, edge_weights.contiguous())
+        incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
     return ops.gru(list(residual_states) + [incoming], h, cell.gates_kernel, cell.gates_bias,
                    cell.candidate_kernel, cell.candidate_bias, activation)
 

@@ -103,7 +103,8 @@ extern "C" int ggnn_gemm_f32(const float* const* a_segs, int nseg, int D, int ld
 
 extern "C" size_t ggnn_gru_workspace_bytes(int V, int D) {
     if (V < 0 || D <= 0) return 0;
-    return (size_t)2 * (size_t)V * (size_t)D * sizeof(float);   // r*h and u
+    // un-fused path: r*h and u; fused path: the packed weight images (up to nx = 3)
+    return (size_t)2 * (size_t)V * (size_t)D * sizeof(float) + (size_t)gru_pack_floats(D, 3) * sizeof(float);
 }
 
 static int gru_args_check(const float* const* x_segs, int nx, const float* h, int V, int D) {
@@ -168,7 +169,7 @@ extern "C" int ggnn_gru_f32(const float* const* x_segs, int nx, const float* h, 
         for (int s = 0; s < nx; ++s) { a.x[s] = x_segs[s]; GGNN_CHECK_ARG(x_segs[s] != h_out, "h_out aliases an input"); }
         a.nx = nx; a.h = h; a.Wg = Wg; a.bg = bg; a.Wc = Wc; a.bc = bc; a.h_out = h_out;
         a.save_r = save_r; a.save_u = save_u; a.save_c = save_c; a.V = V; a.act = act;
-        return gru_fused_dispatch(a, D, (hipStream_t)stream);
+        return gru_fused_dispatch(a, D, static_cast<float*>(ws), (hipStream_t)stream);
     }
     float* rh = static_cast<float*>(ws);
     float* u = save_u ? save_u : rh + (size_t)V * D;

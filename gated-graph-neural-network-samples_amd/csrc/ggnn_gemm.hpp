@@ -38,7 +38,12 @@ struct GemmOperands {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Epilogue transcendentals on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each): the
+// libm expf / tanhf / IEEE division sequences cost ~30-40 VALU instructions per element, which at 84
+// elements per lane per 16-row tile was ~18 % of the fused GRU's time with the matrix pipe idle.
+// Absolute error of sigmoid / tanh stays < 3e-7 (outputs are in (-1,1)); parity tolerance is 1e-6.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // ---- epilogues: called once per (row, 4 consecutive columns) ---------------------------------
 struct EpiStore {
@@ -76,7 +81,7 @@ struct EpiGruCand {
         const size_t o = (size_t)row * D + col;
         f32x4 c = v + b;
         if (act == GGNN_ACT_TANH) {
-            c.x = tanhf(c.x); c.y = tanhf(c.y); c.z = tanhf(c.z); c.w = tanhf(c.w);
+            c.x = tanh_f(c.x); c.y = tanh_f(c.y); c.z = tanh_f(c.z); c.w = tanh_f(c.w);
         } else {
             c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
         }
@@ -97,7 +102,8 @@ struct GruFusedArgs {
 };
 
 int gru_fused_supported(int D);
-int gru_fused_dispatch(const GruFusedArgs& a, int D, hipStream_t st);
+int gru_pack_floats(int D, int nx);      // floats of scratch the fused kernel needs for its packed weight images
+int gru_fused_dispatch(const GruFusedArgs& a, int D, float* packed, hipStream_t st);
 
 // ---- the kernel ---------------------------------------------------------------------------------
 // KC: K-slice per stage (D % KC == 0, KC % 4 == 0).  MT: 16-row tiles per wave.  NT: 16-column tiles

@@ -314,3 +314,88 @@ def dense_aggregate(adjacency: torch.Tensor, Hm: torch.Tensor, edge_biases: Opti
     _launch("dense_aggregate", lambda: lib.ggnn_dense_aggregate_f32(_ptr(adjacency), _ptr(Hm), _ptr(edge_biases), _ptr(out),
                                                                    b, v, E, D, _stream()))
     return out
+
+
+# ---- source-compacted message transform -----------------------------------------------------------------
+@dataclass
+class CompactSources:
+    """Active (source node, edge type) pairs of a batch, type-major / node-ascending (built once per batch).
+
+    pair_node     [R] int32   compact row -> source node
+    type_row_off  list[T+1]   host: rows of type t are type_row_off[t] .. type_row_off[t+1]-1
+    gather_row    [M] int32   message slot (MessageIndex order) -> compact row
+    """
+    pair_node: torch.Tensor
+    type_row_off: List[int]
+    gather_row: torch.Tensor
+
+    @property
+    def num_rows(self) -> int:
+        return int(self.type_row_off[-1])
+
+
+def compact_supported(D: int) -> bool:
+    return bool(_lib.load().ggnn_msg_transform_compact_supported(D))
+
+
+def build_compact_sources(index: MessageIndex) -> CompactSources:
+    """Enumerate the (node, type) pairs that emit at least one message and re-target the segment-sum's
+    gather rows at them.  index: the by-target MessageIndex of the batch (build_message_index)."""
+    lib = _lib.load()
+    T, V, M = index.num_edge_types, index.num_nodes, index.num_messages
+    dev = index.adj.device
+    lists = [index.adj[index.type_off[t]:index.type_off[t + 1]] for t in range(T)]
+    src_index = build_source_index(lists, V)
+    index._source_index = src_index                       # the backward pass wants the same structure
+    pair_node = torch.empty(max(min(M, V * T), 1), dtype=torch.int32, device=dev)
+    pair_id = torch.empty(max(V * T, 1), dtype=torch.int32, device=dev)
+    off = torch.zeros(T + 1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.ggnn_compact_workspace_bytes(V, T)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.ggnn_build_compact_sources(_ptr(src_index.row_ptr), V, T, _ptr(pair_node), _ptr(pair_id), _ptr(off), _ptr(ws),
+                                         ws_bytes, _stream()))
+    gather_c = torch.empty(M, dtype=torch.int32, device=dev)
+    check(lib.ggnn_remap_gather_rows(_ptr(index.gather_row), _ptr(pair_id), _ptr(gather_c), M, _stream()))
+    type_row_off = [int(x) for x in off.cpu().tolist()]   # one device->host sync, once per batch
+    return CompactSources(pair_node[:max(type_row_off[-1], 1)], type_row_off, gather_c)
+
+
+def msg_transform_compact(h: torch.Tensor, edge_weights: torch.Tensor, comp: CompactSources,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Hc[r] = h[pair_node[r]] @ edge_weights[type(r)] for the active (node,type) pairs only
+    (chem_tensorflow_sparse.py:160-164 without the duplicate / unused rows).  -> [R, D]."""
+    lib = _lib.load()
+    _req(h, torch.float32, "h"); _req(edge_weights, torch.float32, "edge_weights")
+    V, D = h.shape
+    T = edge_weights.shape[0]
+    if edge_weights.shape != (T, D, D) or len(comp.type_row_off) != T + 1:
+        raise ValueError("edge_weights must be [T,D,D] matching the compact index")
+    R = comp.num_rows
+    if out is None:
+        out = torch.empty((max(R, 1), D), dtype=torch.float32, device=h.device)
+    ws_bytes = lib.ggnn_msg_transform_compact_workspace_bytes(D, T)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=h.device)
+    off = (ctypes.c_int64 * (T + 1))(*comp.type_row_off)
+    _launch("msg_transform_compact", lambda: lib.ggnn_msg_transform_compact_f32(
+        _ptr(h), _ptr(edge_weights), _ptr(comp.pair_node), off, _ptr(out), _ptr(ws), ws_bytes, V, D, T, _stream()))
+    return out
+
+
+def gather_segment_sum_compact(Hc: torch.Tensor, index: MessageIndex, comp: CompactSources,
+                               num_incoming_edges_per_type: Optional[torch.Tensor], edge_biases: Optional[torch.Tensor],
+                               use_avg: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gather_segment_sum over compact transformed rows (Hc from msg_transform_compact)."""
+    lib = _lib.load()
+    _req(Hc, torch.float32, "Hc")
+    V, T, D = index.num_nodes, index.num_edge_types, Hc.shape[1]
+    nin = num_incoming_edges_per_type
+    if nin is not None:
+        _req(nin, torch.float32, "num_incoming_edges_per_type")
+    if edge_biases is not None:
+        _req(edge_biases, torch.float32, "edge_biases")
+    if out is None:
+        out = torch.empty((V, D), dtype=torch.float32, device=Hc.device)
+    _launch("gather_segment_sum", lambda: lib.ggnn_gather_segment_sum_f32(
+        _ptr(Hc), _ptr(index.row_ptr), _ptr(comp.gather_row), _ptr(nin), _ptr(edge_biases), 1 if use_avg else 0,
+        _ptr(out), V, D, T, _stream()))
+    return out

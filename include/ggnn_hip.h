@@ -81,6 +81,29 @@ int ggnn_build_source_csr(const int32_t* adj, const int64_t* type_off, int T, in
 int ggnn_msg_transform_f32(const float* h, int ldh, const float* W, float* H, int V, int D, int T,
                            ggnn_stream_t stream);
 
+/* ---- (a-3, compacted) message transform over the ACTIVE (source node, edge type) pairs only ----------
+ * The reference transforms every message row h[src] W_t (M rows, :161-164); a node with several outgoing
+ * edges of one type sends the same row several times, and most (node,type) pairs emit nothing.  The
+ * active pairs are enumerated once per batch, type-major / node-ascending ("compact rows"):
+ *
+ *   ggnn_build_compact_sources   src_row_ptr [V*T+1] (row_ptr of ggnn_build_source_csr) ->
+ *                                pair_node [R] (compact row -> node; caller sizes it min(M, V*T)),
+ *                                pair_id [V*T] ((v*T+t) -> compact row, -1 if inactive),
+ *                                type_row_off DEVICE [T+1] (rows of type t are type_row_off[t] .. [t+1]-1)
+ *   ggnn_remap_gather_rows       gather_row [M] (src*T+type) -> compact rows, for ggnn_gather_segment_sum_f32
+ *   ggnn_msg_transform_compact_f32  Hc[r,:] = h[pair_node[r],:] @ W[type(r)]   (Hc [R,D]; type_row_off on the HOST)
+ * Supported hidden sizes: ggnn_msg_transform_compact_supported(D) (32, 64, 100).
+ */
+int ggnn_msg_transform_compact_supported(int D);
+size_t ggnn_compact_workspace_bytes(int V, int T);
+int ggnn_build_compact_sources(const int32_t* src_row_ptr, int V, int T, int32_t* pair_node, int32_t* pair_id,
+                               int32_t* type_row_off, void* ws, size_t ws_bytes, ggnn_stream_t stream);
+int ggnn_remap_gather_rows(const int32_t* gather_row, const int32_t* pair_id, int32_t* gather_row_compact, int64_t M,
+                           ggnn_stream_t stream);
+size_t ggnn_msg_transform_compact_workspace_bytes(int D, int T);
+int ggnn_msg_transform_compact_f32(const float* h, const float* W, const int32_t* pair_node, const int64_t* type_row_off,
+                                   float* Hc, void* ws, size_t ws_bytes, int V, int D, int T, ggnn_stream_t stream);
+
 /* ---- (a-2,a-4..a-7) gather + segment sum + bias + mean: chem_tensorflow_sparse.py:160-162,168,
  *      198-209 ------------------------------------------------------------------------------------
  * out[v,:] = ( sum_{slot in row_ptr[v]..row_ptr[v+1]} Hrows[gather_row[slot], :]

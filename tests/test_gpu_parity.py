@@ -239,3 +239,46 @@ def test_golden_fixture_on_gpu(pkg, oracle, cuda):
         model.feed(feed)
         got = model.compute_final_node_representations().cpu().numpy()
     np.testing.assert_allclose(got, g["state_2"], **MODEL_TOL)
+
+
+@pytest.mark.parametrize("V,M,D,T", [(50, 200, 100, 4), (3000, 9000, 100, 4), (700, 300, 64, 3), (129, 4000, 32, 8),
+                                     (1000, 0, 100, 4), (40, 30, 100, 1)])
+def test_compact_transform_equals_dense_form(pkg, oracle, cuda, V, M, D, T):
+    """Compact rows are exactly the rows of the dense transform that some message reads; the segment sum over
+    compact rows equals the segment sum over dense rows bit for bit (same fmaf chains, same slot order)."""
+    rng = np.random.default_rng(V + M)
+    h, adj, nin = random_graph_batch(rng, V, M, T, D, sorted_src=True)
+    W = rng.uniform(-0.3, 0.3, (T, D, D)).astype(np.float32)
+    dadj = [dev(a, cuda) for a in adj]
+    index = pkg.ops.build_message_index(dadj, V)
+    comp = pkg.ops.build_compact_sources(index)
+    # index structure: pairs are unique, type-major, node-ascending, and cover exactly the sources
+    want_pairs = sorted({(t, int(s)) for t in range(T) for s in adj[t][:, 0]})
+    pn = comp.pair_node.cpu().numpy()[:comp.num_rows]
+    got_pairs = [(t, int(pn[r])) for t in range(T) for r in range(comp.type_row_off[t], comp.type_row_off[t + 1])]
+    assert got_pairs == want_pairs and comp.num_rows == len(want_pairs)
+    hd, Wd, nd = dev(h, cuda), dev(W, cuda), dev(nin, cuda)
+    H = pkg.ops.msg_transform(hd, Wd)
+    Hc = pkg.ops.msg_transform_compact(hd, Wd, comp)
+    Hn = H.cpu().numpy().reshape(V, T, D)
+    Hcn = Hc.cpu().numpy()
+    for r, (t, v) in enumerate(got_pairs[:2000]):
+        assert np.array_equal(Hcn[r], Hn[v, t])
+    a = pkg.ops.gather_segment_sum(H, index, nd, None, True)
+    b = pkg.ops.gather_segment_sum_compact(Hc, index, comp, nd, None, True)
+    assert torch.equal(a, b)
+
+
+def test_sparse_model_compact_and_dense_transform_agree(pkg, oracle, cuda):
+    ms = pkg.synthetic_qm9(300, mean_nodes=16, seed=8)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms)
+    with torch.no_grad():
+        model.feed(feeds[0])
+        a = model.compute_final_node_representations().clone()
+        pkg.autograd.USE_COMPACT_TRANSFORM = False
+        try:
+            feeds[0]["message_index"]._compact = None
+            b = model.compute_final_node_representations().clone()
+        finally:
+            pkg.autograd.USE_COMPACT_TRANSFORM = True
+    assert torch.equal(a, b)
