@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--mean-nodes", type=float, default=18.0, help="mean atoms per molecule (18 = QM9 with H)")
     ap.add_argument("--batches", type=int, default=6, help="distinct resident batches to cycle through")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent batches are issued on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
@@ -97,12 +98,24 @@ def main():
     msgs = [f["message_index"].num_messages for f in feeds]
     graphs = [int(f["num_graphs"]) for f in feeds]
 
-    def step(i):
+    # Batches are independent, so consecutive steps may be issued on different HIP streams (--streams N):
+    # the tail of one batch's kernel (a partially filled last wave of workgroups) is then back-filled by the
+    # next batch's kernels.  Every step still runs the full 8-step forward of one batch; K steps are timed.
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, 1))] if args.streams > 1 else None
+
+    def step(i, multi=True):
         f = feeds[i % len(feeds)]
-        model.feed(f)
-        return model.compute_final_node_representations()
+        if streams is None or not multi:
+            model.feed(f)
+            return model.compute_final_node_representations()
+        with torch.cuda.stream(streams[i % len(streams)]):
+            model.feed(f)
+            return model.compute_final_node_representations()
 
     with torch.no_grad():
+        if streams is not None:
+            for s in streams:
+                s.wait_stream(torch.cuda.current_stream())
         for i in range(args.warmup):
             step(i)
         torch.cuda.synchronize()
@@ -135,7 +148,7 @@ def main():
                    "layer_timesteps": params["layer_timesteps"], "residual_connections": params["residual_connections"],
                    "nodes_per_batch": int(np.mean(nodes)), "messages_per_batch": int(np.mean(msgs)),
                    "graphs_per_batch": int(np.mean(graphs)), "mean_nodes_per_graph": args.mean_nodes,
-                   "active_source_type_pairs_per_batch": None,
+                   "active_source_type_pairs_per_batch": None, "hip_streams": max(args.streams, 1),
                    "batch_size_param": params["batch_size"], "parallelism": "dp%d (independent graph batches)" % world},
         "graphs_per_sec": total_graphs / elapsed,
     }
@@ -145,7 +158,7 @@ def main():
         reps = max(4, min(args.steps, 12))
         with torch.no_grad(), pkg.ops.kernel_timing() as kt:
             for i in range(reps):
-                step(i)
+                step(i, multi=False)          # single stream: launches must not overlap while they are timed
         res = kt.results()
         Vb, Mb = float(np.mean([nodes[i % len(feeds)] for i in range(reps)])), float(np.mean([msgs[i % len(feeds)] for i in range(reps)]))
         comps = [getattr(f["message_index"], "_compact", None) for f in feeds]

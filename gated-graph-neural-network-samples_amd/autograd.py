@@ -19,6 +19,9 @@ from . import ops
 # supports it; set False to force the dense [V,D]x[D,T*D] form (the form the training path uses).
 USE_COMPACT_TRANSFORM = True
 
+# LDS stage images of the weights, rebuilt only when a weight tensor's version counter changes
+_PACKED = ops.PackedWeights()
+
 
 def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tensor, edge_weights: torch.Tensor,
                      edge_biases: Optional[torch.Tensor], use_avg: bool, residual_states: Sequence[torch.Tensor],
@@ -34,13 +37,17 @@ def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tens
         comp = getattr(index, "_compact", None)
         if comp is None:
             comp = index._compact = ops.build_compact_sources(index)
-        Hc = ops.msg_transform_compact(h, edge_weights.contiguous(), comp)
+        ew = edge_weights.contiguous()
+        Hc = ops.msg_transform_compact_packed(h, _PACKED.edge(ew), ew.shape[0], comp)
         incoming = ops.gather_segment_sum_compact(Hc, index, comp, nin, edge_biases, use_avg)
     else:
         H = ops.msg_transform(h, edge_weights.contiguous())
         incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
-    return ops.gru(list(residual_states) + [incoming], h, cell.gates_kernel, cell.gates_bias,
-                   cell.candidate_kernel, cell.candidate_bias, activation)
+    xs = list(residual_states) + [incoming]
+    if ops.gru_is_fused(D):
+        packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, len(xs), D)
+        return ops.gru_packed(xs, h, packed, cell.gates_bias, cell.candidate_bias, activation)
+    return ops.gru(xs, h, cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias, activation)
 
 
 class _SegmentSumRows(torch.autograd.Function):

@@ -176,3 +176,34 @@ extern "C" int ggnn_gru_f32(const float* const* x_segs, int nx, const float* h, 
     if (int rc = ggnn_gru_gates_f32(x_segs, nx, h, Wg, bg, rh, u, save_r, V, D, stream)) return rc;
     return ggnn_gru_candidate_f32(x_segs, nx, rh, h, u, Wc, bc, h_out, save_c, V, D, act, stream);
 }
+
+// ---- pre-packed weights: build the fused kernel's stage images once per weight version ----------------
+extern "C" size_t ggnn_gru_packed_bytes(int D, int nx) {
+    return (size_t)gru_pack_floats(D, nx) * sizeof(float);
+}
+
+extern "C" int ggnn_gru_pack_weights_f32(const float* Wg, const float* Wc, int nx, int D, float* packed,
+                                         ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(nx >= 1 && nx <= 3, "nx %d outside 1..3", nx);
+    if (!gru_fused_supported(D)) return fail(GGNN_E_UNSUPPORTED, "no fused GRU (hence no packed weights) for hidden size %d", D);
+    GGNN_CHECK_ARG(Wg && Wc && packed && aligned16(packed), "null or misaligned pointer");
+    GruFusedArgs a{};
+    a.nx = nx; a.Wg = Wg; a.Wc = Wc; a.h = nullptr;          // h == nullptr: pack only
+    return gru_fused_dispatch(a, D, packed, (hipStream_t)stream);
+}
+
+extern "C" int ggnn_gru_packed_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
+                                   const float* bc, float* h_out, float* save_r, float* save_u, float* save_c, int V, int D,
+                                   int act, ggnn_stream_t stream) {
+    if (int rc = gru_args_check(x_segs, nx, h, V, D)) return rc;
+    GGNN_CHECK_ARG(act == GGNN_ACT_TANH || act == GGNN_ACT_RELU, "unknown activation %d", act);
+    if (!gru_fused_supported(D)) return fail(GGNN_E_UNSUPPORTED, "no fused GRU for hidden size %d", D);
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(packed && bg && bc && h_out && h_out != h, "null pointer or h_out aliases h");
+    GGNN_CHECK_ARG(aligned16(packed) && aligned16(bg) && aligned16(bc) && aligned16(h_out), "pointers must be 16-byte aligned");
+    GruFusedArgs a{};
+    for (int s = 0; s < nx; ++s) { a.x[s] = x_segs[s]; GGNN_CHECK_ARG(x_segs[s] != h_out, "h_out aliases an input"); }
+    a.nx = nx; a.h = h; a.Wg = nullptr; a.Wc = nullptr; a.bg = bg; a.bc = bc; a.h_out = h_out;
+    a.save_r = save_r; a.save_u = save_u; a.save_c = save_c; a.V = V; a.act = act;
+    return gru_fused_dispatch(a, D, const_cast<float*>(packed), (hipStream_t)stream);
+}

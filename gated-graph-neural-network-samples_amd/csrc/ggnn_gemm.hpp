@@ -99,6 +99,7 @@ struct GruFusedArgs {
     const float* Wg; const float* bg; const float* Wc; const float* bc;
     float* h_out; float* save_r; float* save_u; float* save_c;
     int V; int act;
+    int dbg;               // ablation bitmask from GGNN_GRU_DBG (0 in production)
 };
 
 int gru_fused_supported(int D);

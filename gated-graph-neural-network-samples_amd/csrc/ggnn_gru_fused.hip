@@ -38,11 +38,14 @@ __global__ void gru_pack_weights_kernel(const float* __restrict__ Wg, const floa
                         gridDim.x * blockDim.x);
 }
 
-template <int D, int NX, int NW>
+// SAVE: also write r, u, c (all three) for a backward pass.
+template <int D, int NX, int NW, bool SAVE>
 __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a, const float* __restrict__ packed) {
     using C = StageCfg<D>;
     constexpr int NT = C::NT, NC = C::NC, NR = C::NR;
     constexpr int NSTAGE = 3 * (NX + 1);
+    constexpr int DMA_PER_WAVE = C::IMG_BYTES / (NW * 1024);
+    static_assert(DMA_PER_WAVE <= C::NC * ((NT + 3) / 4), "more DMA pieces than MFMA groups to hide them behind");
     extern __shared__ __attribute__((aligned(16))) float ring[];    // [2][IMG]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -53,11 +56,29 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     const int nb = gridDim.x;
     const int t_beg = (int)(((long long)wt_total * blockIdx.x) / nb);
     const int t_end = (int)(((long long)wt_total * (blockIdx.x + 1)) / nb);
-    const int max_tiles = (wt_total + nb - 1) / nb;
-    const int passes = (max_tiles + NW - 1) / NW;
+    // passes of THIS workgroup: one with fewer tiles leaves early and frees its CU (LDS + registers) for
+    // whatever the other streams have queued, instead of idling through the tail pass of its neighbours
+    const int passes = (t_end - t_beg + NW - 1) / NW;
+
+    // biases live in LDS behind the ring: the epilogues read them with ds_read instead of 7 serialized
+    // global round trips per epilogue
+    float* bias_s = ring + 2 * C::IMG;                              // [bg (2D) | bc (D)]
+    for (int i = tid; i < 3 * D; i += NW * 64) bias_s[i] = i < 2 * D ? a.bg[i] : a.bc[i - 2 * D];
 
     int cur = 0;
     dma_stage_image<D, NW>(packed, ring, wave, lane);
+
+    // x fragments rotate through two register sets (the segment after the current one is prefetched);
+    // with more than one x segment they are re-read for the candidate GEMM rather than kept resident.
+    // The NEXT pass's x[0] fragment (needed by its very first MFMA) is fetched during the last stage of the
+    // current pass and is drained by that stage's barrier, so stage 0 starts without a vmcnt wait (which
+    // would also drain the freshly issued weight DMA); h is loaded at the top of the pass and is not needed
+    // before the third stage.
+    Frag<D> hf, xf[2];
+    if (t_beg + wave < t_end) {
+        const int r0 = (t_beg + wave) * 16 + li;
+        load_frag<D>(xf[0], a.x[0], r0 < a.V ? r0 : a.V - 1, kq);
+    }
     __syncthreads();          // (drains the DMA: hipcc emits vmcnt(0) before the barrier while an LDS-DMA is in flight)
 
     for (int p = 0; p < passes; ++p) {
@@ -66,22 +87,20 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         const int row = tile * 16 + li;
         const int rowc = active ? (row < a.V ? row : a.V - 1) : 0;
         const bool last_pass = (p + 1 == passes);
-
-        // x fragments rotate through two register sets (the segment after the current one is prefetched);
-        // with more than one x segment they are re-read for the candidate GEMM rather than kept resident
-        Frag<D> hf, xf[2];
-        if (active) {
-            load_frag<D>(hf, a.h, rowc, kq);
-            load_frag<D>(xf[0], a.x[0], rowc, kq);
-        }
+        if (active) load_frag<D>(hf, a.h, rowc, kq);
 
         // one stage: start the DMA of the next image, MFMAs on the current one, publish
 #define GGNN_STAGE(CI, ACC, FRAG)                                                                        \
         {                                                                                                \
             constexpr int nci_ = (CI) + 1;                                                               \
-            if (nci_ < NSTAGE) dma_stage_image<D, NW>(packed + (size_t)nci_ * C::IMG, ring + (cur ^ 1) * C::IMG, wave, lane); \
-            else if (!last_pass) dma_stage_image<D, NW>(packed, ring + (cur ^ 1) * C::IMG, wave, lane);  \
-            if (active) stage_mma<D>(ACC, FRAG, ring + cur * C::IMG, li, kq);                            \
+            const bool more_ = (nci_ < NSTAGE) || !last_pass;                                            \
+            const float* nsrc_ = packed + (size_t)(nci_ < NSTAGE ? nci_ : 0) * C::IMG;                   \
+            float* ndst_ = ring + (cur ^ 1) * C::IMG;                                                    \
+            /* whole next image up front (spreading the 6 DMA instructions over the MFMA groups via the   \
+               stage_mma hook measured slower: 152 vs 146 us at nx=1, 323 vs 277 us at nx=3) */          \
+            if (more_) dma_stage_image<D, NW>(nsrc_, ndst_, wave, lane);                                 \
+            __builtin_amdgcn_sched_barrier(0);   /* keep the DMA issue AHEAD of the MFMA block */        \
+            if (active && !(a.dbg & 1)) stage_mma<D>(ACC, FRAG, ring + cur * C::IMG, li, kq);            \
             __syncthreads();                                                                             \
             cur ^= 1;                                                                                    \
         }
@@ -103,21 +122,23 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
 
         // ---- r = sigmoid(.), u = sigmoid(.), rh = r*h in activation-fragment layout -------------------
         Frag<D> rh;
-        if (active) {
+        if (active && !(a.dbg & 2)) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = nt * 16 + 4 * kq;
                 if (col < D) {
-                    const f32x4 br = ld4(a.bg + col), bu = ld4(a.bg + D + col);
+                    const f32x4 br = ld4(bias_s + col), bu = ld4(bias_s + D + col);
                     f32x4 r, u;
                     r.x = sigmoid_f(acc_r[nt].x + br.x); r.y = sigmoid_f(acc_r[nt].y + br.y);
                     r.z = sigmoid_f(acc_r[nt].z + br.z); r.w = sigmoid_f(acc_r[nt].w + br.w);
                     u.x = sigmoid_f(acc_u[nt].x + bu.x); u.y = sigmoid_f(acc_u[nt].y + bu.y);
                     u.z = sigmoid_f(acc_u[nt].z + bu.z); u.w = sigmoid_f(acc_u[nt].w + bu.w);
                     acc_r[nt] = r; acc_u[nt] = u;
-                    if (row < a.V) {
-                        if (a.save_r) st4(a.save_r + (size_t)row * D + col, r);
-                        if (a.save_u) st4(a.save_u + (size_t)row * D + col, u);
+                    if constexpr (SAVE) {
+                        if (row < a.V) {
+                            st4(a.save_r + ((unsigned)row * D + col), r);
+                            st4(a.save_u + ((unsigned)row * D + col), u);
+                        }
                     }
                 }
             }
@@ -144,6 +165,13 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             GGNN_STAGE(2 * NX + 3, acc_c, xf[1])
         }
         if constexpr (NX >= 3) { GGNN_STAGE(2 * NX + 4, acc_c, xf[0]) }
+        {   // next pass's fragments ride under the last stage's MFMAs (xf[0] is dead from here on)
+            const int tile_n = tile + NW;
+            if (!last_pass && tile_n < t_end) {
+                const int rn = tile_n * 16 + li;
+                load_frag<D>(xf[0], a.x[0], rn < a.V ? rn : a.V - 1, kq);
+            }
+        }
         GGNN_STAGE(3 * NX + 2, acc_c, rh)
 #undef GGNN_STAGE
 
@@ -159,7 +187,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                 if (kq == q) hrem = f32x4{h0, h1, h2, h3};
             }
         }
-        if (active && row < a.V) {
+        if (active && row < a.V && !(a.dbg & 4)) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = nt * 16 + 4 * kq;
@@ -167,46 +195,54 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                     f32x4 hv;
                     if (nt < NC) hv = hf.v[nt];
                     else hv = hrem;
-                    const f32x4 b = ld4(a.bc + col);
+                    const f32x4 b = ld4(bias_s + 2 * D + col);
                     f32x4 c = acc_c[nt] + b;
                     if (a.act == GGNN_ACT_TANH) { c.x = tanh_f(c.x); c.y = tanh_f(c.y); c.z = tanh_f(c.z); c.w = tanh_f(c.w); }
                     else { c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f); }
                     const f32x4 u = acc_u[nt];
-                    st4(a.h_out + (size_t)row * D + col, u * hv + (1.0f - u) * c);
-                    if (a.save_c) st4(a.save_c + (size_t)row * D + col, c);
+                    st4(a.h_out + ((unsigned)row * D + col), u * hv + (1.0f - u) * c);
+                    if constexpr (SAVE) st4(a.save_c + ((unsigned)row * D + col), c);
                 }
             }
         }
     }
 }
 
-template <int D, int NX, int NW>
-static int launch_gru_fused(const GruFusedArgs& a, float* packed, hipStream_t st) {
+template <int D, int NX, int NW, bool SAVE>
+static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t st) {
     using C = StageCfg<D>;
-    hipLaunchKernelGGL((gru_pack_weights_kernel<D>), dim3(8, 3 * (NX + 1)), dim3(256), 0, st, a.Wg, a.Wc, NX, packed);
-    GGNN_CHECK_HIP(hipGetLastError());
-    const size_t lds = (size_t)2 * C::IMG_BYTES;
+    GruFusedArgs a = a_in;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GGNN_GRU_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
+    if (a.Wg) {   // raw weights given: build the stage images first (skipped when the caller pre-packed them)
+        hipLaunchKernelGGL((gru_pack_weights_kernel<D>), dim3(8, 3 * (NX + 1)), dim3(256), 0, st, a.Wg, a.Wc, NX, packed);
+        GGNN_CHECK_HIP(hipGetLastError());
+    }
+    if (a.h == nullptr) return GGNN_OK;   // pack-only call
+    const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)(3 * D * sizeof(float) + 15) / 16 * 16;   // ring + biases
     const int wt_total = (a.V + 15) / 16;
     int nb = num_cus();
     const int need = (wt_total + NW - 1) / NW;
     if (nb > need) nb = need;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        GGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggnn_gru_fused_kernel<D, NX, NW>),
+        GGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggnn_gru_fused_kernel<D, NX, NW, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
+    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
 
 template <int D>
 static int dispatch_nx(const GruFusedArgs& a, float* packed, hipStream_t st) {
+    const bool save = a.save_r || a.save_u || a.save_c;
+    if (save && !(a.save_r && a.save_u && a.save_c))
+        return fail(GGNN_E_INVALID, "save_r / save_u / save_c must be given together");
     switch (a.nx) {
-        case 1: return launch_gru_fused<D, 1, 8>(a, packed, st);
-        case 2: return launch_gru_fused<D, 2, 8>(a, packed, st);
-        case 3: return launch_gru_fused<D, 3, 8>(a, packed, st);
+        case 1: return save ? launch_gru_fused<D, 1, 8, true>(a, packed, st) : launch_gru_fused<D, 1, 8, false>(a, packed, st);
+        case 2: return save ? launch_gru_fused<D, 2, 8, true>(a, packed, st) : launch_gru_fused<D, 2, 8, false>(a, packed, st);
+        case 3: return save ? launch_gru_fused<D, 3, 8, true>(a, packed, st) : launch_gru_fused<D, 3, 8, false>(a, packed, st);
         default: return fail(GGNN_E_INVALID, "nx %d outside 1..3", a.nx);
     }
 }

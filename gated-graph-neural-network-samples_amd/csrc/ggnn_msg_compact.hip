@@ -106,10 +106,12 @@ static int launch_compact(const float* h, const float* W, const int* pair_node, 
                           hipStream_t st) {
     constexpr int NW = 8;
     using C = StageCfg<D>;
-    hipLaunchKernelGGL((edge_weight_pack_kernel<D>), dim3(8, tr.T), dim3(256), 0, st, W, packed);
-    GGNN_CHECK_HIP(hipGetLastError());
+    if (W) {      // raw [T,D,D] weights given: build the T stage images (skipped when the caller pre-packed them)
+        hipLaunchKernelGGL((edge_weight_pack_kernel<D>), dim3(8, tr.T), dim3(256), 0, st, W, packed);
+        GGNN_CHECK_HIP(hipGetLastError());
+    }
     const int tiles = tr.tile_off[tr.T];
-    if (tiles == 0) return GGNN_OK;
+    if (tiles == 0 || h == nullptr) return GGNN_OK;
     hipLaunchKernelGGL((msg_transform_compact_kernel<D, NW>), dim3(tiles), dim3(NW * 64), C::IMG_BYTES, st, h, pair_node, tr,
                        (const float*)packed, Hc);
     GGNN_CHECK_HIP(hipGetLastError());
@@ -181,6 +183,23 @@ extern "C" size_t ggnn_msg_transform_compact_workspace_bytes(int D, int T) {
     return (size_t)stage_img_floats(D) * sizeof(float) * (size_t)(T > 0 ? T : 0) + 256;
 }
 
+extern "C" int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* packed, ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(T > 0 && T <= kMaxTypesC, "bad T=%d", T);
+    if (!ggnn_msg_transform_compact_supported(D))
+        return fail(GGNN_E_UNSUPPORTED, "no packed edge weights for hidden size %d", D);
+    GGNN_CHECK_ARG(W && packed && aligned16(packed), "null or misaligned pointer");
+    TypeRows tr{};
+    tr.T = T;                                   // all row counts zero: pack only
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 100: return launch_compact<100>(nullptr, W, nullptr, tr, packed, nullptr, st);
+        case 64: return launch_compact<64>(nullptr, W, nullptr, tr, packed, nullptr, st);
+        default: return launch_compact<32>(nullptr, W, nullptr, tr, packed, nullptr, st);
+    }
+}
+
+// W == NULL: `ws` already holds the images written by ggnn_edge_weights_pack_f32 (inference: weights are
+// constant across batches, so the pack pre-pass is paid once per weight version instead of once per call).
 extern "C" int ggnn_msg_transform_compact_f32(const float* h, const float* W, const int32_t* pair_node,
                                               const int64_t* type_row_off, float* Hc, void* ws, size_t ws_bytes, int V, int D,
                                               int T, ggnn_stream_t stream) {
@@ -199,8 +218,8 @@ extern "C" int ggnn_msg_transform_compact_f32(const float* h, const float* W, co
     }
     tr.row_off[T] = (int)type_row_off[T];
     if (tr.row_off[T] == 0) return GGNN_OK;
-    GGNN_CHECK_ARG(h && W && pair_node && Hc && ws, "null pointer");
-    GGNN_CHECK_ARG(aligned16(h) && aligned16(W) && aligned16(Hc) && aligned16(ws), "pointers must be 16-byte aligned");
+    GGNN_CHECK_ARG(h && pair_node && Hc && ws, "null pointer");
+    GGNN_CHECK_ARG(aligned16(h) && (!W || aligned16(W)) && aligned16(Hc) && aligned16(ws), "pointers must be 16-byte aligned");
     if (ws_bytes < ggnn_msg_transform_compact_workspace_bytes(D, T))
         return fail(GGNN_E_WORKSPACE, "compact transform workspace too small");
     hipStream_t st = (hipStream_t)stream;

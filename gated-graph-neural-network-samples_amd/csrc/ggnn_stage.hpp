@@ -56,36 +56,57 @@ struct Frag {
 template <int D>
 __device__ __forceinline__ void load_frag(Frag<D>& f, const float* base, int row, int kq) {
     constexpr int NC = StageCfg<D>::NC, NR = StageCfg<D>::NR;
-    const float* p = base + (size_t)row * D + 4 * kq;
+    // 32-bit element offsets (V*D < 2^32): one VGPR offset + scalar base per access instead of 64-bit VGPR pairs
+    const unsigned o = (unsigned)row * (unsigned)D + 4u * (unsigned)kq;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) f.v[c] = ld4(p + 16 * c);
+    for (int c = 0; c < NC; ++c) f.v[c] = ld4(base + (o + 16u * c));
 #pragma unroll
-    for (int q = 0; q < NR; ++q) f.r[q] = base[(size_t)row * D + 16 * NC + 4 * q + kq];
+    for (int q = 0; q < NR; ++q) f.r[q] = base[o - 4u * (unsigned)kq + (unsigned)(16 * NC + 4 * q) + (unsigned)kq];
 }
 
 // acc[nt] += A-fragment x stage image.  Per k-chunk c and group of <= 4 tiles: 4 ds_read_b128 feed 16 MFMAs;
 // tiles are walked in the inner loop so consecutive MFMAs hit different accumulators (40-cycle dependent
 // latency of v_mfma_f32_16x16x4_f32 vs 32-cycle issue).
-template <int D>
-__device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const Frag<D>& a, const float* img, int li, int kq) {
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+// `hook(gi)` is called at the start of MFMA group gi (compile-time gi after unrolling): the fused GRU uses it
+// to spread the LDS-DMA instructions of the NEXT stage over the MFMA stream instead of issuing them in one
+// burst (each global_load_lds costs ~60-180 issue cycles during which the matrix pipe would sit idle).
+template <int D, class Hook = NoHook>
+__device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const Frag<D>& a, const float* img, int li, int kq,
+                                          const Hook& hook = Hook()) {
     using C = StageCfg<D>;
     const f32x4* base = reinterpret_cast<const f32x4*>(img) + kq * C::BN + li;
+    // Explicit one-group-ahead software pipeline with bounded register use: the weight operands of group
+    // gi+1 (<= 4 tiles, 16 VGPRs) are read while the <= 16 MFMAs of group gi issue; a scheduling barrier per
+    // group stops the compiler from hoisting further reads (which drove the kernel into scratch spills).
     constexpr int G = 4;
+    constexpr int GPC = (C::NT + G - 1) / G;                 // groups per k-chunk
+    constexpr int NG = C::NC * GPC;
+    f32x4 w[2][G];
+    if constexpr (NG > 0) {
 #pragma unroll
-    for (int c = 0; c < C::NC; ++c) {
+        for (int j = 0; j < G; ++j)
+            if (j < C::NT) w[0][j] = base[j * 16];
+    }
 #pragma unroll
-        for (int g0 = 0; g0 < C::NT; g0 += G) {
-            f32x4 w[G];
+    for (int gi = 0; gi < NG; ++gi) {
+        const int c = gi / GPC, g0 = (gi % GPC) * G;
+        hook(gi);
+        if (gi + 1 < NG) {
+            const int cn = (gi + 1) / GPC, gn = ((gi + 1) % GPC) * G;
 #pragma unroll
             for (int j = 0; j < G; ++j)
-                if (g0 + j < C::NT) w[j] = base[c * 4 * C::BN + (g0 + j) * 16];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int j = 0; j < G; ++j)
-                    if (g0 + j < C::NT)
-                        acc[g0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][e], a.v[c][e], acc[g0 + j], 0, 0, 0);
+                if (gn + j < C::NT) w[(gi + 1) & 1][j] = base[cn * 4 * C::BN + (gn + j) * 16];
+            __builtin_amdgcn_sched_barrier(0);               // reads of group gi+1 are issued BEFORE group gi's MFMAs
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                if (g0 + j < C::NT)
+                    acc[g0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[gi & 1][j][e], a.v[c][e], acc[g0 + j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int q = 0; q < C::NR; ++q) {
@@ -109,11 +130,45 @@ __device__ __forceinline__ void dma_stage_image(const float* src, float* dst, in
     using C = StageCfg<D>;
     constexpr int PER_WAVE = C::IMG_BYTES / (NW * 1024);
     static_assert(C::IMG_BYTES % (NW * 1024) == 0, "image must split into whole KiB per wave");
-    const char* s = reinterpret_cast<const char*>(src) + (size_t)wave * PER_WAVE * 1024 + lane * 16;
+    // scalar (wave-uniform) base + one 32-bit per-lane offset: the DMA addresses of all stages share a single
+    // VGPR (64-bit per-lane address pairs per DMA instruction cost 72 VGPRs in the fused GRU and spilled it)
     char* d = reinterpret_cast<char*>(dst) + (size_t)wave * PER_WAVE * 1024;
+    const unsigned voff = (unsigned)lane * 16u;
 #pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i)
-        __builtin_amdgcn_global_load_lds((glb_void*)(s + i * 1024), (lds_void*)(d + i * 1024), 16, 0, 0);
+    for (int i0 = 0; i0 < PER_WAVE; i0 += 4) {
+        // pin the 4-KiB group base into SGPRs so the access selects the saddr + 32-bit voffset form; the
+        // instruction's immediate offset (applied to the global AND the LDS address) walks the KiB blocks
+        const unsigned long long sb = reinterpret_cast<unsigned long long>(src) + (unsigned long long)wave * PER_WAVE * 1024 + (unsigned long long)i0 * 1024;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+        const char* s = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+        lds_void* dl = (lds_void*)(d + i0 * 1024);
+        if (i0 + 0 < PER_WAVE) __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 0, 0);
+        if (i0 + 1 < PER_WAVE) __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 1024, 0);
+        if (i0 + 2 < PER_WAVE) __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 2048, 0);
+        if (i0 + 3 < PER_WAVE) __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 3072, 0);
+    }
+}
+
+// One KiB piece (piece < IMG_BYTES / (NW*1024)) of the same transfer, for callers that interleave the DMA
+// instructions with other work.  Pieces 4j .. 4j+3 share one pinned scalar base + immediate offsets.
+template <int D, int NW>
+__device__ __forceinline__ void dma_stage_piece(const float* src, float* dst, int wave, int lane, int piece) {
+    using C = StageCfg<D>;
+    constexpr int PER_WAVE = C::IMG_BYTES / (NW * 1024);
+    const int i0 = piece & ~3;
+    const unsigned long long sb = reinterpret_cast<unsigned long long>(src) + (unsigned long long)wave * PER_WAVE * 1024 + (unsigned long long)i0 * 1024;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+    const char* s = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+    lds_void* dl = (lds_void*)(reinterpret_cast<char*>(dst) + (size_t)wave * PER_WAVE * 1024 + i0 * 1024);
+    const unsigned voff = (unsigned)lane * 16u;
+    switch (piece & 3) {
+        case 0: __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 0, 0); break;
+        case 1: __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 1024, 0); break;
+        case 2: __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 2048, 0); break;
+        default: __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 3072, 0); break;
+    }
 }
 
 }  // namespace ggnn

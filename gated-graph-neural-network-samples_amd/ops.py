@@ -338,6 +338,10 @@ def compact_supported(D: int) -> bool:
     return bool(_lib.load().ggnn_msg_transform_compact_supported(D))
 
 
+def gru_is_fused(D: int) -> bool:
+    return bool(_lib.load().ggnn_gru_is_fused(D))
+
+
 def build_compact_sources(index: MessageIndex) -> CompactSources:
     """Enumerate the (node, type) pairs that emit at least one message and re-target the segment-sum's
     gather rows at them.  index: the by-target MessageIndex of the batch (build_message_index)."""
@@ -398,4 +402,107 @@ def gather_segment_sum_compact(Hc: torch.Tensor, index: MessageIndex, comp: Comp
     _launch("gather_segment_sum", lambda: lib.ggnn_gather_segment_sum_f32(
         _ptr(Hc), _ptr(index.row_ptr), _ptr(comp.gather_row), _ptr(nin), _ptr(edge_biases), 1 if use_avg else 0,
         _ptr(out), V, D, T, _stream()))
+    return out
+
+
+# ---- pre-packed weights (inference) ---------------------------------------------------------------------
+class PackedWeights:
+    """Cache of the kernels' LDS stage images of weight tensors, keyed by (storage pointer, version counter):
+    during inference the weights do not change between batches, so the pack pre-pass runs once per weight
+    version instead of once per launch.  Any in-place update of a weight bumps tensor._version and repacks."""
+
+    def __init__(self):
+        self._gru = {}
+        self._edge = {}
+
+    @staticmethod
+    def _base(t: torch.Tensor) -> torch.Tensor:
+        return t._base if t._base is not None else t
+
+    @classmethod
+    def _key(cls, *tensors):
+        # identity of the owning tensor objects (views share their base's version counter) + view geometry
+        return tuple((id(cls._base(t)), t.data_ptr(), tuple(t.shape)) for t in tensors)
+
+    @classmethod
+    def _lookup(cls, table, key, tensors):
+        """A hit is valid only while the SAME tensor objects are alive at the same version: a pointer/version
+        pair alone can be recycled by the allocator for a different model's weights."""
+        entry = table.get(key)
+        if entry is None:
+            return None
+        refs, versions, packed = entry
+        for r, v, t in zip(refs, versions, tensors):
+            if r() is not cls._base(t) or v != t._version:
+                return None
+        return packed
+
+    @classmethod
+    def _store(cls, table, key, tensors, packed):
+        import weakref
+        if len(table) > 64:
+            table.clear()
+        table[key] = ([weakref.ref(cls._base(t)) for t in tensors], [t._version for t in tensors], packed)
+        return packed
+
+    def gru(self, Wg: torch.Tensor, Wc: torch.Tensor, nx: int, D: int) -> torch.Tensor:
+        lib = _lib.load()
+        key = self._key(Wg, Wc)
+        hit = self._lookup(self._gru, key, (Wg, Wc))
+        if hit is None:
+            _req(Wg, torch.float32, "Wg"); _req(Wc, torch.float32, "Wc")
+            packed = torch.empty(lib.ggnn_gru_packed_bytes(D, nx) // 4, dtype=torch.float32, device=Wg.device)
+            check(lib.ggnn_gru_pack_weights_f32(_ptr(Wg), _ptr(Wc), nx, D, _ptr(packed), _stream()))
+            torch.cuda.current_stream().synchronize()    # rare (once per weight version); other streams may read it next
+            hit = self._store(self._gru, key, (Wg, Wc), packed)
+        return hit
+
+    def edge(self, W: torch.Tensor) -> torch.Tensor:
+        lib = _lib.load()
+        key = self._key(W)
+        hit = self._lookup(self._edge, key, (W,))
+        if hit is None:
+            _req(W, torch.float32, "edge_weights")
+            T, D = W.shape[0], W.shape[1]
+            packed = torch.empty(lib.ggnn_msg_transform_compact_workspace_bytes(D, T) // 4, dtype=torch.float32, device=W.device)
+            check(lib.ggnn_edge_weights_pack_f32(_ptr(W), T, D, _ptr(packed), _stream()))
+            torch.cuda.current_stream().synchronize()
+            hit = self._store(self._edge, key, (W,), packed)
+        return hit
+
+
+def gru_packed(x_segs: Sequence[torch.Tensor], h: torch.Tensor, packed: torch.Tensor, bg: torch.Tensor, bc: torch.Tensor,
+               activation: str = "tanh", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ops.gru with pre-packed weight images (fused hidden sizes only)."""
+    lib = _lib.load()
+    _req(h, torch.float32, "h")
+    V, D = h.shape
+    nx = len(x_segs)
+    for i, x in enumerate(x_segs):
+        _req(x, torch.float32, "x_segs[%d]" % i)
+        if x.shape != (V, D):
+            raise ValueError("x_segs[%d] must be [V,D]" % i)
+    act = ACT_IDS.get(activation.lower())
+    if act is None:
+        raise Exception("Unknown activation function type '%s'." % activation)
+    if out is None:
+        out = torch.empty_like(h)
+    segs = (ctypes.c_void_p * nx)(*[x.data_ptr() for x in x_segs])
+    _launch("gru_fused[nx=%d]" % nx, lambda: lib.ggnn_gru_packed_f32(
+        segs, nx, _ptr(h), _ptr(packed), _ptr(bg), _ptr(bc), _ptr(out), None, None, None, V, D, act, _stream()))
+    return out
+
+
+def msg_transform_compact_packed(h: torch.Tensor, packed: torch.Tensor, T: int, comp: CompactSources,
+                                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ops.msg_transform_compact with pre-packed edge-weight images."""
+    lib = _lib.load()
+    _req(h, torch.float32, "h")
+    V, D = h.shape
+    R = comp.num_rows
+    if out is None:
+        out = torch.empty((max(R, 1), D), dtype=torch.float32, device=h.device)
+    off = (ctypes.c_int64 * (T + 1))(*comp.type_row_off)
+    _launch("msg_transform_compact", lambda: lib.ggnn_msg_transform_compact_f32(
+        _ptr(h), None, _ptr(comp.pair_node), off, _ptr(out), _ptr(packed), packed.numel() * 4, V, D, T, _stream()))
     return out

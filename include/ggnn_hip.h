@@ -142,6 +142,21 @@ int ggnn_gru_f32(const float* const* x_segs, int nx, const float* h, const float
  * chained in registers; D in {32, 64, 100}); 0 if it runs as the two launches below (ws is then used). */
 int ggnn_gru_is_fused(int D);
 
+/* Pre-packed weights (inference: weights are constant across batches).  The fused GRU and the compacted
+ * transform consume k-interleaved LDS stage images of their weights; ggnn_gru_f32 /
+ * ggnn_msg_transform_compact_f32 build them in a small pre-pass on every call, the functions below let the
+ * caller build them once per weight version:
+ *   ggnn_gru_pack_weights_f32   Wg [(nx+1)D,2D], Wc [(nx+1)D,D] -> packed (ggnn_gru_packed_bytes(D,nx) bytes)
+ *   ggnn_gru_packed_f32         == ggnn_gru_f32 with the packed images instead of Wg / Wc (fused sizes only)
+ *   ggnn_edge_weights_pack_f32  W [T,D,D] -> packed (ggnn_msg_transform_compact_workspace_bytes(D,T) bytes);
+ *                               then call ggnn_msg_transform_compact_f32 with W = NULL and ws = packed. */
+size_t ggnn_gru_packed_bytes(int D, int nx);
+int ggnn_gru_pack_weights_f32(const float* Wg, const float* Wc, int nx, int D, float* packed, ggnn_stream_t stream);
+int ggnn_gru_packed_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
+                        const float* bc, float* h_out, float* save_r, float* save_u, float* save_c, int V, int D, int act,
+                        ggnn_stream_t stream);
+int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* packed, ggnn_stream_t stream);
+
 /* The two launches of the un-fused ggnn_gru_f32, separately addressable (profiling, large D):
  *   gates:     [r|u] = sigmoid([x|h] Wg + bg) -> rh = r*h [V,D], u [V,D] (save_r optional)
  *   candidate: c = act([x|rh] Wc + bc); h_out = u*h + (1-u)*c            (save_c optional) */

@@ -282,3 +282,43 @@ def test_sparse_model_compact_and_dense_transform_agree(pkg, oracle, cuda):
         finally:
             pkg.autograd.USE_COMPACT_TRANSFORM = True
     assert torch.equal(a, b)
+
+
+def test_packed_weight_cache_follows_weight_updates(pkg, oracle, cuda):
+    """The inference path caches the kernels' packed weight images per weight version; an in-place weight
+    update (optimizer step, restore, set_graph_weights) must be seen by the next forward."""
+    ms = pkg.synthetic_qm9(100, mean_nodes=12, seed=6)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms, seed=0)
+    with torch.no_grad():
+        model.feed(feeds[0])
+        first = model.compute_final_node_representations().cpu().numpy()
+    np.testing.assert_allclose(first, _oracle_states(oracle, feeds[0], layers, model.params), **MODEL_TOL)
+    layers2 = oracle.make_sparse_layers(np.random.default_rng(123), model.params, model.num_edge_types, random_bias=True)
+    model.set_graph_weights(layers2)                       # copy_ into the same storage: same pointers, new version
+    with torch.no_grad():
+        model.feed(feeds[0])
+        second = model.compute_final_node_representations().cpu().numpy()
+    np.testing.assert_allclose(second, _oracle_states(oracle, feeds[0], layers2, model.params), **MODEL_TOL)
+    assert np.abs(first - second).max() > 1e-3
+
+
+def test_two_streams_give_identical_results(pkg, oracle, cuda):
+    """Independent batches issued on two HIP streams (bench.py --streams 2) == issued one after the other."""
+    ms = pkg.synthetic_qm9(400, mean_nodes=14, seed=12)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms, {"batch_size": 2000})
+    assert len(feeds) >= 3
+    with torch.no_grad():
+        ref = []
+        for f in feeds[:4]:
+            model.feed(f); ref.append(model.compute_final_node_representations().clone())
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream())
+        got = []
+        for i, f in enumerate(feeds[:4]):
+            with torch.cuda.stream(streams[i % 2]):
+                model.feed(f); got.append(model.compute_final_node_representations())
+        torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
