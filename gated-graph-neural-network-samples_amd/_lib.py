@@ -47,6 +47,12 @@ SYMBOLS = {
                                    c_int, c_int, c_void_p]),
     "ggnn_gru_candidate_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ggnn_sparse_propagate_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int64]),
+    "ggnn_sparse_propagate_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int64),
+                                          c_void_p, c_int, c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
+                                          POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                          POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int,
+                                          POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
     "ggnn_dense_aggregate_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ggnn_gemm_f32": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_void_p]),

@@ -506,3 +506,44 @@ def msg_transform_compact_packed(h: torch.Tensor, packed: torch.Tensor, T: int, 
     _launch("msg_transform_compact", lambda: lib.ggnn_msg_transform_compact_f32(
         _ptr(h), None, _ptr(comp.pair_node), off, _ptr(out), _ptr(packed), packed.numel() * 4, V, D, T, _stream()))
     return out
+
+
+def _ptr_array(tensors):
+    if tensors is None:
+        return None
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def sparse_propagate(h0: torch.Tensor, index: MessageIndex, comp: Optional[CompactSources], nin: torch.Tensor, use_avg: bool,
+                     layer_timesteps: Sequence[int], residuals: Sequence[Sequence[int]],
+                     edge_w: Sequence[torch.Tensor], edge_packed: Optional[Sequence[torch.Tensor]],
+                     edge_bias: Optional[Sequence[Optional[torch.Tensor]]],
+                     Wg: Sequence[torch.Tensor], bg: Sequence[torch.Tensor], Wc: Sequence[torch.Tensor], bc: Sequence[torch.Tensor],
+                     gru_packed: Optional[Sequence[torch.Tensor]], activation: str) -> List[torch.Tensor]:
+    """chem_tensorflow_sparse.py:131-218 in ONE native call (ggnn_sparse_propagate_f32): returns
+    node_states_per_layer[1:], the last entry being the final node representations."""
+    lib = _lib.load()
+    _req(h0, torch.float32, "h0")
+    V, D = h0.shape
+    T, L = index.num_edge_types, len(layer_timesteps)
+    act = ACT_IDS.get(activation.lower())
+    if act is None:
+        raise Exception("Unknown activation function type '%s'." % activation)
+    rows = comp.num_rows if comp is not None else -1
+    ws_bytes = lib.ggnn_sparse_propagate_workspace_bytes(V, D, T, rows)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=h0.device)
+    outs = [torch.empty_like(h0) for _ in range(L)]
+    res_ptr = [0]
+    res_idx = []
+    for r in residuals:
+        res_idx.extend(int(i) for i in r)
+        res_ptr.append(len(res_idx))
+    i32 = lambda xs: (ctypes.c_int32 * max(len(xs), 1))(*xs)
+    off = None if comp is None else (ctypes.c_int64 * (T + 1))(*comp.type_row_off)
+    gather = index.gather_row if comp is None else comp.gather_row
+    _launch("sparse_propagate", lambda: lib.ggnn_sparse_propagate_f32(
+        _ptr(h0), V, D, T, _ptr(index.row_ptr), _ptr(gather), None if comp is None else _ptr(comp.pair_node), off,
+        _ptr(nin), 1 if use_avg else 0, L, i32([int(x) for x in layer_timesteps]), i32(res_ptr), i32(res_idx),
+        _ptr_array(edge_w), _ptr_array(edge_packed), _ptr_array(edge_bias), _ptr_array(Wg), _ptr_array(bg), _ptr_array(Wc),
+        _ptr_array(bc), _ptr_array(gru_packed), act, _ptr_array(outs), _ptr(ws), ws_bytes, _stream()))
+    return outs

@@ -150,6 +150,10 @@ class SparseGGNNChemModel(ChemModel):
         st_keep = float(ph.get('graph_state_keep_prob', 1.0))
         need_grad = self.training and torch.is_grad_enabled()
 
+        if not need_grad and ew_keep >= 1.0 and st_keep >= 1.0 and ops._timing is None:
+            # inference: the whole layer/timestep loop below runs inside ONE native call
+            return self._propagate_native(h0, index, nin, use_avg, act)
+
         for (layer_idx, num_timesteps) in enumerate(self.params['layer_timesteps']):   # :131
             layer_residual_connections = self.params['residual_connections'].get(str(layer_idx))   # :140
             if layer_residual_connections is None:
@@ -170,6 +174,32 @@ class SparseGGNNChemModel(ChemModel):
                 cur = tf_dropout(cur, st_keep)                                     # :113-114 DropoutWrapper(state)
             node_states_per_layer.append(cur)
         return node_states_per_layer[-1]                                           # :218
+
+    def _propagate_native(self, h0, index, nin, use_avg, act) -> torch.Tensor:
+        """compute_final_node_representations through ggnn_sparse_propagate_f32 (the loop of :131-218 in C):
+        source-compacted transform and pre-packed weight images where the hidden size supports them."""
+        from .autograd import USE_COMPACT_TRANSFORM, _PACKED
+        D, T = self.params['hidden_size'], self.num_edge_types
+        L = len(self.params['layer_timesteps'])
+        comp = None
+        if USE_COMPACT_TRANSFORM and ops.compact_supported(D):
+            comp = getattr(index, "_compact", None)
+            if comp is None:
+                comp = index._compact = ops.build_compact_sources(index)
+        edge_w = [self._edge_weight_vars[l].view(T, D, D) for l in range(L)]
+        edge_packed = [_PACKED.edge(w) for w in edge_w] if comp is not None else None
+        edge_bias = list(self.gnn_weights.edge_biases) if self.params['use_edge_bias'] else None
+        cells = self.gnn_weights.rnn_cells
+        residuals = [self.params['residual_connections'].get(str(l)) or [] for l in range(L)]
+        gru_packed = None
+        if ops.gru_is_fused(D):
+            gru_packed = [_PACKED.gru(c.gates_kernel, c.candidate_kernel, len(residuals[l]) + 1, D) for l, c in enumerate(cells)]
+        outs = ops.sparse_propagate(h0, index, comp, nin, use_avg, self.params['layer_timesteps'], residuals,
+                                    edge_w, edge_packed, edge_bias,
+                                    [c.gates_kernel for c in cells], [c.gates_bias for c in cells],
+                                    [c.candidate_kernel for c in cells], [c.candidate_bias for c in cells],
+                                    gru_packed, act)
+        return outs[-1]
 
     def gated_regression(self, last_h, regression_gate, regression_transform):
         """chem_tensorflow_sparse.py:220-231."""

@@ -166,6 +166,31 @@ int ggnn_gru_candidate_f32(const float* const* x_segs, int nx, const float* rh, 
                            const float* Wc, const float* bc, float* h_out, float* save_c, int V, int D, int act,
                            ggnn_stream_t stream);
 
+/* ---- (a-9) layer / timestep driver: chem_tensorflow_sparse.py:131-218 -------------------------------
+ * The whole forward propagation (every layer and timestep: transform -> gather/segment-sum -> GRU) enqueued
+ * by ONE call.  All `const T* const*` parameters are HOST arrays of `num_layers` DEVICE pointers.
+ *   row_ptr / gather_row        message index by target (ggnn_build_target_csr); with the compacted transform
+ *                               gather_row must be the remapped rows (ggnn_remap_gather_rows)
+ *   pair_node, type_row_off     compacted transform (type_row_off on the HOST); both NULL -> dense transform
+ *   layer_timesteps             HOST [num_layers]                                  (:53, :131)
+ *   res_ptr / res_idx           HOST CSR of residual_connections: layer l reads the states
+ *                               res_idx[res_ptr[l] .. res_ptr[l+1]-1] (0 = h0, k = output of layer k-1), :140-145
+ *   edge_w [T,D,D] raw and/or edge_packed (ggnn_edge_weights_pack_f32); edge_bias entries may be NULL
+ *   Wg/Wc raw and/or gru_packed (ggnn_gru_pack_weights_f32); bg [2D], bc [D]
+ *   layer_out                   HOST [num_layers] of DEVICE [V,D]: node_states_per_layer[l+1]; the last one is
+ *                               the function's return value (:218)
+ *   ws                          ggnn_sparse_propagate_workspace_bytes(V, D, T, compact_rows or -1) bytes
+ */
+size_t ggnn_sparse_propagate_workspace_bytes(int V, int D, int T, int64_t compact_rows);
+int ggnn_sparse_propagate_f32(const float* h0, int V, int D, int T,
+                              const int32_t* row_ptr, const int32_t* gather_row, const int32_t* pair_node,
+                              const int64_t* type_row_off, const float* nin, int use_avg,
+                              int num_layers, const int32_t* layer_timesteps, const int32_t* res_ptr, const int32_t* res_idx,
+                              const float* const* edge_w, const float* const* edge_packed, const float* const* edge_bias,
+                              const float* const* Wg, const float* const* bg, const float* const* Wc, const float* const* bc,
+                              const float* const* gru_packed, int act,
+                              float* const* layer_out, void* ws, size_t ws_bytes, ggnn_stream_t stream);
+
 /* ---- (a-D) dense-adjacency aggregation: chem_tensorflow_dense.py:103-112 ---------------------------
  * acts[g,i,:] = sum_e sum_j A[g,e,i,j] * ( Hm[g*v+j, e*D:(e+1)*D] + bias[e,:] )
  *   A [b,e,v,v] fp32 (A[g,e,dst,src], chem_tensorflow_dense.py:30-36), Hm [b*v, e*D] = h W_e for all e

@@ -302,6 +302,24 @@ def test_packed_weight_cache_follows_weight_updates(pkg, oracle, cuda):
     assert np.abs(first - second).max() > 1e-3
 
 
+@pytest.mark.parametrize("config", [{}, {"use_edge_bias": True, "hidden_size": 64}, {"hidden_size": 256, "layer_timesteps": [2, 1],
+                                                                                     "residual_connections": {"1": [0]}}])
+def test_native_driver_equals_python_loop(pkg, oracle, cuda, config):
+    """ggnn_sparse_propagate_f32 (one native call for the whole layer/timestep loop) == the per-op Python loop
+    (which the per-kernel timing mode uses), bit for bit; D=256 exercises the dense-transform / two-launch GRU route."""
+    ms = pkg.synthetic_qm9(150, mean_nodes=12, seed=21)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms, config)
+    with torch.no_grad():
+        model.feed(feeds[0])
+        native = model.compute_final_node_representations().clone()
+        with pkg.ops.kernel_timing() as kt:
+            model.feed(feeds[0])
+            loop = model.compute_final_node_representations().clone()
+        assert len(kt.results()) >= 3
+    assert torch.equal(native, loop)
+    np.testing.assert_allclose(native.cpu().numpy(), _oracle_states(oracle, feeds[0], layers, model.params), **MODEL_TOL)
+
+
 def test_two_streams_give_identical_results(pkg, oracle, cuda):
     """Independent batches issued on two HIP streams (bench.py --streams 2) == issued one after the other."""
     ms = pkg.synthetic_qm9(400, mean_nodes=14, seed=12)
