@@ -37,6 +37,12 @@ SYMBOLS = {
     "ggnn_gru_workspace_bytes": (c_size_t, [c_int, c_int]),
     "ggnn_gru_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ggnn_gather_segment_sum_attn_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                 c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ggnn_rnn_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ggnn_cudnn_gru_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "ggnn_cudnn_gru_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "ggnn_gru_is_fused": (c_int, [c_int]),
     "ggnn_gru_packed_bytes": (c_size_t, [c_int, c_int]),
     "ggnn_gru_pack_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

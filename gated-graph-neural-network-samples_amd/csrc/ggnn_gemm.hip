@@ -207,3 +207,55 @@ extern "C" int ggnn_gru_packed_f32(const float* const* x_segs, int nx, const flo
     a.save_r = save_r; a.save_u = save_u; a.save_c = save_c; a.V = V; a.act = act;
     return gru_fused_dispatch(a, D, const_cast<float*>(packed), (hipStream_t)stream);
 }
+
+// ---- the other two cell types of chem_tensorflow_sparse.py:102-112 ------------------------------------------
+// BasicRNNCell: h' = act([x | h] W + b)
+extern "C" int ggnn_rnn_f32(const float* const* x_segs, int nx, const float* h, const float* W, const float* b, float* h_out,
+                            int V, int D, int act, ggnn_stream_t stream) {
+    if (int rc = gru_args_check(x_segs, nx, h, V, D)) return rc;
+    GGNN_CHECK_ARG(act == GGNN_ACT_TANH || act == GGNN_ACT_RELU, "unknown activation %d", act);
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(W && b && h_out && h_out != h && aligned16(W) && aligned16(b) && aligned16(h_out), "null/misaligned/aliasing pointer");
+    GemmOperands g{};
+    for (int s = 0; s < nx; ++s) { g.A[s] = x_segs[s]; g.lda[s] = D; }
+    g.A[nx] = h; g.lda[nx] = D;
+    g.nseg = nx + 1; g.D = D; g.M = V;
+    g.B = W; g.ldb = D; g.b_blk_cols = D; g.b_blk_stride = 0; g.N = D;
+    EpiBiasAct e{b, h_out, D, act};
+    return dispatch_gemm(g, e, (hipStream_t)stream);
+}
+
+// CudnnCompatibleGRUCell: [r|u] = sigmoid([x|h] Wg + bg); c = tanh(x Wcx + bcx + r*(h Wch + bch)); h' = u*h + (1-u)*c
+// ws: 4*V*D floats (r*h (unused by-product), u, r, h Wch + bch).
+extern "C" size_t ggnn_cudnn_gru_workspace_bytes(int V, int D) {
+    return V < 0 || D <= 0 ? 0 : (size_t)4 * V * D * sizeof(float);
+}
+
+extern "C" int ggnn_cudnn_gru_f32(const float* const* x_segs, int nx, const float* h, const float* Wg, const float* bg,
+                                  const float* Wcx, const float* bcx, const float* Wch, const float* bch, float* h_out,
+                                  void* ws, size_t ws_bytes, int V, int D, ggnn_stream_t stream) {
+    if (int rc = gru_args_check(x_segs, nx, h, V, D)) return rc;
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(Wg && bg && Wcx && bcx && Wch && bch && h_out && ws && h_out != h, "null pointer or h_out aliases h");
+    GGNN_CHECK_ARG(aligned16(Wg) && aligned16(bg) && aligned16(Wcx) && aligned16(bcx) && aligned16(Wch) && aligned16(bch) &&
+                   aligned16(h_out) && aligned16(ws), "pointers must be 16-byte aligned");
+    if (ws_bytes < ggnn_cudnn_gru_workspace_bytes(V, D)) return fail(GGNN_E_WORKSPACE, "cudnn-GRU workspace too small");
+    const size_t vd = (size_t)V * D;
+    float* rh = static_cast<float*>(ws);
+    float* u = rh + vd; float* r = u + vd; float* hc = r + vd;
+    if (int rc = ggnn_gru_gates_f32(x_segs, nx, h, Wg, bg, rh, u, r, V, D, stream)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    {   // hc = h Wch + bch
+        GemmOperands g{};
+        g.A[0] = h; g.lda[0] = D; g.nseg = 1; g.D = D; g.M = V;
+        g.B = Wch; g.ldb = D; g.b_blk_cols = D; g.b_blk_stride = 0; g.N = D;
+        EpiBiasAct e{bch, hc, D, GGNN_ACT_NONE};
+        if (int rc = dispatch_gemm(g, e, st)) return rc;
+    }
+    GemmOperands g{};
+    for (int s = 0; s < nx; ++s) { g.A[s] = x_segs[s]; g.lda[s] = D; }
+    g.nseg = nx; g.D = D; g.M = V;
+    g.B = Wcx; g.ldb = D; g.b_blk_cols = D; g.b_blk_stride = 0; g.N = D;
+    EpiCudnnCand e{bcx, r, hc, h, u, h_out, D};
+    return dispatch_gemm(g, e, st);
+}

@@ -92,6 +92,32 @@ struct EpiGruCand {
     }
 };
 
+// out = act(acc + b): BasicRNNCell (chem_tensorflow_sparse.py:109-110) with act = tanh/relu, and a plain biased
+// projection with act = GGNN_ACT_NONE (the hidden projection of CudnnCompatibleGRUCell).
+#define GGNN_ACT_NONE 2
+struct EpiBiasAct {
+    const float* b; float* out; int ldo; int act;
+    __device__ __forceinline__ void operator()(int row, int col, f32x4 v) const {
+        f32x4 c = v + ld4(b + col);
+        if (act == GGNN_ACT_TANH) { c.x = tanh_f(c.x); c.y = tanh_f(c.y); c.z = tanh_f(c.z); c.w = tanh_f(c.w); }
+        else if (act == GGNN_ACT_RELU) { c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f); }
+        st4(out + (size_t)row * ldo + col, c);
+    }
+};
+
+// CudnnCompatibleGRUCell candidate (chem_tensorflow_sparse.py:105-108):
+//   c = tanh(x Wcx + bcx + r * (h Wch + bch)); h' = u*h + (1-u)*c     (hc = h Wch + bch precomputed)
+struct EpiCudnnCand {
+    const float* bcx; const float* r; const float* hc; const float* h; const float* u; float* h_out; int D;
+    __device__ __forceinline__ void operator()(int row, int col, f32x4 v) const {
+        const size_t o = (size_t)row * D + col;
+        f32x4 c = v + ld4(bcx + col) + ld4(r + o) * ld4(hc + o);
+        c.x = tanh_f(c.x); c.y = tanh_f(c.y); c.z = tanh_f(c.z); c.w = tanh_f(c.w);
+        const f32x4 uv = ld4(u + o);
+        st4(h_out + o, uv * ld4(h + o) + (1.0f - uv) * c);
+    }
+};
+
 struct GruFusedArgs {
     const float* x[3];
     int nx;

@@ -134,6 +134,62 @@ __global__ __launch_bounds__(256) void gather_segment_sum_kernel(
     }
 }
 
+// ---- propagation attention (chem_tensorflow_sparse.py:147-149, 170-196) fused into the segment sum ---------
+// score_m = <h[src_m], h[tgt_m]> * factor[type_m]; a_m = softmax over the messages INTO each target (max-shifted,
+// denominator + 1e-7); incoming[v] = sum_m a_m * msg_m.  One sub-wave per target: pass 1 finds the max score,
+// pass 2 recomputes the scores, and accumulates e_m * msg_m and sum e_m; the division by (sum + 1e-7) is applied
+// once to the accumulated row (== scaling every message first, up to fp32 rounding order).
+template <int LPR>
+__global__ __launch_bounds__(256) void gather_segment_sum_attn_kernel(
+        const float* __restrict__ H, const float* __restrict__ h, const int* __restrict__ row_ptr,
+        const int* __restrict__ gidx, const float* __restrict__ factors, const float* __restrict__ nin,
+        const float* __restrict__ bias, int use_avg, float* __restrict__ out, int V, int D, int T) {
+    constexpr int NODES = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    int v = blockIdx.x * NODES + threadIdx.x / LPR;
+    const bool live = v < V;
+    v = live ? v : V - 1;
+    const int beg = row_ptr[v], end = live ? row_ptr[v + 1] : beg;
+    const int D4 = D >> 2;                                  // D4 <= LPR (checked by the launcher)
+    const bool col_ok = l < D4;
+    const int c4 = col_ok ? l : 0;
+    const f32x4 hv = col_ok ? *reinterpret_cast<const f32x4*>(h + (size_t)v * D + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto score = [&](int g) {
+        const int src = g / T, t = g - src * T;
+        f32x4 hs = {0.f, 0.f, 0.f, 0.f};
+        if (col_ok) hs = *reinterpret_cast<const f32x4*>(h + (size_t)src * D + 4 * c4);
+        float part = hs.x * hv.x + hs.y * hv.y + hs.z * hv.z + hs.w * hv.w;
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) part += __shfl_xor(part, off, LPR);
+        return part * factors[t];
+    };
+    float m = -3.402823466e+38f;
+    for (int e = beg; e < end; ++e) m = fmaxf(m, score(gidx[e]));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float S = 0.f;
+    for (int e = beg; e < end; ++e) {
+        const int g = gidx[e];
+        const float w = expf(score(g) - m);
+        S += w;
+        if (col_ok) acc += w * *reinterpret_cast<const f32x4*>(H + (size_t)g * D + 4 * c4);
+    }
+    if (col_ok && live) {
+        acc = acc / (S + 1e-7f);                            // :194
+        float deg = 0.f;
+        if ((use_avg || bias) && nin)
+            for (int t = 0; t < T; ++t) deg += nin[(size_t)v * T + t];
+        if (bias) {
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < T; ++t)
+                b += nin[(size_t)v * T + t] * *reinterpret_cast<const f32x4*>(bias + (size_t)t * D + 4 * c4);
+            acc += b;
+        }
+        if (use_avg) acc = acc / (deg + 1e-7f);
+        *reinterpret_cast<f32x4*>(out + (size_t)v * D + 4 * c4) = acc;
+    }
+}
+
 __global__ void unsorted_segment_sum_kernel(const float* __restrict__ data, const int* __restrict__ ids,
                                             float* out, long long total, int D, int num_segments) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -235,6 +291,31 @@ extern "C" int ggnn_gather_segment_sum_f32(const float* Hrows, const int32_t* ro
         hipLaunchKernelGGL(gather_segment_sum_kernel<64>, dim3((V + 3) / 4), dim3(256), 0, st, Hrows, row_ptr,
                            gather_row, nin, bias, use_avg, out, V, D, T);
     }
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+extern "C" int ggnn_gather_segment_sum_attn_f32(const float* Hrows, const float* h, const int32_t* row_ptr,
+                                                const int32_t* gather_row, const float* type_factors, const float* nin,
+                                                const float* bias, int use_avg, float* out, int V, int D, int T,
+                                                ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(V >= 0 && D > 0 && D % 4 == 0 && T > 0, "bad sizes V=%d D=%d T=%d", V, D, T);
+    if (D > 256) return fail(GGNN_E_UNSUPPORTED, "propagation attention supports hidden sizes up to 256 (got %d)", D);
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(Hrows && h && row_ptr && type_factors && out, "null pointer");
+    GGNN_CHECK_ARG(!(bias || use_avg) || nin, "nin is required with bias or mean aggregation");
+    GGNN_CHECK_ARG(aligned16(Hrows) && aligned16(h) && aligned16(out) && (!bias || aligned16(bias)), "pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int D4 = D / 4;
+    if (D4 <= 16)
+        hipLaunchKernelGGL(gather_segment_sum_attn_kernel<16>, dim3((V + 15) / 16), dim3(256), 0, st, Hrows, h, row_ptr, gather_row,
+                           type_factors, nin, bias, use_avg, out, V, D, T);
+    else if (D4 <= 32)
+        hipLaunchKernelGGL(gather_segment_sum_attn_kernel<32>, dim3((V + 7) / 8), dim3(256), 0, st, Hrows, h, row_ptr, gather_row,
+                           type_factors, nin, bias, use_avg, out, V, D, T);
+    else
+        hipLaunchKernelGGL(gather_segment_sum_attn_kernel<64>, dim3((V + 3) / 4), dim3(256), 0, st, Hrows, h, row_ptr, gather_row,
+                           type_factors, nin, bias, use_avg, out, V, D, T);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }

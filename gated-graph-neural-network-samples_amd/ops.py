@@ -547,3 +547,60 @@ def sparse_propagate(h0: torch.Tensor, index: MessageIndex, comp: Optional[Compa
         _ptr_array(edge_w), _ptr_array(edge_packed), _ptr_array(edge_bias), _ptr_array(Wg), _ptr_array(bg), _ptr_array(Wc),
         _ptr_array(bc), _ptr_array(gru_packed), act, _ptr_array(outs), _ptr(ws), ws_bytes, _stream()))
     return outs
+
+
+# ---- the remaining switches of the same function: attention, RNN cell, cudnn-compatible GRU cell ------------------
+def gather_segment_sum_attn(H: torch.Tensor, h: torch.Tensor, index: MessageIndex, type_factors: torch.Tensor,
+                            num_incoming_edges_per_type: Optional[torch.Tensor], edge_biases: Optional[torch.Tensor],
+                            use_avg: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """use_propagation_attention (chem_tensorflow_sparse.py:147-149, 170-196) fused into the segment sum.
+    H [V, T*D] from msg_transform (dense form), h [V,D] current states, type_factors [T]."""
+    lib = _lib.load()
+    _req(H, torch.float32, "H"); _req(h, torch.float32, "h"); _req(type_factors, torch.float32, "type_factors")
+    V, T = index.num_nodes, index.num_edge_types
+    D = h.shape[1]
+    if H.shape != (V, T * D) or type_factors.shape != (T,):
+        raise ValueError("shape mismatch: H [V,T*D], h [V,D], type_factors [T]")
+    nin = num_incoming_edges_per_type
+    if out is None:
+        out = torch.empty((V, D), dtype=torch.float32, device=h.device)
+    _launch("gather_segment_sum_attn", lambda: lib.ggnn_gather_segment_sum_attn_f32(
+        _ptr(H), _ptr(h), _ptr(index.row_ptr), _ptr(index.gather_row), _ptr(type_factors), _ptr(nin), _ptr(edge_biases),
+        1 if use_avg else 0, _ptr(out), V, D, T, _stream()))
+    return out
+
+
+def rnn(x_segs: Sequence[torch.Tensor], h: torch.Tensor, W: torch.Tensor, b: torch.Tensor, activation: str = "tanh") -> torch.Tensor:
+    """tf.nn.rnn_cell.BasicRNNCell (chem_tensorflow_sparse.py:109-110): act([x|h] W + b)."""
+    lib = _lib.load()
+    _req(h, torch.float32, "h"); _req(W, torch.float32, "W"); _req(b, torch.float32, "b")
+    V, D = h.shape
+    nx = len(x_segs)
+    if tuple(W.shape) != ((nx + 1) * D, D) or tuple(b.shape) != (D,):
+        raise ValueError("W must be [(nx+1)D, D] and b [D]")
+    out = torch.empty_like(h)
+    segs = (ctypes.c_void_p * nx)(*[_req(x, torch.float32, "x").data_ptr() for x in x_segs])
+    act = ACT_IDS.get(activation.lower())
+    if act is None:
+        raise Exception("Unknown activation function type '%s'." % activation)
+    _launch("rnn[nx=%d]" % nx, lambda: lib.ggnn_rnn_f32(segs, nx, _ptr(h), _ptr(W), _ptr(b), _ptr(out), V, D, act, _stream()))
+    return out
+
+
+def cudnn_gru(x_segs: Sequence[torch.Tensor], h: torch.Tensor, Wg, bg, Wcx, bcx, Wch, bch) -> torch.Tensor:
+    """tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell (chem_tensorflow_sparse.py:105-108)."""
+    lib = _lib.load()
+    V, D = h.shape
+    nx = len(x_segs)
+    for n, w, shp in (("Wg", Wg, ((nx + 1) * D, 2 * D)), ("bg", bg, (2 * D,)), ("Wcx", Wcx, (nx * D, D)), ("bcx", bcx, (D,)),
+                      ("Wch", Wch, (D, D)), ("bch", bch, (D,))):
+        _req(w, torch.float32, n)
+        if tuple(w.shape) != shp:
+            raise ValueError("%s must have shape %s, got %s" % (n, shp, tuple(w.shape)))
+    out = torch.empty_like(h)
+    ws_bytes = lib.ggnn_cudnn_gru_workspace_bytes(V, D)
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=h.device)
+    segs = (ctypes.c_void_p * nx)(*[_req(x, torch.float32, "x").data_ptr() for x in x_segs])
+    _launch("cudnn_gru[nx=%d]" % nx, lambda: lib.ggnn_cudnn_gru_f32(segs, nx, _ptr(h), _ptr(Wg), _ptr(bg), _ptr(Wcx), _ptr(bcx),
+                                                                    _ptr(Wch), _ptr(bch), _ptr(out), _ptr(ws), ws_bytes, V, D, _stream()))
+    return out

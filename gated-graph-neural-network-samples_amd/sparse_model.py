@@ -27,6 +27,29 @@ GGNNWeights = namedtuple('GGNNWeights', ['edge_weights',
                                          'rnn_cells', ])
 
 GRUCellWeights = namedtuple('GRUCellWeights', ['gates_kernel', 'gates_bias', 'candidate_kernel', 'candidate_bias'])
+RNNCellWeights = namedtuple('RNNCellWeights', ['kernel', 'bias'])
+CudnnGRUCellWeights = namedtuple('CudnnGRUCellWeights', ['gates_kernel', 'gates_bias', 'input_kernel', 'input_bias',
+                                                         'hidden_kernel', 'hidden_bias'])
+
+# graph_rnn_cell (lower-cased, chem_tensorflow_sparse.py:102-112) -> (weights tuple, per field:
+#   (oracle key, TF-1.3 variable suffix under <layer scope>/timestep_0/, shape(in_dim, D), initial value))
+CELL_SPECS = {
+    'gru': (GRUCellWeights, [
+        ('Wg', 'gru_cell/gates/kernel:0', lambda i, d: (i + d, 2 * d), 'glorot'),
+        ('bg', 'gru_cell/gates/bias:0', lambda i, d: (2 * d,), 1.0),
+        ('Wc', 'gru_cell/candidate/kernel:0', lambda i, d: (i + d, d), 'glorot'),
+        ('bc', 'gru_cell/candidate/bias:0', lambda i, d: (d,), 0.0)]),
+    'rnn': (RNNCellWeights, [
+        ('W', 'basic_rnn_cell/kernel:0', lambda i, d: (i + d, d), 'glorot'),
+        ('b', 'basic_rnn_cell/bias:0', lambda i, d: (d,), 0.0)]),
+    'cudnncompatiblegrucell': (CudnnGRUCellWeights, [
+        ('Wg', 'cudnn_compatible_gru_cell/gates/kernel:0', lambda i, d: (i + d, 2 * d), 'glorot'),
+        ('bg', 'cudnn_compatible_gru_cell/gates/bias:0', lambda i, d: (2 * d,), 1.0),
+        ('Wcx', 'cudnn_compatible_gru_cell/candidate/input_projection/kernel:0', lambda i, d: (i, d), 'glorot'),
+        ('bcx', 'cudnn_compatible_gru_cell/candidate/input_projection/bias:0', lambda i, d: (d,), 0.0),
+        ('Wch', 'cudnn_compatible_gru_cell/candidate/hidden_projection/kernel:0', lambda i, d: (d, d), 'glorot'),
+        ('bch', 'cudnn_compatible_gru_cell/candidate/hidden_projection/bias:0', lambda i, d: (d,), 0.0)]),
+}
 
 
 class SparseGGNNChemModel(ChemModel):
@@ -71,15 +94,12 @@ class SparseGGNNChemModel(ChemModel):
         activation_name = self.params['graph_rnn_activation'].lower()
         if activation_name not in ('tanh', 'relu'):
             raise Exception("Unknown activation function type '%s'." % activation_name)
-        if self.params['use_propagation_attention']:
-            raise NotImplementedError("use_propagation_attention (chem_tensorflow_sparse.py:170-196) is a "
-                                      "'next' row of the scope table (SURVEY 8f-4); default is off")
         cell_type = self.params['graph_rnn_cell'].lower()
-        if cell_type != 'gru':
-            if cell_type in ('cudnncompatiblegrucell', 'rnn'):
-                raise NotImplementedError("graph_rnn_cell '%s' is a 'next' row of the scope table "
-                                          "(SURVEY 8f-4); default is GRU" % cell_type)
+        if cell_type not in CELL_SPECS:
             raise Exception("Unknown RNN cell type '%s'." % cell_type)
+        if cell_type == 'cudnncompatiblegrucell':
+            assert (activation_name == 'tanh')                                  # :106
+        self.cell_type = cell_type
 
         # Generate per-layer values for edge weights, biases and gated units:
         self.gnn_weights = GGNNWeights([], [], [], [])
@@ -90,17 +110,24 @@ class SparseGGNNChemModel(ChemModel):
             ew = torch.from_numpy(glorot_init([self.num_edge_types * h_dim, h_dim])).to(dev)
             self._edge_weight_vars.append(ew)
             self.gnn_weights.edge_weights.append(ew.view(self.num_edge_types, h_dim, h_dim))
+            if self.params['use_propagation_attention']:                        # :94-96
+                self.gnn_weights.edge_type_attention_weights.append(
+                    torch.ones([self.num_edge_types], dtype=torch.float32, device=dev))
             if self.params['use_edge_bias']:
                 self.gnn_weights.edge_biases.append(torch.zeros([self.num_edge_types, h_dim], dtype=torch.float32, device=dev))
             res = self.params['residual_connections'].get(str(layer_idx)) or []
             in_dim = h_dim * (len(res) + 1)
-            # TF-1.3 GRUCell: gates/kernel [(in+D),2D] glorot_uniform (the scope's default initializer),
-            # gates/bias = 1.0, candidate/kernel [(in+D),D], candidate/bias = 0
-            cell = GRUCellWeights(torch.from_numpy(glorot_init([in_dim + h_dim, 2 * h_dim])).to(dev),
-                                  torch.ones(2 * h_dim, dtype=torch.float32, device=dev),
-                                  torch.from_numpy(glorot_init([in_dim + h_dim, h_dim])).to(dev),
-                                  torch.zeros(h_dim, dtype=torch.float32, device=dev))
-            self.gnn_weights.rnn_cells.append(cell)
+            # TF-1.3 cells: kernels glorot_uniform (the variable scope's default initializer); GRU gate bias 1.0,
+            # every other bias 0 (shapes: CELL_SPECS)
+            cls, fields = CELL_SPECS[cell_type]
+            tensors = []
+            for (_, _, shape_fn, init) in fields:
+                shape = shape_fn(in_dim, h_dim)
+                if init == 'glorot':
+                    tensors.append(torch.from_numpy(glorot_init(list(shape))).to(dev))
+                else:
+                    tensors.append(torch.full(shape, float(init), dtype=torch.float32, device=dev))
+            self.gnn_weights.rnn_cells.append(cls(*tensors))
 
     def graph_model_variables(self) -> Dict[str, torch.Tensor]:
         """graph_model/* variables under the names TF-1.3 gives them (used by the pickle checkpoints,
@@ -111,12 +138,11 @@ class SparseGGNNChemModel(ChemModel):
             out["%s/gnn_edge_weights_%i:0" % (scope, l)] = self._edge_weight_vars[l]
             if self.params['use_edge_bias']:
                 out["%s/gnn_edge_biases_%i:0" % (scope, l)] = self.gnn_weights.edge_biases[l]
+            if self.params['use_propagation_attention']:
+                out["%s/edge_type_attention_weights_%i:0" % (scope, l)] = self.gnn_weights.edge_type_attention_weights[l]
             cell = self.gnn_weights.rnn_cells[l]
-            base = "%s/timestep_0/gru_cell" % scope
-            out[base + "/gates/kernel:0"] = cell.gates_kernel
-            out[base + "/gates/bias:0"] = cell.gates_bias
-            out[base + "/candidate/kernel:0"] = cell.candidate_kernel
-            out[base + "/candidate/bias:0"] = cell.candidate_bias
+            for (_, suffix, _, _), t in zip(CELL_SPECS[self.cell_type][1], cell):
+                out["%s/timestep_0/%s" % (scope, suffix)] = t
         return out
 
     def set_graph_weights(self, layers: Sequence[dict]) -> None:
@@ -128,9 +154,11 @@ class SparseGGNNChemModel(ChemModel):
                 self._edge_weight_vars[l].copy_(as_t(L['edge_weights']).reshape(self._edge_weight_vars[l].shape))
                 if self.params['use_edge_bias']:
                     self.gnn_weights.edge_biases[l].copy_(as_t(L['edge_biases']))
+                if self.params['use_propagation_attention']:
+                    self.gnn_weights.edge_type_attention_weights[l].copy_(as_t(L['edge_type_attention_weights']))
                 cell = self.gnn_weights.rnn_cells[l]
-                cell.gates_kernel.copy_(as_t(L['Wg'])); cell.gates_bias.copy_(as_t(L['bg']))
-                cell.candidate_kernel.copy_(as_t(L['Wc'])); cell.candidate_bias.copy_(as_t(L['bc']))
+                for (key, _, _, _), t in zip(CELL_SPECS[self.cell_type][1], cell):
+                    t.copy_(as_t(L[key]))
 
     # ---- the hot path -----------------------------------------------------------------------------------
     def compute_final_node_representations(self) -> torch.Tensor:
@@ -149,8 +177,12 @@ class SparseGGNNChemModel(ChemModel):
         ew_keep = float(ph.get('edge_weight_dropout_keep_prob', 1.0))
         st_keep = float(ph.get('graph_state_keep_prob', 1.0))
         need_grad = self.training and torch.is_grad_enabled()
+        variant = self.params['use_propagation_attention'] or self.cell_type != 'gru'
+        if variant and need_grad:
+            raise NotImplementedError("training is built for the default switches (GRU cell, no propagation attention); "
+                                      "the attention / RNN / CudnnCompatibleGRUCell variants are inference-only here")
 
-        if not need_grad and ew_keep >= 1.0 and st_keep >= 1.0 and ops._timing is None:
+        if not variant and not need_grad and ew_keep >= 1.0 and st_keep >= 1.0 and ops._timing is None:
             # inference: the whole layer/timestep loop below runs inside ONE native call
             return self._propagate_native(h0, index, nin, use_avg, act)
 
@@ -169,11 +201,32 @@ class SparseGGNNChemModel(ChemModel):
             cell = self.gnn_weights.rnn_cells[layer_idx]
             cur = node_states_per_layer[-1]                                        # :152
             for step in range(num_timesteps):                                      # :153
-                cur = propagation_step(cur, index, nin, edge_weights, edge_biases, use_avg,
-                                       layer_residual_states, cell, act, need_grad)
+                if variant:
+                    cur = self._variant_step(cur, index, nin, edge_weights.contiguous(), edge_biases, use_avg,
+                                             layer_residual_states, layer_idx, act)
+                else:
+                    cur = propagation_step(cur, index, nin, edge_weights, edge_biases, use_avg,
+                                           layer_residual_states, cell, act, need_grad)
                 cur = tf_dropout(cur, st_keep)                                     # :113-114 DropoutWrapper(state)
             node_states_per_layer.append(cur)
         return node_states_per_layer[-1]                                           # :218
+
+    def _variant_step(self, h, index, nin, edge_weights, edge_biases, use_avg, residual_states, layer_idx, act):
+        """One timestep with the non-default switches of chem_tensorflow_sparse.py: propagation attention
+        (:147-149, 170-196) and/or the BasicRNNCell / CudnnCompatibleGRUCell cells (:105-110).  Dense transform."""
+        H = ops.msg_transform(h, edge_weights)
+        if self.params['use_propagation_attention']:
+            incoming = ops.gather_segment_sum_attn(H, h, index, self.gnn_weights.edge_type_attention_weights[layer_idx],
+                                                   nin, edge_biases, use_avg)
+        else:
+            incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
+        xs = list(residual_states) + [incoming]
+        cell = self.gnn_weights.rnn_cells[layer_idx]
+        if self.cell_type == 'gru':
+            return ops.gru(xs, h, cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias, act)
+        if self.cell_type == 'rnn':
+            return ops.rnn(xs, h, cell.kernel, cell.bias, act)
+        return ops.cudnn_gru(xs, h, *cell)
 
     def _propagate_native(self, h0, index, nin, use_avg, act) -> torch.Tensor:
         """compute_final_node_representations through ggnn_sparse_propagate_f32 (the loop of :131-218 in C):

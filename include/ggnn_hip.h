@@ -117,6 +117,15 @@ int ggnn_gather_segment_sum_f32(const float* Hrows, const int32_t* row_ptr, cons
                                 const float* nin, const float* bias, int use_avg, float* out,
                                 int V, int D, int T, ggnn_stream_t stream);
 
+/* use_propagation_attention (chem_tensorflow_sparse.py:147-149, 170-196) fused into the segment sum:
+ *   score_m = <h[src_m], h[tgt_m]> * type_factors[type_m];  a = per-target softmax of the scores (max-shifted,
+ *   denominator + 1e-7);  incoming[v] = sum_m a_m * Hrows[gather_row[m]]  (then bias / mean as above).
+ * gather_row must be the dense form src*T + type (ggnn_build_target_csr); h [V,D] are the un-transformed states;
+ * type_factors [T] = edge_type_attention_weights (:94-96).  D <= 256. */
+int ggnn_gather_segment_sum_attn_f32(const float* Hrows, const float* h, const int32_t* row_ptr, const int32_t* gather_row,
+                                     const float* type_factors, const float* nin, const float* bias, int use_avg,
+                                     float* out, int V, int D, int T, ggnn_stream_t stream);
+
 /* tf.unsorted_segment_sum in its general form (chem_tensorflow_sparse.py:198-200, 226-228):
  * out[ids[m],:] += data[m,:] with out zero-filled first; fp32 atomics, any id order.  Used for the
  * readout's per-graph sum and available for un-bucketed message lists. */
@@ -137,6 +146,18 @@ int ggnn_gru_f32(const float* const* x_segs, int nx, const float* h, const float
                  const float* Wc, const float* bc, float* h_out, void* ws, size_t ws_bytes,
                  float* save_r, float* save_u, float* save_c, int V, int D, int act,
                  ggnn_stream_t stream);
+
+/* The other two cell types of chem_tensorflow_sparse.py:102-112 (forward):
+ *   ggnn_rnn_f32        tf.nn.rnn_cell.BasicRNNCell (:109-110): h' = act([x|h] W + b), W [(nx+1)D, D], b [D]
+ *   ggnn_cudnn_gru_f32  tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell (:105-108): gates as GRUCell, then
+ *                       c = tanh(x Wcx + bcx + r * (h Wch + bch)); h' = u*h + (1-u)*c
+ *                       Wg [(nx+1)D,2D], Wcx [nx*D, D], Wch [D,D]; ws = ggnn_cudnn_gru_workspace_bytes(V,D). */
+int ggnn_rnn_f32(const float* const* x_segs, int nx, const float* h, const float* W, const float* b, float* h_out,
+                 int V, int D, int act, ggnn_stream_t stream);
+size_t ggnn_cudnn_gru_workspace_bytes(int V, int D);
+int ggnn_cudnn_gru_f32(const float* const* x_segs, int nx, const float* h, const float* Wg, const float* bg,
+                       const float* Wcx, const float* bcx, const float* Wch, const float* bch, float* h_out,
+                       void* ws, size_t ws_bytes, int V, int D, ggnn_stream_t stream);
 
 /* 1 if ggnn_gru_f32 runs as ONE fused launch for this hidden size (gates -> r*h -> candidate -> blend
  * chained in registers; D in {32, 64, 100}); 0 if it runs as the two launches below (ws is then used). */

@@ -98,9 +98,17 @@ def basic_rnn_cell(x, h, W, b, act=np.tanh):
 # ----------------------------------------------------------------------------------------------
 # One sparse propagation step and the layer/timestep driver
 # ----------------------------------------------------------------------------------------------
+def unsorted_segment_max(data, segment_ids, num_segments):
+    """tf.unsorted_segment_max (chem_tensorflow_sparse.py:180-182): segments without entries hold the lowest
+    representable value of the dtype."""
+    out = np.full((num_segments,) + data.shape[1:], np.finfo(data.dtype).min, dtype=data.dtype)
+    np.maximum.at(out, np.asarray(segment_ids), data)
+    return out
+
+
 def sparse_step(h, adjacency_lists, nin, edge_weights, gru, residual_states=(), edge_biases=None,
                 use_edge_msg_avg_aggregation=True, act=np.tanh, cell="gru",
-                return_intermediates=False):
+                return_intermediates=False, attention_weights=None):
     """One timestep of chem_tensorflow_sparse.py:153-216 (attention branch off).
 
     h                [V,D]      current node states
@@ -112,14 +120,28 @@ def sparse_step(h, adjacency_lists, nin, edge_weights, gru, residual_states=(), 
     edge_biases      [T,D] or None                                     (:98-100, :202-204)
     """
     V = h.shape[0]
-    messages, targets = [], []
+    messages, targets, source_states, edge_types = [], [], [], []
     for t, adj in enumerate(adjacency_lists):                     # :159
         adj = np.asarray(adj).reshape(-1, 2)
         edge_source_states = embedding_lookup(h, adj[:, 0])       # :161-162
         messages.append(edge_source_states @ edge_weights[t])     # :163-164
+        source_states.append(edge_source_states)                  # :166
         targets.append(adj[:, 1])                                 # :125-126
+        edge_types.append(np.full(len(adj), t, dtype=np.int64))   # :127
     messages = np.concatenate(messages, axis=0)                   # :168   [M,D]
     targets = np.concatenate(targets, axis=0)                     # :128   [M]
+    if attention_weights is not None:                             # use_propagation_attention (:170-196)
+        edge_types = np.concatenate(edge_types, axis=0)
+        factors = np.asarray(attention_weights, dtype=h.dtype)[edge_types]            # :148-149
+        src_states = np.concatenate(source_states, axis=0)                            # :171
+        tgt_states = embedding_lookup(h, targets)                                     # :172-173
+        scores = np.einsum('mi,mi->m', src_states, tgt_states) * factors              # :174-175
+        smax = unsorted_segment_max(scores, targets, V)                               # :180-182
+        scores = scores - smax[targets]                                               # :184-186
+        exped = np.exp(scores)                                                        # :188
+        ssum = unsorted_segment_sum(exped, targets, V)                                # :189-191
+        attention = exped / (ssum[targets] + h.dtype.type(SMALL_NUMBER))              # :192-194
+        messages = messages * attention[:, None]                                      # :196
     incoming = unsorted_segment_sum(messages, targets, V)         # :198-200
     if edge_biases is not None:
         incoming = incoming + nin.astype(h.dtype) @ edge_biases   # :202-204
@@ -160,14 +182,15 @@ def sparse_propagate(h0, adjacency_lists, nin, layers, params, dtype=np.float64,
         res_ids = params.get("residual_connections", {}).get(str(layer_idx))  # :140
         residual_states = [] if res_ids is None else [node_states_per_layer[i] for i in res_ids]
         L = layers[layer_idx]
-        gru = {k: cast(v) for k, v in L.items() if k not in ("edge_weights", "edge_biases")}
+        gru = {k: cast(v) for k, v in L.items() if k not in ("edge_weights", "edge_biases", "edge_type_attention_weights")}
         ew = cast(L["edge_weights"])
         eb = cast(L.get("edge_biases")) if params.get("use_edge_bias", False) else None
+        aw = cast(L.get("edge_type_attention_weights")) if params.get("use_propagation_attention", False) else None
         node_states_per_layer.append(node_states_per_layer[-1])          # :152
         for _ in range(num_timesteps):                                   # :153
             node_states_per_layer[-1] = sparse_step(
                 node_states_per_layer[-1], adjacency_lists, nin, ew, gru, residual_states, eb,
-                params.get("use_edge_msg_avg_aggregation", True), act, cell)
+                params.get("use_edge_msg_avg_aggregation", True), act, cell, attention_weights=aw)
     return node_states_per_layer if return_all_layers else node_states_per_layer[-1]  # :218
 
 
@@ -334,6 +357,8 @@ def make_sparse_layers(rng, params, num_edge_types, random_bias=False):
         L = {"edge_weights": glorot_init(rng, [T * D, D]).reshape(T, D, D)}
         if params.get("use_edge_bias", False):
             L["edge_biases"] = (rng.normal(0, 0.1, [T, D]) if random_bias else np.zeros([T, D])).astype(np.float32)
+        if params.get("use_propagation_attention", False):   # :94-96 ones; perturbed so tests see the per-type factor
+            L["edge_type_attention_weights"] = (np.ones(T) + (rng.normal(0, 0.3, T) if random_bias else 0)).astype(np.float32)
         cell = params.get("graph_rnn_cell", "GRU").lower()
         if cell == "gru":
             L["Wg"] = glorot_init(rng, [in_dim + D, 2 * D])

@@ -35,24 +35,50 @@ def gru(x, h, Wg, bg, Wc, bc, act=torch.tanh):
     return u * h + (1 - u) * c
 
 
+def rnn_cell(x, h, cell, kind, act):
+    """The three cell types of chem_tensorflow_sparse.py:102-112 (TF-1.3 semantics)."""
+    if kind == "gru":
+        return gru(x, h, cell["Wg"], cell["bg"], cell["Wc"], cell["bc"], act)
+    if kind == "rnn":                       # BasicRNNCell: act([x,h] W + b)
+        return act(torch.cat([x, h], dim=1).matmul(cell["W"]) + cell["b"])
+    if kind == "cudnncompatiblegrucell":    # c = tanh(x Wcx + bcx + r * (h Wch + bch))
+        D = h.shape[1]
+        g = torch.sigmoid(torch.cat([x, h], dim=1).matmul(cell["Wg"]) + cell["bg"])
+        r, u = g[:, :D], g[:, D:]
+        c = torch.tanh(x.matmul(cell["Wcx"]) + cell["bcx"] + r * (h.matmul(cell["Wch"]) + cell["bch"]))
+        return u * h + (1 - u) * c
+    raise Exception("Unknown RNN cell type '%s'." % kind)
+
+
 def sparse_step(h, adjacency_lists, nin, edge_weights, cell, residual_states=(), edge_biases=None,
-                avg=True, act=torch.tanh):
-    """chem_tensorflow_sparse.py:153-216, one timestep, attention off."""
+                avg=True, act=torch.tanh, kind="gru", attention_weights=None):
+    """chem_tensorflow_sparse.py:153-216, one timestep."""
     V = h.shape[0]
-    msgs, tgts = [], []
+    msgs, tgts, srcs, types = [], [], [], []
     for t, adj in enumerate(adjacency_lists):                          # :159
         src = adj[:, 0].long()
         msgs.append(h.index_select(0, src).matmul(edge_weights[t]))    # :161-164
         tgts.append(adj[:, 1].long())
+        srcs.append(src)
+        types.append(torch.full((adj.shape[0],), t, dtype=torch.long))
     msgs = torch.cat(msgs, 0)                                          # :168
     tgts = torch.cat(tgts, 0)                                          # :128
+    if attention_weights is not None:                                  # :170-196, written with per-target loops
+        srcs = torch.cat(srcs, 0); types = torch.cat(types, 0)
+        scores = (h[srcs] * h[tgts]).sum(-1) * attention_weights[types]
+        att = torch.zeros_like(scores)
+        for v in tgts.unique().tolist():
+            sel = (tgts == v).nonzero().flatten()
+            e = torch.exp(scores[sel] - scores[sel].max())
+            att[sel] = e / (e.sum() + SMALL_NUMBER)
+        msgs = msgs * att[:, None]
     incoming = torch.zeros(V, h.shape[1], dtype=h.dtype).index_add_(0, tgts, msgs)  # :198-200
     if edge_biases is not None:
         incoming = incoming + nin.matmul(edge_biases)                  # :202-204
     if avg:
         incoming = incoming / (nin.sum(dim=-1, keepdim=True) + SMALL_NUMBER)  # :206-209
     x = torch.cat(list(residual_states) + [incoming], dim=-1)          # :211-212
-    return gru(x, h, cell["Wg"], cell["bg"], cell["Wc"], cell["bc"], act)  # :215-216
+    return rnn_cell(x, h, cell, kind, act)                             # :215-216
 
 
 def sparse_propagate(h0, adjacency_lists, nin, layers, params, return_all_layers=False):
@@ -65,10 +91,12 @@ def sparse_propagate(h0, adjacency_lists, nin, layers, params, return_all_layers
         res = [] if res_ids is None else [states[i] for i in res_ids]
         L = layers[li]
         eb = L.get("edge_biases") if params.get("use_edge_bias", False) else None
+        aw = L.get("edge_type_attention_weights") if params.get("use_propagation_attention", False) else None
+        kind = params.get("graph_rnn_cell", "GRU").lower()
         cur = states[-1]
         for _ in range(nts):
             cur = sparse_step(cur, adjacency_lists, nin, L["edge_weights"], L, res, eb,
-                              params.get("use_edge_msg_avg_aggregation", True), act)
+                              params.get("use_edge_msg_avg_aggregation", True), act, kind, aw)
         states.append(cur)
     return states if return_all_layers else states[-1]
 

@@ -149,6 +149,14 @@ def _oracle_states(oracle, feed, layers, params, dtype=np.float64):
     {"graph_rnn_activation": "ReLU"},
     {"hidden_size": 64, "layer_timesteps": [3], "residual_connections": {}},
     {"tie_fwd_bkwd": False},
+    # the remaining switches of the same function
+    {"graph_rnn_cell": "RNN"},
+    {"graph_rnn_cell": "RNN", "graph_rnn_activation": "ReLU", "hidden_size": 64},
+    {"graph_rnn_cell": "CudnnCompatibleGRUCell"},
+    {"use_propagation_attention": True},
+    {"use_propagation_attention": True, "use_edge_bias": True, "use_edge_msg_avg_aggregation": False, "hidden_size": 256,
+     "layer_timesteps": [2, 1], "residual_connections": {"1": [0]}},
+    {"use_propagation_attention": True, "graph_rnn_cell": "CudnnCompatibleGRUCell", "hidden_size": 32},
 ])
 def test_sparse_model_matches_oracle(pkg, oracle, cuda, config):
     ms = pkg.synthetic_qm9(200, mean_nodes=14, seed=1)

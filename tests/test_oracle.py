@@ -38,7 +38,9 @@ def test_fp64_vs_fp32(oracle, pkg):
 
 
 @pytest.mark.parametrize("over", [{}, {"use_edge_bias": True}, {"use_edge_msg_avg_aggregation": False},
-                                  {"graph_rnn_activation": "relu"}, {"tie_fwd_bkwd": False}])
+                                  {"graph_rnn_activation": "relu"}, {"tie_fwd_bkwd": False},
+                                  {"graph_rnn_cell": "RNN"}, {"graph_rnn_cell": "CudnnCompatibleGRUCell"},
+                                  {"use_propagation_attention": True}, {"use_propagation_attention": True, "use_edge_bias": True}])
 def test_numpy_vs_torch(oracle, oracle_torch, pkg, over):
     p, b, layers, h0 = make_case(oracle, pkg, seed=3, **over)
     a = oracle.sparse_propagate(h0, b.adjacency_lists, b.num_incoming_edges_per_type, layers, p, np.float64)

@@ -95,3 +95,35 @@ def test_data_parallel_reduction_equals_single_batch_gloo(pkg):
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["grad_err"] < 1e-6 and ret["loss_err"] < 1e-6 and ret["bcast_ok"]
+
+
+def test_checkpoint_roundtrip_reference_pickle_schema(pkg, tmp_path):
+    """chem_tensorflow.py:309-359: pickle {params, weights{tf var name -> ndarray}, train_step, valid_step},
+    restore by variable name incl. Adam slots; runs on CPU (weights only, no kernels)."""
+    import pickle
+    ms = pkg.synthetic_qm9(30, mean_nodes=8, seed=1)
+    args = {"--quiet": True, "--device": "cpu", "train_data": ms, "valid_data": ms}
+    m1 = pkg.SparseGGNNChemModel(dict(args))
+    g = [torch.randn_like(v) for v in m1.trainable_variables.values()]
+    m1.optimizer.apply_gradients(g)
+    path = str(tmp_path / "model.pickle")
+    m1.save_progress(path, 7, 3)
+    blob = pickle.load(open(path, "rb"))
+    assert set(blob) == {"params", "weights", "train_step", "valid_step"} and blob["train_step"] == 7
+    names = set(blob["weights"])
+    assert "graph_model/gnn_layer_0/gnn_edge_weights_0:0" in names
+    assert "graph_model/gnn_layer_4/timestep_0/gru_cell/gates/kernel:0" in names
+    assert "out_layer_task0/regression_gate/MLP_W_layer0:0" in names
+    assert "graph_model/gnn_layer_0/gnn_edge_weights_0/Adam:0" in names and "beta1_power:0" in names
+    assert blob["weights"]["graph_model/gnn_layer_0/gnn_edge_weights_0:0"].shape == (400, 100)
+    assert blob["weights"]["graph_model/gnn_layer_4/timestep_0/gru_cell/gates/kernel:0"].shape == (400, 200)
+    a2 = dict(args); a2["--restore"] = path
+    m2 = pkg.SparseGGNNChemModel(a2)
+    assert (m2.train_step_id, m2.valid_step_id) == (7, 3)
+    for (n1, v1), (n2, v2) in zip(m1.named_variables().items(), m2.named_variables().items()):
+        assert n1 == n2 and torch.equal(v1, v2)
+    assert m2.optimizer.t == 1 and all(torch.equal(a, b) for a, b in zip(m1.optimizer.m, m2.optimizer.m))
+    # frozen graph model: only the readout MLPs stay trainable (chem_tensorflow.py:174-182)
+    a3 = dict(args); a3["--freeze-graph-model"] = True
+    m3 = pkg.SparseGGNNChemModel(a3)
+    assert all(k.startswith("out_layer_task") for k in m3.trainable_variables) and len(m3.trainable_variables) == 4
