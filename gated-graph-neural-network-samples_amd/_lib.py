@@ -34,6 +34,8 @@ SYMBOLS = {
     "ggnn_gather_segment_sum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                             c_int, c_int, c_int, c_void_p]),
     "ggnn_unsorted_segment_sum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "ggnn_gated_readout_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_int, c_int, c_void_p]),
     "ggnn_gru_workspace_bytes": (c_size_t, [c_int, c_int]),
     "ggnn_gru_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

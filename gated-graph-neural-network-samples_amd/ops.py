@@ -549,6 +549,23 @@ def sparse_propagate(h0: torch.Tensor, index: MessageIndex, comp: Optional[Compa
     return outs
 
 
+def gated_readout(last_h: torch.Tensor, h0: torch.Tensor, graph_nodes_list: torch.Tensor, num_graphs: int,
+                  gate_W: torch.Tensor, gate_b: torch.Tensor, transform_W: torch.Tensor, transform_b: torch.Tensor) -> torch.Tensor:
+    """Fused gated_regression (chem_tensorflow_sparse.py:220-231): per-graph sum of sigmoid(gate)*transform."""
+    lib = _lib.load()
+    _req(last_h, torch.float32, "last_h"); _req(h0, torch.float32, "h0"); _req(graph_nodes_list, torch.int32, "graph_nodes_list")
+    V, D = last_h.shape
+    for n, w, numel in (("gate_W", gate_W, 2 * D), ("gate_b", gate_b, 1), ("transform_W", transform_W, D), ("transform_b", transform_b, 1)):
+        _req(w, torch.float32, n)
+        if w.numel() != numel:
+            raise ValueError("%s must have %d elements" % (n, numel))
+    out = torch.empty(int(num_graphs), dtype=torch.float32, device=last_h.device)
+    _launch("gated_readout", lambda: lib.ggnn_gated_readout_f32(_ptr(last_h), _ptr(h0), _ptr(graph_nodes_list), _ptr(gate_W),
+                                                                _ptr(gate_b), _ptr(transform_W), _ptr(transform_b), _ptr(out),
+                                                                V, D, int(num_graphs), _stream()))
+    return out
+
+
 # ---- the remaining switches of the same function: attention, RNN cell, cudnn-compatible GRU cell ------------------
 def gather_segment_sum_attn(H: torch.Tensor, h: torch.Tensor, index: MessageIndex, type_factors: torch.Tensor,
                             num_incoming_edges_per_type: Optional[torch.Tensor], edge_biases: Optional[torch.Tensor],

@@ -257,6 +257,15 @@ class SparseGGNNChemModel(ChemModel):
     def gated_regression(self, last_h, regression_gate, regression_transform):
         """chem_tensorflow_sparse.py:220-231."""
         from .autograd import segment_sum_rows
+        keep = float(self.placeholders.get('out_layer_dropout_keep_prob', 1.0))
+        if not (self.training and torch.is_grad_enabled()) and keep >= 1.0 and last_h.is_cuda:
+            # inference: one fused HIP pass (no [V,2D] concat, no per-node intermediates)
+            g, t = regression_gate.params, regression_transform.params
+            output = ops.gated_readout(last_h.contiguous(), self.placeholders['initial_node_representation'],
+                                       self.placeholders['graph_nodes_list'], self.placeholders['num_graphs'],
+                                       g["weights"][0], g["biases"][0], t["weights"][0], t["biases"][0])
+            self.output = output
+            return output
         gate_input = torch.cat([last_h, self.placeholders['initial_node_representation']], dim=-1)   # [v x 2h]
         gated_outputs = torch.sigmoid(regression_gate(gate_input)) * regression_transform(last_h)    # [v x 1]
         # Sum up all nodes per-graph

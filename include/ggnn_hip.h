@@ -132,6 +132,14 @@ int ggnn_gather_segment_sum_attn_f32(const float* Hrows, const float* h, const i
 int ggnn_unsorted_segment_sum_f32(const float* data, const int32_t* ids, float* out, int64_t M, int D,
                                   int num_segments, ggnn_stream_t stream);
 
+/* ---- (a-R) fused graph-level readout: chem_tensorflow_sparse.py:220-231 + utils.py:39-70 -------------
+ * out[g] = sum_{v in graph g} sigmoid([hT[v] | h0[v]] . gate_W + gate_b) * (hT[v] . transform_W + transform_b)
+ *   hT, h0 [V,D]; graph_nodes_list [V] int32 (:71, :304); gate_W [2D] (the [2D,1] MLP weight), transform_W [D];
+ *   gate_b, transform_b DEVICE [1]; out [num_graphs] (zero-filled by the call).  fp32 atomics (one add per node). */
+int ggnn_gated_readout_f32(const float* hT, const float* h0, const int32_t* graph_nodes_list, const float* gate_W,
+                           const float* gate_b, const float* transform_W, const float* transform_b, float* out, int V,
+                           int D, int num_graphs, ggnn_stream_t stream);
+
 /* ---- (a-8, a-G) residual concat + GRU node update: chem_tensorflow_sparse.py:211-216 -----------
  * TF-1.3 GRUCell: [r|u] = sigmoid([x|h] Wg + bg); c = act([x | r*h] Wc + bc); h' = u*h + (1-u)*c
  * with x = [x_segs[0] | ... | x_segs[nx-1]] read through nx pointers (no concat is materialised;
