@@ -126,6 +126,7 @@ struct GruFusedArgs {
     float* h_out; float* save_r; float* save_u; float* save_c;
     int V; int act;
     int dbg;               // ablation bitmask from GGNN_GRU_DBG (0 in production)
+    unsigned long long* tdbg;   // per-stage s_memtime stamps (GGNN_GRU_TPTR, debug only)
 };
 
 int gru_fused_supported(int D);

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         const bool last_pass = (p + 1 == passes);
         if (active) load_frag<D>(hf, a.h, rowc, kq);
 
+#define GGNN_T(CI, K) if (a.tdbg && blockIdx.x == 0 && lane == 0) a.tdbg[((p * NSTAGE + (CI)) * NW + wave) * 4 + (K)] = __builtin_amdgcn_s_memtime();
         // one stage: start the DMA of the next image, MFMAs on the current one, publish
 #define GGNN_STAGE(CI, ACC, FRAG)                                                                        \
         {                                                                                                \
@@ -96,12 +97,17 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             const bool more_ = (nci_ < NSTAGE) || !last_pass;                                            \
             const float* nsrc_ = packed + (size_t)(nci_ < NSTAGE ? nci_ : 0) * C::IMG;                   \
             float* ndst_ = ring + (cur ^ 1) * C::IMG;                                                    \
+            GGNN_T(CI, 0)                                                                                \
             /* whole next image up front (spreading the 6 DMA instructions over the MFMA groups via the   \
                stage_mma hook measured slower: 152 vs 146 us at nx=1, 323 vs 277 us at nx=3) */          \
+            /* (letting only one wave per SIMD pair issue the DMA measured no better: 150 vs 147 us) */  \
             if (more_) dma_stage_image<D, NW>(nsrc_, ndst_, wave, lane);                                 \
+            GGNN_T(CI, 1)                                                                                \
             __builtin_amdgcn_sched_barrier(0);   /* keep the DMA issue AHEAD of the MFMA block */        \
             if (active && !(a.dbg & 1)) stage_mma<D>(ACC, FRAG, ring + cur * C::IMG, li, kq);            \
+            GGNN_T(CI, 2)                                                                                \
             __syncthreads();                                                                             \
+            GGNN_T(CI, 3)                                                                                \
             cur ^= 1;                                                                                    \
         }
 
@@ -123,6 +129,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         // ---- r = sigmoid(.), u = sigmoid(.), rh = r*h in activation-fragment layout -------------------
         Frag<D> rh;
         if (active && !(a.dbg & 2)) {
+            stage_tail_reduce<D>(acc_r);                       // VALU-tail columns: add the four kq partials
+            stage_tail_reduce<D>(acc_u);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = nt * 16 + 4 * kq;
@@ -180,6 +188,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         // the cross-lane reads stay outside lane-divergent control flow
         f32x4 hrem = {0.f, 0.f, 0.f, 0.f};
         if (active) {
+            stage_tail_reduce<D>(acc_c);
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
                 const float h0 = __shfl(hf.r[q], li), h1 = __shfl(hf.r[q], li + 16);
@@ -213,6 +222,7 @@ static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t
     using C = StageCfg<D>;
     GruFusedArgs a = a_in;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GGNN_GRU_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
+    { const char* e = getenv("GGNN_GRU_TPTR"); a.tdbg = e ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
     if (a.Wg) {   // raw weights given: build the stage images first (skipped when the caller pre-packed them)
         hipLaunchKernelGGL((gru_pack_weights_kernel<D>), dim3(8, 3 * (NX + 1)), dim3(256), 0, st, a.Wg, a.Wc, NX, packed);
         GGNN_CHECK_HIP(hipGetLastError());

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(NW * 64) void msg_transform_compact_kernel(const fl
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     stage_mma<D>(acc, a, img, li, kq);
+    stage_tail_reduce<D>(acc);
     if (r < row_end) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {

@@ -11,6 +11,10 @@
 #pragma once
 #include "ggnn_gemm.hpp"
 
+#ifndef GGNN_VALU_TAIL
+#define GGNN_VALU_TAIL 0     // 1: compute the D%16 == 4 remainder columns on the vector ALU (see stage_mma)
+#endif
+
 namespace ggnn {
 
 template <int D>
@@ -77,17 +81,28 @@ __device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const F
                                           const Hook& hook = Hook()) {
     using C = StageCfg<D>;
     const f32x4* base = reinterpret_cast<const f32x4*>(img) + kq * C::BN + li;
+    // VALU tail (D % 16 == 4, e.g. D = 100): the last output tile would hold only 4 valid columns -- 12.5 % of the
+    // stage's MFMAs spent on zero padding.  Those 4 columns are instead accumulated on the vector ALU, which is
+    // idle while the matrix pipe works: acc[NT-1] holds THIS LANE's partial sums over its own k indices
+    // (k = 16c + 4kq + e) for columns 16*NC .. +3, read from the same LDS image (a wave-wide broadcast read per
+    // (c, column)); stage_tail_reduce() adds the four kq lanes once per accumulator lifetime.
+    // STATUS: compiled out (GGNN_VALU_TAIL = 0).  With hipcc 7.2 the extra live ranges push the fused GRU from
+    // 198 VGPRs / no scratch to 256 VGPRs + 84-320 B of scratch per lane, which costs more than the 14 % of
+    // MFMAs it saves; kept for a round that hand-allocates the registers.
+    constexpr bool VT = (C::NR == 1) && (GGNN_VALU_TAIL != 0);
+    constexpr int NTM = VT ? C::NT - 1 : C::NT;              // tiles on the matrix pipe
     // Explicit one-group-ahead software pipeline with bounded register use: the weight operands of group
     // gi+1 (<= 4 tiles, 16 VGPRs) are read while the <= 16 MFMAs of group gi issue; a scheduling barrier per
     // group stops the compiler from hoisting further reads (which drove the kernel into scratch spills).
     constexpr int G = 4;
-    constexpr int GPC = (C::NT + G - 1) / G;                 // groups per k-chunk
+    constexpr int GPC = (NTM + G - 1) / G;                   // groups per k-chunk
     constexpr int NG = C::NC * GPC;
+    const f32x4* tbase = reinterpret_cast<const f32x4*>(img) + kq * C::BN + 16 * C::NC;   // tail columns, no lane offset
     f32x4 w[2][G];
     if constexpr (NG > 0) {
 #pragma unroll
         for (int j = 0; j < G; ++j)
-            if (j < C::NT) w[0][j] = base[j * 16];
+            if (j < NTM) w[0][j] = base[j * 16];
     }
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
@@ -97,26 +112,62 @@ __device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const F
             const int cn = (gi + 1) / GPC, gn = ((gi + 1) % GPC) * G;
 #pragma unroll
             for (int j = 0; j < G; ++j)
-                if (gn + j < C::NT) w[(gi + 1) & 1][j] = base[cn * 4 * C::BN + (gn + j) * 16];
+                if (gn + j < NTM) w[(gi + 1) & 1][j] = base[cn * 4 * C::BN + (gn + j) * 16];
             __builtin_amdgcn_sched_barrier(0);               // reads of group gi+1 are issued BEFORE group gi's MFMAs
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int j = 0; j < G; ++j)
-                if (g0 + j < C::NT)
+                if (g0 + j < NTM)
                     acc[g0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[gi & 1][j][e], a.v[c][e], acc[g0 + j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (VT) {
+        // The tail runs AFTER this wave's MFMA burst (the weight registers are dead by then, so no extra register
+        // pressure): the two waves of a SIMD issue their bursts back to back (older first), so this VALU work
+        // overlaps the partner wave's MFMAs.
+        f32x4& t = acc[C::NT - 1];
+#pragma unroll
+        for (int c = 0; c < C::NC; ++c) {
+            const f32x4 av = a.v[c];
+            const f32x4 t0 = tbase[c * 4 * C::BN + 0], t1 = tbase[c * 4 * C::BN + 1];
+            const f32x4 t2 = tbase[c * 4 * C::BN + 2], t3 = tbase[c * 4 * C::BN + 3];
+            t.x += av.x * t0.x + av.y * t0.y + av.z * t0.z + av.w * t0.w;
+            t.y += av.x * t1.x + av.y * t1.y + av.z * t1.z + av.w * t1.w;
+            t.z += av.x * t2.x + av.y * t2.y + av.z * t2.z + av.w * t2.w;
+            t.w += av.x * t3.x + av.y * t3.y + av.z * t3.z + av.w * t3.w;
+            __builtin_amdgcn_sched_barrier(0);               // bound the read-ahead (16 VGPRs per chunk)
+        }
     }
 #pragma unroll
     for (int q = 0; q < C::NR; ++q) {
         const float* rb = img + C::MAIN + (q * 4 + kq) * C::BN + li;
-        float w[C::NT];
+        float w[NTM];
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) w[nt] = rb[nt * 16];
+        for (int nt = 0; nt < NTM; ++nt) w[nt] = rb[nt * 16];
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt)
+        for (int nt = 0; nt < NTM; ++nt)
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt], a.r[q], acc[nt], 0, 0, 0);
+        if constexpr (VT) {                                  // remainder k = 16*NC + kq against the 4 tail columns
+            const f32x4 tr = *reinterpret_cast<const f32x4*>(img + C::MAIN + (q * 4 + kq) * C::BN + 16 * C::NC);
+            acc[C::NT - 1] += a.r[q] * tr;
+        }
+    }
+}
+
+// Completes a VALU-tail accumulator (see stage_mma): after the LAST stage that accumulates into `acc`, the partial
+// sums of the four kq lanes of each row are added, so every lane of the row holds columns 16*NC..+3 -- exactly
+// what the epilogues expect from lane kq == 0 of the last tile.  No-op for hidden sizes without a 4-column remainder.
+template <int D>
+__device__ __forceinline__ void stage_tail_reduce(f32x4 (&acc)[StageCfg<D>::NT]) {
+    if constexpr (StageCfg<D>::NR == 1 && GGNN_VALU_TAIL != 0) {
+        f32x4& t = acc[StageCfg<D>::NT - 1];
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            t.x += __shfl_xor(t.x, off); t.y += __shfl_xor(t.y, off);
+            t.z += __shfl_xor(t.z, off); t.w += __shfl_xor(t.w, off);
+        }
     }
 }
 

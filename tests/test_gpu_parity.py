@@ -270,11 +270,16 @@ def test_compact_transform_equals_dense_form(pkg, oracle, cuda, V, M, D, T):
     Hc = pkg.ops.msg_transform_compact(hd, Wd, comp)
     Hn = H.cpu().numpy().reshape(V, T, D)
     Hcn = Hc.cpu().numpy()
+    # same fmaf chains on the MFMA columns; with D % 16 == 4 the last 4 columns are summed on the vector ALU in a
+    # different order (per-lane partials + tree), hence closeness instead of bit equality there
+    full = (D // 16) * 16
     for r, (t, v) in enumerate(got_pairs[:2000]):
-        assert np.array_equal(Hcn[r], Hn[v, t])
+        assert np.array_equal(Hcn[r, :full], Hn[v, t, :full])
+        np.testing.assert_allclose(Hcn[r, full:], Hn[v, t, full:], atol=2e-6, rtol=1e-5)
     a = pkg.ops.gather_segment_sum(H, index, nd, None, True)
     b = pkg.ops.gather_segment_sum_compact(Hc, index, comp, nd, None, True)
-    assert torch.equal(a, b)
+    assert torch.equal(a[:, :full], b[:, :full])
+    assert torch.allclose(a, b, atol=2e-6, rtol=1e-5)
 
 
 def test_sparse_model_compact_and_dense_transform_agree(pkg, oracle, cuda):
@@ -289,7 +294,7 @@ def test_sparse_model_compact_and_dense_transform_agree(pkg, oracle, cuda):
             b = model.compute_final_node_representations().clone()
         finally:
             pkg.autograd.USE_COMPACT_TRANSFORM = True
-    assert torch.equal(a, b)
+    assert torch.allclose(a, b, atol=1e-5, rtol=1e-4)          # (VALU-tail columns are summed in a different order)
 
 
 def test_packed_weight_cache_follows_weight_updates(pkg, oracle, cuda):
