@@ -61,6 +61,9 @@ SYMBOLS = {
                                           POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                           POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int,
                                           POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+    "ggnn_gru_bwd_stage1_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ggnn_gru_bwd_stage2_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ggnn_dense_aggregate_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ggnn_gemm_f32": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_void_p]),

@@ -2,18 +2,36 @@
 chem_tensorflow_sparse.py:153-216 via optimizer.compute_gradients, chem_tensorflow.py:184).
 
 Forward runs on the hand-written HIP kernels and saves r, u, c.  Backward:
-  * GRU gate algebra: elementwise torch ops (bandwidth-bound passes over [V,D]);
+  * GRU gate algebra: two fused HIP element-wise passes (ggnn_gru_bwd_stage{1,2}_f32);
   * d(gather/segment-sum) = the SAME HIP gather/segment-sum kernel driven by the transpose index
     (messages bucketed by (src,type), gathering d_incoming[dst]) -- atomics-free and deterministic;
-  * the dense contractions (dX = dY W^T, dW = X^T dY) go to the vendor BLAS through torch.matmul: plain
-    library GEMMs, two of them reductions over all V nodes.
+  * the dense contractions (dX = dY W^T, dW = X^T dY) go to the vendor BLAS through torch: plain library
+    GEMMs; the tall-skinny X^T dY reductions over all V nodes are batched along V (tn_matmul).
 """
 from __future__ import annotations
 
 import torch
 
-from . import ops
+from . import _lib, ops
+from ._lib import check
 from .utils import SMALL_NUMBER
+
+
+def tn_matmul(x: torch.Tensor, dy: torch.Tensor, chunk: int = 2048) -> torch.Tensor:
+    """x^T @ dy for tall-skinny operands ([V,K]^T [V,N] -> [K,N], V ~ 1e5, K,N <= 400).
+
+    A single vendor-BLAS GEMM launches only ceil(K/64)*ceil(N/64) ~ 12 workgroups for this shape (no split along
+    the 1e5-long reduction) and took ~340 us; batching the reduction into V/chunk independent [K,chunk]x[chunk,N]
+    products fills the GPU, and the [V/chunk, K, N] partials are summed in one small reduction."""
+    V = x.shape[0]
+    nb = V // chunk
+    if nb < 8:
+        return x.t().matmul(dy)
+    main = nb * chunk
+    part = torch.bmm(x[:main].view(nb, chunk, x.shape[1]).transpose(1, 2), dy[:main].view(nb, chunk, dy.shape[1])).sum(0)
+    if main < V:
+        part = part + x[main:].t().matmul(dy[main:])
+    return part
 
 
 def _source_index(index: "ops.MessageIndex", num_nodes: int) -> "ops.MessageIndex":
@@ -41,34 +59,36 @@ class PropagationStepFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        lib = _lib.load()
         h, nin, W, Wg, Wc, incoming, r, u, c, *residuals = ctx.saved_tensors
         V, D = h.shape
         T = W.shape[0]
         nx = len(residuals) + 1
+        K = (nx + 1) * D
         g = g.contiguous()
-        xs = list(residuals) + [incoming]
+        st = torch.cuda.current_stream().cuda_stream
+        act = ops.ACT_IDS[ctx.activation]
 
         # ---- GRU blend and candidate:  h' = u*h + (1-u)*c,  c = act([x | r*h] Wc + bc)
-        one_minus_u = 1.0 - u
-        dpc = g * one_minus_u
-        dpc = dpc * (1.0 - c * c) if ctx.activation == "tanh" else dpc * (c > 0).to(c.dtype)
-        dpu = g * (h - c) * u * one_minus_u
-        dh = g * u
-        rh = r * h
-        a_c = torch.cat(xs + [rh], dim=1)                      # [V, (nx+1)D]
-        dWc = a_c.t().matmul(dpc)
+        a_c = torch.empty((V, K), dtype=torch.float32, device=h.device)        # [x_0 | .. | incoming | r*h]
+        for i, x in enumerate(list(residuals) + [incoming]):
+            a_c[:, i * D:(i + 1) * D] = x
+        dpc = torch.empty_like(h)
+        dpg = torch.empty((V, 2 * D), dtype=torch.float32, device=h.device)    # [d pre-r | d pre-u]
+        dh = torch.empty_like(h)
+        check(lib.ggnn_gru_bwd_stage1_f32(g.data_ptr(), h.data_ptr(), r.data_ptr(), u.data_ptr(), c.data_ptr(), act,
+                                          dpc.data_ptr(), dpg.data_ptr(), dh.data_ptr(), a_c.data_ptr(), K, nx * D, V, D, st))
+        dWc = tn_matmul(a_c, dpc)
         dbc = dpc.sum(0)
-        dxrh = dpc.matmul(Wc.t())                              # [V, (nx+1)D]
-        drh = dxrh[:, nx * D:]
-        dh = dh + drh * r
-        dpr = drh * h * r * (1.0 - r)
+        dxrh = dpc.matmul(Wc.t())                                              # [V, (nx+1)D]
         # ---- gates: [r|u] = sigmoid([x | h] Wg + bg)
-        dpg = torch.cat([dpr, dpu], dim=1)                     # [V, 2D]
-        a_c[:, nx * D:] = h                                    # reuse the buffer as [x | h]
-        dWg = a_c.t().matmul(dpg)
+        drh = dxrh[:, nx * D:]
+        check(lib.ggnn_gru_bwd_stage2_f32(drh.data_ptr(), K, h.data_ptr(), r.data_ptr(), dh.data_ptr(), dpg.data_ptr(), V, D, st))
+        a_c[:, nx * D:] = h                                                    # reuse the buffer as [x | h]
+        dWg = tn_matmul(a_c, dpg)
         dbg = dpg.sum(0)
         dxh = dpg.matmul(Wg.t())
-        dh = dh + dxh[:, nx * D:]
+        dh += dxh[:, nx * D:]
         dx = dxrh[:, :nx * D] + dxh[:, :nx * D]
         d_res = [dx[:, i * D:(i + 1) * D] for i in range(nx - 1)]
         dinc = dx[:, (nx - 1) * D:]
@@ -81,7 +101,7 @@ class PropagationStepFn(torch.autograd.Function):
         dH = ops.segment_sum_rows_by_index(dinc, _source_index(ctx.index, V)).view(V, T * D)
 
         # ---- message transform H = h [W_0 | .. | W_{T-1}]
-        dh = dh + dH.matmul(W.transpose(1, 2).reshape(T * D, D))
-        dW = h.t().matmul(dH).view(D, T, D).transpose(0, 1)
+        dh += dH.matmul(W.transpose(1, 2).reshape(T * D, D))
+        dW = tn_matmul(h, dH).view(D, T, D).transpose(0, 1)
 
         return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, *d_res)

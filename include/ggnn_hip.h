@@ -220,6 +220,17 @@ int ggnn_sparse_propagate_f32(const float* h0, int V, int D, int T,
                               const float* const* gru_packed, int act,
                               float* const* layer_out, void* ws, size_t ws_bytes, ggnn_stream_t stream);
 
+/* ---- (a-B) element-wise stages of the GRU backward (TF autodiff of GRUCell, chem_tensorflow.py:184) -------
+ * stage 1: dpc = g*(1-u)*act'(c) -> dpc [V,D];  g*(h-c)*u*(1-u) -> dpg[:, D:2D];  g*u -> dh [V,D];
+ *          r*h -> a_c[:, col0:col0+D] (row stride lda: the [x | r*h] operand of the dWc product)
+ * stage 2: dh += drh*r;  drh*h*r*(1-r) -> dpg[:, 0:D]   (drh [V,D] with row stride ld_drh)
+ * The dense contractions between the stages (dX = dY W^T, dW = X^T dY) are left to the vendor BLAS. */
+int ggnn_gru_bwd_stage1_f32(const float* g, const float* h, const float* r, const float* u, const float* c, int act,
+                            float* dpc, float* dpg, float* dh, float* a_c, int lda, int col0, int V, int D,
+                            ggnn_stream_t stream);
+int ggnn_gru_bwd_stage2_f32(const float* drh, int ld_drh, const float* h, const float* r, float* dh, float* dpg,
+                            int V, int D, ggnn_stream_t stream);
+
 /* ---- (a-D) dense-adjacency aggregation: chem_tensorflow_dense.py:103-112 ---------------------------
  * acts[g,i,:] = sum_e sum_j A[g,e,i,j] * ( Hm[g*v+j, e*D:(e+1)*D] + bias[e,:] )
  *   A [b,e,v,v] fp32 (A[g,e,dst,src], chem_tensorflow_dense.py:30-36), Hm [b*v, e*D] = h W_e for all e
