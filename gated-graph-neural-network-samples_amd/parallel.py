@@ -35,7 +35,9 @@ class DataParallelContext:
         """Initialise from torchrun's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* variables."""
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        # GGNN_LOCAL_DEVICE / GGNN_DIST_BACKEND: test hooks (several ranks sharing one GPU over gloo on a 1-GPU box)
+        local = int(os.environ.get("GGNN_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        backend = backend or os.environ.get("GGNN_DIST_BACKEND")
         use_cuda = torch.cuda.is_available()
         device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
         if use_cuda:
@@ -43,8 +45,9 @@ class DataParallelContext:
         if world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            kwargs = {"device_id": device} if use_cuda else {}
-            dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world, **kwargs)
+            backend = backend or ("nccl" if use_cuda else "gloo")
+            kwargs = {"device_id": device} if (use_cuda and backend == "nccl") else {}
+            dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
         return cls(rank, world, device)
 
     # ---- collectives ------------------------------------------------------------------------------
