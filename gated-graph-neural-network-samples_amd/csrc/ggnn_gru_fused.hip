@@ -228,6 +228,8 @@ static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t
         GGNN_CHECK_HIP(hipGetLastError());
     }
     if (a.h == nullptr) return GGNN_OK;   // pack-only call
+    if ((unsigned long long)a.V * D >= (1ULL << 32))
+        return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit element offsets: V*D must be < 2^32 (V=%d, D=%d)", a.V, D);
     const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)(3 * D * sizeof(float) + 15) / 16 * 16;   // ring + biases
     const int wt_total = (a.V + 15) / 16;
     int nb = num_cus();

@@ -134,6 +134,43 @@ __global__ __launch_bounds__(256) void gather_segment_sum_kernel(
     }
 }
 
+// Flat variant: one lane per (node, float4 column) with no idle lanes (D/4 = 25 lanes per node do not divide a wave:
+// the sub-wave form keeps 50 of 64 lanes busy).  Lanes of one node read the same row_ptr / slot indices (served as
+// broadcasts by the vector cache); no cross-lane traffic.  Slots are walked 2 at a time.
+__global__ __launch_bounds__(256) void gather_segment_sum_flat_kernel(
+        const float* __restrict__ H, const int* __restrict__ row_ptr, const int* __restrict__ gidx,
+        const float* __restrict__ nin, const float* __restrict__ bias, int use_avg, float* __restrict__ out,
+        long long total4, int D, int T) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int D4 = D >> 2;
+    const int v = (int)(i / D4);
+    const int c4 = (int)(i - (long long)v * D4);
+    const int beg = row_ptr[v], end = row_ptr[v + 1];
+    const float* hcol = H + 4 * c4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int e = beg;
+    for (; e + 2 <= end; e += 2) {
+        const int i0 = gidx[e], i1 = gidx[e + 1];
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(hcol + (size_t)i0 * D);
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(hcol + (size_t)i1 * D);
+        acc += r0; acc += r1;
+    }
+    if (e < end) acc += *reinterpret_cast<const f32x4*>(hcol + (size_t)gidx[e] * D);
+    if (bias || use_avg) {
+        float deg = 0.f;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) {
+            const float n = nin[(size_t)v * T + t];
+            deg += n;
+            if (bias) b += n * *reinterpret_cast<const f32x4*>(bias + (size_t)t * D + 4 * c4);
+        }
+        if (bias) acc += b;
+        if (use_avg) acc = acc / (deg + 1e-7f);
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)v * D + 4 * c4) = acc;
+}
+
 // ---- propagation attention (chem_tensorflow_sparse.py:147-149, 170-196) fused into the segment sum ---------
 // score_m = <h[src_m], h[tgt_m]> * factor[type_m]; a_m = softmax over the messages INTO each target (max-shifted,
 // denominator + 1e-7); incoming[v] = sum_m a_m * msg_m.  One sub-wave per target: pass 1 finds the max score,
@@ -281,7 +318,16 @@ extern "C" int ggnn_gather_segment_sum_f32(const float* Hrows, const int32_t* ro
     GGNN_CHECK_ARG(aligned16(Hrows) && aligned16(out) && (!bias || aligned16(bias)), "pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int D4 = D / 4;
-    if (D4 <= 16) {
+    // lane-per-element when D/4 lanes per node do not tile a wave (D=100: 25 lanes -> 27.9 vs 29.8 us at config 2);
+    // sub-wave-per-node otherwise (D=256, deg 10: 158 vs 166 us at config 5).  GGNN_K2_FLAT=0/1 overrides.
+    static int flat_env = -2;
+    if (flat_env == -2) { const char* e = getenv("GGNN_K2_FLAT"); flat_env = e ? atoi(e) : -1; }
+    const bool flat = flat_env >= 0 ? flat_env != 0 : (D4 < 64 && (64 % D4) != 0);
+    if (flat) {
+        const long long total4 = (long long)V * D4;
+        hipLaunchKernelGGL(gather_segment_sum_flat_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, Hrows,
+                           row_ptr, gather_row, nin, bias, use_avg, out, total4, D, T);
+    } else if (D4 <= 16) {
         hipLaunchKernelGGL(gather_segment_sum_kernel<16>, dim3((V + 15) / 16), dim3(256), 0, st, Hrows, row_ptr,
                            gather_row, nin, bias, use_avg, out, V, D, T);
     } else if (D4 <= 32) {

@@ -440,8 +440,11 @@ class PackedWeights:
     @classmethod
     def _store(cls, table, key, tensors, packed):
         import weakref
-        if len(table) > 64:
-            table.clear()
+        if len(table) >= 64:     # drop the images of weights that no longer exist; never evict a live model's
+            for k in [k for k, (refs, _, _) in table.items() if any(r() is None for r in refs)]:
+                del table[k]
+            if len(table) >= 1024:
+                table.clear()
         table[key] = ([weakref.ref(cls._base(t)) for t in tensors], [t._version for t in tensors], packed)
         return packed
 

@@ -333,6 +333,33 @@ def test_native_driver_equals_python_loop(pkg, oracle, cuda, config):
     np.testing.assert_allclose(native.cpu().numpy(), _oracle_states(oracle, feeds[0], layers, model.params), **MODEL_TOL)
 
 
+def test_forward_is_hip_graph_capturable(pkg, oracle, cuda):
+    """The C ABI promises: asynchronous, no allocation, no sync -- so a whole forward can be captured in a hipGraph
+    (after one eager warm-up that builds the per-batch index and the packed weight images) and replayed."""
+    ms = pkg.synthetic_qm9(300, mean_nodes=14, seed=17)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms)
+    feed = feeds[0]
+    with torch.no_grad():
+        model.feed(feed)
+        eager = model.compute_final_node_representations().clone()       # warm-up: index, compaction, weight images
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            model.feed(feed)
+            captured = model.compute_final_node_representations()
+        captured.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(captured, eager)
+        # replay after changing the input in place: the graph reads the same buffers
+        feed["initial_node_representation"].mul_(0.5)
+        graph.replay()
+        model.feed(feed)
+        again = model.compute_final_node_representations()
+        torch.cuda.synchronize()
+        assert torch.equal(captured, again)
+
+
 def test_two_streams_give_identical_results(pkg, oracle, cuda):
     """Independent batches issued on two HIP streams (bench.py --streams 2) == issued one after the other."""
     ms = pkg.synthetic_qm9(400, mean_nodes=14, seed=12)
