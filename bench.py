@@ -74,6 +74,26 @@ def kernel_model(name, V, M, D, T, R=None):
     raise KeyError(name)
 
 
+def kernel_bytes(name, V, M, D, T, R=None):
+    """Algorithmic (compulsory) HBM bytes per launch: every operand read once, every result written once."""
+    if name == "msg_transform":
+        return float(V * D * 4 + V * T * D * 4)
+    if name == "msg_transform_compact":
+        return float(V * D * 4 + R * 4 + R * D * 4)          # states (each read once) + pair list + compact rows
+    if name == "gather_segment_sum":
+        return float(M * D * 4 + M * 8 + V * D * 4)
+    nx = int(name.split("nx=")[1].rstrip("]"))
+    if name.startswith("gru_fused_gather"):                  # residual segments + h + h_out + gathered rows + slots
+        return float((nx - 1 + 2) * V * D * 4 + M * D * 4 + M * 4 + V * 4 + V * T * 4)
+    if name.startswith("gru_fused"):
+        return float((nx + 2) * V * D * 4)
+    if name.startswith("gru_gates"):
+        return float((nx + 1 + 2) * V * D * 4)
+    if name.startswith("gru_candidate"):
+        return float((nx + 3 + 1) * V * D * 4)
+    raise KeyError(name)
+
+
 def main():
     args = parse_args()
     pkg = importlib.import_module(PKG)
@@ -173,10 +193,28 @@ def main():
                 ach, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBPS, "GB/s"
             kernels[name] = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
                              "avg_us": avg_ms * 1e3, "launches_per_step": len(times) / reps,
-                             "time_share": None, "traffic": None}
+                             "time_share": None, "traffic": None,
+                             "algorithmic_bytes": kernel_bytes(name, Vb, Mb, D, T, Rb),
+                             "hbm_frac": kernel_bytes(name, Vb, Mb, D, T, Rb) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         tot_ms = sum(float(np.sum(t)) for t in res.values())
         for name, times in res.items():
             kernels[name]["time_share"] = float(np.sum(times)) / tot_ms
+        # HBM traffic per launch cannot be read from inside this process: it comes from the committed rocprofv3
+        # PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as MI355X_MICROARCH.md
+        # prescribes for gfx950), same workload, same kernels -- profiles/*_pmc_summary.json
+        pmc_file = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")
+        if os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            for name in kernels:
+                key = {"msg_transform_compact": "msg_transform_compact", "gather_segment_sum": "gather_segment_sum"}.get(name)
+                if key is None and name.startswith("gru_fused"):      # template args <D, NX, NW, SAVE, GATHER>
+                    nx = name.split("nx=")[1].rstrip("]")
+                    tail = "true>" if name.startswith("gru_fused_gather") else "false>"
+                    key = next((k for k in pmc if k.startswith("gru_fused<%d, %s," % (D, nx)) and k.endswith(tail)
+                                and k.count(",") == 4), None)
+                if key in pmc:
+                    kernels[name]["traffic"] = pmc[key]["hbm_bytes_fetch_x2_plus_write"]
+                    kernels[name]["traffic_source"] = "profiles/r01_final_pmc_summary.json"
         dom = max(kernels, key=lambda k: kernels[k]["time_share"])
         out["roofline"] = dict(kernels[dom], kernel=dom)
         out["config"]["active_source_type_pairs_per_batch"] = None if Rb is None else int(Rb)

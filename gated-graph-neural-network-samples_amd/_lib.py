@@ -51,6 +51,8 @@ SYMBOLS = {
     "ggnn_gru_packed_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ggnn_edge_weights_pack_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ggnn_gru_packed_gather_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ggnn_gru_gates_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_void_p]),
     "ggnn_gru_candidate_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -59,7 +61,7 @@ SYMBOLS = {
     "ggnn_sparse_propagate_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int64),
                                           c_void_p, c_int, c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                           POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
-                                          POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int,
+                                          POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int, c_int,
                                           POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
     "ggnn_gru_bwd_stage1_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

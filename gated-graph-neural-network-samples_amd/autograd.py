@@ -32,6 +32,8 @@ def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tens
                                        cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias,
                                        *residual_states)
     D = h.shape[1]
+    # same choice as the native driver (ggnn_propagate.hip): segment sum gathered inside the GRU kernel
+    gather_in_gru = ops.FUSE_GATHER and ops.gru_is_fused(D) and edge_biases is None
     if USE_COMPACT_TRANSFORM and ops.compact_supported(D):
         # transform only the (node, type) pairs that emit a message; the pair list is built once per batch
         comp = getattr(index, "_compact", None)
@@ -39,10 +41,20 @@ def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tens
             comp = index._compact = ops.build_compact_sources(index)
         ew = edge_weights.contiguous()
         Hc = ops.msg_transform_compact_packed(h, _PACKED.edge(ew), ew.shape[0], comp)
-        incoming = ops.gather_segment_sum_compact(Hc, index, comp, nin, edge_biases, use_avg)
+        if gather_in_gru:
+            Hrows, gather_row = Hc, comp.gather_row
+        else:
+            incoming = ops.gather_segment_sum_compact(Hc, index, comp, nin, edge_biases, use_avg)
     else:
         H = ops.msg_transform(h, edge_weights.contiguous())
-        incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
+        if gather_in_gru:
+            Hrows, gather_row = H.view(-1, D), None
+        else:
+            incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
+    if gather_in_gru:
+        packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, len(residual_states) + 1, D)
+        return ops.gru_packed_gather(list(residual_states), h, packed, cell.gates_bias, cell.candidate_bias, Hrows, index,
+                                     gather_row, nin if use_avg else None, activation)
     xs = list(residual_states) + [incoming]
     if ops.gru_is_fused(D):
         packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, len(xs), D)

@@ -259,3 +259,29 @@ extern "C" int ggnn_cudnn_gru_f32(const float* const* x_segs, int nx, const floa
     EpiCudnnCand e{bcx, r, hc, h, u, h_out, D};
     return dispatch_gemm(g, e, st);
 }
+
+// GRU with the segment sum fused in: the aggregated-messages input (the LAST x segment) is not passed but gathered
+// inside the kernel from the transformed-state rows.  x_segs holds the nx-1 residual segments (may be NULL for nx = 1).
+extern "C" int ggnn_gru_packed_gather_f32(const float* const* x_segs, int nx, const float* h, const float* packed,
+                                          const float* bg, const float* bc, float* h_out, const float* Hrows,
+                                          const int32_t* row_ptr, const int32_t* gather_row, const float* nin, int T, int use_avg,
+                                          int V, int D, int act, ggnn_stream_t stream) {
+    if (int rc = check_common(V, D)) return rc;
+    GGNN_CHECK_ARG(nx >= 1 && nx <= 3, "nx %d outside 1..3", nx);
+    GGNN_CHECK_ARG(act == GGNN_ACT_TANH || act == GGNN_ACT_RELU, "unknown activation %d", act);
+    if (!gru_fused_supported(D)) return fail(GGNN_E_UNSUPPORTED, "no fused GRU for hidden size %d", D);
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(h && packed && bg && bc && h_out && h_out != h && Hrows && row_ptr && T > 0, "null pointer or h_out aliases h");
+    GGNN_CHECK_ARG(!use_avg || nin, "nin is required for mean aggregation");
+    GGNN_CHECK_ARG(nx == 1 || x_segs, "residual segments missing");
+    GGNN_CHECK_ARG(aligned16(h) && aligned16(packed) && aligned16(bg) && aligned16(bc) && aligned16(h_out) && aligned16(Hrows),
+                   "pointers must be 16-byte aligned");
+    GruFusedArgs a{};
+    for (int s = 0; s + 1 < nx; ++s) {
+        GGNN_CHECK_ARG(x_segs[s] && aligned16(x_segs[s]) && x_segs[s] != h_out, "residual segment %d null, misaligned or aliasing h_out", s);
+        a.x[s] = x_segs[s];
+    }
+    a.nx = nx; a.h = h; a.bg = bg; a.bc = bc; a.h_out = h_out; a.V = V; a.act = act;
+    a.g_H = Hrows; a.g_row_ptr = row_ptr; a.g_idx = gather_row; a.g_nin = nin; a.g_T = T; a.g_use_avg = use_avg;
+    return gru_fused_dispatch(a, D, const_cast<float*>(packed), (hipStream_t)stream);
+}

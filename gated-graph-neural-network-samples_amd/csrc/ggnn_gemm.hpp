@@ -125,6 +125,8 @@ struct GruFusedArgs {
     const float* Wg; const float* bg; const float* Wc; const float* bc;
     float* h_out; float* save_r; float* save_u; float* save_c;
     int V; int act;
+    // gather-fused variant: the last x segment = segment sum of g_H rows (NULL: plain loads from x[nx-1])
+    const float* g_H; const int* g_row_ptr; const int* g_idx; const float* g_nin; int g_T; int g_use_avg;
     int dbg;               // ablation bitmask from GGNN_GRU_DBG (0 in production)
     unsigned long long* tdbg;   // per-stage s_memtime stamps (GGNN_GRU_TPTR, debug only)
 };

@@ -39,7 +39,11 @@ __global__ void gru_pack_weights_kernel(const float* __restrict__ Wg, const floa
 }
 
 // SAVE: also write r, u, c (all three) for a backward pass.
-template <int D, int NX, int NW, bool SAVE>
+// GATHER: the LAST x segment (the aggregated messages, chem_tensorflow_sparse.py:198-212) is not read from memory but
+// computed on the fly: incoming[row] = (sum over the row's message slots of Hrows[gather_row[slot]]) / (deg + 1e-7),
+// same slot order and arithmetic as ggnn_gather_segment_sum_f32 (bit-identical), fetched in the shadow of the previous
+// stage's MFMAs -- the separate segment-sum launch and the [V,D] round trip of `incoming` through HBM disappear.
+template <int D, int NX, int NW, bool SAVE, bool GATHER>
 __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a, const float* __restrict__ packed) {
     using C = StageCfg<D>;
     constexpr int NT = C::NT, NC = C::NC, NR = C::NR;
@@ -74,10 +78,35 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     // current pass and is drained by that stage's barrier, so stage 0 starts without a vmcnt wait (which
     // would also drain the freshly issued weight DMA); h is loaded at the top of the pass and is not needed
     // before the third stage.
+    auto gather_frag = [&](Frag<D>& f, int r) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) f.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NR; ++q) f.r[q] = 0.f;
+        const int beg = a.g_row_ptr[r], end = a.g_row_ptr[r + 1];
+        for (int e = beg; e < end; ++e) {                       // slot order == reference accumulation order
+            Frag<D> t;
+            load_frag<D>(t, a.g_H, a.g_idx[e], kq);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) f.v[c] += t.v[c];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) f.r[q] += t.r[q];
+        }
+        if (a.g_use_avg) {                                      // :206-209
+            float deg = 0.f;
+            for (int t = 0; t < a.g_T; ++t) deg += a.g_nin[(size_t)r * a.g_T + t];
+            const float den = deg + 1e-7f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) f.v[c] = f.v[c] / den;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) f.r[q] = f.r[q] / den;
+        }
+    };
+#define GGNN_LOAD_X(F, S, R) { if constexpr (GATHER && (S) == NX - 1) gather_frag(F, R); else load_frag<D>(F, a.x[S], R, kq); }
     Frag<D> hf, xf[2];
     if (t_beg + wave < t_end) {
         const int r0 = (t_beg + wave) * 16 + li;
-        load_frag<D>(xf[0], a.x[0], r0 < a.V ? r0 : a.V - 1, kq);
+        GGNN_LOAD_X(xf[0], 0, r0 < a.V ? r0 : a.V - 1)
     }
     __syncthreads();          // (drains the DMA: hipcc emits vmcnt(0) before the barrier while an LDS-DMA is in flight)
 
@@ -115,14 +144,14 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         f32x4 acc_r[NT], acc_u[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { acc_r[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_u[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        if constexpr (NX >= 2) { if (active) load_frag<D>(xf[1], a.x[1], rowc, kq); }
+        if constexpr (NX >= 2) { if (active) GGNN_LOAD_X(xf[1], 1, rowc) }
         GGNN_STAGE(0, acc_r, xf[0]) GGNN_STAGE(1, acc_u, xf[0])
         if constexpr (NX >= 2) {
-            if constexpr (NX >= 3) { if (active) load_frag<D>(xf[0], a.x[2], rowc, kq); }
+            if constexpr (NX >= 3) { if (active) GGNN_LOAD_X(xf[0], 2, rowc) }
             GGNN_STAGE(2, acc_r, xf[1]) GGNN_STAGE(3, acc_u, xf[1])
         }
         if constexpr (NX >= 3) { GGNN_STAGE(4, acc_r, xf[0]) GGNN_STAGE(5, acc_u, xf[0]) }
-        if constexpr (NX >= 2) { if (active) load_frag<D>(xf[0], a.x[0], rowc, kq); }   // for the candidate GEMM
+        if constexpr (NX >= 2) { if (active) GGNN_LOAD_X(xf[0], 0, rowc) }   // for the candidate GEMM
         GGNN_STAGE(2 * NX, acc_r, hf)
         GGNN_STAGE(2 * NX + 1, acc_u, hf)
 
@@ -166,10 +195,10 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         f32x4 acc_c[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc_c[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (NX >= 2) { if (active) load_frag<D>(xf[1], a.x[1], rowc, kq); }
+        if constexpr (NX >= 2) { if (active) GGNN_LOAD_X(xf[1], 1, rowc) }
         GGNN_STAGE(2 * NX + 2, acc_c, xf[0])
         if constexpr (NX >= 2) {
-            if constexpr (NX >= 3) { if (active) load_frag<D>(xf[0], a.x[2], rowc, kq); }
+            if constexpr (NX >= 3) { if (active) GGNN_LOAD_X(xf[0], 2, rowc) }
             GGNN_STAGE(2 * NX + 3, acc_c, xf[1])
         }
         if constexpr (NX >= 3) { GGNN_STAGE(2 * NX + 4, acc_c, xf[0]) }
@@ -177,7 +206,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             const int tile_n = tile + NW;
             if (!last_pass && tile_n < t_end) {
                 const int rn = tile_n * 16 + li;
-                load_frag<D>(xf[0], a.x[0], rn < a.V ? rn : a.V - 1, kq);
+                GGNN_LOAD_X(xf[0], 0, rn < a.V ? rn : a.V - 1)
             }
         }
         GGNN_STAGE(3 * NX + 2, acc_c, rh)
@@ -217,7 +246,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     }
 }
 
-template <int D, int NX, int NW, bool SAVE>
+template <int D, int NX, int NW, bool SAVE, bool GATHER>
 static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t st) {
     using C = StageCfg<D>;
     GruFusedArgs a = a_in;
@@ -237,11 +266,11 @@ static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t
     if (nb > need) nb = need;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        GGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggnn_gru_fused_kernel<D, NX, NW, SAVE>),
+        GGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
+    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
@@ -251,10 +280,19 @@ static int dispatch_nx(const GruFusedArgs& a, float* packed, hipStream_t st) {
     const bool save = a.save_r || a.save_u || a.save_c;
     if (save && !(a.save_r && a.save_u && a.save_c))
         return fail(GGNN_E_INVALID, "save_r / save_u / save_c must be given together");
+    if (a.g_H) {
+        if (save) return fail(GGNN_E_UNSUPPORTED, "the gather-fused GRU has no save_r/u/c variant");
+        switch (a.nx) {
+            case 1: return launch_gru_fused<D, 1, 8, false, true>(a, packed, st);
+            case 2: return launch_gru_fused<D, 2, 8, false, true>(a, packed, st);
+            case 3: return launch_gru_fused<D, 3, 8, false, true>(a, packed, st);
+            default: return fail(GGNN_E_INVALID, "nx %d outside 1..3", a.nx);
+        }
+    }
     switch (a.nx) {
-        case 1: return save ? launch_gru_fused<D, 1, 8, true>(a, packed, st) : launch_gru_fused<D, 1, 8, false>(a, packed, st);
-        case 2: return save ? launch_gru_fused<D, 2, 8, true>(a, packed, st) : launch_gru_fused<D, 2, 8, false>(a, packed, st);
-        case 3: return save ? launch_gru_fused<D, 3, 8, true>(a, packed, st) : launch_gru_fused<D, 3, 8, false>(a, packed, st);
+        case 1: return save ? launch_gru_fused<D, 1, 8, true, false>(a, packed, st) : launch_gru_fused<D, 1, 8, false, false>(a, packed, st);
+        case 2: return save ? launch_gru_fused<D, 2, 8, true, false>(a, packed, st) : launch_gru_fused<D, 2, 8, false, false>(a, packed, st);
+        case 3: return save ? launch_gru_fused<D, 3, 8, true, false>(a, packed, st) : launch_gru_fused<D, 3, 8, false, false>(a, packed, st);
         default: return fail(GGNN_E_INVALID, "nx %d outside 1..3", a.nx);
     }
 }

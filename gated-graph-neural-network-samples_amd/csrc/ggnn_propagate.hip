@@ -3,6 +3,10 @@
 // stream.  The Python host layer would otherwise make ~3 ctypes calls and ~5 tensor allocations per timestep
 // (24 + 40 per 8-step forward, ~1.2 ms of host time against ~1.6 ms of GPU time: the loop was close to
 // host-bound on slow hosts).  No allocation, no sync: scratch comes from the caller.
+//
+// Per timestep it launches either 3 kernels (transform, gather/segment-sum, GRU) or -- with `fuse_gather`, packed
+// GRU weights, a fused hidden size and no edge bias -- 2 kernels (transform, GRU with the segment sum gathered
+// inside: ggnn_gru_packed_gather_f32).
 #include "ggnn_common.h"
 #include <cstring>
 
@@ -28,7 +32,7 @@ extern "C" int ggnn_sparse_propagate_f32(
         int num_layers, const int32_t* layer_timesteps, const int32_t* res_ptr, const int32_t* res_idx,
         const float* const* edge_w, const float* const* edge_packed, const float* const* edge_bias,
         const float* const* Wg, const float* const* bg, const float* const* Wc, const float* const* bc,
-        const float* const* gru_packed, int act,
+        const float* const* gru_packed, int act, int fuse_gather,
         float* const* layer_out, void* ws, size_t ws_bytes, ggnn_stream_t stream) {
     GGNN_CHECK_ARG(V >= 0 && D > 0 && D % 4 == 0 && T > 0, "bad sizes V=%d D=%d T=%d", V, D, T);
     GGNN_CHECK_ARG(num_layers > 0 && layer_timesteps && res_ptr && layer_out, "bad layer description");
@@ -68,6 +72,9 @@ extern "C" int ggnn_sparse_propagate_f32(
         GGNN_CHECK_ARG(layer_out[l], "layer_out[%d] is null", l);
         const float* cur = states[l];              // :152
         const int steps = layer_timesteps[l];
+        const float* bias_l = edge_bias ? edge_bias[l] : nullptr;
+        const bool packed_gru = gru_packed && gru_packed[l] && ggnn_gru_is_fused(D);
+        const bool gather_in_gru = fuse_gather && packed_gru && bias_l == nullptr;
         for (int s = 0; s < steps; ++s) {          // :153
             int rc;
             if (compact) {
@@ -81,15 +88,19 @@ extern "C" int ggnn_sparse_propagate_f32(
                 rc = ggnn_msg_transform_f32(cur, D, edge_w[l], H, V, D, T, stream);
             }
             if (rc) return rc;
-            rc = ggnn_gather_segment_sum_f32(H, row_ptr, gather_row, nin, edge_bias ? edge_bias[l] : nullptr, use_avg,
-                                             incoming, V, D, T, stream);
-            if (rc) return rc;
             float* out = (s + 1 == steps) ? layer_out[l] : ping[s & 1];
-            if (gru_packed && gru_packed[l] && ggnn_gru_is_fused(D))
-                rc = ggnn_gru_packed_f32(xs, nx, cur, gru_packed[l], bg[l], bc[l], out, nullptr, nullptr, nullptr, V, D, act, stream);
-            else
-                rc = ggnn_gru_f32(xs, nx, cur, Wg[l], bg[l], Wc[l], bc[l], out, gru_ws, gru_ws_bytes, nullptr, nullptr,
-                                  nullptr, V, D, act, stream);
+            if (gather_in_gru) {
+                rc = ggnn_gru_packed_gather_f32(xs, nx, cur, gru_packed[l], bg[l], bc[l], out, H, row_ptr, gather_row, nin, T,
+                                                use_avg, V, D, act, stream);
+            } else {
+                rc = ggnn_gather_segment_sum_f32(H, row_ptr, gather_row, nin, bias_l, use_avg, incoming, V, D, T, stream);
+                if (rc) return rc;
+                if (packed_gru)
+                    rc = ggnn_gru_packed_f32(xs, nx, cur, gru_packed[l], bg[l], bc[l], out, nullptr, nullptr, nullptr, V, D, act, stream);
+                else
+                    rc = ggnn_gru_f32(xs, nx, cur, Wg[l], bg[l], Wc[l], bc[l], out, gru_ws, gru_ws_bytes, nullptr, nullptr,
+                                      nullptr, V, D, act, stream);
+            }
             if (rc) return rc;
             cur = out;
         }

@@ -15,6 +15,7 @@ raises if the extension is missing -- there is no CPU path here.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -24,6 +25,8 @@ from . import _lib
 from ._lib import check
 
 ACT_IDS = {"tanh": 0, "relu": 1}
+# sparse_propagate: gather the segment sum inside the fused GRU (2 launches per timestep instead of 3)
+FUSE_GATHER = os.environ.get("GGNN_FUSE_GATHER", "1") != "0"
 
 
 # ---- optional per-launch timing (bench.py's roofline leg) ---------------------------------------------
@@ -522,9 +525,13 @@ def sparse_propagate(h0: torch.Tensor, index: MessageIndex, comp: Optional[Compa
                      edge_w: Sequence[torch.Tensor], edge_packed: Optional[Sequence[torch.Tensor]],
                      edge_bias: Optional[Sequence[Optional[torch.Tensor]]],
                      Wg: Sequence[torch.Tensor], bg: Sequence[torch.Tensor], Wc: Sequence[torch.Tensor], bc: Sequence[torch.Tensor],
-                     gru_packed: Optional[Sequence[torch.Tensor]], activation: str) -> List[torch.Tensor]:
+                     gru_packed: Optional[Sequence[torch.Tensor]], activation: str,
+                     fuse_gather: Optional[bool] = None) -> List[torch.Tensor]:
     """chem_tensorflow_sparse.py:131-218 in ONE native call (ggnn_sparse_propagate_f32): returns
-    node_states_per_layer[1:], the last entry being the final node representations."""
+    node_states_per_layer[1:], the last entry being the final node representations.
+    fuse_gather (default FUSE_GATHER): gather the segment sum inside the GRU kernel where the layer allows it."""
+    if fuse_gather is None:
+        fuse_gather = FUSE_GATHER
     lib = _lib.load()
     _req(h0, torch.float32, "h0")
     V, D = h0.shape
@@ -548,8 +555,29 @@ def sparse_propagate(h0: torch.Tensor, index: MessageIndex, comp: Optional[Compa
         _ptr(h0), V, D, T, _ptr(index.row_ptr), _ptr(gather), None if comp is None else _ptr(comp.pair_node), off,
         _ptr(nin), 1 if use_avg else 0, L, i32([int(x) for x in layer_timesteps]), i32(res_ptr), i32(res_idx),
         _ptr_array(edge_w), _ptr_array(edge_packed), _ptr_array(edge_bias), _ptr_array(Wg), _ptr_array(bg), _ptr_array(Wc),
-        _ptr_array(bc), _ptr_array(gru_packed), act, _ptr_array(outs), _ptr(ws), ws_bytes, _stream()))
+        _ptr_array(bc), _ptr_array(gru_packed), act, 1 if fuse_gather else 0, _ptr_array(outs), _ptr(ws), ws_bytes, _stream()))
     return outs
+
+
+def gru_packed_gather(residual_segs: Sequence[torch.Tensor], h: torch.Tensor, packed: torch.Tensor, bg: torch.Tensor,
+                      bc: torch.Tensor, H: torch.Tensor, index: MessageIndex, gather_row: Optional[torch.Tensor],
+                      num_incoming_edges_per_type: Optional[torch.Tensor], activation: str = "tanh") -> torch.Tensor:
+    """chem_tensorflow_sparse.py:198-216 in one launch (ggnn_gru_packed_gather_f32): the GRU whose last input
+    segment -- the aggregated messages -- is summed from the transformed rows `H` inside the kernel."""
+    lib = _lib.load()
+    _req(h, torch.float32, "h"); _req(H, torch.float32, "H")
+    V, D = h.shape
+    act = ACT_IDS.get(activation.lower())
+    if act is None:
+        raise Exception("Unknown activation function type '%s'." % activation)
+    segs = (ctypes.c_void_p * max(len(residual_segs), 1))(*[s.data_ptr() for s in residual_segs])
+    out = torch.empty_like(h)
+    nin = num_incoming_edges_per_type
+    gather = index.gather_row if gather_row is None else gather_row
+    _launch("gru_fused_gather[nx=%d]" % (len(residual_segs) + 1), lambda: lib.ggnn_gru_packed_gather_f32(
+        segs, len(residual_segs) + 1, _ptr(h), _ptr(packed), _ptr(bg), _ptr(bc), _ptr(out), _ptr(H), _ptr(index.row_ptr),
+        _ptr(gather), None if nin is None else _ptr(nin), index.num_edge_types, 0 if nin is None else 1, V, D, act, _stream()))
+    return out
 
 
 def gated_readout(last_h: torch.Tensor, h0: torch.Tensor, graph_nodes_list: torch.Tensor, num_graphs: int,

@@ -186,6 +186,16 @@ int ggnn_gru_packed_f32(const float* const* x_segs, int nx, const float* h, cons
                         ggnn_stream_t stream);
 int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* packed, ggnn_stream_t stream);
 
+/* GRU with the segment sum fused in (chem_tensorflow_sparse.py:198-216 in one launch, no edge bias): the
+ * aggregated-messages input -- the LAST of the nx concatenated inputs -- is gathered inside the kernel,
+ *   incoming[v] = (sum over the slots row_ptr[v]..row_ptr[v+1] of Hrows[gather_row[slot]]) / (sum_t nin[v,t] + 1e-7),
+ * in the same slot order and arithmetic as ggnn_gather_segment_sum_f32 (bit-identical results), so the separate
+ * segment-sum launch and the HBM round trip of `incoming` disappear.  x_segs: the nx-1 residual segments. */
+int ggnn_gru_packed_gather_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
+                               const float* bc, float* h_out, const float* Hrows, const int32_t* row_ptr,
+                               const int32_t* gather_row, const float* nin, int T, int use_avg, int V, int D, int act,
+                               ggnn_stream_t stream);
+
 /* The two launches of the un-fused ggnn_gru_f32, separately addressable (profiling, large D):
  *   gates:     [r|u] = sigmoid([x|h] Wg + bg) -> rh = r*h [V,D], u [V,D] (save_r optional)
  *   candidate: c = act([x|rh] Wc + bc); h_out = u*h + (1-u)*c            (save_c optional) */
@@ -208,6 +218,8 @@ int ggnn_gru_candidate_f32(const float* const* x_segs, int nx, const float* rh, 
  *   Wg/Wc raw and/or gru_packed (ggnn_gru_pack_weights_f32); bg [2D], bc [D]
  *   layer_out                   HOST [num_layers] of DEVICE [V,D]: node_states_per_layer[l+1]; the last one is
  *                               the function's return value (:218)
+ *   fuse_gather                 nonzero: layers with packed GRU weights, a fused hidden size and no edge bias run
+ *                               2 launches per timestep (transform, ggnn_gru_packed_gather_f32) instead of 3
  *   ws                          ggnn_sparse_propagate_workspace_bytes(V, D, T, compact_rows or -1) bytes
  */
 size_t ggnn_sparse_propagate_workspace_bytes(int V, int D, int T, int64_t compact_rows);
@@ -217,7 +229,7 @@ int ggnn_sparse_propagate_f32(const float* h0, int V, int D, int T,
                               int num_layers, const int32_t* layer_timesteps, const int32_t* res_ptr, const int32_t* res_idx,
                               const float* const* edge_w, const float* const* edge_packed, const float* const* edge_bias,
                               const float* const* Wg, const float* const* bg, const float* const* Wc, const float* const* bc,
-                              const float* const* gru_packed, int act,
+                              const float* const* gru_packed, int act, int fuse_gather,
                               float* const* layer_out, void* ws, size_t ws_bytes, ggnn_stream_t stream);
 
 /* ---- (a-B) element-wise stages of the GRU backward (TF autodiff of GRUCell, chem_tensorflow.py:184) -------

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Reduce the rocprofv3 PMC passes of tools/profile_round.sh to profiles/<round>_pmc_summary.json.
+
+Input: a directory holding {fetch,write,mfma}_counter_collection.csv -- three SEPARATE --pmc passes of the same
+command (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE), as MI355X_MICROARCH.md prescribes.
+Per ggnn kernel (averaged over its launches):
+  hbm_bytes_fetch_x2_plus_write = 2 * FETCH_SIZE_KB * 1024 + WRITE_SIZE_KB * 1024     (gfx950: FETCH_SIZE is doubled)
+  gpu_cycles = GRBM_GUI_ACTIVE / 8 XCDs;  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (gpu_cycles * 1024 SIMDs)
+  avg_us from the dispatch timestamps of the mfma pass (counter collection serialises kernels).
+"""
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short_name(kernel_name):
+    m = re.search(r"ggnn::(\w+?)(?:_kernel)?(<[^(]*>)?\(", kernel_name) or re.search(r"(\w+?)(?:_kernel)?(<[^(]*>)?\(", kernel_name)
+    if not m:
+        return kernel_name
+    base, targs = m.group(1), m.group(2) or ""
+    base = base[5:] if base.startswith("ggnn_") else base
+    return base + (targs if base.startswith("gru_fused") else "")
+
+
+def read_pass(path):
+    per = defaultdict(lambda: defaultdict(list))      # kernel -> counter -> per-dispatch values
+    dur = defaultdict(dict)                           # kernel -> dispatch -> ns
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            name = row["Kernel_Name"]
+            if "ggnn" not in name:
+                continue
+            k = short_name(name)
+            per[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            dur[k][row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+    return per, dur
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    fetch, _ = read_pass(os.path.join(src, "fetch_counter_collection.csv"))
+    write, _ = read_pass(os.path.join(src, "write_counter_collection.csv"))
+    mfma, dur = read_pass(os.path.join(src, "mfma_counter_collection.csv"))
+    mean = lambda xs: sum(xs) / len(xs) if xs else 0.0
+    out = {}
+    for k in sorted(mfma):
+        fkb, wkb = mean(fetch[k]["FETCH_SIZE"]), mean(write[k]["WRITE_SIZE"])
+        cyc = mean(mfma[k]["GRBM_GUI_ACTIVE"]) / 8.0
+        busy = mean(mfma[k]["SQ_VALU_MFMA_BUSY_CYCLES"])
+        us = mean(list(dur[k].values())) / 1e3
+        out[k] = {"FETCH_SIZE_KB": fkb, "WRITE_SIZE_KB": wkb, "hbm_bytes_fetch_x2_plus_write": 2 * fkb * 1024 + wkb * 1024,
+                  "avg_us": us, "launches": len(dur[k]), "mfma_busy_cycles": busy, "gpu_cycles": cyc,
+                  "clock_GHz": cyc / us / 1e3 if us else 0.0, "mfma_util": busy / (cyc * 1024) if cyc else 0.0}
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1)
+    for k, v in out.items():
+        print("%-34s %8.1f us  hbm %7.1f MB  mfma_util %.3f  clk %.2f GHz" % (k, v["avg_us"], v["hbm_bytes_fetch_x2_plus_write"] / 1e6,
+                                                                            v["mfma_util"], v["clock_GHz"]))
+
+
+if __name__ == "__main__":
+    main()
