@@ -49,10 +49,10 @@ SYMBOLS = {
     "ggnn_gru_packed_bytes": (c_size_t, [c_int, c_int]),
     "ggnn_gru_pack_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_gru_packed_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+                                    c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_edge_weights_pack_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_gru_packed_gather_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                           c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                           c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_gru_gates_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_void_p]),
     "ggnn_gru_candidate_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -194,7 +194,7 @@ extern "C" int ggnn_gru_pack_weights_f32(const float* Wg, const float* Wc, int n
 
 extern "C" int ggnn_gru_packed_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
                                    const float* bc, float* h_out, float* save_r, float* save_u, float* save_c, int V, int D,
-                                   int act, ggnn_stream_t stream) {
+                                   int act, int32_t* tile_counter, ggnn_stream_t stream) {
     if (int rc = gru_args_check(x_segs, nx, h, V, D)) return rc;
     GGNN_CHECK_ARG(act == GGNN_ACT_TANH || act == GGNN_ACT_RELU, "unknown activation %d", act);
     if (!gru_fused_supported(D)) return fail(GGNN_E_UNSUPPORTED, "no fused GRU for hidden size %d", D);
@@ -204,7 +204,7 @@ extern "C" int ggnn_gru_packed_f32(const float* const* x_segs, int nx, const flo
     GruFusedArgs a{};
     for (int s = 0; s < nx; ++s) { a.x[s] = x_segs[s]; GGNN_CHECK_ARG(x_segs[s] != h_out, "h_out aliases an input"); }
     a.nx = nx; a.h = h; a.Wg = nullptr; a.Wc = nullptr; a.bg = bg; a.bc = bc; a.h_out = h_out;
-    a.save_r = save_r; a.save_u = save_u; a.save_c = save_c; a.V = V; a.act = act;
+    a.save_r = save_r; a.save_u = save_u; a.save_c = save_c; a.V = V; a.act = act; a.tickets = tile_counter;
     return gru_fused_dispatch(a, D, const_cast<float*>(packed), (hipStream_t)stream);
 }
 
@@ -265,7 +265,7 @@ extern "C" int ggnn_cudnn_gru_f32(const float* const* x_segs, int nx, const floa
 extern "C" int ggnn_gru_packed_gather_f32(const float* const* x_segs, int nx, const float* h, const float* packed,
                                           const float* bg, const float* bc, float* h_out, const float* Hrows,
                                           const int32_t* row_ptr, const int32_t* gather_row, const float* nin, int T, int use_avg,
-                                          int V, int D, int act, ggnn_stream_t stream) {
+                                          int V, int D, int act, int32_t* tile_counter, ggnn_stream_t stream) {
     if (int rc = check_common(V, D)) return rc;
     GGNN_CHECK_ARG(nx >= 1 && nx <= 3, "nx %d outside 1..3", nx);
     GGNN_CHECK_ARG(act == GGNN_ACT_TANH || act == GGNN_ACT_RELU, "unknown activation %d", act);
@@ -283,5 +283,6 @@ extern "C" int ggnn_gru_packed_gather_f32(const float* const* x_segs, int nx, co
     }
     a.nx = nx; a.h = h; a.bg = bg; a.bc = bc; a.h_out = h_out; a.V = V; a.act = act;
     a.g_H = Hrows; a.g_row_ptr = row_ptr; a.g_idx = gather_row; a.g_nin = nin; a.g_T = T; a.g_use_avg = use_avg;
+    a.tickets = tile_counter;
     return gru_fused_dispatch(a, D, const_cast<float*>(packed), (hipStream_t)stream);
 }

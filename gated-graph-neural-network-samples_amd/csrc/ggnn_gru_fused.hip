@@ -13,7 +13,15 @@
 // (ggnn_stage.hpp; stage = one D x D block: the [x_s|h] rows of the r columns, of the u columns, then of
 // Wc).  Stages are brought in by LDS-DMA into a 2-deep ring; the DMA of stage i+1 is issued before the
 // MFMAs of stage i.  Workgroups are persistent over a contiguous, evenly split range of 16-row tiles.
+//
+// Stage ORDER of one pass (3 * (NX+1) stages): every input segment is consumed by three consecutive stages
+//     x_s -> r columns, x_s -> u columns, x_s -> candidate columns          (s = 0 .. NX-1)
+//     h   -> r columns, h   -> u columns, [gates epilogue], r*h -> candidate columns
+// so each x fragment is read from memory once and dies after its third stage; the fragment of the next
+// segment (or of the next pass's first segment) is fetched while the current one is being multiplied.
+// All accumulation orders are those of the plain [x|h] / [x|r*h] products (segments in order, h last).
 #include "ggnn_stage.hpp"
+#include <type_traits>
 
 namespace ggnn {
 
@@ -26,7 +34,7 @@ int gru_pack_floats(int D, int nx) {
     }
 }
 
-// stage ci of the sequence: gates (s = 0..nx) x {r,u}, then candidate (s = 0..nx)
+// image ci of the packed weights: gates (s = 0..nx) x {r,u}, then candidate (s = 0..nx)
 template <int D>
 __global__ void gru_pack_weights_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx,
                                         float* __restrict__ out) {
@@ -38,11 +46,36 @@ __global__ void gru_pack_weights_kernel(const float* __restrict__ Wg, const floa
                         gridDim.x * blockDim.x);
 }
 
+// position in the per-pass stage sequence -> packed image (segment s = pos / 3; 0,1: its r / u gate columns, 2: candidate)
+template <int NX>
+__host__ __device__ constexpr int gru_stage_image(int pos) {
+    return (pos % 3) < 2 ? 2 * (pos / 3) + (pos % 3) : 2 * (NX + 1) + pos / 3;
+}
+
+template <int D>
+__device__ __forceinline__ void frag_zero(Frag<D>& f) {
+#pragma unroll
+    for (int c = 0; c < StageCfg<D>::NC; ++c) f.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < StageCfg<D>::NR; ++q) f.r[q] = 0.f;
+}
+
+template <int D>
+__device__ __forceinline__ void frag_add(Frag<D>& f, const Frag<D>& t) {
+#pragma unroll
+    for (int c = 0; c < StageCfg<D>::NC; ++c) f.v[c] += t.v[c];
+#pragma unroll
+    for (int q = 0; q < StageCfg<D>::NR; ++q) f.r[q] += t.r[q];
+}
+
 // SAVE: also write r, u, c (all three) for a backward pass.
 // GATHER: the LAST x segment (the aggregated messages, chem_tensorflow_sparse.py:198-212) is not read from memory but
 // computed on the fly: incoming[row] = (sum over the row's message slots of Hrows[gather_row[slot]]) / (deg + 1e-7),
-// same slot order and arithmetic as ggnn_gather_segment_sum_f32 (bit-identical), fetched in the shadow of the previous
-// stage's MFMAs -- the separate segment-sum launch and the [V,D] round trip of `incoming` through HBM disappear.
+// same slot order and arithmetic as ggnn_gather_segment_sum_f32 (bit-identical) -- the separate segment-sum launch and
+// the [V,D] round trip of `incoming` through HBM disappear.  The gather is a 3-level dependent chain (row_ptr ->
+// gather_row -> rows); it is software-pipelined over the stage boundaries BEFORE the stage that consumes it: every
+// level is issued at the start of a stage and has landed by that stage's closing barrier, so the MFMAs never wait
+// for it (only slots beyond the pipelined depth, 3 or 5 per row, are fetched synchronously).
 template <int D, int NX, int NW, bool SAVE, bool GATHER>
 __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a, const float* __restrict__ packed) {
     using C = StageCfg<D>;
@@ -50,110 +83,214 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     constexpr int NSTAGE = 3 * (NX + 1);
     constexpr int DMA_PER_WAVE = C::IMG_BYTES / (NW * 1024);
     static_assert(DMA_PER_WAVE <= C::NC * ((NT + 3) / 4), "more DMA pieces than MFMA groups to hide them behind");
-    extern __shared__ __attribute__((aligned(16))) float ring[];    // [2][IMG]
+    extern __shared__ __attribute__((aligned(16))) float lds_[];    // [biases | ring [2][IMG]]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
 
+    // Work is handed out in TICKETS, one per pass of a workgroup.  Full rounds: ticket t = tiles [t*NW, (t+1)*NW),
+    // all waves busy.  The rest (< NW*nb tiles) is spread thin: tail tickets of tail_w = ceil(rest / nb) tiles each, so
+    // the last round keeps every CU busy for as short as possible instead of a few CUs for a whole pass.
+    // Ticket order: workgroup b starts with ticket b; the next ones are b + nb, b + 2nb, ... (a.tickets == NULL), or
+    // come from a global counter (a.tickets: a device int that is 0 at launch).  With the counter a workgroup that
+    // starts late -- another stream held its CU -- simply takes fewer tickets and the launch ends when the tickets
+    // run out, not when the last-started workgroup has worked through a fixed share.
     const int wt_total = (a.V + 15) / 16;
     const int nb = gridDim.x;
-    const int t_beg = (int)(((long long)wt_total * blockIdx.x) / nb);
-    const int t_end = (int)(((long long)wt_total * (blockIdx.x + 1)) / nb);
-    // passes of THIS workgroup: one with fewer tiles leaves early and frees its CU (LDS + registers) for
-    // whatever the other streams have queued, instead of idling through the tail pass of its neighbours
-    const int passes = (t_end - t_beg + NW - 1) / NW;
+    const int full_tk = wt_total / (NW * nb) * nb;
+    const int rest = wt_total - full_tk * NW;
+    const int tail_w = (rest + nb - 1) / nb;                        // 0 (no tail) .. NW
+    const int n_tk = full_tk + (tail_w ? (rest + tail_w - 1) / tail_w : 0);
+    auto tile_of = [&](int t) -> int {                              // this wave's tile of ticket t, or -1
+        if (t < full_tk) return t * NW + wave;
+        const int tl = full_tk * NW + (t - full_tk) * tail_w + wave;
+        return (t < n_tk && wave < tail_w && tl < wt_total) ? tl : -1;
+    };
 
-    // biases live in LDS behind the ring: the epilogues read them with ds_read instead of 7 serialized
+    // biases live in LDS IN FRONT of the ring (small offsets: every epilogue read is one lane register + an
+    // immediate; behind the ring each of the 21 addresses was a loop-invariant register of its own, and those
+    // were spilled to scratch): the epilogues read them with ds_read instead of 7 serialized
     // global round trips per epilogue
-    float* bias_s = ring + 2 * C::IMG;                              // [bg (2D) | bc (D)]
+    constexpr int BIAS_FLOATS = (3 * D + 4 + 63) / 64 * 64;
+    float* bias_s = lds_;                                           // [bg (2D) | bc (D) | next ticket]
+    float* ring = lds_ + BIAS_FLOATS;
+    int* tk_slot = reinterpret_cast<int*>(bias_s + 3 * D);
     for (int i = tid; i < 3 * D; i += NW * 64) bias_s[i] = i < 2 * D ? a.bg[i] : a.bc[i - 2 * D];
+    int tk = blockIdx.x, tk_next = blockIdx.x + nb;                 // current / next pass's ticket (workgroup-uniform)
+    if (a.tickets && tid == 0) *tk_slot = nb + atomicAdd(a.tickets, 1);
 
     int cur = 0;
     dma_stage_image<D, NW>(packed, ring, wave, lane);
 
-    // x fragments rotate through two register sets (the segment after the current one is prefetched);
-    // with more than one x segment they are re-read for the candidate GEMM rather than kept resident.
-    // The NEXT pass's x[0] fragment (needed by its very first MFMA) is fetched during the last stage of the
-    // current pass and is drained by that stage's barrier, so stage 0 starts without a vmcnt wait (which
-    // would also drain the freshly issued weight DMA); h is loaded at the top of the pass and is not needed
-    // before the third stage.
-    auto gather_frag = [&](Frag<D>& f, int r) {
+    // ---- the pipelined gather of the aggregated-messages segment (GATHER) --------------------------------------
+    // Phases, each issued at a stage start and landed by that stage's closing barrier (U = the stage that consumes
+    // the fragment, counted in the consuming pass; a negative position lies in the previous pass):
+    //     U-5 row_ptr + in-degree | U-4 first KI source rows | U-3 rows of slots 0,1 | U-2 add 1, row of slot 2 |
+    //     U-1 add 2, row of slot 3 | U add 3, further slots synchronously, mean
+    // NX == 1 consumes at stage 0 of the NEXT pass (U = NSTAGE: the x fragment is dead after stage 2).
+    constexpr int GSEG = NX - 1, GBUF = GSEG & 1;     // gathered segment and its fragment buffer
+    constexpr int KI = 4;                             // slots covered by the pipeline
+    constexpr int G_U = NX == 1 ? NSTAGE : 3 * (NX - 1);
+    constexpr bool G_NEXT = (NX == 1);                // all phases run one pass ahead of the consumer
+    int g_beg = 0, g_end = 0;
+    int g_i[KI];
+    f32x4 g_n = {0.f, 0.f, 0.f, 0.f};
+    float g_den = 1.f;
+    Frag<D> gt;
+
+    auto g_ptrs = [&](int r, bool on) {               // level 1: slot range + in-degree of row r
+        const int b = a.g_row_ptr[r], e = a.g_row_ptr[r + 1];        // r is a valid (clamped) row even when !on
+        g_beg = on ? b : 0; g_end = on ? e : 0;
+        if (a.g_use_avg) {
+            if (a.g_T == 4) {
+                g_n = ld4(a.g_nin + (unsigned)r * 4u);
+            } else {
+                float deg = 0.f;
+                for (int t = 0; t < a.g_T; ++t) deg += a.g_nin[(size_t)r * a.g_T + t];
+                g_n = f32x4{deg, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto g_index = [&]() {                            // level 2: the first KI source rows
+#pragma unroll
+        for (int j = 0; j < KI; ++j)
+            if (g_beg + j < g_end) g_i[j] = a.g_idx[g_beg + j];
+        g_den = (((g_n.x + g_n.y) + g_n.z) + g_n.w) + 1e-7f;    // the in-degrees landed with the slot range
+    };
+    auto g_rows0 = [&](Frag<D>& f) {                  // level 3: slot 0 straight into f, slot 1 into the temporary
 #pragma unroll
         for (int c = 0; c < NC; ++c) f.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < NR; ++q) f.r[q] = 0.f;
-        const int beg = a.g_row_ptr[r], end = a.g_row_ptr[r + 1];
-        for (int e = beg; e < end; ++e) {                       // slot order == reference accumulation order
-            Frag<D> t;
-            load_frag<D>(t, a.g_H, a.g_idx[e], kq);
+        frag_zero<D>(gt);                             // (ends the live range of the previous tile's temporary)
+        if (g_beg < g_end) load_frag<D>(f, a.g_H, g_i[0], kq);
+        if (g_beg + 1 < g_end) load_frag<D>(gt, a.g_H, g_i[1], kq);
+    };
+    auto g_rows = [&](Frag<D>& f, int k) {            // add slot k-1 (landed), fetch slot k
+        if (k == 2) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) f.v[c] += t.v[c];
+            for (int c = 0; c < NC; ++c) f.v[c] = f.v[c] + 0.f;      // 0 + slot 0, as the segment-sum kernel starts
 #pragma unroll
-            for (int q = 0; q < NR; ++q) f.r[q] += t.r[q];
+            for (int q = 0; q < NR; ++q) f.r[q] = f.r[q] + 0.f;
         }
-        if (a.g_use_avg) {                                      // :206-209
-            float deg = 0.f;
-            for (int t = 0; t < a.g_T; ++t) deg += a.g_nin[(size_t)r * a.g_T + t];
-            const float den = deg + 1e-7f;
+        if (g_beg + k - 1 < g_end) frag_add<D>(f, gt);
+        if (g_beg + k < g_end) load_frag<D>(gt, a.g_H, g_i[k], kq);
+    };
+    auto g_finish = [&](Frag<D>& f) {                 // slot 3, any further slots (synchronously), mean
+        if (g_beg + KI - 1 < g_end) frag_add<D>(f, gt);
+        for (int e = g_beg + KI; e < g_end; ++e) {
+            load_frag<D>(gt, a.g_H, a.g_idx[e], kq);
+            frag_add<D>(f, gt);
+        }
+        if (a.g_use_avg) {                                            // :206-209
 #pragma unroll
-            for (int c = 0; c < NC; ++c) f.v[c] = f.v[c] / den;
+            for (int c = 0; c < NC; ++c) f.v[c] = f.v[c] / g_den;
 #pragma unroll
-            for (int q = 0; q < NR; ++q) f.r[q] = f.r[q] / den;
+            for (int q = 0; q < NR; ++q) f.r[q] = f.r[q] / g_den;
         }
     };
-#define GGNN_LOAD_X(F, S, R) { if constexpr (GATHER && (S) == NX - 1) gather_frag(F, R); else load_frag<D>(F, a.x[S], R, kq); }
+
+    // x fragments rotate through two register sets: segment s lives in xf[s & 1].
     Frag<D> hf, xf[2];
-    if (t_beg + wave < t_end) {
-        const int r0 = (t_beg + wave) * 16 + li;
-        GGNN_LOAD_X(xf[0], 0, r0 < a.V ? r0 : a.V - 1)
+    {
+        const int t0 = tile_of(tk);
+        const bool on = t0 >= 0;
+        const int r0 = (on ? t0 : 0) * 16 + li;
+        const int r0c = r0 < a.V ? r0 : a.V - 1;
+        if constexpr (GATHER) {                       // first tile: the phases of the previous pass, synchronously
+            if constexpr (G_NEXT) {
+                g_ptrs(r0c, on);
+                if (on) { g_index(); g_rows0(xf[0]); g_rows(xf[0], 2); g_rows(xf[0], 3); g_finish(xf[0]); }
+            } else {
+                if constexpr (G_U - 5 < 0) g_ptrs(r0c, on);
+                if constexpr (G_U - 4 < 0) { if (on) g_index(); }
+                load_frag<D>(xf[0], a.x[0], r0c, kq);
+            }
+        } else {
+            load_frag<D>(xf[0], a.x[0], r0c, kq);
+        }
     }
     __syncthreads();          // (drains the DMA: hipcc emits vmcnt(0) before the barrier while an LDS-DMA is in flight)
 
-    for (int p = 0; p < passes; ++p) {
-        const int tile = t_beg + p * NW + wave;
-        const bool active = tile < t_end;                      // wave-uniform
-        const int row = tile * 16 + li;
-        const int rowc = active ? (row < a.V ? row : a.V - 1) : 0;
-        const bool last_pass = (p + 1 == passes);
-        if (active) load_frag<D>(hf, a.h, rowc, kq);
+    if (a.tickets) tk_next = __builtin_amdgcn_readfirstlane(*tk_slot);
+
+    for (int p = 0; tk < n_tk; ++p) {
+        const int tile_ = tile_of(tk);
+        const bool active = tile_ >= 0;                        // wave-uniform
+        const int tile = active ? tile_ : 0;
+        const int row = active ? tile * 16 + li : a.V;         // (>= V: nothing is stored)
+        const int rowc = row < a.V ? row : a.V - 1;
+        const bool last_pass = tk_next >= n_tk;
+        const int tile_n = last_pass ? -1 : tile_of(tk_next);
+        const bool has_next = tile_n >= 0;
+        const int rown_ = (has_next ? tile_n : 0) * 16 + li;
+        const int rown = rown_ < a.V ? rown_ : a.V - 1;
+        // the ticket after the next one: requested now, published before the last stage's barrier, read after it
+        int tk_fetch = 0;
+        if (a.tickets && tid == 0) tk_fetch = atomicAdd(a.tickets, 1);
+
+        // what is fetched at the START of stage POS (it lands in the shadow of that stage's MFMAs and is drained
+        // by its closing barrier)
+        auto prefetch = [&](auto posc) {
+            constexpr int POS = decltype(posc)::value;
+            constexpr int s = POS / 3, j = POS % 3;
+            if constexpr (GATHER) {
+                // a phase at position v < 0 (or any phase when G_NEXT) runs one pass ahead, for the next tile's row
+                constexpr int P_PTR = G_U - 5, P_IDX = G_U - 4, P_R0 = G_U - 3, P_R1 = G_U - 2, P_R2 = G_U - 1;
+                if constexpr (POS == G_U % NSTAGE) { if (active && (!G_NEXT || p > 0)) g_finish(xf[GBUF]); }
+                if constexpr (POS == (P_PTR + NSTAGE) % NSTAGE) {
+                    if constexpr (G_NEXT || P_PTR < 0) g_ptrs(rown, has_next);
+                    else g_ptrs(rowc, active);
+                }
+                if constexpr (POS == (P_IDX + NSTAGE) % NSTAGE) g_index();
+                if constexpr (POS == (P_R0 + NSTAGE) % NSTAGE) g_rows0(xf[GBUF]);
+                if constexpr (POS == (P_R1 + NSTAGE) % NSTAGE) g_rows(xf[GBUF], 2);
+                if constexpr (POS == (P_R2 + NSTAGE) % NSTAGE) g_rows(xf[GBUF], 3);
+            }
+            // h: one stage before its first use (kept out of the registers until then)
+            if constexpr (POS == 3 * NX - 1) load_frag<D>(hf, a.h, rowc, kq);
+            // the next plain segment, one stage before its first use
+            if constexpr (j == 2 && s + 1 < NX && !(GATHER && s + 1 == GSEG)) load_frag<D>(xf[(s + 1) & 1], a.x[s + 1], rowc, kq);
+            // the next pass's first segment (xf[0] is dead by the last stage)
+            if constexpr (POS == NSTAGE - 1 && !(GATHER && GSEG == 0)) load_frag<D>(xf[0], a.x[0], rown, kq);
+        };
 
 #define GGNN_T(CI, K) if (a.tdbg && blockIdx.x == 0 && lane == 0) a.tdbg[((p * NSTAGE + (CI)) * NW + wave) * 4 + (K)] = __builtin_amdgcn_s_memtime();
-        // one stage: start the DMA of the next image, MFMAs on the current one, publish
-#define GGNN_STAGE(CI, ACC, FRAG)                                                                        \
+        // one stage: prefetches, start the DMA of the next image, MFMAs on the current one, publish
+#define GGNN_STAGE(POS, ACC, FRAG)                                                                       \
         {                                                                                                \
-            constexpr int nci_ = (CI) + 1;                                                               \
-            const bool more_ = (nci_ < NSTAGE) || !last_pass;                                            \
-            const float* nsrc_ = packed + (size_t)(nci_ < NSTAGE ? nci_ : 0) * C::IMG;                   \
+            constexpr int npos_ = (POS) + 1;                                                             \
+            const bool more_ = (npos_ < NSTAGE) || !last_pass;                                           \
+            const float* nsrc_ = packed + (size_t)gru_stage_image<NX>(npos_ < NSTAGE ? npos_ : 0) * C::IMG; \
             float* ndst_ = ring + (cur ^ 1) * C::IMG;                                                    \
-            GGNN_T(CI, 0)                                                                                \
+            GGNN_T(POS, 0)                                                                               \
+            prefetch(std::integral_constant<int, (POS)>{});                                              \
             /* whole next image up front (spreading the 6 DMA instructions over the MFMA groups via the   \
                stage_mma hook measured slower: 152 vs 146 us at nx=1, 323 vs 277 us at nx=3) */          \
             /* (letting only one wave per SIMD pair issue the DMA measured no better: 150 vs 147 us) */  \
             if (more_) dma_stage_image<D, NW>(nsrc_, ndst_, wave, lane);                                 \
-            GGNN_T(CI, 1)                                                                                \
+            GGNN_T(POS, 1)                                                                               \
             __builtin_amdgcn_sched_barrier(0);   /* keep the DMA issue AHEAD of the MFMA block */        \
             if (active && !(a.dbg & 1)) stage_mma<D>(ACC, FRAG, ring + cur * C::IMG, li, kq);            \
-            GGNN_T(CI, 2)                                                                                \
+            GGNN_T(POS, 2)                                                                               \
             __syncthreads();                                                                             \
-            GGNN_T(CI, 3)                                                                                \
+            GGNN_T(POS, 3)                                                                               \
             cur ^= 1;                                                                                    \
         }
 
-        // ---- gates: [x | h] Wg, r columns then u columns of each K segment --------------------------
-        f32x4 acc_r[NT], acc_u[NT];
+        f32x4 acc_r[NT], acc_u[NT], acc_c[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { acc_r[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_u[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        if constexpr (NX >= 2) { if (active) GGNN_LOAD_X(xf[1], 1, rowc) }
-        GGNN_STAGE(0, acc_r, xf[0]) GGNN_STAGE(1, acc_u, xf[0])
-        if constexpr (NX >= 2) {
-            if constexpr (NX >= 3) { if (active) GGNN_LOAD_X(xf[0], 2, rowc) }
-            GGNN_STAGE(2, acc_r, xf[1]) GGNN_STAGE(3, acc_u, xf[1])
+        for (int nt = 0; nt < NT; ++nt) {
+            acc_r[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_u[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_c[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if constexpr (NX >= 3) { GGNN_STAGE(4, acc_r, xf[0]) GGNN_STAGE(5, acc_u, xf[0]) }
-        if constexpr (NX >= 2) { if (active) GGNN_LOAD_X(xf[0], 0, rowc) }   // for the candidate GEMM
-        GGNN_STAGE(2 * NX, acc_r, hf)
-        GGNN_STAGE(2 * NX + 1, acc_u, hf)
+        // ---- x segments: r, u and candidate columns of each -------------------------------------------
+        GGNN_STAGE(0, acc_r, xf[0]) GGNN_STAGE(1, acc_u, xf[0]) GGNN_STAGE(2, acc_c, xf[0])
+        if constexpr (NX >= 2) { GGNN_STAGE(3, acc_r, xf[1]) GGNN_STAGE(4, acc_u, xf[1]) GGNN_STAGE(5, acc_c, xf[1]) }
+        if constexpr (NX >= 3) { GGNN_STAGE(6, acc_r, xf[0]) GGNN_STAGE(7, acc_u, xf[0]) GGNN_STAGE(8, acc_c, xf[0]) }
+        // ---- h: r and u columns -----------------------------------------------------------------------------
+        GGNN_STAGE(3 * NX, acc_r, hf)
+        GGNN_STAGE(3 * NX + 1, acc_u, hf)
 
         // ---- r = sigmoid(.), u = sigmoid(.), rh = r*h in activation-fragment layout -------------------
         Frag<D> rh;
@@ -191,26 +328,12 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             }
         }
 
-        // ---- candidate: [x | r*h] Wc --------------------------------------------------------------------
-        f32x4 acc_c[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc_c[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (NX >= 2) { if (active) GGNN_LOAD_X(xf[1], 1, rowc) }
-        GGNN_STAGE(2 * NX + 2, acc_c, xf[0])
-        if constexpr (NX >= 2) {
-            if constexpr (NX >= 3) { if (active) GGNN_LOAD_X(xf[0], 2, rowc) }
-            GGNN_STAGE(2 * NX + 3, acc_c, xf[1])
-        }
-        if constexpr (NX >= 3) { GGNN_STAGE(2 * NX + 4, acc_c, xf[0]) }
-        {   // next pass's fragments ride under the last stage's MFMAs (xf[0] is dead from here on)
-            const int tile_n = tile + NW;
-            if (!last_pass && tile_n < t_end) {
-                const int rn = tile_n * 16 + li;
-                GGNN_LOAD_X(xf[0], 0, rn < a.V ? rn : a.V - 1)
-            }
-        }
+        // ---- candidate: the r*h rows of Wc ----------------------------------------------------------------
+        if (a.tickets && tid == 0) tk_slot[(p + 1) & 1] = nb + tk_fetch;
         GGNN_STAGE(3 * NX + 2, acc_c, rh)
 #undef GGNN_STAGE
+        tk = tk_next;
+        tk_next = a.tickets ? __builtin_amdgcn_readfirstlane(tk_slot[(p + 1) & 1]) : tk_next + nb;
 
         // ---- c = act(.), h' = u*h + (1-u)*c ----------------------------------------------------------------
         // remainder tile: lane (li,kq) needs h cols 16NC + 4kq + e = remainder frag q = kq of lane (li, e);
@@ -259,7 +382,7 @@ static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t
     if (a.h == nullptr) return GGNN_OK;   // pack-only call
     if ((unsigned long long)a.V * D >= (1ULL << 32))
         return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit element offsets: V*D must be < 2^32 (V=%d, D=%d)", a.V, D);
-    const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)(3 * D * sizeof(float) + 15) / 16 * 16;   // ring + biases
+    const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)((3 * D + 4 + 63) / 64 * 64) * sizeof(float);   // biases, ticket slots + ring
     const int wt_total = (a.V + 15) / 16;
     int nb = num_cus();
     const int need = (wt_total + NW - 1) / NW;

@@ -10,13 +10,16 @@
 #include "ggnn_common.h"
 #include <cstring>
 
+static constexpr int kTileCounters = 1024;     // timesteps per call that get a dynamic tile counter (the rest split statically)
+
 extern "C" size_t ggnn_sparse_propagate_workspace_bytes(int V, int D, int T, int64_t compact_rows) {
     if (V < 0 || D <= 0 || T <= 0) return 0;
     const size_t vd = (size_t)V * D * sizeof(float);
     const size_t hrows = compact_rows >= 0 ? (size_t)(compact_rows > 0 ? compact_rows : 1) * D * sizeof(float)
                                            : (size_t)V * T * D * sizeof(float);
-    // transformed states + incoming + two ping-pong states + GRU scratch (un-fused sizes) + 256-B alignment slack
-    return hrows + 3 * vd + ggnn_gru_workspace_bytes(V, D) + 5 * 256;
+    // transformed states + incoming + two ping-pong states + GRU scratch (un-fused sizes) + tile counters of the
+    // fused GRU launches (one int32 per timestep) + 256-B alignment slack
+    return hrows + 3 * vd + ggnn_gru_workspace_bytes(V, D) + kTileCounters * sizeof(int32_t) + 6 * 256;
 }
 
 static inline char* bump(char*& p, size_t bytes) {
@@ -52,8 +55,16 @@ extern "C" int ggnn_sparse_propagate_f32(
     float* incoming = reinterpret_cast<float*>(bump(p, vd));
     float* ping[2] = {reinterpret_cast<float*>(bump(p, vd)), nullptr};
     ping[1] = reinterpret_cast<float*>(bump(p, vd));
+    int32_t* counters = reinterpret_cast<int32_t*>(bump(p, kTileCounters * sizeof(int32_t)));
     void* gru_ws = p;
     const size_t gru_ws_bytes = ggnn_gru_workspace_bytes(V, D);
+    int step_no = 0;
+    {
+        int total_steps = 0;
+        for (int l = 0; l < num_layers; ++l) total_steps += layer_timesteps[l] > 0 ? layer_timesteps[l] : 0;
+        if (total_steps > kTileCounters) total_steps = kTileCounters;
+        if (total_steps > 0) GGNN_CHECK_HIP(hipMemsetAsync(counters, 0, (size_t)total_steps * sizeof(int32_t), (hipStream_t)stream));
+    }
 
     const float* states[64];                       // node_states_per_layer (:118-119, :152)
     GGNN_CHECK_ARG(num_layers < 63, "too many layers");
@@ -89,14 +100,18 @@ extern "C" int ggnn_sparse_propagate_f32(
             }
             if (rc) return rc;
             float* out = (s + 1 == steps) ? layer_out[l] : ping[s & 1];
+            static const bool dyn_tiles = [] { const char* e = getenv("GGNN_DYN_TILES"); return !e || atoi(e) != 0; }();
+            int32_t* counter = (dyn_tiles && step_no < kTileCounters) ? counters + step_no : nullptr;
+            ++step_no;
             if (gather_in_gru) {
                 rc = ggnn_gru_packed_gather_f32(xs, nx, cur, gru_packed[l], bg[l], bc[l], out, H, row_ptr, gather_row, nin, T,
-                                                use_avg, V, D, act, stream);
+                                                use_avg, V, D, act, counter, stream);
             } else {
                 rc = ggnn_gather_segment_sum_f32(H, row_ptr, gather_row, nin, bias_l, use_avg, incoming, V, D, T, stream);
                 if (rc) return rc;
                 if (packed_gru)
-                    rc = ggnn_gru_packed_f32(xs, nx, cur, gru_packed[l], bg[l], bc[l], out, nullptr, nullptr, nullptr, V, D, act, stream);
+                    rc = ggnn_gru_packed_f32(xs, nx, cur, gru_packed[l], bg[l], bc[l], out, nullptr, nullptr, nullptr, V, D, act,
+                                             counter, stream);
                 else
                     rc = ggnn_gru_f32(xs, nx, cur, Wg[l], bg[l], Wc[l], bc[l], out, gru_ws, gru_ws_bytes, nullptr, nullptr,
                                       nullptr, V, D, act, stream);

@@ -94,7 +94,10 @@ __device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const F
     // Explicit one-group-ahead software pipeline with bounded register use: the weight operands of group
     // gi+1 (<= 4 tiles, 16 VGPRs) are read while the <= 16 MFMAs of group gi issue; a scheduling barrier per
     // group stops the compiler from hoisting further reads (which drove the kernel into scratch spills).
-    constexpr int G = 4;
+#ifndef GGNN_STAGE_G
+#define GGNN_STAGE_G 4
+#endif
+    constexpr int G = GGNN_STAGE_G;
     constexpr int GPC = (NTM + G - 1) / G;                   // groups per k-chunk
     constexpr int NG = C::NC * GPC;
     const f32x4* tbase = reinterpret_cast<const f32x4*>(img) + kq * C::BN + 16 * C::NC;   // tail columns, no lane offset

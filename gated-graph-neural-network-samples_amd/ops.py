@@ -478,8 +478,10 @@ class PackedWeights:
 
 
 def gru_packed(x_segs: Sequence[torch.Tensor], h: torch.Tensor, packed: torch.Tensor, bg: torch.Tensor, bc: torch.Tensor,
-               activation: str = "tanh", out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """ops.gru with pre-packed weight images (fused hidden sizes only)."""
+               activation: str = "tanh", out: Optional[torch.Tensor] = None,
+               tile_counter: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ops.gru with pre-packed weight images (fused hidden sizes only).  tile_counter: optional int32 device tensor
+    holding 0 (one element, consumed by this launch): dynamic tile hand-out, see include/ggnn_hip.h."""
     lib = _lib.load()
     _req(h, torch.float32, "h")
     V, D = h.shape
@@ -495,7 +497,7 @@ def gru_packed(x_segs: Sequence[torch.Tensor], h: torch.Tensor, packed: torch.Te
         out = torch.empty_like(h)
     segs = (ctypes.c_void_p * nx)(*[x.data_ptr() for x in x_segs])
     _launch("gru_fused[nx=%d]" % nx, lambda: lib.ggnn_gru_packed_f32(
-        segs, nx, _ptr(h), _ptr(packed), _ptr(bg), _ptr(bc), _ptr(out), None, None, None, V, D, act, _stream()))
+        segs, nx, _ptr(h), _ptr(packed), _ptr(bg), _ptr(bc), _ptr(out), None, None, None, V, D, act, _ptr(tile_counter), _stream()))
     return out
 
 
@@ -561,7 +563,8 @@ def sparse_propagate(h0: torch.Tensor, index: MessageIndex, comp: Optional[Compa
 
 def gru_packed_gather(residual_segs: Sequence[torch.Tensor], h: torch.Tensor, packed: torch.Tensor, bg: torch.Tensor,
                       bc: torch.Tensor, H: torch.Tensor, index: MessageIndex, gather_row: Optional[torch.Tensor],
-                      num_incoming_edges_per_type: Optional[torch.Tensor], activation: str = "tanh") -> torch.Tensor:
+                      num_incoming_edges_per_type: Optional[torch.Tensor], activation: str = "tanh",
+                      tile_counter: Optional[torch.Tensor] = None) -> torch.Tensor:
     """chem_tensorflow_sparse.py:198-216 in one launch (ggnn_gru_packed_gather_f32): the GRU whose last input
     segment -- the aggregated messages -- is summed from the transformed rows `H` inside the kernel."""
     lib = _lib.load()
@@ -576,7 +579,8 @@ def gru_packed_gather(residual_segs: Sequence[torch.Tensor], h: torch.Tensor, pa
     gather = index.gather_row if gather_row is None else gather_row
     _launch("gru_fused_gather[nx=%d]" % (len(residual_segs) + 1), lambda: lib.ggnn_gru_packed_gather_f32(
         segs, len(residual_segs) + 1, _ptr(h), _ptr(packed), _ptr(bg), _ptr(bc), _ptr(out), _ptr(H), _ptr(index.row_ptr),
-        _ptr(gather), None if nin is None else _ptr(nin), index.num_edge_types, 0 if nin is None else 1, V, D, act, _stream()))
+        _ptr(gather), None if nin is None else _ptr(nin), index.num_edge_types, 0 if nin is None else 1, V, D, act,
+        _ptr(tile_counter), _stream()))
     return out
 
 

@@ -178,12 +178,15 @@ int ggnn_gru_is_fused(int D);
  *   ggnn_gru_pack_weights_f32   Wg [(nx+1)D,2D], Wc [(nx+1)D,D] -> packed (ggnn_gru_packed_bytes(D,nx) bytes)
  *   ggnn_gru_packed_f32         == ggnn_gru_f32 with the packed images instead of Wg / Wc (fused sizes only)
  *   ggnn_edge_weights_pack_f32  W [T,D,D] -> packed (ggnn_msg_transform_compact_workspace_bytes(D,T) bytes);
- *                               then call ggnn_msg_transform_compact_f32 with W = NULL and ws = packed. */
+ *                               then call ggnn_msg_transform_compact_f32 with W = NULL and ws = packed.
+ * tile_counter (ggnn_gru_packed_f32, ggnn_gru_packed_gather_f32): NULL, or a DEVICE int32 that is 0 when the launch
+ * starts (the kernel leaves it non-zero).  With a counter the 16-row tiles are handed to the workgroups dynamically:
+ * same results, but the launch no longer stretches when other streams hold part of the GPU while it starts. */
 size_t ggnn_gru_packed_bytes(int D, int nx);
 int ggnn_gru_pack_weights_f32(const float* Wg, const float* Wc, int nx, int D, float* packed, ggnn_stream_t stream);
 int ggnn_gru_packed_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
                         const float* bc, float* h_out, float* save_r, float* save_u, float* save_c, int V, int D, int act,
-                        ggnn_stream_t stream);
+                        int32_t* tile_counter, ggnn_stream_t stream);
 int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* packed, ggnn_stream_t stream);
 
 /* GRU with the segment sum fused in (chem_tensorflow_sparse.py:198-216 in one launch, no edge bias): the
@@ -194,7 +197,7 @@ int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* packed, ggnn
 int ggnn_gru_packed_gather_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
                                const float* bc, float* h_out, const float* Hrows, const int32_t* row_ptr,
                                const int32_t* gather_row, const float* nin, int T, int use_avg, int V, int D, int act,
-                               ggnn_stream_t stream);
+                               int32_t* tile_counter, ggnn_stream_t stream);
 
 /* The two launches of the un-fused ggnn_gru_f32, separately addressable (profiling, large D):
  *   gates:     [r|u] = sigmoid([x|h] Wg + bg) -> rh = r*h [V,D], u [V,D] (save_r optional)

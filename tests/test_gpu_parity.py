@@ -304,6 +304,12 @@ def test_gru_with_gathered_segment_sum(pkg, oracle, cuda, V, M, D, T, R, avg):
     want = pkg.ops.gru_packed(res + [incoming], hd, packed, bgd, bcd)
     got = pkg.ops.gru_packed_gather(res, hd, packed, bgd, bcd, H.view(V * T, D), index, None, nd)
     assert torch.equal(got, want)
+    # dynamic tile hand-out (a zeroed device counter per launch): same tiles, same results
+    cnt = torch.zeros(2, dtype=torch.int32, device=cuda)
+    got_dyn = pkg.ops.gru_packed_gather(res, hd, packed, bgd, bcd, H.view(V * T, D), index, None, nd, tile_counter=cnt[0:1])
+    want_dyn = pkg.ops.gru_packed(res + [incoming], hd, packed, bgd, bcd, tile_counter=cnt[1:2])
+    assert torch.equal(got_dyn, want) and torch.equal(want_dyn, want)
+    assert int(cnt[0]) > 0 and int(cnt[1]) > 0
     ref = oracle.gru_cell(np.concatenate([r.cpu().numpy() for r in res] + [incoming.cpu().numpy()], axis=1).astype(np.float64),
                           h.astype(np.float64), Wg.astype(np.float64), bg.astype(np.float64), Wc.astype(np.float64),
                           bc.astype(np.float64))[0]
