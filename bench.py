@@ -139,10 +139,10 @@ def main():
                 s.wait_stream(torch.cuda.current_stream())
         for i in range(args.warmup):
             step(i)
-        # The synthetic dataset is millions of Python objects (lists of graphs, like the reference's
-        # process_raw_graphs output): one generation-2 pass of the cyclic garbage collector over them blocks the
-        # host for ~45 ms, the launch queue runs dry, and a 70 ms timed region reads 30-40 % slow
-        # (tools/stream_jitter.py shows the single gap).  Nothing in the timed region creates cycles.
+        # One generation-2 pass of Python's cyclic garbage collector over the interpreter's long-lived objects
+        # (torch, numpy, the model) blocks the host for ~45 ms; the launch queue runs dry and a 70-140 ms timed
+        # region reads 20-40 % slow, depending on where the allocation counter happens to trip
+        # (tools/stream_jitter.py shows the single gap).  Nothing in the timed region creates reference cycles.
         gc.collect()
         gc.freeze()
         gc.disable()

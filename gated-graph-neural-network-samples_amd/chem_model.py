@@ -272,6 +272,11 @@ class ChemModel(object):
         """chem_tensorflow.py:255-307."""
         log_to_save = []
         total_time_start = time.time()
+        # Move everything alive so far (torch, the datasets, the model) out of the cyclic collector's reach: a full
+        # collection over them stalls the launching thread for tens of ms, during which the GPU queue runs dry.
+        import gc
+        gc.collect()
+        gc.freeze()
         if self.args.get('--restore') is not None:
             _, valid_accs, _, _, steps = self.run_epoch("Resumed (validation)", self.valid_data, False)
             best_val_acc = np.sum(valid_accs)
