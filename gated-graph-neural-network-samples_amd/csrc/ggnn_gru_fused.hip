@@ -88,6 +88,10 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
+    if (a.tdbg && tid == 0) {   // debug: per-workgroup [start, end] in shader-clock and 100 MHz real-time ticks
+        a.tdbg[4096 + blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+        a.tdbg[4096 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 
     // Work is handed out in TICKETS, one per pass of a workgroup.  Full rounds: ticket t = tiles [t*NW, (t+1)*NW),
     // all waves busy.  The rest (< NW*nb tiles) is spread thin: tail tickets of tail_w = ceil(rest / nb) tiles each, so
@@ -117,6 +121,10 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     float* ring = lds_ + BIAS_FLOATS;
     int* tk_slot = reinterpret_cast<int*>(bias_s + 3 * D);
     for (int i = tid; i < 3 * D; i += NW * 64) bias_s[i] = i < 2 * D ? a.bg[i] : a.bc[i - 2 * D];
+    // The two waves of a SIMD (w and w + NW/2) do not interleave on the matrix pipe: the older one issues its whole
+    // MFMA burst first.  The stage loop leans on that: the waves of the first half ("early") burst first and do
+    // their side work afterwards, the second half ("late") the other way round.
+    const bool late = wave >= NW / 2;
     int tk = blockIdx.x, tk_next = blockIdx.x + nb;                 // current / next pass's ticket (workgroup-uniform)
     if (a.tickets && tid == 0) *tk_slot = nb + atomicAdd(a.tickets, 1);
 
@@ -238,7 +246,6 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             if constexpr (GATHER) {
                 // a phase at position v < 0 (or any phase when G_NEXT) runs one pass ahead, for the next tile's row
                 constexpr int P_PTR = G_U - 5, P_IDX = G_U - 4, P_R0 = G_U - 3, P_R1 = G_U - 2, P_R2 = G_U - 1;
-                if constexpr (POS == G_U % NSTAGE) { if (active && (!G_NEXT || p > 0)) g_finish(xf[GBUF]); }
                 if constexpr (POS == (P_PTR + NSTAGE) % NSTAGE) {
                     if constexpr (G_NEXT || P_PTR < 0) g_ptrs(rown, has_next);
                     else g_ptrs(rowc, active);
@@ -265,14 +272,25 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             const float* nsrc_ = packed + (size_t)gru_stage_image<NX>(npos_ < NSTAGE ? npos_ : 0) * C::IMG; \
             float* ndst_ = ring + (cur ^ 1) * C::IMG;                                                    \
             GGNN_T(POS, 0)                                                                               \
-            prefetch(std::integral_constant<int, (POS)>{});                                              \
-            /* whole next image up front (spreading the 6 DMA instructions over the MFMA groups via the   \
-               stage_mma hook measured slower: 152 vs 146 us at nx=1, 323 vs 277 us at nx=3) */          \
-            /* (letting only one wave per SIMD pair issue the DMA measured no better: 150 vs 147 us) */  \
-            if (more_) dma_stage_image<D, NW>(nsrc_, ndst_, wave, lane);                                 \
+            if constexpr (GATHER && (POS) == G_U % NSTAGE) {   /* the fragment this stage multiplies */  \
+                if (active && (!G_NEXT || p > 0)) g_finish(xf[GBUF]);                                    \
+            }                                                                                            \
+            /* Side work of the stage (prefetches, the DMA of the whole next image): the LATE waves do it  \
+               before their MFMA burst, the EARLY waves after theirs -- each in the shadow of the other    \
+               wave's burst on the shared matrix pipe.  (Spreading the DMA instructions over the MFMA      \
+               groups via the stage_mma hook measured slower.) */                                         \
+            if (late) {                                                                                  \
+                prefetch(std::integral_constant<int, (POS)>{});                                          \
+                if (more_) dma_stage_image<D, NW>(nsrc_, ndst_, wave, lane);                             \
+            }                                                                                            \
             GGNN_T(POS, 1)                                                                               \
-            __builtin_amdgcn_sched_barrier(0);   /* keep the DMA issue AHEAD of the MFMA block */        \
+            __builtin_amdgcn_sched_barrier(0);   /* keep the side work on its side of the MFMA block */  \
             if (active && !(a.dbg & 1)) stage_mma<D>(ACC, FRAG, ring + cur * C::IMG, li, kq);            \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            if (!late) {                                                                                 \
+                prefetch(std::integral_constant<int, (POS)>{});                                          \
+                if (more_) dma_stage_image<D, NW>(nsrc_, ndst_, wave, lane);                             \
+            }                                                                                            \
             GGNN_T(POS, 2)                                                                               \
             __syncthreads();                                                                             \
             GGNN_T(POS, 3)                                                                               \
@@ -366,6 +384,10 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                 }
             }
         }
+    }
+    if (a.tdbg && tid == 0) {
+        a.tdbg[4096 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+        a.tdbg[4096 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

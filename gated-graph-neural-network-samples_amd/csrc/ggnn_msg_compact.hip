@@ -61,11 +61,19 @@ __global__ void edge_weight_pack_kernel(const float* __restrict__ W, float* __re
                         blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
-// ---- the transform: one workgroup = one 16*NW-row tile of one type ------------------------------------------
+// ---- the transform: persistent workgroups, each bound to ONE edge type ---------------------------------------
+// tr.tile_off[t] .. tile_off[t+1] are the workgroups of type t.  A workgroup brings its type's weight image into LDS
+// once (LDS-DMA) and then every wave walks, independently of the others (no barrier after the first), over its share
+// of the type's 16-row wave tiles: j-th workgroup of the type, wave w -> tiles (j*NW + w) + k * (NW * workgroups of
+// the type).  The rows of tile k+1 (pair list -> gathered state rows) are fetched while tile k is multiplied, the
+// pair-list entry of tile k+2 with them, so no wave waits on a dependent load chain inside the loop.
+// Two workgroups fit a CU (LDS 2 x 48 KiB, <= 128 VGPRs): 4 waves per SIMD keep the matrix pipe fed while others
+// store and fetch.  The host sizes the per-type workgroup counts so that every wave gets the same number of tiles
+// (+-1) across ALL types (launch_compact).
 template <int D, int NW>
-__global__ __launch_bounds__(NW * 64) void msg_transform_compact_kernel(const float* __restrict__ h, const int* __restrict__ pair_node,
-                                                                        TypeRows tr, const float* __restrict__ packed,
-                                                                        float* __restrict__ Hc) {
+__global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per CU */ void msg_transform_compact_kernel(const float* __restrict__ h, const int* __restrict__ pair_node,
+                                                                           TypeRows tr, const float* __restrict__ packed,
+                                                                           float* __restrict__ Hc) {
     using C = StageCfg<D>;
     constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) float img[];
@@ -75,35 +83,44 @@ __global__ __launch_bounds__(NW * 64) void msg_transform_compact_kernel(const fl
 
     int t = 0;
     while (t + 1 < tr.T && (int)blockIdx.x >= tr.tile_off[t + 1]) ++t;
-    const int row_end = tr.row_off[t + 1];
-    const int row0 = tr.row_off[t] + ((int)blockIdx.x - tr.tile_off[t]) * (NW * 16) + wave * 16;
-    const bool active = row0 < row_end;                    // wave-uniform
+    const int row_beg = tr.row_off[t], row_end = tr.row_off[t + 1];
+    const int n_wt = (row_end - row_beg + 15) / 16;                     // wave tiles of this type
+    const int stride = (tr.tile_off[t + 1] - tr.tile_off[t]) * NW;
+    int idx = ((int)blockIdx.x - tr.tile_off[t]) * NW + wave;           // wave-uniform
 
     dma_stage_image<D, NW>(packed + (size_t)t * C::IMG, img, wave, lane);
-    Frag<D> a;
-    const int r = row0 + li;
-    if (active) {
-        const int node = pair_node[r < row_end ? r : row_end - 1];
-        load_frag<D>(a, h, node, kq);
-    }
+    auto row_of = [&](int i) { const int r = row_beg + i * 16 + li; return r < row_end ? r : row_end - 1; };
+    Frag<D> a, an;
+    int node_n = 0;
+    if (idx < n_wt) load_frag<D>(a, h, pair_node[row_of(idx)], kq);
+    if (idx + stride < n_wt) node_n = pair_node[row_of(idx + stride)];
     __syncthreads();                                        // the image has landed (vmcnt(0) + barrier)
-    if (!active) return;
-    f32x4 acc[NT];
+
+    while (idx < n_wt) {
+        const int idx_n = idx + stride;
+        if (idx_n < n_wt) load_frag<D>(an, h, node_n, kq);             // rows of the next tile
+        if (idx_n + stride < n_wt) node_n = pair_node[row_of(idx_n + stride)];
+        f32x4 acc[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    stage_mma<D>(acc, a, img, li, kq);
-    stage_tail_reduce<D>(acc);
-    if (r < row_end) {
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);                  // the fetches are issued BEFORE the MFMA block
+        stage_mma<D>(acc, a, img, li, kq);
+        stage_tail_reduce<D>(acc);
+        const int r = row_beg + idx * 16 + li;
+        if (r < row_end) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = nt * 16 + 4 * kq;
-            if (col < D) st4(Hc + (size_t)r * D + col, acc[nt]);
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = nt * 16 + 4 * kq;
+                if (col < D) st4(Hc + ((unsigned)r * (unsigned)D + col), acc[nt]);
+            }
         }
+        a = an;
+        idx = idx_n;
     }
 }
 
 template <int D>
-static int launch_compact(const float* h, const float* W, const int* pair_node, const TypeRows& tr, float* packed, float* Hc,
+static int launch_compact(const float* h, const float* W, const int* pair_node, TypeRows& tr, float* packed, float* Hc,
                           hipStream_t st) {
     constexpr int NW = 8;
     using C = StageCfg<D>;
@@ -111,10 +128,32 @@ static int launch_compact(const float* h, const float* W, const int* pair_node, 
         hipLaunchKernelGGL((edge_weight_pack_kernel<D>), dim3(8, tr.T), dim3(256), 0, st, W, packed);
         GGNN_CHECK_HIP(hipGetLastError());
     }
-    const int tiles = tr.tile_off[tr.T];
-    if (tiles == 0 || h == nullptr) return GGNN_OK;
-    hipLaunchKernelGGL((msg_transform_compact_kernel<D, NW>), dim3(tiles), dim3(NW * 64), C::IMG_BYTES, st, h, pair_node, tr,
-                       (const float*)packed, Hc);
+    if (tr.row_off[tr.T] == 0 || h == nullptr) return GGNN_OK;
+    if ((unsigned long long)tr.row_off[tr.T] * D >= (1ULL << 32))
+        return fail(GGNN_E_UNSUPPORTED, "compacted transform indexes with 32-bit element offsets: rows*D must be < 2^32");
+    // Workgroups per type: the smallest number of rounds R (wave tiles per wave) for which all types together fit
+    // two workgroups per CU, then ceil(wave tiles of the type / (R * NW)) workgroups for each type.
+    long long total_wt = 0;
+    for (int t = 0; t < tr.T; ++t) total_wt += (tr.row_off[t + 1] - tr.row_off[t] + 15) / 16;
+    const long long budget = 2LL * num_cus();
+    long long R = total_wt / (budget * NW);
+    if (R < 1) R = 1;
+    for (;; ++R) {
+        long long blocks = 0;
+        for (int t = 0; t < tr.T; ++t) blocks += ((tr.row_off[t + 1] - tr.row_off[t] + 15) / 16 + R * NW - 1) / (R * NW);
+        if (blocks <= budget) break;
+    }
+    tr.tile_off[0] = 0;
+    for (int t = 0; t < tr.T; ++t)
+        tr.tile_off[t + 1] = tr.tile_off[t] + (int)(((tr.row_off[t + 1] - tr.row_off[t] + 15) / 16 + R * NW - 1) / (R * NW));
+    static bool attr_set = false;
+    if (!attr_set && C::IMG_BYTES > 48 * 1024) {
+        GGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&msg_transform_compact_kernel<D, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::IMG_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((msg_transform_compact_kernel<D, NW>), dim3(tr.tile_off[tr.T]), dim3(NW * 64), C::IMG_BYTES, st, h, pair_node,
+                       tr, (const float*)packed, Hc);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
