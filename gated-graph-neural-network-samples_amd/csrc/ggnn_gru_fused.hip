@@ -40,10 +40,14 @@ __global__ void gru_pack_weights_kernel(const float* __restrict__ Wg, const floa
                                         float* __restrict__ out) {
     const int ci = blockIdx.y;
     const float* W; int r0, c0, ldw;
-    if (ci < 2 * (nx + 1)) { W = Wg; r0 = (ci >> 1) * D; c0 = (ci & 1) * D; ldw = 2 * D; }
-    else { W = Wc; r0 = (ci - 2 * (nx + 1)) * D; c0 = 0; ldw = D; }
+    int c_alt = -1;
+    if (ci < 2 * (nx + 1)) {
+        W = Wg; r0 = (ci >> 1) * D; c0 = (ci & 1) * D; ldw = 2 * D;
+        // r images carry the u gate's last (partly filled) tile in their padding columns: the u stages then skip it
+        if (StageCfg<D>::TAILPACK && (ci & 1) == 0) c_alt = D + (D / 16) * 16;
+    } else { W = Wc; r0 = (ci - 2 * (nx + 1)) * D; c0 = 0; ldw = D; }
     pack_stage_image<D>(W, r0, c0, ldw, out + (size_t)ci * StageCfg<D>::IMG, blockIdx.x * blockDim.x + threadIdx.x,
-                        gridDim.x * blockDim.x);
+                        gridDim.x * blockDim.x, c_alt);
 }
 
 // position in the per-pass stage sequence -> packed image (segment s = pos / 3; 0,1: its r / u gate columns, 2: candidate)
@@ -285,7 +289,9 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             }                                                                                            \
             GGNN_T(POS, 1)                                                                               \
             __builtin_amdgcn_sched_barrier(0);   /* keep the side work on its side of the MFMA block */  \
-            if (active && !(a.dbg & 1)) stage_mma<D>(ACC, FRAG, ring + cur * C::IMG, li, kq);            \
+            /* u-gate stages (POS % 3 == 1) skip their last tile when it rides in the r image */          \
+            constexpr int ntl_ = (C::TAILPACK && (POS) % 3 == 1) ? NT - 1 : NT;                          \
+            if (active && !(a.dbg & 1)) stage_mma<D, NoHook, ntl_>(ACC, FRAG, ring + cur * C::IMG, li, kq); \
             __builtin_amdgcn_sched_barrier(0);                                                           \
             if (!late) {                                                                                 \
                 prefetch(std::integral_constant<int, (POS)>{});                                          \
@@ -315,6 +321,15 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         if (active && !(a.dbg & 2)) {
             stage_tail_reduce<D>(acc_r);                       // VALU-tail columns: add the four kq partials
             stage_tail_reduce<D>(acc_u);
+            if constexpr (C::TAILPACK) {
+                // the u gate's last tile was accumulated in the padding columns of the r gate's last tile:
+                // column D + j of that tile (lane kq + (D%16)/4) is u column 16*NC + j (lane kq)
+                constexpr int SH = 16 * ((D % 16) / 4);
+                f32x4 ut;
+                ut.x = __shfl(acc_r[NT - 1].x, lane + SH); ut.y = __shfl(acc_r[NT - 1].y, lane + SH);
+                ut.z = __shfl(acc_r[NT - 1].z, lane + SH); ut.w = __shfl(acc_r[NT - 1].w, lane + SH);
+                acc_u[NT - 1] = ut;
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = nt * 16 + 4 * kq;

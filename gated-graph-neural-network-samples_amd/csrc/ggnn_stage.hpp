@@ -27,24 +27,32 @@ struct StageCfg {
     static constexpr int REM = NR * 4 * BN;             // floats in the remainder part
     static constexpr int IMG_BYTES = ((MAIN + REM) * 4 + 8191) / 8192 * 8192;   // whole KiB per wave of an 8-wave group
     static constexpr int IMG = IMG_BYTES / 4;
+    // the last tile holds D % 16 <= 8 valid columns: a second block's tail fits beside it (see pack_stage_image)
+    static constexpr bool TAILPACK = (D % 16 != 0) && (D % 16 <= 8) && (D % 4 == 0);
 };
 
 // Writes the stage image of the D x D block W[r0 .. r0+D-1][c0 .. c0+D-1] (row stride ldw) to img.
+// c_alt >= 0: the first D % 16 PADDING columns of the last tile (n = D .. D + D%16 - 1) are not zero but the columns
+// c_alt .. c_alt + D%16 - 1 of the same rows -- the last, partly filled tile of ANOTHER D x D block that shares these
+// rows rides along in this image's padding (StageCfg::TAILPACK; the fused GRU packs the u-gate tail into the r image).
 template <int D>
 __device__ __forceinline__ void pack_stage_image(const float* __restrict__ W, int r0, int c0, int ldw,
-                                                 float* __restrict__ img, int first, int stride) {
+                                                 float* __restrict__ img, int first, int stride, int c_alt = -1) {
     using C = StageCfg<D>;
+    constexpr int TC = D % 16;
     for (int i = first; i < C::IMG; i += stride) {
         float v = 0.f;
         if (i < C::MAIN) {
             const int e = i & 3, n = (i >> 2) % C::BN, ck = (i >> 2) / C::BN;     // ck = c*4 + kq
             const int k = 4 * ck + e;                                              // = 16c + 4kq + e
             if (n < D) v = W[(size_t)(r0 + k) * ldw + c0 + n];
+            else if (c_alt >= 0 && n < D + TC) v = W[(size_t)(r0 + k) * ldw + c_alt + (n - D)];
         } else if (i < C::MAIN + C::REM) {
             const int j = i - C::MAIN;
             const int n = j % C::BN, qk = j / C::BN;                               // qk = q*4 + kq
             const int k = 16 * C::NC + qk;
             if (n < D) v = W[(size_t)(r0 + k) * ldw + c0 + n];
+            else if (c_alt >= 0 && n < D + TC) v = W[(size_t)(r0 + k) * ldw + c_alt + (n - D)];
         }
         img[i] = v;
     }
@@ -76,7 +84,9 @@ struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 // `hook(gi)` is called at the start of MFMA group gi (compile-time gi after unrolling): the fused GRU uses it
 // to spread the LDS-DMA instructions of the NEXT stage over the MFMA stream instead of issuing them in one
 // burst (each global_load_lds costs ~60-180 issue cycles during which the matrix pipe would sit idle).
-template <int D, class Hook = NoHook>
+// NTILES < NT: only the first NTILES output tiles are computed (the fused GRU's u-gate stage, whose last tile is
+// computed by the r-gate stage: StageCfg::TAILPACK).
+template <int D, class Hook = NoHook, int NTILES = StageCfg<D>::NT>
 __device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const Frag<D>& a, const float* img, int li, int kq,
                                           const Hook& hook = Hook()) {
     using C = StageCfg<D>;
@@ -90,7 +100,7 @@ __device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const F
     // 198 VGPRs / no scratch to 256 VGPRs + 84-320 B of scratch per lane, which costs more than the 14 % of
     // MFMAs it saves; kept for a round that hand-allocates the registers.
     constexpr bool VT = (C::NR == 1) && (GGNN_VALU_TAIL != 0);
-    constexpr int NTM = VT ? C::NT - 1 : C::NT;              // tiles on the matrix pipe
+    constexpr int NTM = VT ? C::NT - 1 : NTILES;             // tiles on the matrix pipe
     // Explicit one-group-ahead software pipeline with bounded register use: the weight operands of group
     // gi+1 (<= 4 tiles, 16 VGPRs) are read while the <= 16 MFMAs of group gi issue; a scheduling barrier per
     // group stops the compiler from hoisting further reads (which drove the kernel into scratch spills).
