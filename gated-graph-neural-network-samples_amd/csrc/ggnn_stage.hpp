@@ -112,6 +112,8 @@ __device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const F
     constexpr int NG = C::NC * GPC;
     const f32x4* tbase = reinterpret_cast<const f32x4*>(img) + kq * C::BN + 16 * C::NC;   // tail columns, no lane offset
     f32x4 w[2][G];
+    float wr[C::NR > 0 ? C::NR : 1][C::NT];
+    static_assert(NG > 0 || C::NR == 0, "remainder weights are fetched inside the main loop");
     if constexpr (NG > 0) {
 #pragma unroll
         for (int j = 0; j < G; ++j)
@@ -127,6 +129,13 @@ __device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const F
             for (int j = 0; j < G; ++j)
                 if (gn + j < NTM) w[(gi + 1) & 1][j] = base[cn * 4 * C::BN + (gn + j) * 16];
             __builtin_amdgcn_sched_barrier(0);               // reads of group gi+1 are issued BEFORE group gi's MFMAs
+        } else {
+            // last group: the weights of the remainder MFMAs (k = 16*NC ..) are read under its MFMAs, not after them
+#pragma unroll
+            for (int q = 0; q < C::NR; ++q)
+#pragma unroll
+                for (int nt = 0; nt < NTM; ++nt) wr[q][nt] = img[C::MAIN + (q * 4 + kq) * C::BN + li + nt * 16];
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -155,13 +164,9 @@ __device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const F
     }
 #pragma unroll
     for (int q = 0; q < C::NR; ++q) {
-        const float* rb = img + C::MAIN + (q * 4 + kq) * C::BN + li;
-        float w[NTM];
-#pragma unroll
-        for (int nt = 0; nt < NTM; ++nt) w[nt] = rb[nt * 16];
 #pragma unroll
         for (int nt = 0; nt < NTM; ++nt)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt], a.r[q], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q][nt], a.r[q], acc[nt], 0, 0, 0);
         if constexpr (VT) {                                  // remainder k = 16*NC + kq against the 4 tail columns
             const f32x4 tr = *reinterpret_cast<const f32x4*>(img + C::MAIN + (q * 4 + kq) * C::BN + 16 * C::NC);
             acc[C::NT - 1] += a.r[q] * tr;
