@@ -113,11 +113,12 @@ def _ranges(starts: np.ndarray, lengths: np.ndarray) -> np.ndarray:
 
 
 def synthetic_qm9(num_graphs: int, mean_nodes: float = 18.0, seed: int = 0, num_bond_types: int = 4,
-                  annotation_size: int = 5, num_tasks: int = 1) -> MoleculeSet:
+                  annotation_size: int = 5, num_tasks: int = 1, max_degree: Optional[int] = 4) -> MoleculeSet:
     """Synthetic QM9-shaped molecules.
 
     n ~ clip(round(N(mean_nodes,3)), 3, 29) atoms (29 = the dense model's largest bucket,
-    chem_tensorflow_dense.py:134); a random spanning tree plus 0-2 ring-closure bonds; bond type ~
+    chem_tensorflow_dense.py:134); a random spanning tree plus 0-2 ring-closure bonds, no atom with more than
+    `max_degree` bonds (4 = the largest valence in QM9: C; None = unconstrained recursive tree); bond type ~
     Categorical(0.85, 0.07, 0.03, 0.05) over {1..4} (get_data.py:62); one-hot atom annotation
     uniform over `annotation_size`; z-scored scalar targets.  mean_nodes = 18 is QM9 with hydrogens
     (get_data.py:66 AddHs); BASELINE.json's "~9 nodes" is the heavy-atom count.
@@ -130,9 +131,17 @@ def synthetic_qm9(num_graphs: int, mean_nodes: float = 18.0, seed: int = 0, num_
     N = int(node_ptr[-1])
     local = np.arange(N, dtype=np.int64) - np.repeat(node_ptr[:-1], n)
     graph_of = np.repeat(np.arange(num_graphs, dtype=np.int64), n)
-    # spanning tree: node i>=1 bonds to a uniformly random earlier node of its graph
     nonroot = local > 0
-    parent = np.floor(rng.random(N) * np.maximum(local, 1)).astype(np.int64)
+    if max_degree is None:
+        # spanning tree: node i>=1 bonds to a uniformly random earlier node of its graph (unbounded degrees)
+        parent = np.floor(rng.random(N) * np.maximum(local, 1)).astype(np.int64)
+    else:
+        # valence-bounded tree: node i bonds to one of the max_degree-1 nodes before it, so a node has at most
+        # max_degree-1 children + 1 parent (QM9: no atom has more than 4 bonds)
+        if max_degree < 2:
+            raise ValueError("max_degree must be >= 2")
+        back = 1 + np.floor(rng.random(N) * np.minimum(np.maximum(local, 1), max_degree - 1)).astype(np.int64)
+        parent = np.maximum(local - back, 0)
     t_src = parent[nonroot]
     t_dst = local[nonroot]
     t_g = graph_of[nonroot]
@@ -147,6 +156,19 @@ def synthetic_qm9(num_graphs: int, mean_nodes: float = 18.0, seed: int = 0, num_
     key = (r_g * 32 + lo) * 32 + hi
     _, first = np.unique(key, return_index=True)
     r_g, lo, hi = r_g[first], lo[first], hi[first]
+    if max_degree is not None and len(r_g):
+        # keep a ring closure only while both atoms still have a free valence (first, then second closure of a graph)
+        deg = np.bincount(np.concatenate([node_ptr[t_g] + t_src, node_ptr[t_g] + t_dst]), minlength=N)
+        nth = np.arange(len(r_g)) - np.searchsorted(r_g, r_g, side="left")      # 0 / 1 within the graph (r_g is sorted)
+        keep = np.zeros(len(r_g), dtype=bool)
+        for j in range(int(nth.max()) + 1):
+            sel = np.nonzero(nth == j)[0]
+            ga, gb = node_ptr[r_g[sel]] + lo[sel], node_ptr[r_g[sel]] + hi[sel]
+            good = (deg[ga] < max_degree) & (deg[gb] < max_degree)
+            keep[sel[good]] = True
+            np.add.at(deg, ga[good], 1)
+            np.add.at(deg, gb[good], 1)
+        r_g, lo, hi = r_g[keep], lo[keep], hi[keep]
     g_all = np.concatenate([t_g, r_g])
     s_all = np.concatenate([t_src, lo])
     d_all = np.concatenate([t_dst, hi])

@@ -89,7 +89,9 @@ def test_train_step_matches_restated_tf_adam(pkg, oracle, oracle_torch, cuda):
         lr_t = lr * np.sqrt(1 - b2) / (1 - b1)
         want = before[name] - lr_t * m / (vv.sqrt() + eps)
         got = v.detach().cpu().double()
-        assert float((got - want).abs().max()) < 2e-6, name
+        # first Adam step = lr * g / (|g| + eps/sqrt(1-b2)): for gradient entries near 3e-7 an fp32-level gradient
+        # difference (1e-9) moves the update by ~1e-6; 5e-6 = 0.5 % of the step size lr
+        assert float((got - want).abs().max()) < 5e-6, name
 
 
 def test_training_reduces_loss(pkg, oracle, cuda):
