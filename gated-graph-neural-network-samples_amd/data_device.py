@@ -1,0 +1,129 @@
+"""Device-side batch packer: the tensorised twin of data.pack_batch.
+
+The reference packs every minibatch in pure Python on the host (chem_tensorflow_sparse.py:278-350); data.pack_batch
+is its vectorised NumPy twin (~14 ms per 100k-node batch, plus the upload).  With the propagation at ~1.4 ms per
+batch the packer -- the step immediately before the path -- would cap end-to-end throughput, so here the whole
+dataset is uploaded ONCE in structure-of-arrays form and a batch is assembled on the GPU from the graph ids alone:
+index arithmetic, one key sort, two bincounts.  Same outputs as data.pack_batch, bit for bit (tests/test_gpu_parity.py).
+
+Only the batch boundaries (a greedy scan over at most G node counts, data.batch_boundaries) and the per-type message
+counts (T integers, needed as host sizes by the index builder) touch the host.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from .data import MoleculeSet, batch_boundaries
+
+
+class DeviceMoleculeSet:
+    """data.MoleculeSet resident in HBM (QM9: 134k molecules = 2.4M atoms -> 60 MB)."""
+
+    def __init__(self, ms: MoleculeSet, device, label_mask: Optional[np.ndarray] = None):
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)
+        self.host = ms
+        self.device = torch.device(device)
+        self.node_ptr = t(ms.node_ptr, torch.int64)
+        self.node_feat = t(ms.node_feat, torch.float32)
+        self.bond_ptr = t(ms.bond_ptr, torch.int64)
+        self.bonds = t(ms.bonds, torch.int64)                  # (src_local, bond_type 1..F, dst_local)
+        self.targets = t(ms.targets, torch.float32)
+        self.label_mask = None if label_mask is None else t(label_mask, torch.float32)
+        self.nodes_per_graph = np.diff(ms.node_ptr)            # host copies of the sizes: no sync to size outputs
+        self.bonds_per_graph = np.diff(ms.bond_ptr)
+        self.max_bond_type = int(ms.bonds[:, 1].max()) if len(ms.bonds) else 0
+        self.min_bond_type = int(ms.bonds[:, 1].min()) if len(ms.bonds) else 1
+
+
+def _ranges(starts: torch.Tensor, lengths: torch.Tensor, total: int) -> torch.Tensor:
+    """cat_i arange(starts[i], starts[i] + lengths[i]) on the device; `total` = sum(lengths), known on the host."""
+    if total == 0:
+        return torch.zeros(0, dtype=torch.int64, device=starts.device)
+    ends = torch.cumsum(lengths, 0)
+    base = torch.repeat_interleave(starts - (ends - lengths), lengths, output_size=total)
+    return base + torch.arange(total, dtype=torch.int64, device=starts.device)
+
+
+def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_types: int, hidden_size: int,
+                      tie_fwd_bkwd: bool = True, task_ids: Sequence[int] = (0,)) -> Dict[str, Any]:
+    """One batch from graphs `graph_ids` (in this order), assembled on the GPU: the feed dict of
+    SparseGGNNChemModel.to_device_batch (chem_tensorflow_sparse.py:254-276, 298-348), message index included."""
+    dev = dms.device
+    gids_h = np.asarray(graph_ids, dtype=np.int64)
+    G = len(gids_h)
+    T = int(num_edge_types)
+    V = int(dms.nodes_per_graph[gids_h].sum()) if G else 0
+    B = int(dms.bonds_per_graph[gids_h].sum()) if G else 0
+    A = dms.node_feat.shape[1]
+    if A > hidden_size:
+        raise ValueError("annotation_size %d exceeds hidden_size %d" % (A, hidden_size))
+    F = T if tie_fwd_bkwd else T // 2
+    if B and (dms.min_bond_type < 1 or dms.max_bond_type > F):
+        raise IndexError("edge type outside [0, num_edge_types)")
+    gids = torch.from_numpy(gids_h).to(dev)
+    n = dms.node_ptr[gids + 1] - dms.node_ptr[gids]
+    offs = torch.cumsum(n, 0) - n                                                   # node offset of each graph (:297)
+    nsel = _ranges(dms.node_ptr[gids], n, V)
+    h0 = torch.zeros((V, hidden_size), dtype=torch.float32, device=dev)             # :300-302 zero-pad to D
+    if V:
+        h0[:, :A] = dms.node_feat[nsel]
+    gnl = torch.repeat_interleave(torch.arange(G, dtype=torch.int32, device=dev), n, output_size=V)   # :304
+    nb = dms.bond_ptr[gids + 1] - dms.bond_ptr[gids]
+    bsel = _ranges(dms.bond_ptr[gids], nb, B)
+    bonds = dms.bonds[bsel]
+    boff = torch.repeat_interleave(offs, nb, output_size=B)
+    src = bonds[:, 0] + boff                                                        # :307 (+ node_offset)
+    dst = bonds[:, 2] + boff
+    typ = bonds[:, 1] - 1                                                           # :258
+    s_all = torch.cat([src, dst]); d_all = torch.cat([dst, src])                    # :259-263 both directions
+    t_all = torch.cat([typ, typ]) if tie_fwd_bkwd else torch.cat([typ, typ + F])
+    # :265 sorted((src,dst)) per type, graphs in order == one sort on (type, src, dst) of the offset ids
+    Vk = max(V, 1)
+    key, _ = torch.sort((t_all * Vk + s_all) * Vk + d_all)
+    d_sorted = key % Vk
+    ts = key // Vk
+    s_sorted = ts % Vk
+    t_sorted = ts // Vk
+    cnt = torch.bincount(t_sorted, minlength=T)
+    nin = torch.bincount(d_sorted * T + t_sorted, minlength=V * T).view(V, T).to(torch.float32)   # :310-313
+    adj = torch.stack([s_sorted, d_sorted], dim=1).to(torch.int32)
+    counts: List[int] = [int(c) for c in cnt.tolist()]                              # the one host sync: T integers
+    adjacency, o = [], 0
+    for t in range(T):
+        adjacency.append(adj[o:o + counts[t]])                                      # :343-348 (empty types: [0,2])
+        o += counts[t]
+    tids = torch.as_tensor(list(task_ids), dtype=torch.int64, device=dev)
+    tv = dms.targets[gids][:, tids].t().contiguous()                                # :335
+    tm = torch.ones_like(tv) if dms.label_mask is None else dms.label_mask[gids][:, tids].t().contiguous()
+    tv = tv * tm                                                                    # masked labels feed 0. (:319-321)
+    return {
+        'initial_node_representation': h0,
+        'adjacency_lists': adjacency,
+        'num_incoming_edges_per_type': nin,
+        'graph_nodes_list': gnl,
+        'target_values': tv,
+        'target_mask': tm,
+        'num_graphs': G,
+        'message_index': ops.build_message_index(adjacency, V, validate=False),     # ids are offsets we just built
+    }
+
+
+def pack_batches_device(dms: DeviceMoleculeSet, params: dict, num_edge_types: int, order: Optional[np.ndarray] = None,
+                        rank: int = 0, world_size: int = 1):
+    """Generator over one epoch's batches for graph order `order` -- data.pack_batches on the device (same batch
+    boundaries, same rank assignment, same empty padding batches)."""
+    ms = dms.host
+    G = ms.num_graphs
+    order = np.arange(G, dtype=np.int64) if order is None else np.asarray(order, np.int64)
+    bounds = batch_boundaries(dms.nodes_per_graph[order], params["batch_size"])
+    nb = len(bounds) - 1
+    steps = (nb + world_size - 1) // world_size
+    for s in range(steps):
+        i = s * world_size + rank
+        ids = order[bounds[i]:bounds[i + 1]] if i < nb else np.zeros(0, np.int64)
+        yield pack_batch_device(dms, ids, num_edge_types, params["hidden_size"], params.get("tie_fwd_bkwd", True),
+                                params.get("task_ids", [0]))

@@ -19,6 +19,7 @@ import torch
 from . import ops
 from .chem_model import ChemModel
 from .data import MoleculeSet, SparseBatch, pack_batches
+from .data_device import DeviceMoleculeSet, pack_batches_device
 from .utils import glorot_init, SMALL_NUMBER, tf_dropout
 
 GGNNWeights = namedtuple('GGNNWeights', ['edge_weights',
@@ -315,22 +316,31 @@ class SparseGGNNChemModel(ChemModel):
 
     def make_minibatch_iterator(self, data: Any, is_training: bool):
         """chem_tensorflow_sparse.py:278-350: minibatches as one disconnected super-graph each.
-        Packing is vectorised (data.pack_batches); validation batches are packed and uploaded once and
+        Batches are assembled on the GPU from the resident dataset (data_device.py; params['pack_on_device']=False
+        selects the NumPy packer data.pack_batches + upload, same results); validation batches are packed once and
         stay resident in HBM; training batches are re-packed per epoch after the shuffle (:281-282)."""
         ms: MoleculeSet = data["molecules"]
         state_dropout_keep_prob = self.params['graph_state_dropout_keep_prob'] if is_training else 1.
         edge_weights_dropout_keep_prob = self.params['edge_weight_dropout_keep_prob'] if is_training else 1.
         rank = self.dist.rank if self.dist is not None else 0
         world = self.dist.world_size if self.dist is not None else 1
+        on_device = bool(self.params.get('pack_on_device', True))
+        if on_device and data.get("molecules_dev") is None:
+            # the dataset goes to HBM once; batches are then assembled on the GPU from graph ids (data_device.py)
+            data["molecules_dev"] = DeviceMoleculeSet(ms, self.device, data["label_mask"])
+
+        def epoch_batches(order):
+            if on_device:
+                return pack_batches_device(data["molecules_dev"], self.params, self.num_edge_types, order, rank, world)
+            return (self.to_device_batch(b) for b in
+                    pack_batches(ms, self.params, self.num_edge_types, order, data["label_mask"], rank, world))
+
         if is_training:
             order = np.random.permutation(ms.num_graphs)      # same seed on every rank -> same order
-            batches = pack_batches(ms, self.params, self.num_edge_types, order, data["label_mask"], rank, world)
-            device_batches = (self.to_device_batch(b) for b in batches)
+            device_batches = epoch_batches(order)
         else:
             if data["device_batches"] is None:
-                data["device_batches"] = [self.to_device_batch(b) for b in
-                                          pack_batches(ms, self.params, self.num_edge_types, None,
-                                                       data["label_mask"], rank, world)]
+                data["device_batches"] = list(epoch_batches(None))
             device_batches = data["device_batches"]
         for db in device_batches:
             feed = dict(db)

@@ -169,6 +169,38 @@ def test_sparse_model_matches_oracle(pkg, oracle, cuda, config):
     np.testing.assert_allclose(got, want, **MODEL_TOL)
 
 
+@pytest.mark.parametrize("tie", [True, False])
+def test_device_packer_equals_host_packer(pkg, cuda, tie):
+    """data_device.pack_batches_device (batches assembled on the GPU from the resident dataset) == data.pack_batches
+    (the vectorised twin of chem_tensorflow_sparse.py:254-350) uploaded, field by field and bit for bit: shuffled
+    graph order, several batches, label mask, both edge-direction modes, two ranks incl. an empty padding batch."""
+    ms = pkg.synthetic_qm9(700, mean_nodes=12, seed=33)
+    rng = np.random.default_rng(5)
+    T = 4 if tie else 8
+    params = {"batch_size": 2500, "hidden_size": 32, "tie_fwd_bkwd": tie, "task_ids": [0]}
+    label_mask = (rng.random((ms.num_graphs, ms.targets.shape[1])) < 0.7).astype(np.float32)
+    order = rng.permutation(ms.num_graphs)
+    dms = pkg.data_device.DeviceMoleculeSet(ms, cuda, label_mask)
+    nb = len(pkg.data.pack_batches(ms, params, T, order, label_mask))
+    assert nb >= 3
+    for rank, world in ((0, 1), (1, 2), (nb, nb + 1)):     # the last: one more rank than batches -> a padding batch
+        host = pkg.data.pack_batches(ms, params, T, order, label_mask, rank, world)
+        devb = list(pkg.data_device.pack_batches_device(dms, params, T, order, rank, world))
+        assert len(host) == len(devb) and len(host) >= 1
+        for hb, db in zip(host, devb):
+            assert db["num_graphs"] == hb.num_graphs
+            assert np.array_equal(db["initial_node_representation"].cpu().numpy(), hb.initial_node_representation)
+            assert len(db["adjacency_lists"]) == T
+            for a, b in zip(db["adjacency_lists"], hb.adjacency_lists):
+                assert a.dtype == torch.int32 and np.array_equal(a.cpu().numpy().reshape(-1, 2), b)
+            assert np.array_equal(db["num_incoming_edges_per_type"].cpu().numpy(), hb.num_incoming_edges_per_type)
+            assert np.array_equal(db["graph_nodes_list"].cpu().numpy(), hb.graph_nodes_list)
+            assert np.array_equal(db["target_values"].cpu().numpy(), hb.target_values)
+            assert np.array_equal(db["target_mask"].cpu().numpy(), hb.target_mask)
+            assert db["message_index"].num_messages == hb.num_messages
+    assert devb[-1]["num_graphs"] == 0 and devb[-1]["initial_node_representation"].shape[0] == 0
+
+
 def test_sparse_model_graph_disjointness(pkg, oracle, cuda):
     """A batch of G graphs == G single-graph runs (no cross-graph leakage)."""
     ms = pkg.synthetic_qm9(12, mean_nodes=9, seed=2)

@@ -113,5 +113,29 @@ def train():
                       "ms_per_step": dt * 1e3, "node_state_updates_per_sec": V * 8 / dt, "graphs_per_sec": G / dt}))
 
 
+def pack():
+    """The step before the path: one epoch of ~100k-node batches packed by the NumPy packer (+ upload + index build)
+    and by the device packer (data_device.py), shuffled graph order as in training."""
+    ms = pkg.synthetic_qm9(5700 * 8, mean_nodes=18, seed=0)
+    model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": DEV, "train_data": None, "valid_data": ms})
+    order = np.random.default_rng(0).permutation(ms.num_graphs)
+    lm = model.valid_data["label_mask"]
+    T = model.num_edge_types
+
+    def host():
+        return [model.to_device_batch(b) for b in pkg.data.pack_batches(ms, model.params, T, order, lm)]
+    dms = pkg.data_device.DeviceMoleculeSet(ms, DEV, lm)
+
+    def device():
+        return list(pkg.data_device.pack_batches_device(dms, model.params, T, order))
+    nb = len(device())
+    th = timed(host, 1, 3) / nb
+    td = timed(device, 1, 5) / nb
+    V = int(np.diff(ms.node_ptr).sum() / nb)
+    print(json.dumps({"workload": "batch packing, %d batches of ~%d nodes per epoch" % (nb, V),
+                      "host_numpy_pack_upload_index_ms_per_batch": th * 1e3, "device_pack_index_ms_per_batch": td * 1e3,
+                      "speedup": th / td}))
+
+
 if __name__ == "__main__":
-    {"dense": dense, "large": large, "train": train}[sys.argv[1]]()
+    {"dense": dense, "large": large, "train": train, "pack": pack}[sys.argv[1]]()
