@@ -5,8 +5,10 @@ Forward runs on the hand-written HIP kernels and saves r, u, c.  Backward:
   * GRU gate algebra: two fused HIP element-wise passes (ggnn_gru_bwd_stage{1,2}_f32);
   * d(gather/segment-sum) = the SAME HIP gather/segment-sum kernel driven by the transpose index
     (messages bucketed by (src,type), gathering d_incoming[dst]) -- atomics-free and deterministic;
-  * the dense contractions (dX = dY W^T, dW = X^T dY) go to the vendor BLAS through torch: plain library
-    GEMMs; the tall-skinny X^T dY reductions over all V nodes are batched along V (tn_matmul).
+  * dX = dY W^T runs on the package's own FP32-MFMA GEMM (ggnn_gemm_f32 on the transposed weights; ~2.5x the vendor
+    BLAS at these skinny shapes: M = 1e5, K and N = 100..400);
+  * the weight gradients dW = X^T dY -- plain tall-skinny library GEMMs -- go to the vendor BLAS through torch,
+    batched along the 1e5-long reduction (tn_matmul).
 """
 from __future__ import annotations
 
@@ -80,14 +82,14 @@ class PropagationStepFn(torch.autograd.Function):
                                           dpc.data_ptr(), dpg.data_ptr(), dh.data_ptr(), a_c.data_ptr(), K, nx * D, V, D, st))
         dWc = tn_matmul(a_c, dpc)
         dbc = dpc.sum(0)
-        dxrh = dpc.matmul(Wc.t())                                              # [V, (nx+1)D]
+        dxrh = ops.gemm([dpc], Wc.t().contiguous())                            # [V, (nx+1)D] = dpc Wc^T
         # ---- gates: [r|u] = sigmoid([x | h] Wg + bg)
         drh = dxrh[:, nx * D:]
         check(lib.ggnn_gru_bwd_stage2_f32(drh.data_ptr(), K, h.data_ptr(), r.data_ptr(), dh.data_ptr(), dpg.data_ptr(), V, D, st))
         a_c[:, nx * D:] = h                                                    # reuse the buffer as [x | h]
         dWg = tn_matmul(a_c, dpg)
         dbg = dpg.sum(0)
-        dxh = dpg.matmul(Wg.t())
+        dxh = ops.gemm([dpg[:, :D], dpg[:, D:]], Wg.t().contiguous())           # [V, (nx+1)D] = dpg Wg^T
         dh += dxh[:, nx * D:]
         dx = dxrh[:, :nx * D] + dxh[:, :nx * D]
         d_res = [dx[:, i * D:(i + 1) * D] for i in range(nx - 1)]
@@ -101,7 +103,10 @@ class PropagationStepFn(torch.autograd.Function):
         dH = ops.segment_sum_rows_by_index(dinc, _source_index(ctx.index, V)).view(V, T * D)
 
         # ---- message transform H = h [W_0 | .. | W_{T-1}]
-        dh += dH.matmul(W.transpose(1, 2).reshape(T * D, D))
+        WT = W.transpose(1, 2).reshape(T * D, D).contiguous()                  # rows t*D..: W_t^T
+        for t0 in range(0, T, 4):                                              # (the GEMM takes <= 4 K segments)
+            t1 = min(t0 + 4, T)
+            dh += ops.gemm([dH[:, t * D:(t + 1) * D] for t in range(t0, t1)], WT[t0 * D:t1 * D])
         dW = tn_matmul(h, dH).view(D, T, D).transpose(0, 1)
 
         return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, *d_res)
