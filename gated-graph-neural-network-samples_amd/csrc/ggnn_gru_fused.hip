@@ -421,9 +421,11 @@ static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t
         return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit element offsets: V*D must be < 2^32 (V=%d, D=%d)", a.V, D);
     const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)((3 * D + 4 + 63) / 64 * 64) * sizeof(float);   // biases, ticket slots + ring
     const int wt_total = (a.V + 15) / 16;
+    // one workgroup per CU; with fewer than NW tiles per CU the tiles are spread over ALL CUs as thin tickets (the
+    // kernel's tail rule: ceil(tiles / nb) waves busy per workgroup) rather than packed 8 to a workgroup on a few CUs --
+    // a pass with one or two busy waves takes less than half the time of a full one
     int nb = num_cus();
-    const int need = (wt_total + NW - 1) / NW;
-    if (nb > need) nb = need;
+    if (nb > wt_total) nb = wt_total;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         GGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER>),
