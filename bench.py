@@ -215,7 +215,9 @@ def main():
         if os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             for name in kernels:
-                key = {"msg_transform_compact": "msg_transform_compact", "gather_segment_sum": "gather_segment_sum"}.get(name)
+                key = {"msg_transform_compact": "msg_transform_compact"}.get(name)
+                if name == "gather_segment_sum":
+                    key = next((k for k in pmc if k.startswith("gather_segment_sum") and "attn" not in k), None)
                 if key is None and name.startswith("gru_fused"):      # template args <D, NX, NW, SAVE, GATHER>
                     nx = name.split("nx=")[1].rstrip("]")
                     tail = "true>" if name.startswith("gru_fused_gather") else "false>"
@@ -243,8 +245,11 @@ def main():
                                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": by / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                       "avg_us": avg_ms * 1e3, "algorithmic_bytes": by, "in_timed_path": False,
                                       "traffic": None}
-                if os.path.exists(pmc_file) and "gather_segment_sum" in pmc:
-                    out["scatter_add"]["traffic"] = pmc["gather_segment_sum"]["hbm_bytes_fetch_x2_plus_write"]
+                if os.path.exists(pmc_file):       # (kernel variants: gather_segment_sum / gather_segment_sum_flat)
+                    key = next((k for k in pmc if k.startswith("gather_segment_sum") and "attn" not in k), None)
+                    if key:
+                        out["scatter_add"]["traffic"] = pmc[key]["hbm_bytes_fetch_x2_plus_write"]
+                        out["scatter_add"]["traffic_source"] = "profiles/r01_final_pmc_summary.json"
         dom = max(kernels, key=lambda k: kernels[k]["time_share"])
         out["roofline"] = dict(kernels[dom], kernel=dom)
         out["config"]["active_source_type_pairs_per_batch"] = None if Rb is None else int(Rb)

@@ -367,6 +367,56 @@ def build_compact_sources(index: MessageIndex) -> CompactSources:
     return CompactSources(pair_node[:max(type_row_off[-1], 1)], type_row_off, gather_c)
 
 
+class SegmentIndex:
+    """row_ptr / gather_row pair for segment_sum_rows_by_index (the fields of MessageIndex that kernel reads)."""
+
+    def __init__(self, row_ptr: torch.Tensor, gather_row: torch.Tensor, num_nodes: int):
+        self.row_ptr, self.gather_row, self.num_nodes = row_ptr, gather_row, num_nodes
+
+
+class CompactBackward:
+    """Index structures of the compacted transform's backward pass (built once per batch, torch index arithmetic):
+
+    rows_index   segments = compact rows (type-major): the message slots leaving (node,type) pair r, gather_row = dst
+                 -> dHc[r] = sum of d_incoming[dst]            (the transpose of the forward gather)
+    node_index   segments = nodes: the compact rows of node v (type ascending)
+                 -> dh[v] += sum_t (dHc W_t^T)[row(v,t)]
+    identity     CompactSources whose pair_node is arange(R): runs the compact transform kernel on [R,D] rows as they are
+    """
+
+    def __init__(self, index: MessageIndex, comp: CompactSources):
+        V, T, M = index.num_nodes, index.num_edge_types, index.num_messages
+        R = comp.num_rows
+        dev = index.adj.device
+        src = getattr(index, "_source_index", None)
+        if src is None:
+            lists = [index.adj[index.type_off[t]:index.type_off[t + 1]] for t in range(T)]
+            src = index._source_index = build_source_index(lists, V)
+        pn = comp.pair_node[:R].long()
+        typ = torch.repeat_interleave(torch.arange(T, device=dev), torch.as_tensor(
+            [comp.type_row_off[t + 1] - comp.type_row_off[t] for t in range(T)], device=dev), output_size=R)
+        seg = pn * T + typ                                              # segment of the by-(src*T+type) index
+        rp = src.row_ptr.long()
+        start, length = rp[seg], rp[seg + 1] - rp[seg]
+        ends = torch.cumsum(length, 0)
+        rp_c = torch.zeros(R + 1, dtype=torch.int32, device=dev)
+        rp_c[1:] = ends.to(torch.int32)
+        slots = torch.repeat_interleave(start - (ends - length), length, output_size=M) + torch.arange(M, device=dev)
+        self.rows_index = SegmentIndex(rp_c, src.gather_row[slots].contiguous(), R)
+        order = torch.sort(pn, stable=True)[1]                          # rows by node, type ascending inside a node
+        rp_n = torch.zeros(V + 1, dtype=torch.int32, device=dev)
+        rp_n[1:] = torch.cumsum(torch.bincount(pn, minlength=V), 0).to(torch.int32)
+        self.node_index = SegmentIndex(rp_n, order.to(torch.int32).contiguous(), V)
+        self.identity = CompactSources(torch.arange(max(R, 1), dtype=torch.int32, device=dev), comp.type_row_off, comp.gather_row)
+
+
+def compact_backward(index: MessageIndex, comp: CompactSources) -> CompactBackward:
+    bwd = getattr(comp, "_bwd", None)
+    if bwd is None:
+        bwd = comp._bwd = CompactBackward(index, comp)
+    return bwd
+
+
 def msg_transform_compact(h: torch.Tensor, edge_weights: torch.Tensor, comp: CompactSources,
                           out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Hc[r] = h[pair_node[r]] @ edge_weights[type(r)] for the active (node,type) pairs only

@@ -24,6 +24,45 @@ def tf_dropout(x: torch.Tensor, keep_prob: float, generator=None) -> torch.Tenso
     return x / keep_prob * torch.floor(keep_prob + u)
 
 
+def tn_matmul(x: torch.Tensor, dy: torch.Tensor, chunk: int = 2048) -> torch.Tensor:
+    """x^T @ dy for tall-skinny operands ([V,K]^T [V,N] -> [K,N], V ~ 1e5, K,N <= 400).
+
+    A single vendor-BLAS GEMM launches only ceil(K/64)*ceil(N/64) ~ 12 workgroups for this shape (no split along
+    the 1e5-long reduction) and took ~340 us; batching the reduction into V/chunk independent [K,chunk]x[chunk,N]
+    products fills the GPU, and the [V/chunk, K, N] partials are summed in one small reduction."""
+    V = x.shape[0]
+    nb = V // chunk
+    if nb < 8:
+        return x.t().matmul(dy)
+    main = nb * chunk
+    part = torch.bmm(x[:main].view(nb, chunk, x.shape[1]).transpose(1, 2), dy[:main].view(nb, chunk, dy.shape[1])).sum(0)
+    if main < V:
+        part = part + x[main:].t().matmul(dy[main:])
+    return part
+
+
+class _TallLinear(torch.autograd.Function):
+    """x @ W + b for tall x ([V,K], V ~ 1e5): same forward as torch, but the weight gradient x^T dy -- a reduction over
+    all V rows that the vendor BLAS runs on a dozen workgroups (~330 us for the [V,200]^T [V,1] of the readout) -- is
+    batched along V (tn_matmul)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        return x.matmul(W) + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy.matmul(W.t()) if ctx.needs_input_grad[0] else None
+        if W.shape[1] == 1:
+            dW = (x * dy).sum(0).unsqueeze(1)
+        else:
+            dW = tn_matmul(x, dy)
+        return dx, dW, dy.sum(0)
+
+
 class MLP(object):
     """utils.py:39-70.  With hid_sizes=[] (the only use, chem_tensorflow.py:153-157) the call returns
     the PRE-activation of the single layer: inputs @ dropout(W) + b  (utils.py:64-70)."""
@@ -53,6 +92,6 @@ class MLP(object):
         keep = self.dropout_keep_prob() if callable(self.dropout_keep_prob) else self.dropout_keep_prob
         hid = acts
         for W, b in zip(self.params["weights"], self.params["biases"]):
-            hid = acts.matmul(tf_dropout(W, keep)) + b
+            hid = _TallLinear.apply(acts, tf_dropout(W, keep), b)
             acts = torch.relu(hid)
         return hid

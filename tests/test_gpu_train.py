@@ -54,7 +54,11 @@ def _oracle_loss_and_grads(oracle_torch, model, layers, feed):
 @pytest.mark.parametrize("config", [{}, {"use_edge_bias": True, "graph_rnn_activation": "relu"},
                                     {"use_edge_msg_avg_aggregation": False, "hidden_size": 64,
                                      "layer_timesteps": [2, 1], "residual_connections": {"1": [0]}}])
-def test_gradients_match_oracle_autograd(pkg, oracle, oracle_torch, cuda, config):
+@pytest.mark.parametrize("compact", [False, True])
+def test_gradients_match_oracle_autograd(pkg, oracle, oracle_torch, cuda, config, compact, monkeypatch):
+    """compact: the message transform (forward AND backward) on the active (node,type) pairs only vs the dense
+    [V, T*D] form -- both must reproduce the oracle's autograd gradients."""
+    monkeypatch.setattr(pkg.backward, "USE_COMPACT_TRANSFORM", compact)
     model, layers, feed = _setup(pkg, oracle, config)
     want_loss, want = _oracle_loss_and_grads(oracle_torch, model, layers, feed)
     variables = model.trainable_variables

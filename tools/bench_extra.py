@@ -25,14 +25,18 @@ DEV = "cuda:0"
 
 
 def timed(fn, warmup, steps):
+    import gc
     for _ in range(warmup):
         fn()
+    gc.collect(); gc.freeze(); gc.disable()        # no 45 ms cyclic-GC pause inside the timed region (see bench.py)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    dt = (time.perf_counter() - t0) / steps
+    gc.enable()
+    return dt
 
 
 def kernel_table(fn, reps=6):
