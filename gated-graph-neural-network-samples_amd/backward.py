@@ -5,9 +5,9 @@ Forward runs on the hand-written HIP kernels and saves r, u, c.  Backward:
   * GRU gate algebra: two fused HIP element-wise passes (ggnn_gru_bwd_stage{1,2}_f32);
   * d(gather/segment-sum) = the SAME HIP gather/segment-sum kernel driven by the transpose index
     (messages bucketed by (src,type), gathering d_incoming[dst]) -- atomics-free and deterministic;
-  * the message transform runs in its compacted form in both directions (active (node,type) pairs only): the
-    transpose gather lands on compact rows, dHc W_t^T is the forward kernel on transposed weights, the per-node
-    sum over types is one more segment sum;
+  * optionally (USE_COMPACT_TRANSFORM) the message transform runs in its compacted form in both directions (active
+    (node,type) pairs only): the transpose gather lands on compact rows, dHc W_t^T is the forward kernel on
+    transposed weights, the per-node sum over types is one more segment sum;
   * dX = dY W^T runs on the package's own FP32-MFMA GEMM (ggnn_gemm_f32 on the transposed weights; ~2.5x the vendor
     BLAS at these skinny shapes: M = 1e5, K and N = 100..400);
   * the weight gradients dW = X^T dY -- plain tall-skinny library GEMMs -- go to the vendor BLAS through torch,
