@@ -315,7 +315,11 @@ def test_compact_transform_equals_dense_form(pkg, oracle, cuda, V, M, D, T):
 
 
 @pytest.mark.parametrize("V,M,D,T,R,avg", [(500, 1200, 100, 4, 0, True), (3001, 9000, 100, 4, 1, True), (777, 900, 100, 4, 2, False),
-                                           (260, 2000, 64, 3, 1, True), (100, 0, 32, 2, 0, True), (17, 60, 100, 1, 2, True)])
+                                           (260, 2000, 64, 3, 1, True), (100, 0, 32, 2, 0, True), (17, 60, 100, 1, 2, True),
+                                           # several passes per workgroup: full rounds + thin tail tickets, gather phases
+                                           # running one pass ahead (R=0) / across the pass boundary (R=1)
+                                           (70001, 150000, 100, 4, 0, True), (70001, 150000, 100, 4, 1, True),
+                                           (66000, 140000, 100, 4, 2, True)])
 def test_gru_with_gathered_segment_sum(pkg, oracle, cuda, V, M, D, T, R, avg):
     """ggnn_gru_packed_gather_f32 (segment sum gathered inside the GRU kernel) == ggnn_gather_segment_sum_f32 followed
     by ggnn_gru_packed_f32, bit for bit: same slot order, same fp32 adds, same division."""
