@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     int g_beg = 0, g_end = 0;
     int g_i[KI];
     f32x4 g_n = {0.f, 0.f, 0.f, 0.f};
-    float g_den = 1.f;
+    float g_den = 1.f, g_rcp = 1.f;
     Frag<D> gt;
 
     auto g_ptrs = [&](int r, bool on) {               // level 1: slot range + in-degree of row r
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
 #pragma unroll
         for (int j = 0; j < KI; ++j)
             if (g_beg + j < g_end) g_i[j] = a.g_idx[g_beg + j];
-        g_den = (((g_n.x + g_n.y) + g_n.z) + g_n.w) + 1e-7f;    // the in-degrees landed with the slot range
+        g_den = (((g_n.x + g_n.y) + g_n.z) + g_n.w) + 1e-7f;
+        if constexpr (NX == 1) g_rcp = 1.0f / g_den;    // the in-degrees landed with the slot range
     };
     auto g_rows0 = [&](Frag<D>& f) {                  // level 3: slot 0 straight into f, slot 1 into the temporary
 #pragma unroll
@@ -196,10 +197,20 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             frag_add<D>(f, gt);
         }
         if (a.g_use_avg) {                                            // :206-209
+            // x / den for the 25+ values of the row with ONE division: r = RN(1/den), q = RN(x r), then the FMA
+            // residual step q + (x - den q) r.  With a correctly rounded r this IS the correctly rounded quotient
+            // (Markstein) -- bit-identical to the `/` of the stand-alone kernel, asserted by the tests -- for 3 vector-ALU
+            // instructions per value instead of ~11 (vector-ALU work is paid in matrix-pipe time).
+            // (NX >= 2 keeps the plain division: one more long-lived register pushes those variants deeper into scratch)
+            const float den = g_den, r = g_rcp;
+            auto dv = [&](float x) {
+                if constexpr (NX == 1) { const float q = x * r; return fmaf(fmaf(-den, q, x), r, q); }
+                else return x / den;
+            };
 #pragma unroll
-            for (int c = 0; c < NC; ++c) f.v[c] = f.v[c] / g_den;
+            for (int c = 0; c < NC; ++c) f.v[c] = f32x4{dv(f.v[c].x), dv(f.v[c].y), dv(f.v[c].z), dv(f.v[c].w)};
 #pragma unroll
-            for (int q = 0; q < NR; ++q) f.r[q] = f.r[q] / g_den;
+            for (int q = 0; q < NR; ++q) f.r[q] = dv(f.r[q]);
         }
     };
 
@@ -291,7 +302,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             __builtin_amdgcn_sched_barrier(0);   /* keep the side work on its side of the MFMA block */  \
             /* u-gate stages (POS % 3 == 1) skip their last tile when it rides in the r image */          \
             constexpr int ntl_ = (C::TAILPACK && (POS) % 3 == 1) ? NT - 1 : NT;                          \
-            if (active && !(a.dbg & 1)) stage_mma<D, NoHook, ntl_>(ACC, FRAG, ring + cur * C::IMG, li, kq); \
+            /* stages 0..2 open the three accumulator sets: they start from the constant 0 */            \
+            if (active && !(a.dbg & 1)) stage_mma<D, NoHook, ntl_, ((POS) < 3)>(ACC, FRAG, ring + cur * C::IMG, li, kq); \
             __builtin_amdgcn_sched_barrier(0);                                                           \
             if (!late) {                                                                                 \
                 prefetch(std::integral_constant<int, (POS)>{});                                          \
@@ -303,11 +315,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             cur ^= 1;                                                                                    \
         }
 
-        f32x4 acc_r[NT], acc_u[NT], acc_c[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            acc_r[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_u[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_c[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        f32x4 acc_r[NT], acc_u[NT], acc_c[NT];       // opened by stages 0, 1, 2 (first MFMA of each tile: C = 0)
+        if constexpr (C::TAILPACK) acc_u[NT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};   // (never computed: it rides in acc_r)
         // ---- x segments: r, u and candidate columns of each -------------------------------------------
         GGNN_STAGE(0, acc_r, xf[0]) GGNN_STAGE(1, acc_u, xf[0]) GGNN_STAGE(2, acc_c, xf[0])
         if constexpr (NX >= 2) { GGNN_STAGE(3, acc_r, xf[1]) GGNN_STAGE(4, acc_u, xf[1]) GGNN_STAGE(5, acc_c, xf[1]) }

@@ -101,10 +101,8 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
         if (idx_n < n_wt) load_frag<D>(an, h, node_n, kq);             // rows of the next tile
         if (idx_n + stride < n_wt) node_n = pair_node[row_of(idx_n + stride)];
         f32x4 acc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);                  // the fetches are issued BEFORE the MFMA block
-        stage_mma<D>(acc, a, img, li, kq);
+        stage_mma<D, NoHook, NT, true>(acc, a, img, li, kq);    // (first MFMA of each tile starts from C = 0)
         stage_tail_reduce<D>(acc);
         const int r = row_beg + idx * 16 + li;
         if (r < row_end) {

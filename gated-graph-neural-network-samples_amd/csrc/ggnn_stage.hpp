@@ -86,7 +86,9 @@ struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 // burst (each global_load_lds costs ~60-180 issue cycles during which the matrix pipe would sit idle).
 // NTILES < NT: only the first NTILES output tiles are computed (the fused GRU's u-gate stage, whose last tile is
 // computed by the r-gate stage: StageCfg::TAILPACK).
-template <int D, class Hook = NoHook, int NTILES = StageCfg<D>::NT>
+// ZERO: the accumulators are not read: the first MFMA of every tile takes the constant 0 as its C operand (saves
+// zeroing 4*NT registers per accumulator set with vector-ALU moves).
+template <int D, class Hook = NoHook, int NTILES = StageCfg<D>::NT, bool ZERO = false>
 __device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const Frag<D>& a, const float* img, int li, int kq,
                                           const Hook& hook = Hook()) {
     using C = StageCfg<D>;
@@ -141,8 +143,10 @@ __device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const F
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int j = 0; j < G; ++j)
-                if (g0 + j < NTM)
-                    acc[g0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[gi & 1][j][e], a.v[c][e], acc[g0 + j], 0, 0, 0);
+                if (g0 + j < NTM) {
+                    const f32x4 cin = (ZERO && c == 0 && e == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[g0 + j];
+                    acc[g0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[gi & 1][j][e], a.v[c][e], cin, 0, 0, 0);
+                }
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (VT) {

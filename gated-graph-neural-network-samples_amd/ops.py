@@ -25,8 +25,9 @@ from . import _lib
 from ._lib import check
 
 ACT_IDS = {"tanh": 0, "relu": 1}
-# sparse_propagate: gather the segment sum inside the fused GRU (2 launches per timestep instead of 3)
-FUSE_GATHER = os.environ.get("GGNN_FUSE_GATHER", "1") != "0"
+# sparse_propagate: gather the segment sum inside the fused GRU (2 launches per timestep instead of 3) for layers with at
+# most FUSE_GATHER concatenated GRU inputs (1 = layers without residual inputs, where it pays; 0 = never; 3 = always)
+FUSE_GATHER = int(os.environ.get("GGNN_FUSE_GATHER", "1"))
 
 
 # ---- optional per-launch timing (bench.py's roofline leg) ---------------------------------------------
@@ -607,7 +608,7 @@ def sparse_propagate(h0: torch.Tensor, index: MessageIndex, comp: Optional[Compa
         _ptr(h0), V, D, T, _ptr(index.row_ptr), _ptr(gather), None if comp is None else _ptr(comp.pair_node), off,
         _ptr(nin), 1 if use_avg else 0, L, i32([int(x) for x in layer_timesteps]), i32(res_ptr), i32(res_idx),
         _ptr_array(edge_w), _ptr_array(edge_packed), _ptr_array(edge_bias), _ptr_array(Wg), _ptr_array(bg), _ptr_array(Wc),
-        _ptr_array(bc), _ptr_array(gru_packed), act, 1 if fuse_gather else 0, _ptr_array(outs), _ptr(ws), ws_bytes, _stream()))
+        _ptr_array(bc), _ptr_array(gru_packed), act, int(fuse_gather), _ptr_array(outs), _ptr(ws), ws_bytes, _stream()))
     return outs
 
 

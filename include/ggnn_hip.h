@@ -221,8 +221,9 @@ int ggnn_gru_candidate_f32(const float* const* x_segs, int nx, const float* rh, 
  *   Wg/Wc raw and/or gru_packed (ggnn_gru_pack_weights_f32); bg [2D], bc [D]
  *   layer_out                   HOST [num_layers] of DEVICE [V,D]: node_states_per_layer[l+1]; the last one is
  *                               the function's return value (:218)
- *   fuse_gather                 nonzero: layers with packed GRU weights, a fused hidden size and no edge bias run
- *                               2 launches per timestep (transform, ggnn_gru_packed_gather_f32) instead of 3
+ *   fuse_gather                 k > 0: layers with at most k concatenated GRU inputs (residuals + messages; 1 = no
+ *                               residual inputs), packed GRU weights, a fused hidden size and no edge bias run 2 launches
+ *                               per timestep (transform, ggnn_gru_packed_gather_f32) instead of 3;  0: never
  *   ws                          ggnn_sparse_propagate_workspace_bytes(V, D, T, compact_rows or -1) bytes
  */
 size_t ggnn_sparse_propagate_workspace_bytes(int V, int D, int T, int64_t compact_rows);

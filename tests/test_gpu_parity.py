@@ -399,12 +399,19 @@ def test_native_driver_equals_python_loop(pkg, oracle, cuda, config, monkeypatch
             model.feed(feeds[0])
             loop = model.compute_final_node_representations().clone()
         assert len(kt.results()) >= 2
-        # three launches per timestep (separate segment sum) == two launches (segment sum gathered inside the GRU)
-        monkeypatch.setattr(pkg.ops, "FUSE_GATHER", not pkg.ops.FUSE_GATHER)
-        model.feed(feeds[0])
-        other = model.compute_final_node_representations().clone()
+        # three launches per timestep (separate segment sum) == two launches (segment sum gathered inside the GRU):
+        # never fused / fused for every layer, whatever the default mix is
+        others = []
+        for k in (0, 3):
+            monkeypatch.setattr(pkg.ops, "FUSE_GATHER", k)
+            model.feed(feeds[0])
+            others.append(model.compute_final_node_representations().clone())
+            with pkg.ops.kernel_timing():
+                model.feed(feeds[0])
+                others.append(model.compute_final_node_representations().clone())
     assert torch.equal(native, loop)
-    assert torch.equal(native, other)
+    for o in others:
+        assert torch.equal(native, o)
     np.testing.assert_allclose(native.cpu().numpy(), _oracle_states(oracle, feeds[0], layers, model.params), **MODEL_TOL)
 
 
