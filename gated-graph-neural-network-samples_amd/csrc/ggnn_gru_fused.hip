@@ -152,11 +152,11 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     Frag<D> gt;
 
     auto g_ptrs = [&](int r, bool on) {               // level 1: slot range + in-degree of row r
-        const int b = a.g_row_ptr[r], e = a.g_row_ptr[r + 1];        // r is a valid (clamped) row even when !on
+        const int b = ldi_b(a.g_row_ptr, (unsigned)r * 4u), e = ldi_b(a.g_row_ptr, (unsigned)r * 4u + 4u);   // r is valid even when !on
         g_beg = on ? b : 0; g_end = on ? e : 0;
         if (a.g_use_avg) {
             if (a.g_T == 4) {
-                g_n = ld4(a.g_nin + (unsigned)r * 4u);
+                g_n = ld4_b(a.g_nin, (unsigned)r * 16u);
             } else {
                 float deg = 0.f;
                 for (int t = 0; t < a.g_T; ++t) deg += a.g_nin[(size_t)r * a.g_T + t];
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     auto g_index = [&]() {                            // level 2: the first KI source rows
 #pragma unroll
         for (int j = 0; j < KI; ++j)
-            if (g_beg + j < g_end) g_i[j] = a.g_idx[g_beg + j];
+            if (g_beg + j < g_end) g_i[j] = ldi_b(a.g_idx, (unsigned)(g_beg + j) * 4u);
         g_den = (((g_n.x + g_n.y) + g_n.z) + g_n.w) + 1e-7f;
         if constexpr (NX == 1) g_rcp = 1.0f / g_den;    // the in-degrees landed with the slot range
     };
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                     acc_r[nt] = r; acc_u[nt] = u;
                     if constexpr (SAVE) {
                         if (row < a.V) {
-                            st4(a.save_r + ((unsigned)row * D + col), r);
-                            st4(a.save_u + ((unsigned)row * D + col), u);
+                            st4_b(a.save_r, ((unsigned)row * D + col) * 4u, r);
+                            st4_b(a.save_u, ((unsigned)row * D + col) * 4u, u);
                         }
                     }
                 }
@@ -403,8 +403,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                     if (a.act == GGNN_ACT_TANH) { c.x = tanh_f(c.x); c.y = tanh_f(c.y); c.z = tanh_f(c.z); c.w = tanh_f(c.w); }
                     else { c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f); }
                     const f32x4 u = acc_u[nt];
-                    st4(a.h_out + ((unsigned)row * D + col), u * hv + (1.0f - u) * c);
-                    if constexpr (SAVE) st4(a.save_c + ((unsigned)row * D + col), c);
+                    st4_b(a.h_out, ((unsigned)row * D + col) * 4u, u * hv + (1.0f - u) * c);
+                    if constexpr (SAVE) st4_b(a.save_c, ((unsigned)row * D + col) * 4u, c);
                 }
             }
         }
@@ -426,8 +426,9 @@ static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t
         GGNN_CHECK_HIP(hipGetLastError());
     }
     if (a.h == nullptr) return GGNN_OK;   // pack-only call
-    if ((unsigned long long)a.V * D >= (1ULL << 32))
-        return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit element offsets: V*D must be < 2^32 (V=%d, D=%d)", a.V, D);
+    if ((unsigned long long)a.V * D >= (1ULL << 30) || (a.g_H && (unsigned long long)a.V * a.g_T * D >= (1ULL << 30)))
+        return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit byte offsets: V*D (and V*T*D for the gathered rows) "
+                                        "must be < 2^30 (V=%d, D=%d)", a.V, D);
     const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)((3 * D + 4 + 63) / 64 * 64) * sizeof(float);   // biases, ticket slots + ring
     const int wt_total = (a.V + 15) / 16;
     // one workgroup per CU; with fewer than NW tiles per CU the tiles are spread over ALL CUs as thin tickets (the

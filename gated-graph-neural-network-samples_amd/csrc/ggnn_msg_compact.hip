@@ -15,7 +15,7 @@
 namespace ggnn {
 
 constexpr int kMaxTypesC = 64;
-struct TypeRows { int row_off[kMaxTypesC + 1]; int tile_off[kMaxTypesC + 1]; int T; };
+struct TypeRows { int row_off[kMaxTypesC + 1]; int tile_off[kMaxTypesC + 1]; int T; int num_nodes; };
 
 static inline size_t align256c(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = nt * 16 + 4 * kq;
-                if (col < D) st4(Hc + ((unsigned)r * (unsigned)D + col), acc[nt]);
+                if (col < D) st4_b(Hc, ((unsigned)r * (unsigned)D + col) * 4u, acc[nt]);
             }
         }
         a = an;
@@ -127,8 +127,9 @@ static int launch_compact(const float* h, const float* W, const int* pair_node, 
         GGNN_CHECK_HIP(hipGetLastError());
     }
     if (tr.row_off[tr.T] == 0 || h == nullptr) return GGNN_OK;
-    if ((unsigned long long)tr.row_off[tr.T] * D >= (1ULL << 32))
-        return fail(GGNN_E_UNSUPPORTED, "compacted transform indexes with 32-bit element offsets: rows*D must be < 2^32");
+    const int V = tr.num_nodes;
+    if ((unsigned long long)tr.row_off[tr.T] * D >= (1ULL << 30) || (unsigned long long)V * D >= (1ULL << 30))
+        return fail(GGNN_E_UNSUPPORTED, "compacted transform indexes with 32-bit byte offsets: rows*D and V*D must be < 2^30");
     // Workgroups per type: the smallest number of rounds R (wave tiles per wave) for which all types together fit
     // two workgroups per CU, then ceil(wave tiles of the type / (R * NW)) workgroups for each type.
     long long total_wt = 0;
@@ -247,6 +248,7 @@ extern "C" int ggnn_msg_transform_compact_f32(const float* h, const float* W, co
         return fail(GGNN_E_UNSUPPORTED, "compacted message transform supports hidden sizes 32, 64, 100 (got %d)", D);
     TypeRows tr;
     tr.T = T;
+    tr.num_nodes = V;
     tr.tile_off[0] = 0;
     GGNN_CHECK_ARG(type_row_off[0] == 0, "type_row_off must start at 0");
     for (int t = 0; t < T; ++t) {

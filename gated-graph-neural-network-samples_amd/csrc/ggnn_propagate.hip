@@ -88,7 +88,8 @@ extern "C" int ggnn_sparse_propagate_f32(
         // fuse_gather = the largest number of concatenated GRU inputs (residuals + messages) for which the segment sum
         // is gathered inside the GRU kernel; 0 = never.  (Measured: it pays for nx = 1; with residual inputs the fused
         // kernel is register-bound and the separate segment-sum launch is as fast.)
-        const bool gather_in_gru = fuse_gather > 0 && nx <= fuse_gather && packed_gru && bias_l == nullptr;
+        const bool gather_in_gru = fuse_gather > 0 && nx <= fuse_gather && packed_gru && bias_l == nullptr &&
+                                   (unsigned long long)V * T * D < (1ULL << 30);      // (its 32-bit byte offsets)
         for (int s = 0; s < steps; ++s) {          // :153
             int rc;
             if (compact) {

@@ -64,16 +64,34 @@ struct Frag {
     float r[StageCfg<D>::NR > 0 ? StageCfg<D>::NR : 1];
 };
 
+// Accesses at (wave-uniform base) + (32-bit BYTE offset): this shape selects the scalar-base + 32-bit VGPR offset
+// addressing mode of global_load / global_store.  An ELEMENT offset does not -- zext(i) << 2 is not zext(i << 2), so
+// the compiler builds a 64-bit address per access with a vector-ALU instruction (v_lshl_add_u64), and vector-ALU
+// instructions are paid in matrix-pipe time.  The addressed array must be < 4 GiB.
+__device__ __forceinline__ f32x4 ld4_b(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float ld1_b(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ int ldi_b(const int* base, unsigned byte_off) {
+    return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st4_b(float* base, unsigned byte_off, f32x4 v) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 // lane (row = lane&15, kq = lane>>4): float4 A[row][16c + 4kq ..] per chunk + one float per remainder MFMA
 template <int D>
 __device__ __forceinline__ void load_frag(Frag<D>& f, const float* base, int row, int kq) {
     constexpr int NC = StageCfg<D>::NC, NR = StageCfg<D>::NR;
-    // 32-bit element offsets (V*D < 2^32): one VGPR offset + scalar base per access instead of 64-bit VGPR pairs
-    const unsigned o = (unsigned)row * (unsigned)D + 4u * (unsigned)kq;
+    // 32-bit byte offsets (rows * D * 4 < 2^32): one VGPR offset + scalar base + immediate per access
+    const unsigned ob = ((unsigned)row * (unsigned)D + 4u * (unsigned)kq) * 4u;
+    __builtin_assume(ob < 0xF0000000u);          // (so that the +64c below can fold into the instruction's immediate)
 #pragma unroll
-    for (int c = 0; c < NC; ++c) f.v[c] = ld4(base + (o + 16u * c));
+    for (int c = 0; c < NC; ++c) f.v[c] = ld4_b(base, ob + 64u * c);
 #pragma unroll
-    for (int q = 0; q < NR; ++q) f.r[q] = base[o - 4u * (unsigned)kq + (unsigned)(16 * NC + 4 * q) + (unsigned)kq];
+    for (int q = 0; q < NR; ++q) f.r[q] = ld1_b(base, ob - 16u * (unsigned)kq + 4u * (unsigned)(16 * NC + 4 * q) + 4u * (unsigned)kq);
 }
 
 // acc[nt] += A-fragment x stage image.  Per k-chunk c and group of <= 4 tiles: 4 ds_read_b128 feed 16 MFMAs;
