@@ -120,11 +120,12 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     // immediate; behind the ring each of the 21 addresses was a loop-invariant register of its own, and those
     // were spilled to scratch): the epilogues read them with ds_read instead of 7 serialized
     // global round trips per epilogue
-    constexpr int BIAS_FLOATS = (3 * D + 4 + 63) / 64 * 64;
-    float* bias_s = lds_;                                           // [bg (2D) | bc (D) | next ticket]
+    constexpr int BIAS_FLOATS = (4 * D + 4 + 63) / 64 * 64;
+    float* bias_s = lds_;                             // [-log2e*bg (2D) | 2 log2e*bc (D) | bc (D) | next tickets (2)]
     float* ring = lds_ + BIAS_FLOATS;
-    int* tk_slot = reinterpret_cast<int*>(bias_s + 3 * D);
-    for (int i = tid; i < 3 * D; i += NW * 64) bias_s[i] = i < 2 * D ? a.bg[i] : a.bc[i - 2 * D];
+    int* tk_slot = reinterpret_cast<int*>(bias_s + 4 * D);
+    for (int i = tid; i < 4 * D; i += NW * 64)
+        bias_s[i] = i < 2 * D ? -kLog2e * a.bg[i] : (i < 3 * D ? 2.0f * kLog2e * a.bc[i - 2 * D] : a.bc[i - 3 * D]);
     // The two waves of a SIMD (w and w + NW/2) do not interleave on the matrix pipe: the older one issues its whole
     // MFMA burst first.  The stage loop leans on that: the waves of the first half ("early") burst first and do
     // their side work afterwards, the second half ("late") the other way round.
@@ -343,12 +344,10 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = nt * 16 + 4 * kq;
                 if (col < D) {
-                    const f32x4 br = ld4(bias_s + col), bu = ld4(bias_s + D + col);
-                    f32x4 r, u;
-                    r.x = sigmoid_f(acc_r[nt].x + br.x); r.y = sigmoid_f(acc_r[nt].y + br.y);
-                    r.z = sigmoid_f(acc_r[nt].z + br.z); r.w = sigmoid_f(acc_r[nt].w + br.w);
-                    u.x = sigmoid_f(acc_u[nt].x + bu.x); u.y = sigmoid_f(acc_u[nt].y + bu.y);
-                    u.z = sigmoid_f(acc_u[nt].z + bu.z); u.w = sigmoid_f(acc_u[nt].w + bu.w);
+                    // bias_s holds -log2(e)*bg: sigmoid(z + b) = 1 / (1 + 2^(-log2e z - log2e b)), the bias add folded
+                    // into the scaling FMA; written on whole float4s so that the non-transcendental half packs (v_pk_*)
+                    const f32x4 r = sigmoid4_scaled(acc_r[nt], ld4(bias_s + col));
+                    const f32x4 u = sigmoid4_scaled(acc_u[nt], ld4(bias_s + D + col));
                     acc_r[nt] = r; acc_u[nt] = u;
                     if constexpr (SAVE) {
                         if (row < a.V) {
@@ -398,10 +397,13 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                     f32x4 hv;
                     if (nt < NC) hv = hf.v[nt];
                     else hv = hrem;
-                    const f32x4 b = ld4(bias_s + 2 * D + col);
-                    f32x4 c = acc_c[nt] + b;
-                    if (a.act == GGNN_ACT_TANH) { c.x = tanh_f(c.x); c.y = tanh_f(c.y); c.z = tanh_f(c.z); c.w = tanh_f(c.w); }
-                    else { c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f); }
+                    f32x4 c;
+                    if (a.act == GGNN_ACT_TANH) {
+                        c = tanh4_scaled(acc_c[nt], ld4(bias_s + 2 * D + col));           // (2 log2e * bc)
+                    } else {
+                        c = acc_c[nt] + ld4(bias_s + 3 * D + col);                         // (bc itself)
+                        c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
+                    }
                     const f32x4 u = acc_u[nt];
                     st4_b(a.h_out, ((unsigned)row * D + col) * 4u, u * hv + (1.0f - u) * c);
                     if constexpr (SAVE) st4_b(a.save_c, ((unsigned)row * D + col) * 4u, c);
@@ -429,7 +431,7 @@ static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t
     if ((unsigned long long)a.V * D >= (1ULL << 30) || (a.g_H && (unsigned long long)a.V * a.g_T * D >= (1ULL << 30)))
         return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit byte offsets: V*D (and V*T*D for the gathered rows) "
                                         "must be < 2^30 (V=%d, D=%d)", a.V, D);
-    const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)((3 * D + 4 + 63) / 64 * 64) * sizeof(float);   // biases, ticket slots + ring
+    const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)((4 * D + 4 + 63) / 64 * 64) * sizeof(float);   // biases, ticket slots + ring
     const int wt_total = (a.V + 15) / 16;
     // one workgroup per CU; with fewer than NW tiles per CU the tiles are spread over ALL CUs as thin tickets (the
     // kernel's tail rule: ceil(tiles / nb) waves busy per workgroup) rather than packed 8 to a workgroup on a few CUs --
