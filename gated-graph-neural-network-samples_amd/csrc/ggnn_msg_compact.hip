@@ -15,7 +15,7 @@
 namespace ggnn {
 
 constexpr int kMaxTypesC = 64;
-struct TypeRows { int row_off[kMaxTypesC + 1]; int tile_off[kMaxTypesC + 1]; int T; int num_nodes; };
+struct TypeRows { int row_off[kMaxTypesC + 1]; int tile_off[kMaxTypesC + 1]; int T; int num_nodes; unsigned long long* tdbg; };
 
 static inline size_t align256c(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -81,6 +81,8 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
 
+#define K1C_T(K) if (tr.tdbg && lane == 0) tr.tdbg[((size_t)blockIdx.x * NW + wave) * 8 + (K)] = (K) == 0 || (K) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+    K1C_T(0)
     int t = 0;
     while (t + 1 < tr.T && (int)blockIdx.x >= tr.tile_off[t + 1]) ++t;
     const int row_beg = tr.row_off[t], row_end = tr.row_off[t + 1];
@@ -94,7 +96,10 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
     int node_n = 0;
     if (idx < n_wt) load_frag<D>(a, h, pair_node[row_of(idx)], kq);
     if (idx + stride < n_wt) node_n = pair_node[row_of(idx + stride)];
+    K1C_T(1)
     __syncthreads();                                        // the image has landed (vmcnt(0) + barrier)
+    K1C_T(2)
+    int tcount = 0;
 
     while (idx < n_wt) {
         const int idx_n = idx + stride;
@@ -114,7 +119,10 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
         }
         a = an;
         idx = idx_n;
+        if (tcount < 4) { K1C_T(3 + tcount) }
+        ++tcount;
     }
+    K1C_T(7)
 }
 
 template <int D>
@@ -151,6 +159,7 @@ static int launch_compact(const float* h, const float* W, const int* pair_node, 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::IMG_BYTES));
         attr_set = true;
     }
+    { const char* e = getenv("GGNN_K1C_TPTR"); tr.tdbg = e ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
     hipLaunchKernelGGL((msg_transform_compact_kernel<D, NW>), dim3(tr.tile_off[tr.T]), dim3(NW * 64), C::IMG_BYTES, st, h, pair_node,
                        tr, (const float*)packed, Hc);
     GGNN_CHECK_HIP(hipGetLastError());
