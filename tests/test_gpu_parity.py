@@ -314,6 +314,30 @@ def test_compact_transform_equals_dense_form(pkg, oracle, cuda, V, M, D, T):
     assert torch.allclose(a, b, atol=2e-6, rtol=1e-5)
 
 
+def test_compact_transform_with_empty_edge_types(pkg, oracle, cuda):
+    """Edge types without a single edge (first, middle and last: chem_tensorflow_sparse.py:346-347 feeds an empty [0,2]
+    list) get no workgroup in the persistent per-type transform; the others are unaffected."""
+    rng = np.random.default_rng(77)
+    V, D, T = 900, 100, 6
+    h, adj, nin = random_graph_batch(rng, V, 5000, T, D, sorted_src=True)
+    for t in (0, 3, 5):
+        nin[:, t] = 0.0
+        adj[t] = np.zeros((0, 2), np.int32)
+    W = rng.uniform(-0.3, 0.3, (T, D, D)).astype(np.float32)
+    index = pkg.ops.build_message_index([dev(a, cuda) for a in adj], V)
+    comp = pkg.ops.build_compact_sources(index)
+    assert comp.type_row_off[1] == 0 and comp.type_row_off[3] == comp.type_row_off[4] and comp.type_row_off[5] == comp.type_row_off[6]
+    hd, Wd, nd = dev(h, cuda), dev(W, cuda), dev(nin, cuda)
+    a = pkg.ops.gather_segment_sum(pkg.ops.msg_transform(hd, Wd), index, nd, None, True)
+    b = pkg.ops.gather_segment_sum_compact(pkg.ops.msg_transform_compact(hd, Wd, comp), index, comp, nd, None, True)
+    assert torch.allclose(a, b, atol=2e-6, rtol=1e-5)
+    h64, W64 = h.astype(np.float64), W.astype(np.float64)
+    msgs = np.concatenate([h64[adj[t][:, 0]] @ W64[t] for t in range(T)], axis=0)          # :160-168
+    tgt = np.concatenate([adj[t][:, 1] for t in range(T)])
+    want = oracle.unsorted_segment_sum(msgs, tgt, V) / (nin.astype(np.float64).sum(1, keepdims=True) + 1e-7)   # :198-209
+    np.testing.assert_allclose(b.cpu().numpy(), want, atol=2e-6, rtol=1e-5)
+
+
 @pytest.mark.parametrize("V,M,D,T,R,avg", [(500, 1200, 100, 4, 0, True), (3001, 9000, 100, 4, 1, True), (777, 900, 100, 4, 2, False),
                                            (260, 2000, 64, 3, 1, True), (100, 0, 32, 2, 0, True), (17, 60, 100, 1, 2, True),
                                            # several passes per workgroup: full rounds + thin tail tickets, gather phases
