@@ -1,6 +1,7 @@
 // Shared host-side helpers of libggnn_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include "../../include/ggnn_hip.h"
@@ -29,5 +30,19 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // Number of CUs of the current device (cached per process; MI355X = 256).
 int num_cus();
+
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): `done` is a per-kernel bitmask of the devices that have
+// it (the attribute is per device; one process may drive several).  Thread-safe; a lost race only repeats the call.
+template <class Kernel>
+inline hipError_t allow_dynamic_lds(Kernel* kernel, size_t bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const unsigned long long bit = 1ULL << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)bytes); e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
 
 }  // namespace ggnn

@@ -438,12 +438,8 @@ static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t
     // a pass with one or two busy waves takes less than half the time of a full one
     int nb = num_cus();
     if (nb > wt_total) nb = wt_total;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        GGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_ok{0};        // (one per template instantiation)
+    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER>, lds, lds_ok));
     hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;

@@ -153,12 +153,8 @@ static int launch_compact(const float* h, const float* W, const int* pair_node, 
     tr.tile_off[0] = 0;
     for (int t = 0; t < tr.T; ++t)
         tr.tile_off[t + 1] = tr.tile_off[t] + (int)(((tr.row_off[t + 1] - tr.row_off[t] + 15) / 16 + R * NW - 1) / (R * NW));
-    static bool attr_set = false;
-    if (!attr_set && C::IMG_BYTES > 48 * 1024) {
-        GGNN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&msg_transform_compact_kernel<D, NW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::IMG_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (C::IMG_BYTES > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&msg_transform_compact_kernel<D, NW>, C::IMG_BYTES, lds_ok));
     { const char* e = getenv("GGNN_K1C_TPTR"); tr.tdbg = e ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
     hipLaunchKernelGGL((msg_transform_compact_kernel<D, NW>), dim3(tr.tile_off[tr.T]), dim3(NW * 64), C::IMG_BYTES, st, h, pair_node,
                        tr, (const float*)packed, Hc);
