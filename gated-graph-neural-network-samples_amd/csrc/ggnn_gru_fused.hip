@@ -11,8 +11,13 @@
 //
 // Weights: a tiny pre-pass (gru_pack_weights_kernel) rewrites Wg / Wc into per-stage LDS images
 // (ggnn_stage.hpp; stage = one D x D block: the [x_s|h] rows of the r columns, of the u columns, then of
-// Wc).  Stages are brought in by LDS-DMA into a 2-deep ring; the DMA of stage i+1 is issued before the
-// MFMAs of stage i.  Workgroups are persistent over a contiguous, evenly split range of 16-row tiles.
+// Wc).  Stages are brought in by LDS-DMA into a 2-deep ring; the DMA of stage i+1 is issued during stage i.
+// Workgroups are persistent: one per CU, each working through "tickets" of 8 tiles (one pass), see the kernel.
+//
+// Cost model: on gfx950 the vector ALU and the FP32 MFMA share their issue slot -- every VALU
+// instruction of the kernel costs matrix-pipe time -- so the loop is written to need few of them: byte-offset
+// addressing with scalar bases, accumulators opened with C = 0, biases folded into the exponent scaling, one
+// division per gathered row.
 //
 // Stage ORDER of one pass (3 * (NX+1) stages): every input segment is consumed by three consecutive stages
 //     x_s -> r columns, x_s -> u columns, x_s -> candidate columns          (s = 0 .. NX-1)
@@ -79,7 +84,7 @@ __device__ __forceinline__ void frag_add(Frag<D>& f, const Frag<D>& t) {
 // the [V,D] round trip of `incoming` through HBM disappear.  The gather is a 3-level dependent chain (row_ptr ->
 // gather_row -> rows); it is software-pipelined over the stage boundaries BEFORE the stage that consumes it: every
 // level is issued at the start of a stage and has landed by that stage's closing barrier, so the MFMAs never wait
-// for it (only slots beyond the pipelined depth, 3 or 5 per row, are fetched synchronously).
+// for it (only slots beyond the pipelined depth, 4 per row = the largest valence in QM9, are fetched synchronously).
 template <int D, int NX, int NW, bool SAVE, bool GATHER>
 __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a, const float* __restrict__ packed) {
     using C = StageCfg<D>;
@@ -292,9 +297,10 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                 if (active && (!G_NEXT || p > 0)) g_finish(xf[GBUF]);                                    \
             }                                                                                            \
             /* Side work of the stage (prefetches, the DMA of the whole next image): the LATE waves do it  \
-               before their MFMA burst, the EARLY waves after theirs -- each in the shadow of the other    \
-               wave's burst on the shared matrix pipe.  (Spreading the DMA instructions over the MFMA      \
-               groups via the stage_mma hook measured slower.) */                                         \
+               before their MFMA burst, the EARLY waves after theirs, so its memory instructions issue      \
+               while the partner wave owns the matrix pipe (its few VALU instructions do not overlap --    \
+               see the file header; worth 0.4 %).  (Spreading the DMA instructions over the MFMA groups    \
+               via the stage_mma hook measured slower.) */                                                \
             if (late) {                                                                                  \
                 prefetch(std::integral_constant<int, (POS)>{});                                          \
                 if (more_) dma_stage_image<D, NW>(nsrc_, ndst_, wave, lane);                             \
