@@ -69,6 +69,8 @@ SYMBOLS = {
     "ggnn_dense_aggregate_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ggnn_gemm_f32": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                               c_void_p]),
+    "ggnn_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ggnn_gemm_tn_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

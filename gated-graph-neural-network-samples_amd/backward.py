@@ -30,6 +30,19 @@ from .utils import SMALL_NUMBER, tn_matmul
 USE_COMPACT_TRANSFORM = os.environ.get("GGNN_TRAIN_COMPACT", "0") != "0"
 
 
+# Weight gradients X^T dY: vendor BLAS batched along the rows (utils.tn_matmul; default) or the package's row-split TN
+# kernel ggnn_gemm_tn_f32 (GGNN_TN_KERNEL=1).  Measured on MI355X at V = 1e5: [V,400]^T [V,200] 195 us (82 TF) batched
+# BLAS vs 297 us (54 TF) own kernel; [V,200]^T [V,100] 89 vs 138 us -- the own kernel (deterministic, tested) is not
+# yet competitive, so the library product keeps this plain GEMM.
+USE_TN_KERNEL = os.environ.get("GGNN_TN_KERNEL", "0") != "0"
+
+
+def _tn(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    if USE_TN_KERNEL and dy.shape[1] % 4 == 0 and dy.shape[1] <= 512:
+        return ops.gemm_tn(x, dy)
+    return tn_matmul(x, dy)
+
+
 def _source_index(index: "ops.MessageIndex", num_nodes: int) -> "ops.MessageIndex":
     src_index = getattr(index, "_source_index", None)
     if src_index is None:
@@ -84,14 +97,14 @@ class PropagationStepFn(torch.autograd.Function):
         dh = torch.empty_like(h)
         check(lib.ggnn_gru_bwd_stage1_f32(g.data_ptr(), h.data_ptr(), r.data_ptr(), u.data_ptr(), c.data_ptr(), act,
                                           dpc.data_ptr(), dpg.data_ptr(), dh.data_ptr(), a_c.data_ptr(), K, nx * D, V, D, st))
-        dWc = tn_matmul(a_c, dpc)
+        dWc = _tn(a_c, dpc)
         dbc = dpc.sum(0)
         dxrh = ops.gemm([dpc], Wc.t().contiguous())                            # [V, (nx+1)D] = dpc Wc^T
         # ---- gates: [r|u] = sigmoid([x | h] Wg + bg)
         drh = dxrh[:, nx * D:]
         check(lib.ggnn_gru_bwd_stage2_f32(drh.data_ptr(), K, h.data_ptr(), r.data_ptr(), dh.data_ptr(), dpg.data_ptr(), V, D, st))
         a_c[:, nx * D:] = h                                                    # reuse the buffer as [x | h]
-        dWg = tn_matmul(a_c, dpg)
+        dWg = _tn(a_c, dpg)
         dbg = dpg.sum(0)
         dxh = ops.gemm([dpg[:, :D], dpg[:, D:]], Wg.t().contiguous())           # [V, (nx+1)D] = dpg Wg^T
         dh += dxh[:, nx * D:]
@@ -127,6 +140,6 @@ class PropagationStepFn(torch.autograd.Function):
         for t0 in range(0, T, 4):                                              # (the GEMM takes <= 4 K segments)
             t1 = min(t0 + 4, T)
             dh += ops.gemm([dH[:, t * D:(t + 1) * D] for t in range(t0, t1)], WT[t0 * D:t1 * D])
-        dW = tn_matmul(h, dH).view(D, T, D).transpose(0, 1)
+        dW = _tn(h, dH).view(D, T, D).transpose(0, 1)
 
         return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, *d_res)

@@ -273,6 +273,30 @@ def gemm(a_segs: Sequence[torch.Tensor], B: torch.Tensor, out: Optional[torch.Te
     return out
 
 
+def gemm_tn(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """x^T @ dy for tall operands ([M,K]^T [M,N] -> [K,N], M ~ 1e5): the weight-gradient product of the backward
+    pass on ggnn_gemm_tn_f32 (rows split over the whole GPU, deterministic reduction).  x, dy: row-major (any row
+    stride), dy with a row stride and N that are multiples of 4."""
+    lib = _lib.load()
+    for name, t in (("x", x), ("dy", dy)):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or (t.shape[0] > 0 and t.stride(1) != 1):
+            raise TypeError("%s must be a 2-D float32 CUDA/HIP tensor with unit column stride" % name)
+    M, K = x.shape
+    N = dy.shape[1]
+    if dy.shape[0] != M:
+        raise ValueError("x and dy must have the same number of rows")
+    if M == 0:
+        return torch.zeros((K, N), dtype=torch.float32, device=x.device)
+    lda = x.stride(0) if M > 1 else K
+    ldb = dy.stride(0) if M > 1 else N
+    out = torch.empty((K, N), dtype=torch.float32, device=x.device)
+    ws_bytes = lib.ggnn_gemm_tn_workspace_bytes(M, K, N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    _launch("gemm_tn[K=%d,N=%d]" % (K, N), lambda: lib.ggnn_gemm_tn_f32(_ptr(x), lda, _ptr(dy), ldb, _ptr(out), M, K, N,
+                                                                       _ptr(ws), ws_bytes, _stream()))
+    return out
+
+
 def unsorted_segment_sum(data: torch.Tensor, segment_ids: torch.Tensor, num_segments: int) -> torch.Tensor:
     """tf.unsorted_segment_sum (fp32 atomics; any id order).  data [M,D] or [M], ids [M] int32."""
     lib = _lib.load()

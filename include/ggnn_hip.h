@@ -261,6 +261,14 @@ int ggnn_dense_aggregate_f32(const float* A, const float* Hm, const float* bias,
 int ggnn_gemm_f32(const float* const* a_segs, int nseg, int D, int lda, const float* B, int ldb, float* C, int ldc,
                   int M, int N, ggnn_stream_t stream);
 
+/* Weight-gradient product of the backward pass (a-B; TF autodiff of tf.matmul, chem_tensorflow.py:184):
+ * C[K,N] = A[M,K]^T B[M,N], M ~ 1e5 rows reduced into a small matrix.  The rows are split over the whole GPU and
+ * the per-split partials are added in a fixed order (deterministic).  N a multiple of 4, <= 512; A row stride lda,
+ * B row stride ldb (multiple of 4, B 16-byte aligned); ws: ggnn_gemm_tn_workspace_bytes(M, K, N) bytes. */
+size_t ggnn_gemm_tn_workspace_bytes(int M, int K, int N);
+int ggnn_gemm_tn_f32(const float* A, int lda, const float* B, int ldb, float* C, int M, int K, int N, void* ws,
+                     size_t ws_bytes, ggnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

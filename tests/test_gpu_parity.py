@@ -314,6 +314,28 @@ def test_compact_transform_equals_dense_form(pkg, oracle, cuda, V, M, D, T):
     assert torch.allclose(a, b, atol=2e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,K,N,strided", [(1000, 100, 100, False), (33333, 200, 200, False), (70001, 400, 100, True),
+                                           (5, 52, 12, False), (257, 300, 400, True), (0, 100, 100, False)])
+def test_gemm_tn(pkg, cuda, M, K, N, strided):
+    """ggnn_gemm_tn_f32: C = A^T B over M rows (the weight-gradient product of the backward pass), against float64;
+    error bound = the fp32 accumulation bound on sum |a||b|.  strided: operands are column slices of wider matrices."""
+    rng = np.random.default_rng(M + K + N)
+    if strided:
+        Aw = rng.uniform(-1, 1, (M, K + 60)).astype(np.float32); Bw = rng.uniform(-1, 1, (M, N + 100)).astype(np.float32)
+        Ad, Bd = dev(Aw, cuda)[:, 20:20 + K], dev(Bw, cuda)[:, 100:]
+        A, B = Aw[:, 20:20 + K], Bw[:, 100:]
+    else:
+        A = rng.uniform(-1, 1, (M, K)).astype(np.float32); B = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        Ad, Bd = dev(A, cuda), dev(B, cuda)
+    got = pkg.ops.gemm_tn(Ad, Bd).cpu().numpy()
+    want = A.astype(np.float64).T @ B.astype(np.float64)
+    bound = 1e-6 * (np.abs(A).astype(np.float64).T @ np.abs(B).astype(np.float64)) + 1e-30
+    assert got.shape == (K, N)
+    assert np.all(np.abs(got - want) <= bound)
+    again = pkg.ops.gemm_tn(Ad, Bd).cpu().numpy()
+    assert np.array_equal(got, again)                       # fixed reduction order: bit-reproducible
+
+
 def test_compact_transform_with_empty_edge_types(pkg, oracle, cuda):
     """Edge types without a single edge (first, middle and last: chem_tensorflow_sparse.py:346-347 feeds an empty [0,2]
     list) get no workgroup in the persistent per-type transform; the others are unaffected."""
