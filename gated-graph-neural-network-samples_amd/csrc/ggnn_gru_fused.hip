@@ -45,14 +45,17 @@ __global__ void gru_pack_weights_kernel(const float* __restrict__ Wg, const floa
                                         float* __restrict__ out) {
     const int ci = blockIdx.y;
     const float* W; int r0, c0, ldw;
-    int c_alt = -1;
+    int c_alt = -1, c_alt2 = -1, r0_2 = 0;
     if (ci < 2 * (nx + 1)) {
         W = Wg; r0 = (ci >> 1) * D; c0 = (ci & 1) * D; ldw = 2 * D;
-        // r images carry the u gate's last (partly filled) tile in their padding columns: the u stages then skip it
+        // r images carry the u gate's last (partly filled) tile in their padding columns: the u stages then skip it;
+        // the r images of the x segments also carry the candidate's last tile (same input rows; NOT the h segment,
+        // whose candidate rows multiply r*h)
         if (StageCfg<D>::TAILPACK && (ci & 1) == 0) c_alt = D + (D / 16) * 16;
+        if (StageCfg<D>::TAILPACK3 && (ci & 1) == 0 && (ci >> 1) < nx) { c_alt2 = (D / 16) * 16; r0_2 = (ci >> 1) * D; }
     } else { W = Wc; r0 = (ci - 2 * (nx + 1)) * D; c0 = 0; ldw = D; }
     pack_stage_image<D>(W, r0, c0, ldw, out + (size_t)ci * StageCfg<D>::IMG, blockIdx.x * blockDim.x + threadIdx.x,
-                        gridDim.x * blockDim.x, c_alt);
+                        gridDim.x * blockDim.x, c_alt, Wc, r0_2, D, c_alt2);
 }
 
 // position in the per-pass stage sequence -> packed image (segment s = pos / 3; 0,1: its r / u gate columns, 2: candidate)
@@ -308,7 +311,9 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             GGNN_T(POS, 1)                                                                               \
             __builtin_amdgcn_sched_barrier(0);   /* keep the side work on its side of the MFMA block */  \
             /* u-gate stages (POS % 3 == 1) skip their last tile when it rides in the r image */          \
-            constexpr int ntl_ = (C::TAILPACK && (POS) % 3 == 1) ? NT - 1 : NT;                          \
+            /* ... and so do the candidate stages of the x segments (POS % 3 == 2 below the h stages)    */ \
+            constexpr int ntl_ = ((C::TAILPACK && (POS) % 3 == 1) ||                                     \
+                                  (C::TAILPACK3 && (POS) % 3 == 2 && (POS) < 3 * NX)) ? NT - 1 : NT;     \
             /* stages 0..2 open the three accumulator sets: they start from the constant 0 */            \
             if (active && !(a.dbg & 1)) stage_mma<D, NoHook, ntl_, ((POS) < 3)>(ACC, FRAG, ring + cur * C::IMG, li, kq); \
             __builtin_amdgcn_sched_barrier(0);                                                           \
@@ -324,6 +329,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
 
         f32x4 acc_r[NT], acc_u[NT], acc_c[NT];       // opened by stages 0, 1, 2 (first MFMA of each tile: C = 0)
         if constexpr (C::TAILPACK) acc_u[NT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};   // (never computed: it rides in acc_r)
+        if constexpr (C::TAILPACK3) acc_c[NT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};  // (opened by the r*h stage only)
         // ---- x segments: r, u and candidate columns of each -------------------------------------------
         GGNN_STAGE(0, acc_r, xf[0]) GGNN_STAGE(1, acc_u, xf[0]) GGNN_STAGE(2, acc_c, xf[0])
         if constexpr (NX >= 2) { GGNN_STAGE(3, acc_r, xf[1]) GGNN_STAGE(4, acc_u, xf[1]) GGNN_STAGE(5, acc_c, xf[1]) }
@@ -388,6 +394,15 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         f32x4 hrem = {0.f, 0.f, 0.f, 0.f};
         if (active) {
             stage_tail_reduce<D>(acc_c);
+            if constexpr (C::TAILPACK3) {
+                // the x segments' share of the candidate's last tile was accumulated two lane groups up in the r
+                // gate's last tile (which the gates epilogue rewrote only in its own lanes); add it to the r*h share
+                constexpr int SH2 = 32 * ((D % 16) / 4);
+                f32x4 ct;
+                ct.x = __shfl(acc_r[NT - 1].x, lane + SH2); ct.y = __shfl(acc_r[NT - 1].y, lane + SH2);
+                ct.z = __shfl(acc_r[NT - 1].z, lane + SH2); ct.w = __shfl(acc_r[NT - 1].w, lane + SH2);
+                acc_c[NT - 1] = ct + acc_c[NT - 1];
+            }
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
                 const float h0 = __shfl(hf.r[q], li), h1 = __shfl(hf.r[q], li + 16);

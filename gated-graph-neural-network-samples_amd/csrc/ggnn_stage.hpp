@@ -29,30 +29,37 @@ struct StageCfg {
     static constexpr int IMG = IMG_BYTES / 4;
     // the last tile holds D % 16 <= 8 valid columns: a second block's tail fits beside it (see pack_stage_image)
     static constexpr bool TAILPACK = (D % 16 != 0) && (D % 16 <= 8) && (D % 4 == 0);
+    // ... and a third block's tail when the three fit one tile (D % 16 == 4, e.g. D = 100)
+    static constexpr bool TAILPACK3 = TAILPACK && (3 * (D % 16) <= 16);
 };
 
 // Writes the stage image of the D x D block W[r0 .. r0+D-1][c0 .. c0+D-1] (row stride ldw) to img.
 // c_alt >= 0: the first D % 16 PADDING columns of the last tile (n = D .. D + D%16 - 1) are not zero but the columns
 // c_alt .. c_alt + D%16 - 1 of the same rows -- the last, partly filled tile of ANOTHER D x D block that shares these
 // rows rides along in this image's padding (StageCfg::TAILPACK; the fused GRU packs the u-gate tail into the r image).
+// W2 / c_alt2 >= 0: likewise the NEXT D%16 padding columns (n = D + D%16 ..) come from columns c_alt2 .. of rows
+// r0_2 .. of a second matrix W2 (row stride ldw2) -- the fused GRU's candidate-gate tail, StageCfg::TAILPACK3.
 template <int D>
 __device__ __forceinline__ void pack_stage_image(const float* __restrict__ W, int r0, int c0, int ldw,
-                                                 float* __restrict__ img, int first, int stride, int c_alt = -1) {
+                                                 float* __restrict__ img, int first, int stride, int c_alt = -1,
+                                                 const float* __restrict__ W2 = nullptr, int r0_2 = 0, int ldw2 = 0, int c_alt2 = -1) {
     using C = StageCfg<D>;
     constexpr int TC = D % 16;
+    auto value = [&](int k, int n) -> float {
+        if (n < D) return W[(size_t)(r0 + k) * ldw + c0 + n];
+        if (c_alt >= 0 && n < D + TC) return W[(size_t)(r0 + k) * ldw + c_alt + (n - D)];
+        if (W2 && c_alt2 >= 0 && n >= D + TC && n < D + 2 * TC) return W2[(size_t)(r0_2 + k) * ldw2 + c_alt2 + (n - D - TC)];
+        return 0.f;
+    };
     for (int i = first; i < C::IMG; i += stride) {
         float v = 0.f;
         if (i < C::MAIN) {
             const int e = i & 3, n = (i >> 2) % C::BN, ck = (i >> 2) / C::BN;     // ck = c*4 + kq
-            const int k = 4 * ck + e;                                              // = 16c + 4kq + e
-            if (n < D) v = W[(size_t)(r0 + k) * ldw + c0 + n];
-            else if (c_alt >= 0 && n < D + TC) v = W[(size_t)(r0 + k) * ldw + c_alt + (n - D)];
+            v = value(4 * ck + e, n);                                              // k = 16c + 4kq + e
         } else if (i < C::MAIN + C::REM) {
             const int j = i - C::MAIN;
             const int n = j % C::BN, qk = j / C::BN;                               // qk = q*4 + kq
-            const int k = 16 * C::NC + qk;
-            if (n < D) v = W[(size_t)(r0 + k) * ldw + c0 + n];
-            else if (c_alt >= 0 && n < D + TC) v = W[(size_t)(r0 + k) * ldw + c_alt + (n - D)];
+            v = value(16 * C::NC + qk, n);
         }
         img[i] = v;
     }
