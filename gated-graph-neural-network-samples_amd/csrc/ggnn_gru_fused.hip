@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     constexpr int G_U = NX == 1 ? NSTAGE : 3 * (NX - 1);
     constexpr bool G_NEXT = (NX == 1);                // all phases run one pass ahead of the consumer
     int g_beg = 0, g_end = 0;
-    int g_i[KI];
+    int g_i[KI] = {0, 0, 0, 0};                       // (row 0 is always a valid row to fetch)
     f32x4 g_n = {0.f, 0.f, 0.f, 0.f};
     float g_den = 1.f, g_rcp = 1.f;
     Frag<D> gt;
@@ -174,30 +174,24 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         }
     };
     auto g_index = [&]() {                            // level 2: the first KI source rows
+        // a slot beyond the row's degree points at row 0 of Hrows: the row loads below are then UNCONDITIONAL (no
+        // zero-fills, no exec-mask juggling around 7 loads -- vector-ALU instructions cost matrix-pipe time) and only
+        // the adds are predicated; Hrows always has at least one row
 #pragma unroll
-        for (int j = 0; j < KI; ++j)
+        for (int j = 0; j < KI; ++j) {
+            g_i[j] = 0;
             if (g_beg + j < g_end) g_i[j] = ldi_b(a.g_idx, (unsigned)(g_beg + j) * 4u);
+        }
         g_den = (((g_n.x + g_n.y) + g_n.z) + g_n.w) + 1e-7f;
         if constexpr (NX == 1) g_rcp = 1.0f / g_den;    // the in-degrees landed with the slot range
     };
     auto g_rows0 = [&](Frag<D>& f) {                  // level 3: slot 0 straight into f, slot 1 into the temporary
-#pragma unroll
-        for (int c = 0; c < NC; ++c) f.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < NR; ++q) f.r[q] = 0.f;
-        frag_zero<D>(gt);                             // (ends the live range of the previous tile's temporary)
-        if (g_beg < g_end) load_frag<D>(f, a.g_H, g_i[0], kq);
-        if (g_beg + 1 < g_end) load_frag<D>(gt, a.g_H, g_i[1], kq);
+        load_frag<D>(f, a.g_H, g_i[0], kq);           // (0 + slot 0 of the segment-sum kernel: same value, up to -0)
+        load_frag<D>(gt, a.g_H, g_i[1], kq);
     };
     auto g_rows = [&](Frag<D>& f, int k) {            // add slot k-1 (landed), fetch slot k
-        if (k == 2) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) f.v[c] = f.v[c] + 0.f;      // 0 + slot 0, as the segment-sum kernel starts
-#pragma unroll
-            for (int q = 0; q < NR; ++q) f.r[q] = f.r[q] + 0.f;
-        }
         if (g_beg + k - 1 < g_end) frag_add<D>(f, gt);
-        if (g_beg + k < g_end) load_frag<D>(gt, a.g_H, g_i[k], kq);
+        load_frag<D>(gt, a.g_H, g_i[k], kq);
     };
     auto g_finish = [&](Frag<D>& f) {                 // slot 3, any further slots (synchronously), mean
         if (g_beg + KI - 1 < g_end) frag_add<D>(f, gt);
@@ -205,6 +199,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             load_frag<D>(gt, a.g_H, a.g_idx[e], kq);
             frag_add<D>(f, gt);
         }
+        if (g_beg >= g_end) frag_zero<D>(f);          // a node without incoming messages (slot 0 was row 0)
         if (a.g_use_avg) {                                            // :206-209
             // x / den for the 25+ values of the row with ONE division: r = RN(1/den), q = RN(x r), then the FMA
             // residual step q + (x - den q) r.  With a correctly rounded r this IS the correctly rounded quotient
@@ -236,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                 if (on) { g_index(); g_rows0(xf[0]); g_rows(xf[0], 2); g_rows(xf[0], 3); g_finish(xf[0]); }
             } else {
                 if constexpr (G_U - 5 < 0) g_ptrs(r0c, on);
-                if constexpr (G_U - 4 < 0) { if (on) g_index(); }
+                if constexpr (G_U - 4 < 0) g_index();         // (also for a wave without a tile: its slots -> row 0)
                 load_frag<D>(xf[0], a.x[0], r0c, kq);
             }
         } else {

@@ -193,7 +193,8 @@ int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* packed, ggnn
  * aggregated-messages input -- the LAST of the nx concatenated inputs -- is gathered inside the kernel,
  *   incoming[v] = (sum over the slots row_ptr[v]..row_ptr[v+1] of Hrows[gather_row[slot]]) / (sum_t nin[v,t] + 1e-7),
  * in the same slot order and arithmetic as ggnn_gather_segment_sum_f32 (bit-identical results), so the separate
- * segment-sum launch and the HBM round trip of `incoming` disappear.  x_segs: the nx-1 residual segments. */
+ * segment-sum launch and the HBM round trip of `incoming` disappear.  x_segs: the nx-1 residual segments.
+ * Hrows must hold at least one row (row 0 is fetched for the unused slots of low-degree nodes); V*T*D < 2^30. */
 int ggnn_gru_packed_gather_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
                                const float* bc, float* h_out, const float* Hrows, const int32_t* row_ptr,
                                const int32_t* gather_row, const float* nin, int T, int use_avg, int V, int D, int act,
