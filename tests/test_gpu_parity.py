@@ -169,6 +169,39 @@ def test_sparse_model_matches_oracle(pkg, oracle, cuda, config):
     np.testing.assert_allclose(got, want, **MODEL_TOL)
 
 
+@pytest.mark.parametrize("seed", range(32))
+def test_random_model_shapes_match_oracle(pkg, oracle, cuda, seed):
+    """Randomised sweep over dataset size (1 .. ~6000 nodes: single tickets, thin tail tickets, several workgroups),
+    hidden size, layer structure, residual wiring, aggregation switches and segment-sum fusion depth."""
+    rng = np.random.default_rng(1000 + seed)
+    n_graphs = int(rng.choice([1, 3, 17, 60, 200, 420]))
+    mean_nodes = float(rng.choice([4, 9, 14]))
+    n_layers = int(rng.integers(1, 4))
+    timesteps = [int(rng.integers(1, 3)) for _ in range(n_layers)]
+    residuals = {}
+    for l in range(1, n_layers):
+        k = int(rng.integers(0, min(l, 2) + 1))
+        if k:
+            residuals[str(l)] = sorted(int(x) for x in rng.choice(l + 1 if l < 2 else l, size=k, replace=False))
+    config = {"hidden_size": int(rng.choice([32, 64, 100])), "layer_timesteps": timesteps, "residual_connections": residuals,
+              "use_edge_bias": bool(rng.integers(0, 2)), "use_edge_msg_avg_aggregation": bool(rng.integers(0, 2)),
+              "graph_rnn_activation": str(rng.choice(["tanh", "ReLU"])), "tie_fwd_bkwd": bool(rng.integers(0, 2)),
+              "batch_size": int(rng.choice([700, 100000]))}
+    ms = pkg.synthetic_qm9(n_graphs, mean_nodes=mean_nodes, seed=seed)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms, config, seed=seed)
+    old = pkg.ops.FUSE_GATHER
+    try:
+        pkg.ops.FUSE_GATHER = int(rng.choice([0, 1, 3]))
+        with torch.no_grad():
+            for feed in feeds[:3]:
+                model.feed(feed)
+                got = model.compute_final_node_representations().cpu().numpy()
+                want = _oracle_states(oracle, feed, layers, model.params)
+                np.testing.assert_allclose(got, want, err_msg=str(config), **MODEL_TOL)
+    finally:
+        pkg.ops.FUSE_GATHER = old
+
+
 @pytest.mark.parametrize("tie", [True, False])
 def test_device_packer_equals_host_packer(pkg, cuda, tie):
     """data_device.pack_batches_device (batches assembled on the GPU from the resident dataset) == data.pack_batches
