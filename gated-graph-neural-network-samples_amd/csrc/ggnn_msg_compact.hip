@@ -83,6 +83,7 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
 
 #define K1C_T(K) if (tr.tdbg && lane == 0) tr.tdbg[((size_t)blockIdx.x * NW + wave) * 8 + (K)] = (K) == 0 || (K) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
     K1C_T(0)
+    K1C_T(6)                  // (shader-clock twin of the start stamp; a wave has at most 3 tiles in these runs)
     int t = 0;
     while (t + 1 < tr.T && (int)blockIdx.x >= tr.tile_off[t + 1]) ++t;
     const int row_beg = tr.row_off[t], row_end = tr.row_off[t + 1];
@@ -90,12 +91,15 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
     const int stride = (tr.tile_off[t + 1] - tr.tile_off[t]) * NW;
     int idx = ((int)blockIdx.x - tr.tile_off[t]) * NW + wave;           // wave-uniform
 
-    dma_stage_image<D, NW>(packed + (size_t)t * C::IMG, img, wave, lane);
     auto row_of = [&](int i) { const int r = row_beg + i * 16 + li; return r < row_end ? r : row_end - 1; };
     Frag<D> a, an;
-    int node_n = 0;
-    if (idx < n_wt) load_frag<D>(a, h, pair_node[row_of(idx)], kq);
+    // the pair-list entries first (the head of the dependent chain pair -> rows), then the weight image, then the rows:
+    // memory instructions return in order, so the chain is not queued behind 6 KiB of LDS-DMA per wave
+    int node_0 = 0, node_n = 0;
+    if (idx < n_wt) node_0 = pair_node[row_of(idx)];
     if (idx + stride < n_wt) node_n = pair_node[row_of(idx + stride)];
+    dma_stage_image<D, NW>(packed + (size_t)t * C::IMG, img, wave, lane);
+    if (idx < n_wt) load_frag<D>(a, h, node_0, kq);
     K1C_T(1)
     __syncthreads();                                        // the image has landed (vmcnt(0) + barrier)
     K1C_T(2)
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
         }
         a = an;
         idx = idx_n;
-        if (tcount < 4) { K1C_T(3 + tcount) }
+        if (tcount < 3) { K1C_T(3 + tcount) }
         ++tcount;
     }
     K1C_T(7)
@@ -128,6 +132,9 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
 template <int D>
 static int launch_compact(const float* h, const float* W, const int* pair_node, TypeRows& tr, float* packed, float* Hc,
                           hipStream_t st) {
+    // waves per workgroup: 8, two workgroups per CU.  (One 16-wave workgroup per CU halves the image DMA and evens out
+    // the prologues -- the second workgroup of a CU otherwise starts 5 us late behind the first one's MFMA bursts --
+    // but measures the same alone (32.8 us) and 2 % slower with two streams: 608 vs 621 M node-updates/s.)
     constexpr int NW = 8;
     using C = StageCfg<D>;
     if (W) {      // raw [T,D,D] weights given: build the T stage images (skipped when the caller pre-packed them)
@@ -142,7 +149,7 @@ static int launch_compact(const float* h, const float* W, const int* pair_node, 
     // two workgroups per CU, then ceil(wave tiles of the type / (R * NW)) workgroups for each type.
     long long total_wt = 0;
     for (int t = 0; t < tr.T; ++t) total_wt += (tr.row_off[t + 1] - tr.row_off[t] + 15) / 16;
-    const long long budget = 2LL * num_cus();      // (1, 2 and 3 workgroups per CU measured the same: 33 us at QM9 shapes)
+    const long long budget = (long long)(16 / NW) * num_cus();     // 16 waves per CU
     long long R = total_wt / (budget * NW);
     if (R < 1) R = 1;
     for (;; ++R) {

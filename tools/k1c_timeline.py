@@ -14,13 +14,14 @@ W = (torch.rand(T, D, D, device=dev) - 0.5) * 0.3
 for _ in range(3): out = pkg.ops.msg_transform_compact(h, W, comp)
 torch.cuda.synchronize()
 NB = 1024
-tbuf = torch.zeros(NB * 8 * 8, dtype=torch.int64, device=dev)
+NW = int(os.environ.get('NW', 8))           # waves per workgroup of the kernel build
+tbuf = torch.zeros(NB * NW * 8, dtype=torch.int64, device=dev)
 os.environ["GGNN_K1C_TPTR"] = str(tbuf.data_ptr())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); out = pkg.ops.msg_transform_compact(h, W, comp); e1.record()
 torch.cuda.synchronize()
 print("rows %d, launch (pack pre-pass + transform) %.1f us" % (comp.num_rows, e0.elapsed_time(e1) * 1e3))
-t = tbuf.cpu().numpy().astype(np.float64).reshape(NB, 8, 8)
+t = tbuf.cpu().numpy().astype(np.float64).reshape(NB, NW, 8)
 used = t[:, 0, 0] > 0
 t = t[used]
 print("workgroups", len(t))
@@ -28,9 +29,18 @@ start = (t[:, :, 0] - t[:, :, 0].min()) / 100.0           # us, real-time counte
 end = (t[:, :, 7] - t[:, :, 0].min()) / 100.0
 print("start skew over workgroups: max %.1f us | end: median %.1f, max %.1f us | wave duration median %.1f max %.1f us"
       % (start.max(), np.median(end), end.max(), np.median(end - start), (end - start).max()))
+pre = t[:, :, 1] - t[:, :, 6]
+print("start -> first rows requested (clocks): median %d p90 %d max %d" % (np.median(pre), np.percentile(pre, 90), pre.max()))
+print("  by wave id (median):", [int(np.median(pre[:, w])) for w in range(NW)])
+print("  by workgroup index octile (median):", [int(np.median(pre[i * len(pre) // 8:(i + 1) * len(pre) // 8])) for i in range(8)])
+print("  by workgroup % 8 (XCD, median):", [int(np.median(pre[i::8])) for i in range(8)])
 pro = t[:, :, 2] - t[:, :, 1]
 print("barrier wait (clocks): median %d max %d" % (np.median(pro), pro.max()))
-for k in range(3, 7):
+tot = t[:, :, 5].copy()
+for k in (4, 3, 2):
+    tot = np.where(tot > 0, tot, t[:, :, k])
+print("start -> last tile done (clocks): median %d p90 %d max %d" % (np.median(tot - t[:, :, 6]), np.percentile(tot - t[:, :, 6], 90), (tot - t[:, :, 6]).max()))
+for k in range(3, 6):
     ok = t[:, :, k] > 0
     if ok.any():
         prev = t[:, :, k - 1]
