@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--batch-size", type=int, default=0, help="override the reference's batch_size (100000 nodes); experiments only")
     return ap.parse_args()
 
 
@@ -109,6 +110,8 @@ def main():
     ms = pkg.synthetic_qm9(mols_per_batch * args.batches, mean_nodes=args.mean_nodes, seed=1000 + rank)
     model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": str(dev), "train_data": None, "valid_data": ms})
     params = model.params
+    if args.batch_size:
+        params["batch_size"] = args.batch_size
     D, T = params["hidden_size"], model.num_edge_types
     n_prop = sum(params["layer_timesteps"])
     feeds = list(model.make_minibatch_iterator(model.valid_data, is_training=False))[:args.batches]
@@ -226,10 +229,10 @@ def main():
                 if key in pmc:
                     kernels[name]["traffic"] = pmc[key]["hbm_bytes_fetch_x2_plus_write"]
                     kernels[name]["traffic_source"] = "profiles/r01_final_pmc_summary.json"
-        # The edge-indexed scatter-add (chem_tensorflow_sparse.py:198-209) runs INSIDE the GRU launch for the layers
-        # without residual inputs (6 of the 8 timesteps: ggnn_gru_packed_gather_f32).  Its stand-alone kernel -- the one
-        # the other 2 timesteps, the training path, edge-bias layers and non-fused hidden sizes use -- is timed here over
-        # all 8 timesteps of the same batches so that its HBM rate is reported on its own.
+        # The edge-indexed scatter-add (chem_tensorflow_sparse.py:198-209) runs INSIDE the GRU launch on the timed path
+        # (ggnn_gru_packed_gather_f32).  Its stand-alone kernel -- the one the training path, edge-bias layers and
+        # non-fused hidden sizes use -- is timed here over all 8 timesteps of the same batches so that its HBM rate is
+        # reported on its own.
         if pkg.ops.FUSE_GATHER:
             saved, pkg.ops.FUSE_GATHER = pkg.ops.FUSE_GATHER, 0
             try:

@@ -118,10 +118,17 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     const int rest = wt_total - full_tk * NW;
     const int tail_w = (rest + nb - 1) / nb;                        // 0 (no tail) .. NW
     const int n_tk = full_tk + (tail_w ? (rest + tail_w - 1) / tail_w : 0);
+    // One-tile tail tickets (tail_w == 1, the usual case) are worked COOPERATIVELY: all waves take the same 16 rows and
+    // wave w computes output column tile w of every gate (25 MFMAs per stage instead of 175 on one wave while seven
+    // idle); the r*h fragment, which the candidate stage needs whole, is exchanged through LDS.
+    const bool coop_tail = (tail_w == 1) && (NT <= NW);
+    auto is_coop = [&](int t) -> bool { return coop_tail && t >= full_tk && t < n_tk; };
     auto tile_of = [&](int t) -> int {                              // this wave's tile of ticket t, or -1
         if (t < full_tk) return t * NW + wave;
+        if (t >= n_tk) return -1;
+        if (coop_tail) return full_tk * NW + (t - full_tk);          // (every wave: the same tile)
         const int tl = full_tk * NW + (t - full_tk) * tail_w + wave;
-        return (t < n_tk && wave < tail_w && tl < wt_total) ? tl : -1;
+        return (wave < tail_w && tl < wt_total) ? tl : -1;
     };
 
     // biases live in LDS IN FRONT of the ring (small offsets: every epilogue read is one lane register + an
@@ -132,6 +139,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     float* bias_s = lds_;                             // [-log2e*bg (2D) | 2 log2e*bc (D) | bc (D) | next tickets (2)]
     float* ring = lds_ + BIAS_FLOATS;
     int* tk_slot = reinterpret_cast<int*>(bias_s + 4 * D);
+    constexpr int RHP = C::BN + 4;                     // row pitch of the r*h exchange block (cooperative tail pass)
+    float* rh_x = ring + 2 * C::IMG;                   // [16][RHP], behind the ring
     for (int i = tid; i < 4 * D; i += NW * 64)
         bias_s[i] = i < 2 * D ? -kLog2e * a.bg[i] : (i < 3 * D ? 2.0f * kLog2e * a.bc[i - 2 * D] : a.bc[i - 3 * D]);
     // The two waves of a SIMD (w and w + NW/2) do not interleave on the matrix pipe: the older one issues its whole
@@ -242,8 +251,12 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
 
     if (a.tickets) tk_next = __builtin_amdgcn_readfirstlane(*tk_slot);
 
-    for (int p = 0; tk < n_tk; ++p) {
+    // One pass (= one ticket) of the workgroup.  COOP is a compile-time flag: the ordinary passes and the cooperative
+    // tail passes are separate instantiations, run by separate loops below, so the register allocation of the hot loop
+    // does not see the tail code.
+    auto run_pass = [&](auto coop_c, const int p) {
         const int tile_ = tile_of(tk);
+        constexpr bool coop = decltype(coop_c)::value;         // one tile for the workgroup, wave w -> column tile w
         const bool active = tile_ >= 0;                        // wave-uniform
         const int tile = active ? tile_ : 0;
         const int row = active ? tile * 16 + li : a.V;         // (>= V: nothing is stored)
@@ -310,7 +323,10 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             constexpr int ntl_ = ((C::TAILPACK && (POS) % 3 == 1) ||                                     \
                                   (C::TAILPACK3 && (POS) % 3 == 2 && (POS) < 3 * NX)) ? NT - 1 : NT;     \
             /* stages 0..2 open the three accumulator sets: they start from the constant 0 */            \
-            if (active && !(a.dbg & 1)) stage_mma<D, NoHook, ntl_, ((POS) < 3)>(ACC, FRAG, ring + cur * C::IMG, li, kq); \
+            if (active && !(a.dbg & 1)) {                                                                \
+                if constexpr (!coop) stage_mma<D, NoHook, ntl_, ((POS) < 3)>(ACC, FRAG, ring + cur * C::IMG, li, kq); \
+                else { if (wave < NT) stage_mma_one<D, ((POS) < 3)>(ACC[0], FRAG, ring + cur * C::IMG, li, kq, wave); } \
+            }                                                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                           \
             if (!late) {                                                                                 \
                 prefetch(std::integral_constant<int, (POS)>{});                                          \
@@ -335,7 +351,29 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
 
         // ---- r = sigmoid(.), u = sigmoid(.), rh = r*h in activation-fragment layout -------------------
         Frag<D> rh;
-        if (active && !(a.dbg & 2)) {
+        if constexpr (coop) {
+            // cooperative tail pass: this wave holds column tile `wave` of r and u (accumulators [0]).  Its r*h tile goes
+            // to LDS, every wave then reads the whole r*h fragment back; u and the h columns stay in acc_u[0] / acc_r[0].
+            const int col = wave * 16 + 4 * kq;
+            if (wave < NT && col < D && !(a.dbg & 2)) {
+                const f32x4 r = sigmoid4_scaled(acc_r[0], ld4(bias_s + col));
+                const f32x4 u = sigmoid4_scaled(acc_u[0], ld4(bias_s + D + col));
+                const f32x4 hv = ld4_b(a.h, ((unsigned)rowc * D + col) * 4u);
+                if constexpr (SAVE) {
+                    if (row < a.V) {
+                        st4_b(a.save_r, ((unsigned)row * D + col) * 4u, r);
+                        st4_b(a.save_u, ((unsigned)row * D + col) * 4u, u);
+                    }
+                }
+                acc_u[0] = u; acc_r[0] = hv;
+                *reinterpret_cast<f32x4*>(rh_x + li * RHP + col) = r * hv;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < NC; ++c) rh.v[c] = *reinterpret_cast<const f32x4*>(rh_x + li * RHP + 16 * c + 4 * kq);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) rh.r[q] = rh_x[li * RHP + 16 * NC + 4 * q + kq];
+        } else if (active && !(a.dbg & 2)) {                   // (constexpr-else of the cooperative branch)
             stage_tail_reduce<D>(acc_r);                       // VALU-tail columns: add the four kq partials
             stage_tail_reduce<D>(acc_u);
             if constexpr (C::TAILPACK) {
@@ -386,6 +424,22 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         // ---- c = act(.), h' = u*h + (1-u)*c ----------------------------------------------------------------
         // remainder tile: lane (li,kq) needs h cols 16NC + 4kq + e = remainder frag q = kq of lane (li, e);
         // the cross-lane reads stay outside lane-divergent control flow
+        if constexpr (coop) {
+            const int col = wave * 16 + 4 * kq;
+            if (wave < NT && col < D && row < a.V && !(a.dbg & 4)) {
+                f32x4 c;
+                if (a.act == GGNN_ACT_TANH) {
+                    c = tanh4_scaled(acc_c[0], ld4(bias_s + 2 * D + col));
+                } else {
+                    c = acc_c[0] + ld4(bias_s + 3 * D + col);
+                    c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
+                }
+                const f32x4 u = acc_u[0], hv = acc_r[0];
+                st4_b(a.h_out, ((unsigned)row * D + col) * 4u, u * hv + (1.0f - u) * c);
+                if constexpr (SAVE) st4_b(a.save_c, ((unsigned)row * D + col) * 4u, c);
+            }
+            return;
+        }
         f32x4 hrem = {0.f, 0.f, 0.f, 0.f};
         if (active) {
             stage_tail_reduce<D>(acc_c);
@@ -426,7 +480,12 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                 }
             }
         }
-    }
+    };
+    // tickets come to a workgroup in increasing order: its ordinary passes first, then (at most a few) tail passes
+    const int n_main = coop_tail ? full_tk : n_tk;
+    int p = 0;
+    for (; tk < n_main; ++p) run_pass(std::false_type{}, p);
+    for (; tk < n_tk; ++p) run_pass(std::true_type{}, p);
     if (a.tdbg && tid == 0) {
         a.tdbg[4096 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
         a.tdbg[4096 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -447,7 +506,8 @@ static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t
     if ((unsigned long long)a.V * D >= (1ULL << 30) || (a.g_H && (unsigned long long)a.V * a.g_T * D >= (1ULL << 30)))
         return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit byte offsets: V*D (and V*T*D for the gathered rows) "
                                         "must be < 2^30 (V=%d, D=%d)", a.V, D);
-    const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)((4 * D + 4 + 63) / 64 * 64) * sizeof(float);   // biases, ticket slots + ring
+    const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)((4 * D + 4 + 63) / 64 * 64) * sizeof(float)    // biases, ticket slots + ring
+                     + (size_t)16 * (C::BN + 4) * sizeof(float);                                          // + r*h exchange block
     const int wt_total = (a.V + 15) / 16;
     // one workgroup per CU; with fewer than NW tiles per CU the tiles are spread over ALL CUs as thin tickets (the
     // kernel's tail rule: ceil(tiles / nb) waves busy per workgroup) rather than packed 8 to a workgroup on a few CUs --

@@ -203,6 +203,31 @@ __device__ __forceinline__ void stage_mma(f32x4 (&acc)[StageCfg<D>::NT], const F
     }
 }
 
+// ONE output tile (`tile`, wave-uniform, run time) of the same product: acc (+)= A-fragment x columns 16*tile .. of the
+// stage image -- the cooperative tail pass of the fused GRU, where each wave of a workgroup owns one tile of the row block.
+// Same k order per output element as stage_mma.
+template <int D, bool ZERO>
+__device__ __forceinline__ void stage_mma_one(f32x4& acc, const Frag<D>& a, const float* img, int li, int kq, int tile) {
+    using C = StageCfg<D>;
+    const f32x4* base = reinterpret_cast<const f32x4*>(img) + kq * C::BN + li + tile * 16;
+    f32x4 cin = acc;
+    if constexpr (ZERO) cin = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 w = base[0];
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c) {
+        const f32x4 wn = base[(c + 1 < C::NC ? c + 1 : c) * 4 * C::BN];       // next chunk's weights under this chunk's MFMAs
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cin = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], a.v[c][e], cin, 0, 0, 0);
+        w = wn;
+    }
+#pragma unroll
+    for (int q = 0; q < C::NR; ++q) {
+        const float wr = img[C::MAIN + (q * 4 + kq) * C::BN + li + tile * 16];
+        cin = __builtin_amdgcn_mfma_f32_16x16x4f32(wr, a.r[q], cin, 0, 0, 0);
+    }
+    acc = cin;
+}
+
 // Completes a VALU-tail accumulator (see stage_mma): after the LAST stage that accumulates into `acc`, the partial
 // sums of the four kq lanes of each row are added, so every lane of the row holds columns 16*NC..+3 -- exactly
 // what the epilogues expect from lane kq == 0 of the last tile.  No-op for hidden sizes without a 4-column remainder.
