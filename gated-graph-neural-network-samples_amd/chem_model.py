@@ -89,6 +89,7 @@ class ChemModel(object):
         random.seed(params['random_seed'])
         np.random.seed(params['random_seed'])
         torch.manual_seed(params['random_seed'])
+        self.tf_generator = torch.Generator().manual_seed(params['random_seed'])   # stands in for tf.set_random_seed (:85)
 
         # Load data (chem_tensorflow.py:72-77):
         self.max_num_vertices = 0

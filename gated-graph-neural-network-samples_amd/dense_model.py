@@ -19,7 +19,7 @@ from . import ops
 from .chem_model import ChemModel
 from .data import DENSE_BUCKET_SIZES, MoleculeSet, pack_dense_batch
 from .sparse_model import GRUCellWeights
-from .utils import glorot_init, tf_dropout
+from .utils import glorot_init, tf_dropout, tf_glorot_uniform
 
 
 class DenseGGNNChemModel(ChemModel):
@@ -52,9 +52,9 @@ class DenseGGNNChemModel(ChemModel):
         if self.params['use_edge_bias']:
             self.weights['edge_biases'] = torch.zeros([self.num_edge_types, 1, h_dim], dtype=torch.float32, device=dev)
         # :87-90 tf.contrib.rnn.GRUCell(h_dim) (tanh), gate bias 1, candidate bias 0
-        self.weights['node_gru'] = GRUCellWeights(torch.from_numpy(glorot_init([2 * h_dim, 2 * h_dim])).to(dev),
+        self.weights['node_gru'] = GRUCellWeights(tf_glorot_uniform([2 * h_dim, 2 * h_dim], self.tf_generator).to(dev),
                                                   torch.ones(2 * h_dim, dtype=torch.float32, device=dev),
-                                                  torch.from_numpy(glorot_init([2 * h_dim, h_dim])).to(dev),
+                                                  tf_glorot_uniform([2 * h_dim, h_dim], self.tf_generator).to(dev),
                                                   torch.zeros(h_dim, dtype=torch.float32, device=dev))
 
     def graph_model_variables(self) -> Dict[str, torch.Tensor]:

@@ -20,7 +20,7 @@ from . import ops
 from .chem_model import ChemModel
 from .data import MoleculeSet, SparseBatch, pack_batches
 from .data_device import DeviceMoleculeSet, pack_batches_device
-from .utils import glorot_init, SMALL_NUMBER, tf_dropout
+from .utils import glorot_init, SMALL_NUMBER, tf_dropout, tf_glorot_uniform
 
 GGNNWeights = namedtuple('GGNNWeights', ['edge_weights',
                                          'edge_biases',
@@ -125,7 +125,7 @@ class SparseGGNNChemModel(ChemModel):
             for (_, _, shape_fn, init) in fields:
                 shape = shape_fn(in_dim, h_dim)
                 if init == 'glorot':
-                    tensors.append(torch.from_numpy(glorot_init(list(shape))).to(dev))
+                    tensors.append(tf_glorot_uniform(list(shape), self.tf_generator).to(dev))
                 else:
                     tensors.append(torch.full(shape, float(init), dtype=torch.float32, device=dev))
             self.gnn_weights.rnn_cells.append(cls(*tensors))

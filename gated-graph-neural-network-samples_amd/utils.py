@@ -16,6 +16,17 @@ def glorot_init(shape):
     return np.random.uniform(low=-initialization_range, high=initialization_range, size=shape).astype(np.float32)
 
 
+def tf_glorot_uniform(shape, generator: torch.Generator) -> torch.Tensor:
+    """The kernels of TF-1.3's RNN cells (sparse:104-110, dense:88) come from `tf.get_variable`'s default
+    glorot_uniform_initializer, i.e. from TensorFlow's graph-seeded generator (chem_tensorflow.py:85) and NOT from
+    np.random: they must not consume the NumPy stream, or every np.random-drawn variable after the first cell
+    (edge weights of later layers, the readout MLPs; utils.py:11-13,64-65) would differ from the reference's for
+    the same `random_seed`.  TF's Philox stream itself is not reproducible; a torch CPU generator seeded with the
+    same seed stands in for it."""
+    limit = float(np.sqrt(6.0 / (shape[-2] + shape[-1])))
+    return (torch.rand(tuple(shape), generator=generator, dtype=torch.float32) * 2 - 1) * limit
+
+
 def tf_dropout(x: torch.Tensor, keep_prob: float, generator=None) -> torch.Tensor:
     """tf.nn.dropout: x / keep * floor(keep + U[0,1)); identity at keep_prob == 1."""
     if keep_prob >= 1.0:

@@ -1,5 +1,6 @@
 /* CPU ORACLE #3 (test infrastructure, NOT product code): scalar C restatement, fp32, of one sparse
- * GGNN propagation timestep in the reference's op order.  PARITY UNPINNED (see ggnn_oracle.py).
+ * GGNN propagation timestep in the reference's op order.  Parity status: checked against ggnn_oracle.py, which is
+ * held to the reference-run vectors; TensorFlow's kernels themselves unpinned (see ggnn_oracle.py).
  *
  * Follows /root/reference/chem_tensorflow_sparse.py:153-216 (attention off) with TF-1.3 op
  * semantics: embedding_lookup = row gather, matmul = k-ordered dot products,

@@ -1,12 +1,24 @@
 """CPU ORACLE (test infrastructure, NOT product code) for the GGNN propagation hot path.
 
-PARITY UNPINNED: the reference (microsoft/gated-graph-neural-network-samples @ /root/reference)
-ships no tests, golden vectors or fixtures, and its arithmetic lives in the third-party wheel
-``tensorflow==1.3.0`` (requirements.txt:2) which cannot be installed or run here.  This file is a
-NumPy restatement of the reference's algorithm, written from the reference call sites cited on
+PARITY STATUS: pinned to the reference's own PYTHON SOURCE, unpinned below it.  The reference
+(microsoft/gated-graph-neural-network-samples @ /root/reference) ships no tests, golden vectors or fixtures,
+and its arithmetic lives in the third-party wheel ``tensorflow==1.3.0`` (requirements.txt:2), which cannot be
+installed or run here.  What can run here is the reference's Python: tests/golden/make_reference_golden.py
+imports chem_tensorflow{,_sparse,_dense}.py + utils.py from /root/reference unmodified and executes them
+(constructor, data pipeline, graph construction, loss, train op) over oracle/tf13_shim -- a deferred-execution
+restatement of the ~40 TF-1.3 ops they call -- and commits the vectors as tests/golden/reference_*.npz
+(8 configurations: default 5-layer residual model, edge bias, sum aggregation, attention, RNN/ReLU and
+CudnnCompatibleGRU cells, dense tied/untied; forward + Adam steps).  tests/test_reference_golden.py holds this
+file, the torch restatement and the package's host side to those vectors; tests/test_gpu_reference_golden.py
+the HIP path.  So op order, wiring, shapes, packer output, initialisation and the training recipe are pinned to
+reference code that actually ran; the arithmetic of TensorFlow's kernels (GRUCell gate order, _linear,
+unsorted_segment_sum order, Adam's update) is restated from TF-1.3's published source in the shim and is
+NOT pinned by a TensorFlow run -- for that layer parity remains unpinned.
+
+This file is a NumPy restatement of the reference's algorithm, written from the reference call sites cited on
 every function plus TF-1.3's published op semantics (GRUCell / _linear / unsorted_segment_sum /
-embedding_lookup / dropout).  It pins itself through (a) an fp64 and an fp32 instantiation that
-must agree, (b) an independent torch restatement (oracle/ggnn_oracle_torch.py), (c) a scalar C
+embedding_lookup / dropout).  Besides the reference-run vectors it is held by (a) an fp64 and an fp32
+instantiation that must agree, (b) an independent torch restatement (oracle/ggnn_oracle_torch.py), (c) a scalar C
 restatement (oracle/ggnn_oracle.c), (d) the sparse == dense cross-formulation identity, and
 (e) hand-computed known-answer cases (tests/test_oracle.py).
 

@@ -1,5 +1,6 @@
 """CPU ORACLE #2 (test infrastructure, NOT product code): torch-CPU restatement of the sparse and
-dense GGNN propagation in the reference's op order.  PARITY UNPINNED (see ggnn_oracle.py header).
+dense GGNN propagation in the reference's op order.  Parity status: held to the reference-run vectors
+(tests/golden/reference_*.npz); TensorFlow's kernels themselves unpinned -- see the ggnn_oracle.py header.
 
 Independent of ggnn_oracle.py on purpose (torch ops, index_add_, F.linear-free explicit matmuls) so
 the two restatements can be checked against each other; differentiable, so torch autograd of this

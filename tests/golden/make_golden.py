@@ -2,7 +2,7 @@
 
 The reference cannot run here (tensorflow==1.3.0 is not installable) and ships no vectors of its own, so
 these fixtures pin the ORACLE against silent drift and give the GPU tests a committed target; they are
-not outputs of the reference (PARITY UNPINNED, see oracle/ggnn_oracle.py).
+not outputs of the reference (those are reference_*.npz, made by make_reference_golden.py).
 
     python tests/golden/make_golden.py
 """

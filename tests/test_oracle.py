@@ -1,5 +1,6 @@
 """CPU tests that pin the oracle to itself (the reference ships no tests or golden vectors and
-TensorFlow 1.3 cannot run here: PARITY UNPINNED).  Pins: fp64 vs fp32 NumPy, NumPy vs the
+TensorFlow 1.3 cannot run here; the vectors of the reference's own source run over a TF-op shim are in
+test_reference_golden.py).  Pins: fp64 vs fp32 NumPy, NumPy vs the
 independent torch restatement, NumPy vs the scalar C restatement, the sparse == dense cross-formulation
 identity, hand-computed known answers, structural properties, and the committed golden fixtures."""
 import ctypes

@@ -1,0 +1,164 @@
+"""CPU tests against tests/golden/reference_*.npz: vectors recorded while the reference's OWN source files ran
+(under the TF-1.3 op shim of oracle/tf13_shim; see tests/golden/make_reference_golden.py for what was executed
+and what was restated).  They pin, without a GPU:
+  * the oracle restatements (NumPy fp32/fp64, torch) to the reference's graph construction -- op order, residual
+    wiring, layer/timestep loops, weight shapes, readout, loss;
+  * the package's host side to the reference's: variable names + shapes (checkpoint schema), np.random-seeded
+    initial values, the batch packers' feeds, including the training-set shuffle.
+The HIP path is compared with the same vectors in tests/test_gpu_reference_golden.py."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import reference_golden as RG
+
+TOL = dict(rtol=2e-5, atol=2e-6)       # fp32 restatements vs the fp32 torch evaluation under the shim (matmul order differs)
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+@pytest.mark.parametrize("case", RG.SPARSE_CASES)
+def test_numpy_oracle_matches_reference_run(oracle, case):
+    g = RG.Golden(case)
+    layers = g.sparse_layers()
+    for k in range(g.num_valid_batches):
+        f = g.feed("valid%d" % k)
+        h0 = f["initial_node_representation"].astype(np.float32)
+        for dtype in (np.float32, np.float64):
+            h = oracle.sparse_propagate(h0, f["adjacency_lists"], f["num_incoming_edges_per_type"], layers, g.params, dtype=dtype)
+            np.testing.assert_allclose(h, g.result("valid%d" % k, "final_node_representations"), **TOL)
+        gW, gb, tW, tb = [a.astype(np.float64) for a in g.readout()]
+        pred = oracle.gated_regression(h, h0.astype(np.float64), f["graph_nodes_list"], int(f["num_graphs"]), gW, gb, tW, tb)
+        np.testing.assert_allclose(pred, g.result("valid%d" % k, "output"), **TOL)
+        loss, mae = oracle.task_loss(pred, f["target_values"][0], f["target_mask"][0])
+        np.testing.assert_allclose(loss, g.result("valid%d" % k, "loss"), rtol=5e-5)
+        np.testing.assert_allclose(mae, g.result("valid%d" % k, "accuracy"), rtol=5e-5)
+
+
+@pytest.mark.parametrize("case", RG.SPARSE_CASES)
+def test_torch_oracle_matches_reference_run(oracle_torch, case):
+    g = RG.Golden(case)
+    layers = oracle_torch.to_torch(g.sparse_layers())
+    for k in range(g.num_valid_batches):
+        f = g.feed("valid%d" % k)
+        h = oracle_torch.sparse_propagate(torch.from_numpy(f["initial_node_representation"].astype(np.float32)),
+                                          [torch.from_numpy(a.astype(np.int64)) for a in f["adjacency_lists"]],
+                                          torch.from_numpy(f["num_incoming_edges_per_type"].astype(np.float32)), layers, g.params)
+        np.testing.assert_allclose(h.numpy(), g.result("valid%d" % k, "final_node_representations"), **TOL)
+
+
+@pytest.mark.parametrize("case", RG.DENSE_CASES)
+def test_dense_oracle_matches_reference_run(oracle, case):
+    g = RG.Golden(case)
+    W, b, gru = g.dense_weights()
+    for k in range(g.num_valid_batches):
+        f = g.feed("valid%d" % k)
+        h0 = f["initial_node_representation"].astype(np.float32)
+        h = oracle.dense_propagate(h0, f["adjacency_matrix"], W, b if g.params["use_edge_bias"] else None, gru,
+                                   g.params["num_timesteps"], dtype=np.float64)
+        np.testing.assert_allclose(h, g.result("valid%d" % k, "final_node_representations"), **TOL)
+        pred = oracle.dense_gated_regression(h, h0.astype(np.float64), f["node_mask"], *[a.astype(np.float64) for a in g.readout()])
+        np.testing.assert_allclose(pred, g.result("valid%d" % k, "output"), **TOL)
+
+
+def _model(pkg, g, **config):
+    cls = pkg.SparseGGNNChemModel if g.kind == "sparse" else pkg.DenseGGNNChemModel
+    args = g.model_args("cpu")
+    if config:
+        p = dict(g.params); p.update(config)
+        args["--config"] = json.dumps(p)
+    return cls(args)
+
+
+@pytest.mark.parametrize("case", RG.CASES)
+def test_variables_and_seeded_init_match_reference_run(pkg, case):
+    """Same variable names and shapes as the reference's graph (so its checkpoints restore by name, chem_tensorflow.py:
+    343-352), the same set of global variables (Adam slots, beta powers) in what save_progress writes, and -- for the
+    same `random_seed` -- the same initial values for everything the reference draws from np.random (edge weights
+    utils.py:11-13, readout MLPs utils.py:64-65; consumed after the data shuffles of load_data) and the constant
+    initialisers.  (Cell kernels come from TF's own generator in the reference: equal here only because the shim and
+    the package use the same stand-in.)"""
+    g = RG.Golden(case)
+    m = _model(pkg, g)
+    nv = m.named_variables()
+    assert list(nv) and set(nv) == set(g.names)
+    for i, (n, s) in enumerate(zip(g.names, g.shapes)):
+        assert tuple(nv[n].shape) == s, n
+        a = nv[n].numpy()
+        np.testing.assert_allclose(RG.stats(a), g.z["init_stats"][i], rtol=1e-6, atol=1e-6, err_msg=n)
+        np.testing.assert_array_equal(np.resize(a.ravel()[:8], 8), g.z["init_head"][i], err_msg=n)
+    saved = set(nv) | set(m.optimizer.state_variables(m.trainable_variables))
+    assert saved - {"ggnn_amd/adam_step:0"} == set(g.global_names)         # one extra key: the integer step (documented)
+
+
+@pytest.mark.parametrize("case", RG.CASES)
+def test_host_packer_reproduces_reference_feeds(pkg, case):
+    """The reference's make_minibatch_iterator feeds (recorded) == the package's batches for the same JSON molecules,
+    bit for bit: batch boundaries, node order, sorted adjacency lists, in-degree tables, padded annotations, targets
+    and masks -- for the validation set and for the training set after the seeded shuffle of process_raw_graphs."""
+    g = RG.Golden(case)
+    m = _model(pkg, g, pack_on_device=False)
+    for prefix, data in (("valid", m.valid_data), ("train", m.train_data)):
+        if g.kind == "sparse":
+            batches = pkg.data.pack_batches(data["molecules"], m.params, m.num_edge_types, None, data["label_mask"])
+            mine = [dict(initial_node_representation=b.initial_node_representation, adjacency_lists=b.adjacency_lists,
+                         num_incoming_edges_per_type=b.num_incoming_edges_per_type, graph_nodes_list=b.graph_nodes_list,
+                         target_values=b.target_values, target_mask=b.target_mask, num_graphs=b.num_graphs) for b in batches]
+        else:
+            mine = list(m.make_minibatch_iterator(data, False))
+        k = 0
+        while "%s%d_feed_num_graphs" % (prefix, k) in g.z.files:
+            ref, b = g.feed("%s%d" % (prefix, k)), mine[k]
+            for key, r in ref.items():
+                if key.endswith("keep_prob"):
+                    continue
+                if key == "adjacency_lists":
+                    assert len(b[key]) == len(r)
+                    for x, y in zip(b[key], r):
+                        np.testing.assert_array_equal(_np(x).reshape(-1, 2), y)
+                else:
+                    x = _np(b[key])
+                    assert x.shape == np.asarray(r).shape, key
+                    np.testing.assert_array_equal(x.astype(np.float64), np.asarray(r, np.float64), err_msg=key)
+            k += 1
+        if prefix == "valid":
+            assert k == g.num_valid_batches == len(mine)
+        elif k:
+            assert len(mine) == int(g.z["num_train_batches"])
+
+
+@pytest.mark.parametrize("case", [c for c in RG.SPARSE_CASES if len(RG.Golden(c).train_losses)])
+def test_torch_oracle_training_follows_reference_run(oracle_torch, pkg, case):
+    """Loss trajectory and trained weights of the reference's own train op (Adam + per-variable clip_by_norm,
+    chem_tensorflow.py:183-191) vs torch autograd over the torch oracle + the package's TFAdam / clip_by_norm_."""
+    g = RG.Golden(case)
+    train = pkg.train
+    names = g.names
+    w = {n: torch.from_numpy(g.weights[n].copy()).requires_grad_(True) for n in names}
+    opt = train.TFAdam([w[n] for n in names], lr=g.params["learning_rate"])
+    losses = []
+    for s in range(len(g.train_losses)):
+        f = g.feed("train%d" % s)
+        gg = RG.Golden.__new__(RG.Golden); gg.__dict__.update(g.__dict__); gg.weights = w
+        layers = gg.sparse_layers()
+        h0 = torch.from_numpy(f["initial_node_representation"].astype(np.float32))
+        h = oracle_torch.sparse_propagate(h0, [torch.from_numpy(a.astype(np.int64)) for a in f["adjacency_lists"]],
+                                          torch.from_numpy(f["num_incoming_edges_per_type"].astype(np.float32)), layers, g.params)
+        gW, gb, tW, tb = gg.readout()
+        pred = oracle_torch.gated_regression(h, h0, torch.from_numpy(f["graph_nodes_list"].astype(np.int64)),
+                                             int(f["num_graphs"]), gW, gb, tW, tb)
+        loss, _ = oracle_torch.task_loss(pred, torch.from_numpy(f["target_values"][0].astype(np.float32)),
+                                         torch.from_numpy(f["target_mask"][0].astype(np.float32)))
+        grads = list(torch.autograd.grad(loss, [w[n] for n in names]))
+        train.clip_by_norm_(grads, g.params["clamp_gradient_norm"])
+        opt.apply_gradients(grads)
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(losses, g.train_losses, rtol=2e-4)
+    for i, n in enumerate(names):
+        np.testing.assert_allclose(RG.stats(w[n].detach().numpy()), g.z["trained_stats"][i], rtol=2e-4, atol=2e-4, err_msg=n)
+        if "trained/" + n in g.z.files:
+            np.testing.assert_allclose(w[n].detach().numpy(), g.z["trained/" + n], rtol=1e-3, atol=2e-5, err_msg=n)
