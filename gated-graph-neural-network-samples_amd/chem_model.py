@@ -255,8 +255,8 @@ class ChemModel(object):
                 batch_data['out_layer_dropout_keep_prob'] = 1.0
                 with torch.no_grad():
                     batch_loss = self.forward_batch(batch_data)
-            batch_accuracies = [float(self.ops['accuracy_task%i' % t]) for t in self.params['task_ids']]
-            batch_loss = float(batch_loss)
+            batch_accuracies = [float(self.ops['accuracy_task%i' % t].detach()) for t in self.params['task_ids']]
+            batch_loss = float(batch_loss.detach())
             loss += batch_loss * num_graphs
             accuracies.append(np.array(batch_accuracies) * num_graphs)
             if not self.quiet:

@@ -159,8 +159,8 @@ class DenseGGNNChemModel(ChemModel):
     def make_minibatch_iterator(self, data, is_training: bool):
         """chem_tensorflow_dense.py:195-228."""
         ms: MoleculeSet = data["molecules"]
-        bucketed, bucket_sizes, bucket_at_step = data["bucketed"], data["bucket_sizes"], list(data["bucket_at_step"])
-        if is_training:
+        bucketed, bucket_sizes, bucket_at_step = data["bucketed"], data["bucket_sizes"], data["bucket_at_step"]
+        if is_training:                                   # :197-200 both shuffles are in place (orders compose over epochs)
             np.random.shuffle(bucket_at_step)
             for bucket in bucketed.values():
                 np.random.shuffle(bucket)

@@ -336,7 +336,12 @@ class SparseGGNNChemModel(ChemModel):
                     pack_batches(ms, self.params, self.num_edge_types, order, data["label_mask"], rank, world))
 
         if is_training:
-            order = np.random.permutation(ms.num_graphs)      # same seed on every rank -> same order
+            # :281-282 np.random.shuffle(data) shuffles the reference's graph list IN PLACE, so the orders of successive
+            # epochs compose; permutation(n) draws the same swaps as shuffle(list of n).  Same seed on every rank.
+            perm = np.random.permutation(ms.num_graphs)
+            prev = data.get("epoch_order")
+            order = perm if prev is None else prev[perm]
+            data["epoch_order"] = order
             device_batches = epoch_batches(order)
         else:
             if data["device_batches"] is None:

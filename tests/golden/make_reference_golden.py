@@ -135,6 +135,51 @@ def run_case(name, kind, params, train_steps, pkg, tf, models):
     print("%-18s %d valid batches, %d variables, loss %.6f" % (name, nb + 1, len(trainable), out["valid0_loss"]))
 
 
+LOOP_CASES = {
+    # the reference's whole train() loop (chem_tensorflow.py:255-307): per-epoch in-place shuffles, training and
+    # validation epochs, best-model checkpoint.  Edge-weight dropout off (its mask comes from TF's generator).
+    "loop_sparse": ("sparse", {"layer_timesteps": [2, 1], "residual_connections": {"1": [0]}, "batch_size": 100,
+                               "num_epochs": 3, "edge_weight_dropout_keep_prob": 1.0, "random_seed": 4}),
+}
+
+
+def run_loop_case(name, kind, params, pkg, tf, models):
+    import pickle
+    tmp = tempfile.mkdtemp(prefix="ggnn_ref_")
+    train_ms = pkg.synthetic_qm9(60, mean_nodes=9, seed=21)
+    valid_ms = pkg.synthetic_qm9(24, mean_nodes=9, seed=22)
+    for fn, ms in (("molecules_train.json", train_ms), ("molecules_valid.json", valid_ms)):
+        with open(os.path.join(tmp, fn), "w") as f:
+            json.dump(ms.to_json(), f)
+    model = models[kind]({"--data_dir": tmp, "--log_dir": tmp, "--config": json.dumps(params)})
+    # numpy >= 2 (NEP 50) keeps `np.float32 * int` in float32 where the reference's numpy 1.13 promoted to float64, and
+    # json cannot serialise np.float32: give the reference module a json whose dump converts such scalars (its source
+    # is untouched; the epoch sums are then accumulated in fp32 instead of fp64, far inside the test tolerance)
+    import types
+    import chem_tensorflow
+    chem_tensorflow.json = types.SimpleNamespace(
+        dump=lambda o, f, **kw: json.dump(o, f, default=float, **kw), dumps=json.dumps, load=json.load, loads=json.loads)
+    model.train()                                                    # the reference's loop, start to end
+    with open(model.log_file) as f:
+        log = json.load(f)
+    with open(model.best_model_file, "rb") as f:
+        best = pickle.load(f)
+    names = sorted(best["weights"])
+    out = {"params": np.array(json.dumps(model.params)), "kind": np.array(kind),
+           "train_molecules": np.array(json.dumps(train_ms.to_json())),
+           "valid_molecules": np.array(json.dumps(valid_ms.to_json())),
+           "train_loss": np.array([e["train_results"][0] for e in log]),
+           "train_accuracy": np.array([e["train_results"][1] for e in log]),
+           "train_error_ratio": np.array([e["train_results"][2] for e in log]),
+           "valid_loss": np.array([e["valid_results"][0] for e in log]),
+           "valid_accuracy": np.array([e["valid_results"][1] for e in log]),
+           "best_train_step": best["train_step"], "best_valid_step": best["valid_step"],
+           "best_names": np.array(names),
+           "best_stats": np.stack([stats(best["weights"][n]) for n in names])}
+    np.savez_compressed(os.path.join(HERE, "reference_%s.npz" % name), **out)
+    print("%-18s %d epochs, train loss %s, valid loss %s" % (name, len(log), out["train_loss"], out["valid_loss"]))
+
+
 def main():
     import importlib
     sys.path.insert(0, ROOT)
@@ -152,6 +197,9 @@ def main():
         for name, (kind, params, steps) in CASES.items():
             if not only or name in only:
                 run_case(name, kind, params, steps, pkg, tf, models)
+        for name, (kind, params) in LOOP_CASES.items():
+            if not only or name in only:
+                run_loop_case(name, kind, params, pkg, tf, models)
     finally:
         os.chdir(cwd)
 

@@ -11,7 +11,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
-CASES = sorted(os.path.basename(p)[len("reference_"):-len(".npz")] for p in glob.glob(os.path.join(GOLDEN, "reference_*.npz")))
+_ALL = sorted(os.path.basename(p)[len("reference_"):-len(".npz")] for p in glob.glob(os.path.join(GOLDEN, "reference_*.npz")))
+CASES = [c for c in _ALL if not c.startswith("loop_")]
+LOOP_CASES = [c for c in _ALL if c.startswith("loop_")]          # the reference's whole train() loop
 SPARSE_CASES = [c for c in CASES if c.startswith("sparse")]
 DENSE_CASES = [c for c in CASES if c.startswith("dense")]
 
@@ -108,3 +110,15 @@ class Golden:
                 "train_data": self.train_molecules, "valid_data": self.valid_molecules}
         args.update(extra)
         return args
+
+
+class GoldenLoop:
+    """Per-epoch log and best-model checkpoint statistics of the reference's own train() run."""
+
+    def __init__(self, case):
+        z = np.load(os.path.join(GOLDEN, "reference_%s.npz" % case), allow_pickle=False)
+        self.z, self.case, self.kind = z, case, str(z["kind"])
+        self.params = json.loads(str(z["params"]))
+        self.train_molecules = json.loads(str(z["train_molecules"]))
+        self.valid_molecules = json.loads(str(z["valid_molecules"]))
+        self.best_names = [str(n) for n in z["best_names"]]

@@ -87,3 +87,36 @@ def test_training_follows_reference_run(pkg, cuda, tmp_path, case):
         np.testing.assert_allclose(RG.stats(a), g.z["trained_stats"][i], rtol=1e-3, atol=5e-3, err_msg=n)
         if "trained/" + n in g.z.files:
             np.testing.assert_allclose(a.reshape(g.z["trained/" + n].shape), g.z["trained/" + n], rtol=1e-2, atol=3e-3, err_msg=n)
+
+
+@pytest.mark.parametrize("case", RG.LOOP_CASES)
+def test_train_loop_reproduces_reference_log(pkg, cuda, tmp_path, case):
+    """The reference's whole train() (chem_tensorflow.py:255-307) was run for three epochs from its own seeded
+    initialisation: per-epoch in-place shuffles of the training graphs, Adam steps, validation epochs, best-model
+    checkpoint.  The package's train() with the same params and JSON data must print the same log and save the
+    same checkpoint (same variable names incl. Adam slots; weights to fp32 training tolerance)."""
+    import json
+    import pickle
+    g = RG.GoldenLoop(case)
+    cls = pkg.SparseGGNNChemModel if g.kind == "sparse" else pkg.DenseGGNNChemModel
+    m = cls({"--device": str(cuda), "--log_dir": str(tmp_path), "--config": json.dumps(g.params),
+             "train_data": g.train_molecules, "valid_data": g.valid_molecules})
+    log = m.train()
+    assert len(log) == len(g.z["train_loss"])
+    np.testing.assert_allclose([e["train_results"][0] for e in log], g.z["train_loss"], rtol=1e-3)
+    np.testing.assert_allclose([e["train_results"][1] for e in log], g.z["train_accuracy"], rtol=1e-3)
+    np.testing.assert_allclose([e["train_results"][2] for e in log], g.z["train_error_ratio"], rtol=1e-3)
+    np.testing.assert_allclose([e["valid_results"][0] for e in log], g.z["valid_loss"], rtol=1e-3)
+    np.testing.assert_allclose([e["valid_results"][1] for e in log], g.z["valid_accuracy"], rtol=1e-3)
+    with open(m.best_model_file, "rb") as f:
+        best = pickle.load(f)
+    assert best["params"] == g.params
+    assert (best["train_step"], best["valid_step"]) == (int(g.z["best_train_step"]), int(g.z["best_valid_step"]))
+    assert set(best["weights"]) - {"ggnn_amd/adam_step:0"} == set(g.best_names)
+    for i, n in enumerate(g.best_names):
+        a = np.asarray(best["weights"][n], dtype=np.float64)
+        ref = g.z["best_stats"][i]
+        # sums of |w| and w^2 are insensitive to the sign flips of near-zero Adam updates; the plain sum is compared
+        # relative to the L1 norm
+        np.testing.assert_allclose(RG.stats(a)[1:], ref[1:], rtol=2e-3, atol=1e-6, err_msg=n)
+        assert abs(RG.stats(a)[0] - ref[0]) <= 2e-3 * max(ref[1], 1e-3), n

@@ -131,6 +131,16 @@ def test_host_packer_reproduces_reference_feeds(pkg, case):
             assert len(mine) == int(g.z["num_train_batches"])
 
 
+def test_epoch_shuffles_compose_like_the_reference_in_place_list_shuffle():
+    """sparse:281-282 shuffles the graph LIST in place every training epoch; the package keeps an index order and
+    composes it with np.random.permutation(n), which must give the same sequence of graphs for the same seed."""
+    np.random.seed(5)
+    lst = list(range(37)); np.random.shuffle(lst); first = list(lst); np.random.shuffle(lst); second = list(lst)
+    np.random.seed(5)
+    p1 = np.random.permutation(37); p2 = p1[np.random.permutation(37)]
+    assert first == p1.tolist() and second == p2.tolist()
+
+
 @pytest.mark.parametrize("case", [c for c in RG.SPARSE_CASES if len(RG.Golden(c).train_losses)])
 def test_torch_oracle_training_follows_reference_run(oracle_torch, pkg, case):
     """Loss trajectory and trained weights of the reference's own train op (Adam + per-variable clip_by_norm,
