@@ -80,7 +80,7 @@ class DenseGGNNChemModel(ChemModel):
     def compute_final_node_representations(self) -> torch.Tensor:
         """chem_tensorflow_dense.py:93-117."""
         if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("dense training path is not built; train with SparseGGNNChemModel")
+            return self._compute_for_training()
         ph = self.placeholders
         v = ph['num_vertices']
         h_dim = self.params['hidden_size']
@@ -101,6 +101,42 @@ class DenseGGNNChemModel(ChemModel):
                         "tanh")                                        # :115
             h = tf_dropout(h, keep_s)
         return h.reshape(b, v, h_dim)                                  # :116
+
+    def _compute_for_training(self) -> torch.Tensor:
+        """Training form of chem_tensorflow_dense.py:93-117.  A dense step IS a sparse step on the b*v padded nodes:
+        acts[d] = sum_e sum_s A_e[d,s] (h_s W_e + b_e) = segment_sum of the transformed source rows + nin @ b_e, with
+        sum aggregation and the single shared GRU (the identity tests/test_oracle.py pins).  So the 0/1 adjacency
+        tensor is turned into per-type (src, dst) lists once per batch and every timestep runs through the same
+        differentiable step as the sparse model (backward.PropagationStepFn: hand-written backward kernels).  Padded
+        vertices are isolated nodes there -- their state still evolves through the GRU biases, as in the reference,
+        and is masked only at the readout (:126)."""
+        from .autograd import propagation_step
+        ph = self.placeholders
+        v = int(ph['num_vertices'])
+        h_dim, T = self.params['hidden_size'], self.num_edge_types
+        h0 = ph['initial_node_representation']
+        b = h0.shape[0]
+        A = ph['adjacency_matrix']                                      # [b, e, dst, src]
+        sparse_form = ph.get('_sparse_form')
+        if sparse_form is None or sparse_form[0] is not A:
+            nz = A.nonzero()                                            # rows (b, e, dst, src), lexicographic
+            base = nz[:, 0] * v
+            pairs = torch.stack([base + nz[:, 3], base + nz[:, 2]], dim=1).to(torch.int32)
+            etype = nz[:, 1]
+            adjacency_lists = [pairs[etype == t].contiguous() for t in range(T)]
+            nin = A.sum(dim=3).permute(0, 2, 1).reshape(b * v, T).to(torch.float32).contiguous()
+            sparse_form = ph['_sparse_form'] = (A, ops.build_message_index(adjacency_lists, b * v), nin)
+        _, index, nin = sparse_form
+        keep_w = float(ph.get('edge_weight_dropout_keep_prob', 1.0))
+        keep_s = float(ph.get('graph_state_keep_prob', 1.0))
+        bias = self.weights['edge_biases'].reshape(T, h_dim) if self.params['use_edge_bias'] else None
+        cell = self.weights['node_gru']
+        h = h0.reshape(-1, h_dim).contiguous()
+        for i in range(self.params['num_timesteps']):
+            W = tf_dropout(self.weights['edge_weights'], keep_w)        # :104 fresh mask per (timestep, edge type)
+            h = propagation_step(h, index, nin, W, bias, False, [], cell, "tanh", need_grad=True)
+            h = tf_dropout(h, keep_s)
+        return h.reshape(b, v, h_dim)
 
     def gated_regression(self, last_h, regression_gate, regression_transform):
         """chem_tensorflow_dense.py:119-129."""

@@ -140,6 +140,7 @@ LOOP_CASES = {
     # validation epochs, best-model checkpoint.  Edge-weight dropout off (its mask comes from TF's generator).
     "loop_sparse": ("sparse", {"layer_timesteps": [2, 1], "residual_connections": {"1": [0]}, "batch_size": 100,
                                "num_epochs": 3, "edge_weight_dropout_keep_prob": 1.0, "random_seed": 4}),
+    "loop_dense": ("dense", {"batch_size": 4, "num_epochs": 3, "random_seed": 6}),
 }
 
 

@@ -65,7 +65,7 @@ def test_forward_matches_reference_run(pkg, cuda, tmp_path, case):
         np.testing.assert_allclose(float(m.ops["accuracy_task0"]), g.result(pre, "accuracy"), rtol=5e-4)
 
 
-@pytest.mark.parametrize("case", [c for c in RG.SPARSE_CASES if len(RG.Golden(c).train_losses)])
+@pytest.mark.parametrize("case", [c for c in RG.CASES if len(RG.Golden(c).train_losses)])
 def test_training_follows_reference_run(pkg, cuda, tmp_path, case):
     """The reference's own train op (Adam + per-variable clip, chem_tensorflow.py:183-191) was run for a few steps on
     its own training batches; the package's train_batch (hand-written backward kernels, TFAdam) must follow it."""
