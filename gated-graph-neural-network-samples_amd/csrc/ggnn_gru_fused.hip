@@ -28,6 +28,10 @@
 #include "ggnn_stage.hpp"
 #include <type_traits>
 
+#ifndef GGNN_COOP_DEPTH
+#define GGNN_COOP_DEPTH 1
+#endif
+
 namespace ggnn {
 
 int gru_pack_floats(int D, int nx) {
@@ -254,6 +258,13 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     // One pass (= one ticket) of the workgroup.  COOP is a compile-time flag: the ordinary passes and the cooperative
     // tail passes are separate instantiations, run by separate loops below, so the register allocation of the hot loop
     // does not see the tail code.
+    const int n_main = coop_tail ? full_tk : n_tk;             // tickets [n_main, n_tk) are cooperative tail passes
+    // The cooperative pass reads its weights either through the LDS ring like every other pass, or -- COOP_REGS --
+    // straight from the images in global memory into registers (no ring, no per-stage barrier).  The register form
+    // needs 2 x 25 more VGPRs; with residual inputs (NX >= 2) that pushes loop invariants of the ordinary passes into
+    // scratch (measured: NX = 3 launch 224 -> 240 us), so only the single-input kernel uses it (121 -> 120 us).
+    constexpr bool COOP_REGS = (NX == 1);
+    const int n_dma = (coop_tail && COOP_REGS) ? n_main : n_tk; // passes that need the ring filled
     auto run_pass = [&](auto coop_c, const int p) {
         const int tile_ = tile_of(tk);
         constexpr bool coop = decltype(coop_c)::value;         // one tile for the workgroup, wave w -> column tile w
@@ -297,10 +308,33 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
 
 #define GGNN_T(CI, K) if (a.tdbg && blockIdx.x == 0 && lane == 0) a.tdbg[((p * NSTAGE + (CI)) * NW + wave) * 4 + (K)] = __builtin_amdgcn_s_memtime();
         // one stage: prefetches, start the DMA of the next image, MFMAs on the current one, publish
+        // Cooperative tail pass: no ring, no per-stage barrier.  Wave w multiplies by column tile w only, whose weights
+        // (1/NT of the image) it reads from the image in global memory into registers TWD stages ahead.
+#define GGNN_COOP_STAGE(POS, ACC, FRAG)                                                                  \
+        {                                                                                                \
+            GGNN_T(POS, 0)                                                                               \
+            if constexpr (GATHER && (POS) == G_U % NSTAGE) {                                             \
+                if (active && (!G_NEXT || p > 0)) g_finish(xf[GBUF]);                                    \
+            }                                                                                            \
+            if constexpr ((POS) + TWD < NSTAGE) {                                                        \
+                if (wave < NT) load_tile_weights<D>(tw[((POS) + TWD) % (TWD + 1)],                       \
+                                                    packed + (size_t)gru_stage_image<NX>((POS) + TWD) * C::IMG, li, kq, wave); \
+            }                                                                                            \
+            prefetch(std::integral_constant<int, (POS)>{});                                              \
+            if constexpr ((POS) == 3 * NX) {   /* h columns of this wave's tile, for the two epilogues */ \
+                if (wave < NT && wave * 16 + 4 * kq < D) hv_pre = ld4_b(a.h, ((unsigned)rowc * D + wave * 16 + 4 * kq) * 4u); \
+            }                                                                                            \
+            GGNN_T(POS, 1)                                                                               \
+            if (active && wave < NT && !(a.dbg & 1)) tile_mma_regs<D, ((POS) < 3)>(ACC[0], FRAG, tw[(POS) % (TWD + 1)]); \
+            GGNN_T(POS, 2)                                                                               \
+            if constexpr ((POS) == NSTAGE - 1) __syncthreads();   /* (the ticket slot written before this stage) */ \
+            GGNN_T(POS, 3)                                                                               \
+        }
 #define GGNN_STAGE(POS, ACC, FRAG)                                                                       \
+        if constexpr (coop && COOP_REGS) GGNN_COOP_STAGE(POS, ACC, FRAG) else                            \
         {                                                                                                \
             constexpr int npos_ = (POS) + 1;                                                             \
-            const bool more_ = (npos_ < NSTAGE) || !last_pass;                                           \
+            const bool more_ = (npos_ < NSTAGE) || tk_next < n_dma;                                      \
             const float* nsrc_ = packed + (size_t)gru_stage_image<NX>(npos_ < NSTAGE ? npos_ : 0) * C::IMG; \
             float* ndst_ = ring + (cur ^ 1) * C::IMG;                                                    \
             GGNN_T(POS, 0)                                                                               \
@@ -339,6 +373,16 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         }
 
         f32x4 acc_r[NT], acc_u[NT], acc_c[NT];       // opened by stages 0, 1, 2 (first MFMA of each tile: C = 0)
+        constexpr int TWD = GGNN_COOP_DEPTH;         // (cooperative tail pass, COOP_REGS) stages of weight look-ahead
+        TileWeights<D> tw[TWD + 1];                  // this wave's column-tile weights of stages POS .. POS+TWD
+        f32x4 hv_pre = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (coop && COOP_REGS) {
+            if (wave < NT) {
+#pragma unroll
+                for (int i = 0; i < TWD; ++i)
+                    load_tile_weights<D>(tw[i], packed + (size_t)gru_stage_image<NX>(i) * C::IMG, li, kq, wave);
+            }
+        }
         if constexpr (C::TAILPACK) acc_u[NT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};   // (never computed: it rides in acc_r)
         if constexpr (C::TAILPACK3) acc_c[NT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};  // (opened by the r*h stage only)
         // ---- x segments: r, u and candidate columns of each -------------------------------------------
@@ -358,7 +402,9 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             if (wave < NT && col < D && !(a.dbg & 2)) {
                 const f32x4 r = sigmoid4_scaled(acc_r[0], ld4(bias_s + col));
                 const f32x4 u = sigmoid4_scaled(acc_u[0], ld4(bias_s + D + col));
-                const f32x4 hv = ld4_b(a.h, ((unsigned)rowc * D + col) * 4u);
+                f32x4 hv;
+                if constexpr (COOP_REGS) hv = hv_pre;
+                else hv = ld4_b(a.h, ((unsigned)rowc * D + col) * 4u);
                 if constexpr (SAVE) {
                     if (row < a.V) {
                         st4_b(a.save_r, ((unsigned)row * D + col) * 4u, r);
@@ -418,6 +464,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         if (a.tickets && tid == 0) tk_slot[(p + 1) & 1] = nb + tk_fetch;
         GGNN_STAGE(3 * NX + 2, acc_c, rh)
 #undef GGNN_STAGE
+#undef GGNN_COOP_STAGE
         tk = tk_next;
         tk_next = a.tickets ? __builtin_amdgcn_readfirstlane(tk_slot[(p + 1) & 1]) : tk_next + nb;
 
@@ -482,7 +529,6 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         }
     };
     // tickets come to a workgroup in increasing order: its ordinary passes first, then (at most a few) tail passes
-    const int n_main = coop_tail ? full_tk : n_tk;
     int p = 0;
     for (; tk < n_main; ++p) run_pass(std::false_type{}, p);
     for (; tk < n_tk; ++p) run_pass(std::true_type{}, p);

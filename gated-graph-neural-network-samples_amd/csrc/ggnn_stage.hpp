@@ -228,6 +228,41 @@ __device__ __forceinline__ void stage_mma_one(f32x4& acc, const Frag<D>& a, cons
     acc = cin;
 }
 
+// The same tile product with the weights of the column tile held in REGISTERS, fetched straight from the stage image
+// in global memory (25 floats per lane at D = 100): the cooperative tail pass touches 1/NT of an image per wave, so
+// staging the whole 48 KiB image through LDS (and a workgroup barrier per stage) buys nothing there -- each wave
+// requests its slice two stages ahead and no stage of that pass waits on a DMA.
+template <int D>
+struct TileWeights {
+    f32x4 v[StageCfg<D>::NC > 0 ? StageCfg<D>::NC : 1];
+    float r[StageCfg<D>::NR > 0 ? StageCfg<D>::NR : 1];
+};
+
+template <int D>
+__device__ __forceinline__ void load_tile_weights(TileWeights<D>& w, const float* __restrict__ gimg, int li, int kq, int tile) {
+    using C = StageCfg<D>;
+    const f32x4* base = reinterpret_cast<const f32x4*>(gimg) + kq * C::BN + li + tile * 16;
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c) w.v[c] = base[c * 4 * C::BN];
+#pragma unroll
+    for (int q = 0; q < C::NR; ++q) w.r[q] = gimg[C::MAIN + (q * 4 + kq) * C::BN + li + tile * 16];
+}
+
+template <int D, bool ZERO>
+__device__ __forceinline__ void tile_mma_regs(f32x4& acc, const Frag<D>& a, const TileWeights<D>& w) {
+    using C = StageCfg<D>;
+    f32x4 cin = acc;
+    if constexpr (ZERO) cin = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cin = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[c][e], a.v[c][e], cin, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < C::NR; ++q) cin = __builtin_amdgcn_mfma_f32_16x16x4f32(w.r[q], a.r[q], cin, 0, 0, 0);
+    acc = cin;
+}
+
 // Completes a VALU-tail accumulator (see stage_mma): after the LAST stage that accumulates into `acc`, the partial
 // sums of the four kq lanes of each row are added, so every lane of the row holds columns 16*NC..+3 -- exactly
 // what the epilogues expect from lane kq == 0 of the last tile.  No-op for hidden sizes without a 4-column remainder.
