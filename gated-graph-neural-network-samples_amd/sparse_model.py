@@ -179,9 +179,6 @@ class SparseGGNNChemModel(ChemModel):
         st_keep = float(ph.get('graph_state_keep_prob', 1.0))
         need_grad = self.training and torch.is_grad_enabled()
         variant = self.params['use_propagation_attention'] or self.cell_type != 'gru'
-        if variant and need_grad:
-            raise NotImplementedError("training is built for the default switches (GRU cell, no propagation attention); "
-                                      "the attention / RNN / CudnnCompatibleGRUCell variants are inference-only here")
 
         if not variant and not need_grad and ew_keep >= 1.0 and st_keep >= 1.0 and ops._timing is None:
             # inference: the whole layer/timestep loop below runs inside ONE native call
@@ -202,7 +199,14 @@ class SparseGGNNChemModel(ChemModel):
             cell = self.gnn_weights.rnn_cells[layer_idx]
             cur = node_states_per_layer[-1]                                        # :152
             for step in range(num_timesteps):                                      # :153
-                if variant:
+                if variant and need_grad:
+                    # non-default switches, training: HIP forward, autograd-derived backward (variants.py)
+                    from .variants import variant_step
+                    attn = (self.gnn_weights.edge_type_attention_weights[layer_idx]
+                            if self.params['use_propagation_attention'] else None)
+                    cur = variant_step(cur, index, nin, edge_weights, edge_biases, attn, use_avg, layer_residual_states,
+                                       self.cell_type, tuple(cell), act)
+                elif variant:
                     cur = self._variant_step(cur, index, nin, edge_weights.contiguous(), edge_biases, use_avg,
                                              layer_residual_states, layer_idx, act)
                 else:

@@ -52,11 +52,11 @@ CASES = {
     "sparse_sum_agg": ("sparse", {"layer_timesteps": [3], "residual_connections": {}, "use_edge_bias": True,
                                   "use_edge_msg_avg_aggregation": False, "batch_size": 250, "random_seed": 1}, 0),
     "sparse_relu_rnn": ("sparse", {"layer_timesteps": [2, 2], "residual_connections": {"1": [0]},
-                                   "graph_rnn_cell": "RNN", "graph_rnn_activation": "ReLU", "batch_size": 250}, 0),
+                                   "graph_rnn_cell": "RNN", "graph_rnn_activation": "ReLU", "batch_size": 250}, 2),
     "sparse_cudnn_gru": ("sparse", {"layer_timesteps": [2, 1], "residual_connections": {"1": [0]},
-                                    "graph_rnn_cell": "CudnnCompatibleGRUCell", "batch_size": 250}, 0),
+                                    "graph_rnn_cell": "CudnnCompatibleGRUCell", "batch_size": 250}, 2),
     "sparse_attention": ("sparse", {"layer_timesteps": [2, 1], "residual_connections": {"1": [0]},
-                                    "use_propagation_attention": True, "batch_size": 250}, 0),
+                                    "use_propagation_attention": True, "batch_size": 250}, 2),
     # (sparse with tie_fwd_bkwd=False is not a case: the reference raises IndexError in its own packer, sparse:268-272
     #  offsets backward types by the already doubled num_edge_types -- verified by running it under this harness)
     "dense_default": ("dense", {"batch_size": 4, "random_seed": 5}, 3),     # dense drops incomplete batches (dense:160)
