@@ -57,6 +57,10 @@ CASES = {
                                     "graph_rnn_cell": "CudnnCompatibleGRUCell", "batch_size": 250}, 2),
     "sparse_attention": ("sparse", {"layer_timesteps": [2, 1], "residual_connections": {"1": [0]},
                                     "use_propagation_attention": True, "batch_size": 250}, 2),
+    # two regression tasks, the second with labels for the first 50 % of the (shuffled) training graphs only
+    # (sparse:245-250; target_mask, chem_tensorflow.py:161-169)
+    "sparse_multitask": ("sparse", {"layer_timesteps": [2, 1], "residual_connections": {"1": [0]}, "task_ids": [0, 1],
+                                    "task_sample_ratios": {"1": 0.5}, "batch_size": 150, "random_seed": 2}, 2),
     # (sparse with tie_fwd_bkwd=False is not a case: the reference raises IndexError in its own packer, sparse:268-272
     #  offsets backward types by the already doubled num_edge_types -- verified by running it under this harness)
     "dense_default": ("dense", {"batch_size": 4, "random_seed": 5}, 3),     # dense drops incomplete batches (dense:160)
@@ -67,8 +71,9 @@ WEIGHT_SEED = 20
 
 def run_case(name, kind, params, train_steps, pkg, tf, models):
     tmp = tempfile.mkdtemp(prefix="ggnn_ref_")
-    train_ms = pkg.synthetic_qm9(40, mean_nodes=9, seed=11)
-    valid_ms = pkg.synthetic_qm9(24, mean_nodes=9, seed=12)
+    num_tasks = max(params.get("task_ids", [0])) + 1
+    train_ms = pkg.synthetic_qm9(40, mean_nodes=9, seed=11, num_tasks=num_tasks)
+    valid_ms = pkg.synthetic_qm9(24, mean_nodes=9, seed=12, num_tasks=num_tasks)
     for fn, ms in (("molecules_train.json", train_ms), ("molecules_valid.json", valid_ms)):
         with open(os.path.join(tmp, fn), "w") as f:
             json.dump(ms.to_json(), f)

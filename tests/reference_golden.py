@@ -93,8 +93,8 @@ class Golden:
         gru = dict(Wg=w[c + "gates/kernel:0"], bg=w[c + "gates/bias:0"], Wc=w[c + "candidate/kernel:0"], bc=w[c + "candidate/bias:0"])
         return w["graph_model/Variable:0"], w.get("graph_model/Variable_1:0"), gru
 
-    def readout(self):
-        w, p = self.weights, "out_layer_task0/"
+    def readout(self, task_id=0):
+        w, p = self.weights, "out_layer_task%d/" % task_id
         return (w[p + "regression_gate/MLP_W_layer0:0"], w[p + "regression_gate/MLP_b_layer0:0"],
                 w[p + "regression/MLP_W_layer0:0"], w[p + "regression/MLP_b_layer0:0"])
 

@@ -31,12 +31,16 @@ def test_numpy_oracle_matches_reference_run(oracle, case):
         for dtype in (np.float32, np.float64):
             h = oracle.sparse_propagate(h0, f["adjacency_lists"], f["num_incoming_edges_per_type"], layers, g.params, dtype=dtype)
             np.testing.assert_allclose(h, g.result("valid%d" % k, "final_node_representations"), **TOL)
-        gW, gb, tW, tb = [a.astype(np.float64) for a in g.readout()]
-        pred = oracle.gated_regression(h, h0.astype(np.float64), f["graph_nodes_list"], int(f["num_graphs"]), gW, gb, tW, tb)
-        np.testing.assert_allclose(pred, g.result("valid%d" % k, "output"), **TOL)
-        loss, mae = oracle.task_loss(pred, f["target_values"][0], f["target_mask"][0])
-        np.testing.assert_allclose(loss, g.result("valid%d" % k, "loss"), rtol=5e-5)
-        np.testing.assert_allclose(mae, g.result("valid%d" % k, "accuracy"), rtol=5e-5)
+        total, maes = 0.0, []
+        for internal_id, task_id in enumerate(g.params["task_ids"]):          # chem_tensorflow.py:150-170
+            gW, gb, tW, tb = [a.astype(np.float64) for a in g.readout(task_id)]
+            pred = oracle.gated_regression(h, h0.astype(np.float64), f["graph_nodes_list"], int(f["num_graphs"]), gW, gb, tW, tb)
+            loss, mae = oracle.task_loss(pred, f["target_values"][internal_id], f["target_mask"][internal_id])
+            total += loss
+            maes.append(mae)
+        np.testing.assert_allclose(pred, g.result("valid%d" % k, "output"), **TOL)     # self.output = the last task's
+        np.testing.assert_allclose(total, g.result("valid%d" % k, "loss"), rtol=5e-5)
+        np.testing.assert_allclose(maes[0], g.result("valid%d" % k, "accuracy"), rtol=5e-5)
 
 
 @pytest.mark.parametrize("case", RG.SPARSE_CASES)
@@ -158,11 +162,14 @@ def test_torch_oracle_training_follows_reference_run(oracle_torch, pkg, case):
         h0 = torch.from_numpy(f["initial_node_representation"].astype(np.float32))
         h = oracle_torch.sparse_propagate(h0, [torch.from_numpy(a.astype(np.int64)) for a in f["adjacency_lists"]],
                                           torch.from_numpy(f["num_incoming_edges_per_type"].astype(np.float32)), layers, g.params)
-        gW, gb, tW, tb = gg.readout()
-        pred = oracle_torch.gated_regression(h, h0, torch.from_numpy(f["graph_nodes_list"].astype(np.int64)),
-                                             int(f["num_graphs"]), gW, gb, tW, tb)
-        loss, _ = oracle_torch.task_loss(pred, torch.from_numpy(f["target_values"][0].astype(np.float32)),
-                                         torch.from_numpy(f["target_mask"][0].astype(np.float32)))
+        loss = 0.0
+        for internal_id, task_id in enumerate(g.params["task_ids"]):
+            gW, gb, tW, tb = gg.readout(task_id)
+            pred = oracle_torch.gated_regression(h, h0, torch.from_numpy(f["graph_nodes_list"].astype(np.int64)),
+                                                 int(f["num_graphs"]), gW, gb, tW, tb)
+            task_loss, _ = oracle_torch.task_loss(pred, torch.from_numpy(f["target_values"][internal_id].astype(np.float32)),
+                                                  torch.from_numpy(f["target_mask"][internal_id].astype(np.float32)))
+            loss = loss + task_loss
         grads = list(torch.autograd.grad(loss, [w[n] for n in names]))
         train.clip_by_norm_(grads, g.params["clamp_gradient_norm"])
         opt.apply_gradients(grads)
