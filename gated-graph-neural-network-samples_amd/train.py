@@ -52,7 +52,8 @@ class TFAdam:
         if "ggnn_amd/adam_step:0" in weights:
             self.t = int(weights["ggnn_amd/adam_step:0"]); used.add("ggnn_amd/adam_step:0")
         elif "beta1_power:0" in weights:
-            self.t = max(int(round(math.log(float(weights["beta1_power:0"])) / math.log(self.b1))) - 1, 0)
+            b1_power = float(np.asarray(weights["beta1_power:0"]).reshape(-1)[0])      # beta1^(t+1) after t steps
+            self.t = max(int(round(math.log(b1_power) / math.log(self.b1))) - 1, 0)
         used |= {"beta1_power:0", "beta2_power:0"} & set(weights)
         for i, (name, _) in enumerate(named.items()):
             base = name[:-2] if name.endswith(":0") else name
