@@ -325,7 +325,14 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                 if (wave < NT && wave * 16 + 4 * kq < D) hv_pre = ld4_b(a.h, ((unsigned)rowc * D + wave * 16 + 4 * kq) * 4u); \
             }                                                                                            \
             GGNN_T(POS, 1)                                                                               \
-            if (active && wave < NT && !(a.dbg & 1)) tile_mma_regs<D, ((POS) < 3)>(ACC[0], FRAG, tw[(POS) % (TWD + 1)]); \
+            if (active && wave < NT && !(a.dbg & 1)) {                                                   \
+                if (C::TAILPACK3 && (POS) == NSTAGE - 1 && wave == NT - 1) {                             \
+                    /* the candidate's last tile: x part + r*h part as two sums, like the tail-packed ordinary passes */ \
+                    f32x4 t_;                                                                            \
+                    tile_mma_regs<D, true>(t_, FRAG, tw[(POS) % (TWD + 1)]);                             \
+                    ACC[0] = ACC[0] + t_;                                                                \
+                } else tile_mma_regs<D, ((POS) < 3)>(ACC[0], FRAG, tw[(POS) % (TWD + 1)]);               \
+            }                                                                                            \
             GGNN_T(POS, 2)                                                                               \
             if constexpr ((POS) == NSTAGE - 1) __syncthreads();   /* (the ticket slot written before this stage) */ \
             GGNN_T(POS, 3)                                                                               \
@@ -359,7 +366,11 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             /* stages 0..2 open the three accumulator sets: they start from the constant 0 */            \
             if (active && !(a.dbg & 1)) {                                                                \
                 if constexpr (!coop) stage_mma<D, NoHook, ntl_, ((POS) < 3)>(ACC, FRAG, ring + cur * C::IMG, li, kq); \
-                else { if (wave < NT) stage_mma_one<D, ((POS) < 3)>(ACC[0], FRAG, ring + cur * C::IMG, li, kq, wave); } \
+                else if (C::TAILPACK3 && (POS) == NSTAGE - 1 && wave == NT - 1) {                        \
+                    f32x4 t_;        /* (same association as the tail-packed ordinary passes, see GGNN_COOP_STAGE) */ \
+                    stage_mma_one<D, true>(t_, FRAG, ring + cur * C::IMG, li, kq, wave);                 \
+                    ACC[0] = ACC[0] + t_;                                                                \
+                } else { if (wave < NT) stage_mma_one<D, ((POS) < 3)>(ACC[0], FRAG, ring + cur * C::IMG, li, kq, wave); } \
             }                                                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                           \
             if (!late) {                                                                                 \

@@ -494,6 +494,40 @@ def test_native_driver_equals_python_loop(pkg, oracle, cuda, config, monkeypatch
     np.testing.assert_allclose(native.cpu().numpy(), _oracle_states(oracle, feeds[0], layers, model.params), **MODEL_TOL)
 
 
+def test_full_size_batch_equals_its_parts(pkg, oracle, cuda):
+    """BASELINE config 2 size (one 100k-node batch = the bench's workload): graphs are disjoint (sparse:278-350), so
+    propagating the whole batch must give, node for node, what propagating its graphs in three separately packed
+    batches gives -- bit for bit, since a node's arithmetic (k order of the products, slot order of the segment sum)
+    does not depend on which tile, pass, ticket or cooperative tail pass its row lands in.  Also pins the full-size
+    states to the fp32 oracle's on a sample of graphs."""
+    ms = pkg.synthetic_qm9(5600, mean_nodes=18, seed=5)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms)                      # batch_size 100000 -> 1 batch (+ remainder)
+    big = feeds[0]
+    V, G = big["initial_node_representation"].shape[0], int(big["num_graphs"])
+    assert V > 95000
+    with torch.no_grad():
+        model.feed(big)
+        whole = model.compute_final_node_representations().clone()
+        parts = []
+        cuts = [0, G // 3, G // 3 + G // 2, G]                                   # uneven parts: different tile/ticket geometry
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            sub = pkg.data.pack_batch(ms, np.arange(lo, hi), model.num_edge_types, model.params["hidden_size"])
+            feed = model.to_device_batch(sub)
+            model.feed(feed)
+            parts.append(model.compute_final_node_representations().clone())
+    cat = torch.cat(parts, dim=0)
+    assert cat.shape == whole.shape
+    diff = (whole - cat).abs()
+    rows_differing = int((diff.amax(dim=1) > 0).sum())
+    print("full-size batch vs parts: max |diff| = %.3g, rows differing = %d of %d" % (float(diff.max()), rows_differing, V))
+    # (the cooperative tail pass adds the candidate's last-tile partial sums in the same association as the tail-packed
+    #  ordinary passes for exactly this reason)
+    assert rows_differing == 0 and torch.equal(whole, cat)
+    # the last part (a few thousand graphs) against the fp32 NumPy oracle
+    ref = _oracle_states(oracle, feed, layers, model.params, dtype=np.float32)
+    np.testing.assert_allclose(parts[-1].cpu().numpy(), ref, **MODEL_TOL)
+
+
 def test_forward_is_hip_graph_capturable(pkg, oracle, cuda):
     """The C ABI promises: asynchronous, no allocation, no sync -- so a whole forward can be captured in a hipGraph
     (after one eager warm-up that builds the per-batch index and the packed weight images) and replayed."""

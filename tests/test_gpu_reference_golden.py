@@ -7,8 +7,6 @@ where the reference's train op was recorded -- the loss trajectory and the train
 Tolerances: the recorded values are fp32 (torch-CPU matmuls under the shim); the HIP kernels accumulate k in a different
 order on the matrix cores and use exp2-based sigmoid/tanh, so 8 GRU steps agree to ~1e-5 absolute (north_star: fp32,
 1e-4 relative); written out below."""
-import os
-
 import numpy as np
 import pytest
 import torch
