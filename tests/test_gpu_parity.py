@@ -494,7 +494,7 @@ def test_native_driver_equals_python_loop(pkg, oracle, cuda, config, monkeypatch
     np.testing.assert_allclose(native.cpu().numpy(), _oracle_states(oracle, feeds[0], layers, model.params), **MODEL_TOL)
 
 
-def test_full_size_batch_equals_its_parts(pkg, oracle, cuda):
+def test_full_size_batch_equals_its_parts(pkg, oracle, cuda, monkeypatch):
     """BASELINE config 2 size (one 100k-node batch = the bench's workload): graphs are disjoint (sparse:278-350), so
     propagating the whole batch must give, node for node, what propagating its graphs in three separately packed
     batches gives -- bit for bit, since a node's arithmetic (k order of the products, slot order of the segment sum)
@@ -523,6 +523,12 @@ def test_full_size_batch_equals_its_parts(pkg, oracle, cuda):
     # (the cooperative tail pass adds the candidate's last-tile partial sums in the same association as the tail-packed
     #  ordinary passes for exactly this reason)
     assert rows_differing == 0 and torch.equal(whole, cat)
+    # ... and the three-launch form of a timestep (stand-alone segment sum) gives the same bits as the fused one
+    monkeypatch.setattr(pkg.ops, "FUSE_GATHER", 0)
+    with torch.no_grad():
+        model.feed(big)
+        assert torch.equal(whole, model.compute_final_node_representations())
+    monkeypatch.undo()
     # the last part (a few thousand graphs) against the fp32 NumPy oracle
     ref = _oracle_states(oracle, feed, layers, model.params, dtype=np.float32)
     np.testing.assert_allclose(parts[-1].cpu().numpy(), ref, **MODEL_TOL)
