@@ -179,3 +179,36 @@ def test_torch_oracle_training_follows_reference_run(oracle_torch, pkg, case):
         np.testing.assert_allclose(RG.stats(w[n].detach().numpy()), g.z["trained_stats"][i], rtol=2e-4, atol=2e-4, err_msg=n)
         if "trained/" + n in g.z.files:
             np.testing.assert_allclose(w[n].detach().numpy(), g.z["trained/" + n], rtol=1e-3, atol=2e-5, err_msg=n)
+
+
+@pytest.mark.parametrize("case", [c for c in RG.DENSE_CASES if len(RG.Golden(c).train_losses)])
+def test_dense_torch_oracle_training_follows_reference_run(oracle_torch, pkg, case):
+    """Dense model: the reference's own train op on its own bucketed batches vs torch autograd over the torch oracle's
+    dense propagation (chem_tensorflow_dense.py:93-129) + the package's TFAdam / clip_by_norm_."""
+    g = RG.Golden(case)
+    train = pkg.train
+    w = {n: torch.from_numpy(g.weights[n].copy()).requires_grad_(True) for n in g.names}
+    opt = train.TFAdam([w[n] for n in g.names], lr=g.params["learning_rate"])
+    c, p = "graph_model/gru_scope/gru_cell/", "out_layer_task0/"
+    D = g.params["hidden_size"]
+    losses = []
+    for s in range(len(g.train_losses)):
+        f = g.feed("train%d" % s)
+        h0 = torch.from_numpy(f["initial_node_representation"].astype(np.float32))
+        cell = dict(Wg=w[c + "gates/kernel:0"], bg=w[c + "gates/bias:0"], Wc=w[c + "candidate/kernel:0"], bc=w[c + "candidate/bias:0"])
+        last_h = oracle_torch.dense_propagate(h0, torch.from_numpy(f["adjacency_matrix"].astype(np.float32)), w["graph_model/Variable:0"],
+                                              w["graph_model/Variable_1:0"] if g.params["use_edge_bias"] else None, cell,
+                                              g.params["num_timesteps"])
+        gate_input = torch.cat([last_h, h0], dim=2).reshape(-1, 2 * D)                                      # dense:121-122
+        gated = torch.sigmoid(gate_input.matmul(w[p + "regression_gate/MLP_W_layer0:0"]) + w[p + "regression_gate/MLP_b_layer0:0"]) * \
+            (last_h.reshape(-1, D).matmul(w[p + "regression/MLP_W_layer0:0"]) + w[p + "regression/MLP_b_layer0:0"])
+        pred = (gated.reshape(-1, int(f["num_vertices"])) * torch.from_numpy(f["node_mask"].astype(np.float32))).sum(dim=1)   # :125-127
+        loss, _ = oracle_torch.task_loss(pred, torch.from_numpy(f["target_values"][0].astype(np.float32)),
+                                         torch.from_numpy(f["target_mask"][0].astype(np.float32)))
+        grads = list(torch.autograd.grad(loss, [w[n] for n in g.names]))
+        train.clip_by_norm_(grads, g.params["clamp_gradient_norm"])
+        opt.apply_gradients(grads)
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(losses, g.train_losses, rtol=2e-4)
+    for i, n in enumerate(g.names):
+        np.testing.assert_allclose(RG.stats(w[n].detach().numpy()), g.z["trained_stats"][i], rtol=2e-4, atol=2e-4, err_msg=n)
