@@ -196,12 +196,25 @@ class ChemModel(object):
             task_loss = task_loss * (1.0 / (self.params['task_sample_ratios'].get(task_id) or 1.0))
             self.ops['losses'].append(task_loss)
             self.ops['loss_numerator_task%i' % task_id] = (0.5 * diff * diff).sum()
+            self.ops['abs_error_sum_task%i' % task_id] = diff.abs().sum()
             self.ops['loss_denominator_task%i' % task_id] = task_target_mask.sum()
         self.ops['loss'] = torch.stack(self.ops['losses']).sum()                              # :170
         return self.ops['loss']
 
     def feed(self, batch_data: Dict[str, Any]) -> None:
+        """The reference's feed_dict: every placeholder the batch carries is replaced.  Values DERIVED from a fed
+        placeholder and cached next to it (the message index built from 'adjacency_lists', the dense model's sparse
+        form of 'adjacency_matrix') are dropped unless the batch brings its own, so a reference-style feed dict can
+        never run on the previous batch's index."""
+        for src, derived in self.DERIVED_PLACEHOLDERS.items():
+            if src in batch_data and batch_data[src] is not self.placeholders.get(src):   # (same object: cache stays valid)
+                for d in derived:
+                    if d not in batch_data:
+                        self.placeholders[d] = None
         self.placeholders.update(batch_data)
+
+    DERIVED_PLACEHOLDERS = {'adjacency_lists': ('message_index',), 'adjacency_matrix': ('_sparse_form',),
+                            'graph_nodes_list': ('graph_ptr',)}
 
     def make_train_step(self):
         """chem_tensorflow.py:172-193: Adam(lr) on all trainable variables (minus graph_model/* when
@@ -245,6 +258,8 @@ class ChemModel(object):
         start_time = time.time()
         processed_graphs = 0
         steps = 0
+        sharded = self.dist is not None and self.dist.world_size > 1
+        shard_stats, shard_graphs = [], []
         for step, batch_data in enumerate(self.make_minibatch_iterator(data, is_training)):
             num_graphs = batch_data['num_graphs']
             processed_graphs += num_graphs
@@ -255,6 +270,19 @@ class ChemModel(object):
                 batch_data['out_layer_dropout_keep_prob'] = 1.0
                 with torch.no_grad():
                     batch_loss = self.forward_batch(batch_data)
+            if sharded:
+                # Data parallel: this rank saw one shard of the step's global batch (the union of the ranks' batches).
+                # Keep the loss / MAE numerators and the mask counts on the device; they are summed over the ranks once
+                # per epoch (below), so that EVERY rank derives the same epoch statistics -- and hence the same
+                # best-epoch / patience decisions: ranks that disagreed would leave the others hanging in the next
+                # gradient all-reduce.
+                shard_stats.append(torch.stack(
+                    [self.ops[k % t].detach().to(torch.float64).reshape(())
+                     for k in ('loss_numerator_task%i', 'loss_denominator_task%i', 'abs_error_sum_task%i')
+                     for t in self.params['task_ids']]))
+                shard_graphs.append(float(num_graphs))
+                steps += 1
+                continue
             batch_accuracies = [float(self.ops['accuracy_task%i' % t].detach()) for t in self.params['task_ids']]
             batch_loss = float(batch_loss.detach())
             loss += batch_loss * num_graphs
@@ -263,11 +291,32 @@ class ChemModel(object):
                 print("Running %s, batch %i (has %i graphs). Loss so far: %.4f" % (epoch_name, step, num_graphs,
                                                                                    loss / processed_graphs), end='\r')
             steps += 1
-        accuracies = np.sum(accuracies, axis=0) / processed_graphs
-        loss = loss / processed_graphs
+        if sharded:
+            loss, accuracies, processed_graphs = self._reduce_epoch_stats(shard_stats, shard_graphs)
+        else:
+            accuracies = np.sum(accuracies, axis=0) / processed_graphs
+            loss = loss / processed_graphs
         error_ratios = accuracies / chemical_accuracies[self.params["task_ids"]]
         instance_per_sec = processed_graphs / (time.time() - start_time)
         return loss, accuracies, error_ratios, instance_per_sec, steps
+
+    def _reduce_epoch_stats(self, shard_stats, shard_graphs):
+        """Epoch loss / per-task MAE under data parallelism: per step the global batch's loss is
+        sum_tasks (sum_ranks numerator) / (sum_ranks mask count + 1e-7) (chem_tensorflow.py:161-169 on the union of the
+        shards), weighted by the global graph count like the reference's `loss += batch_loss * num_graphs` (:237)."""
+        K = len(self.params['task_ids'])
+        if not shard_stats:
+            return 0.0, np.zeros(K), 0
+        packed = torch.cat([torch.stack(shard_stats),
+                            torch.tensor(shard_graphs, dtype=torch.float64, device=shard_stats[0].device)[:, None]], dim=1)
+        self.dist.all_reduce_sum_(packed)
+        packed = packed.cpu().numpy()
+        num, den, abs_sum, graphs = packed[:, :K], packed[:, K:2 * K], packed[:, 2 * K:3 * K], packed[:, 3 * K]
+        ratios = np.array([1.0 / (self.params['task_sample_ratios'].get(t) or 1.0) for t in self.params['task_ids']])
+        step_loss = (num / (den + SMALL_NUMBER) * ratios).sum(axis=1)
+        step_acc = abs_sum / (den + SMALL_NUMBER)
+        total = graphs.sum()
+        return float((step_loss * graphs).sum() / total), (step_acc * graphs[:, None]).sum(axis=0) / total, int(total)
 
     def train(self):
         """chem_tensorflow.py:255-307."""
@@ -315,7 +364,7 @@ class ChemModel(object):
                     json.dump(log_to_save, f, indent=4)
             val_acc = np.sum(valid_accs)  # type: float
             if val_acc < best_val_acc:
-                if not self.quiet:
+                if not self.quiet and (self.dist is None or self.dist.rank == 0):      # one writer under data parallelism
                     self.save_progress(self.best_model_file, self.train_step_id, self.valid_step_id)
                     print("  (Best epoch so far, cum. val. acc decreased to %.5f from %.5f. Saving to '%s')" % (
                         val_acc, best_val_acc, self.best_model_file))

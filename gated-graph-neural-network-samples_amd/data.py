@@ -325,8 +325,10 @@ DENSE_BUCKET_SIZES = np.array(list(range(4, 28, 2)) + [29])   # chem_tensorflow_
 
 
 def pack_dense_batch(ms: MoleculeSet, graph_ids: np.ndarray, num_vertices: int, num_edge_types: int,
-                     hidden_size: int, tie_fwd_bkwd: bool = True, task_ids: Sequence[int] = (0,)) -> DenseBatch:
-    """chem_tensorflow_dense.py:30-36 (graph_to_adj_mat), :143-153 (pad_annotations + mask)."""
+                     hidden_size: int, tie_fwd_bkwd: bool = True, task_ids: Sequence[int] = (0,),
+                     label_mask: Optional[np.ndarray] = None) -> DenseBatch:
+    """chem_tensorflow_dense.py:30-36 (graph_to_adj_mat), :143-153 (pad_annotations + mask), :175-193 (make_batch:
+    a label masked by task_sample_ratios feeds value 0 / mask 0).  label_mask: [num_graphs, len(task_ids)] or None."""
     graph_ids = np.asarray(graph_ids, np.int64)
     b = len(graph_ids)
     v = num_vertices
@@ -349,4 +351,5 @@ def pack_dense_batch(ms: MoleculeSet, graph_ids: np.ndarray, num_vertices: int, 
     A[bg, bonds[:, 1] - 1, bonds[:, 2], bonds[:, 0]] = 1.0            # amat[e-1, dest, src] = 1
     A[bg, bonds[:, 1] - 1 + bwd, bonds[:, 0], bonds[:, 2]] = 1.0      # amat[e-1+off, src, dest] = 1
     tv = ms.targets[graph_ids][:, list(task_ids)].T.astype(np.float32).copy()
-    return DenseBatch(h0, A, mask, v, tv, np.ones_like(tv), b)
+    tm = np.ones_like(tv) if label_mask is None else label_mask[graph_ids].T.astype(np.float32).copy()
+    return DenseBatch(h0, A, mask, v, tv * tm, tm, b)

@@ -37,6 +37,17 @@ class DeviceMoleculeSet:
         self.bonds_per_graph = np.diff(ms.bond_ptr)
         self.max_bond_type = int(ms.bonds[:, 1].max()) if len(ms.bonds) else 0
         self.min_bond_type = int(ms.bonds[:, 1].min()) if len(ms.bonds) else 1
+        # Bond endpoints come from the data file: check them ONCE against their graph's node count, so that the per-batch
+        # index build can skip validation (pack_batch_device offsets them into the batch; a bad id would otherwise
+        # become an out-of-bounds gather on the GPU).
+        if len(ms.bonds):
+            n_of_bond = np.repeat(self.nodes_per_graph, self.bonds_per_graph)
+            ends = ms.bonds[:, [0, 2]].astype(np.int64)
+            if (ends < 0).any() or (ends >= n_of_bond[:, None]).any():
+                bad = int(np.nonzero(((ends < 0) | (ends >= n_of_bond[:, None])).any(axis=1))[0][0])
+                g = int(np.searchsorted(ms.bond_ptr, bad, side='right') - 1)
+                raise IndexError("bond %d of graph %d mentions node %s outside [0, %d)" % (
+                    bad - int(ms.bond_ptr[g]), g, ends[bad].tolist(), int(self.nodes_per_graph[g])))
 
 
 def _ranges(starts: torch.Tensor, lengths: torch.Tensor, total: int) -> torch.Tensor:
@@ -49,7 +60,7 @@ def _ranges(starts: torch.Tensor, lengths: torch.Tensor, total: int) -> torch.Te
 
 
 def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_types: int, hidden_size: int,
-                      tie_fwd_bkwd: bool = True, task_ids: Sequence[int] = (0,)) -> Dict[str, Any]:
+                      tie_fwd_bkwd: bool = True, task_ids: Sequence[int] = (0,), compact: bool = True) -> Dict[str, Any]:
     """One batch from graphs `graph_ids` (in this order), assembled on the GPU: the feed dict of
     SparseGGNNChemModel.to_device_batch (chem_tensorflow_sparse.py:254-276, 298-348), message index included."""
     dev = dms.device
@@ -108,12 +119,14 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
         'target_values': tv,
         'target_mask': tm,
         'num_graphs': G,
-        'message_index': ops.build_message_index(adjacency, V, validate=False),     # ids are offsets we just built
+        # (ids are offsets we just built from bond endpoints DeviceMoleculeSet checked: no per-batch validation)
+        'message_index': ops.prepare_message_index(ops.build_message_index(adjacency, V, validate=False), hidden_size, compact),
+        'graph_nodes_sorted': True,
     }
 
 
 def pack_batches_device(dms: DeviceMoleculeSet, params: dict, num_edge_types: int, order: Optional[np.ndarray] = None,
-                        rank: int = 0, world_size: int = 1):
+                        rank: int = 0, world_size: int = 1, compact: bool = True):
     """Generator over one epoch's batches for graph order `order` -- data.pack_batches on the device (same batch
     boundaries, same rank assignment, same empty padding batches)."""
     ms = dms.host
@@ -126,4 +139,4 @@ def pack_batches_device(dms: DeviceMoleculeSet, params: dict, num_edge_types: in
         i = s * world_size + rank
         ids = order[bounds[i]:bounds[i + 1]] if i < nb else np.zeros(0, np.int64)
         yield pack_batch_device(dms, ids, num_edge_types, params["hidden_size"], params.get("tie_fwd_bkwd", True),
-                                params.get("task_ids", [0]))
+                                params.get("task_ids", [0]), compact)

@@ -175,15 +175,25 @@ class DenseGGNNChemModel(ChemModel):
         bucketed = defaultdict(list)
         for g, bi in enumerate(chosen):
             bucketed[int(bi)].append(g)
+        # :153-158 per bucket: shuffle, then labels of the examples beyond task_sample_ratios are masked.  The mask
+        # belongs to the graph (it follows it through the later per-epoch shuffles); like the reference's
+        # `labels[task_id] = None` it addresses the label by TASK ID in the per-task label list.
+        label_mask = np.ones((ms.num_graphs, len(self.params['task_ids'])), dtype=np.float32)
         if is_training_data:
             for bucket_list in bucketed.values():
                 np.random.shuffle(bucket_list)
+                for task_id in self.params['task_ids']:
+                    task_sample_ratio = self.params['task_sample_ratios'].get(str(task_id))
+                    if task_sample_ratio is not None:
+                        ex_to_sample = int(len(bucket_list) * task_sample_ratio)
+                        if bucket_list[ex_to_sample:]:
+                            label_mask[np.asarray(bucket_list[ex_to_sample:]), task_id] = 0.0
         # :160-162 one entry per full batch of a bucket (remainder graphs are dropped)
         bucket_at_step = [[bucket_idx for _ in range(len(bucket_data) // self.params['batch_size'])]
                           for bucket_idx, bucket_data in bucketed.items()]
         bucket_at_step = [x for y in bucket_at_step for x in y]
         return {"molecules": ms, "bucketed": dict(bucketed), "bucket_sizes": np.asarray(bucket_sizes),
-                "bucket_at_step": bucket_at_step, "device_batches": {}}
+                "bucket_at_step": bucket_at_step, "device_batches": {}, "label_mask": label_mask}
 
     def to_device_batch(self, db) -> Dict[str, Any]:
         dev = self.device
@@ -210,7 +220,8 @@ class DenseGGNNChemModel(ChemModel):
             key = (bucket, bucket_counters[bucket])
             if is_training or key not in data["device_batches"]:
                 db = pack_dense_batch(ms, ids, int(bucket_sizes[bucket]), self.num_edge_types,
-                                      self.params['hidden_size'], self.params['tie_fwd_bkwd'], self.params['task_ids'])
+                                      self.params['hidden_size'], self.params['tie_fwd_bkwd'], self.params['task_ids'],
+                                      label_mask=data.get("label_mask"))
                 feed = self.to_device_batch(db)
                 if not is_training:
                     data["device_batches"][key] = feed

@@ -393,6 +393,16 @@ def build_compact_sources(index: MessageIndex) -> CompactSources:
     return CompactSources(pair_node[:max(type_row_off[-1], 1)], type_row_off, gather_c)
 
 
+def prepare_message_index(index: MessageIndex, hidden_size: int, compact: bool = True) -> MessageIndex:
+    """Everything the propagation derives from a batch's message index, built EAGERLY when the batch is packed (it
+    used to be built lazily on the first forward of each batch, which put a cold pass -- three small launches and a
+    device->host sync -- inside whatever region timed that forward): the active (source node, edge type) pairs of the
+    compacted message transform for the hidden sizes that have one."""
+    if compact and index.num_messages and compact_supported(hidden_size) and getattr(index, "_compact", None) is None:
+        index._compact = build_compact_sources(index)
+    return index
+
+
 class SegmentIndex:
     """row_ptr / gather_row pair for segment_sum_rows_by_index (the fields of MessageIndex that kernel reads)."""
 

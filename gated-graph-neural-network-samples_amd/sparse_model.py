@@ -86,6 +86,21 @@ class SparseGGNNChemModel(ChemModel):
         """chem_tensorflow_sparse.py:63-115.  Placeholders become dict slots filled by feed(); the
         variables are created here with the reference's shapes and initialisers."""
         h_dim = self.params['hidden_size']
+        # Limits of the HIP kernels behind this model (the reference accepts any hidden size and any number of residual
+        # inputs): rows are moved as 16-byte vectors, and a GRU launch concatenates at most 3 input segments.
+        if h_dim <= 0 or h_dim % 4 != 0:
+            raise ValueError("hidden_size %r is not supported by the gfx950 kernels: it must be a positive multiple of 4 "
+                             "(node-state rows are read and written as 16-byte vectors)" % (h_dim,))
+        if self.annotation_size > h_dim:
+            raise ValueError("annotation_size %d exceeds hidden_size %d" % (self.annotation_size, h_dim))
+        for layer_idx in range(len(self.params['layer_timesteps'])):
+            res = self.params['residual_connections'].get(str(layer_idx)) or []
+            if len(res) > 2:
+                raise ValueError("layer %d has %d residual inputs; the GRU kernels take at most 2 (plus the aggregated "
+                                 "messages)" % (layer_idx, len(res)))
+            for r in res:
+                if not 0 <= int(r) <= layer_idx:
+                    raise ValueError("layer %d: residual connection %r refers to a layer that is not computed yet" % (layer_idx, r))
         for name in ('initial_node_representation', 'adjacency_lists', 'num_incoming_edges_per_type',
                      'graph_nodes_list', 'message_index'):
             self.placeholders[name] = None
@@ -298,7 +313,7 @@ class SparseGGNNChemModel(ChemModel):
                     label_mask[ex_to_sample:, task_id] = 0.0
         return {"molecules": ms, "label_mask": label_mask, "device_batches": None}
 
-    def to_device_batch(self, b: SparseBatch) -> Dict[str, Any]:
+    def to_device_batch(self, b: SparseBatch, compact: bool = True) -> Dict[str, Any]:
         """Upload one packed batch and build its message index (once; reused every epoch)."""
         dev = self.device
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -315,7 +330,8 @@ class SparseGGNNChemModel(ChemModel):
             'target_values': t(b.target_values),
             'target_mask': t(b.target_mask),
             'num_graphs': b.num_graphs,
-            'message_index': ops.build_message_index(adjacency, V),
+            'message_index': ops.prepare_message_index(ops.build_message_index(adjacency, V), b.hidden_size, compact),
+            'graph_nodes_sorted': True,
         }
 
     def make_minibatch_iterator(self, data: Any, is_training: bool):
@@ -333,10 +349,14 @@ class SparseGGNNChemModel(ChemModel):
             # the dataset goes to HBM once; batches are then assembled on the GPU from graph ids (data_device.py)
             data["molecules_dev"] = DeviceMoleculeSet(ms, self.device, data["label_mask"])
 
+        # the compacted-transform pair list is part of the batch unless this epoch trains on the dense transform
+        from . import backward
+        compact = (not is_training) or backward.USE_COMPACT_TRANSFORM
+
         def epoch_batches(order):
             if on_device:
-                return pack_batches_device(data["molecules_dev"], self.params, self.num_edge_types, order, rank, world)
-            return (self.to_device_batch(b) for b in
+                return pack_batches_device(data["molecules_dev"], self.params, self.num_edge_types, order, rank, world, compact)
+            return (self.to_device_batch(b, compact) for b in
                     pack_batches(ms, self.params, self.num_edge_types, order, data["label_mask"], rank, world))
 
         if is_training:

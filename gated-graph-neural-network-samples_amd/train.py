@@ -47,13 +47,36 @@ class TFAdam:
             out[base + "/Adam_1:0"] = v.detach().cpu().numpy()
         return out
 
+    def _step_from_beta_powers(self, weights: Dict[str, np.ndarray]) -> int:
+        """Adam step of a checkpoint written by the reference (no explicit counter): TF keeps beta^(t+1) in float32.
+        0.9^(t+1) underflows to 0 after ~980 steps (a few dozen QM9 epochs) and is denormal -- i.e. wrong -- well before,
+        so the step is read from beta2_power (0.999^(t+1) stays a normal float32 up to t ~ 87,000); beta1_power is only
+        used while it is comfortably normal, and a power that is no longer representable means "many steps": both bias
+        corrections are 1 to float32 precision from there on."""
+        def power(name):
+            if name not in weights:
+                return None
+            return float(np.asarray(weights[name], dtype=np.float64).reshape(-1)[0])
+        b2p, b1p = power("beta2_power:0"), power("beta1_power:0")
+        tiny = float(np.finfo(np.float32).tiny)
+        if b2p is not None and tiny * 1e3 < b2p < 1.0:
+            return max(int(round(math.log(b2p) / math.log(self.b2))) - 1, 0)
+        if b2p is not None and b2p >= 1.0:
+            return 0
+        if b1p is not None and tiny * 1e3 < b1p < 1.0:
+            return max(int(round(math.log(b1p) / math.log(self.b1))) - 1, 0)
+        if b1p is not None and b1p >= 1.0:
+            return 0
+        if b1p is None and b2p is None:
+            return self.t
+        return 1 << 20            # powers underflowed: the bias corrections have converged
+
     def load_state_variables(self, named: Dict[str, torch.Tensor], weights: Dict[str, np.ndarray]) -> set:
         used = set()
         if "ggnn_amd/adam_step:0" in weights:
             self.t = int(weights["ggnn_amd/adam_step:0"]); used.add("ggnn_amd/adam_step:0")
-        elif "beta1_power:0" in weights:
-            b1_power = float(np.asarray(weights["beta1_power:0"]).reshape(-1)[0])      # beta1^(t+1) after t steps
-            self.t = max(int(round(math.log(b1_power) / math.log(self.b1))) - 1, 0)
+        else:
+            self.t = self._step_from_beta_powers(weights)
         used |= {"beta1_power:0", "beta2_power:0"} & set(weights)
         for i, (name, _) in enumerate(named.items()):
             base = name[:-2] if name.endswith(":0") else name

@@ -127,3 +127,109 @@ def test_checkpoint_roundtrip_reference_pickle_schema(pkg, tmp_path):
     a3 = dict(args); a3["--freeze-graph-model"] = True
     m3 = pkg.SparseGGNNChemModel(a3)
     assert all(k.startswith("out_layer_task") for k in m3.trainable_variables) and len(m3.trainable_variables) == 4
+
+
+def test_adam_step_restored_from_long_reference_checkpoint(pkg):
+    """A checkpoint written by the reference has no step counter, only TF's float32 beta powers.  0.9^(t+1) is zero in
+    float32 after ~1000 steps (a few dozen QM9 epochs); the step must then come from beta2_power (round-1 advisor finding:
+    math.log(0.0) crashed --restore)."""
+    v = torch.zeros(3)
+    for t in (0, 1, 7, 250, 900, 1500, 5000, 40000):
+        b1p, b2p = np.float32(1.0), np.float32(1.0)
+        for _ in range(t + 1):                                   # TF: beta_power *= beta after every step, in float32
+            b1p = np.float32(b1p * np.float32(0.9)); b2p = np.float32(b2p * np.float32(0.999))
+        opt = pkg.train.TFAdam([v.clone()])
+        opt.load_state_variables({"w:0": v}, {"beta1_power:0": b1p, "beta2_power:0": b2p})
+        assert abs(opt.t - t) <= max(1, t // 2000), (t, opt.t, float(b1p), float(b2p))
+    # both powers gone (beyond ~87k steps): a large step, no exception; the bias corrections are 1 there
+    opt = pkg.train.TFAdam([v.clone()])
+    opt.load_state_variables({"w:0": v}, {"beta1_power:0": np.float32(0.0), "beta2_power:0": np.float32(0.0)})
+    assert opt.t >= 100000
+    g = torch.ones(3)
+    opt.apply_gradients([g])                                     # lr_t is finite
+    assert torch.isfinite(opt.vars[0]).all()
+
+
+def test_feed_drops_index_derived_from_previous_batch(pkg):
+    """Advisor finding: a reference-style feed (adjacency_lists, no 'message_index') must not reuse the cached index of
+    the previous batch."""
+    ms = pkg.synthetic_qm9(12, mean_nodes=6, seed=2)
+    m = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cpu", "train_data": None, "valid_data": ms})
+    adj1, adj2 = [torch.zeros((1, 2), dtype=torch.int32)], [torch.zeros((2, 2), dtype=torch.int32)]
+    m.feed({"adjacency_lists": adj1, "message_index": "index-of-batch-1"})
+    assert m.placeholders["message_index"] == "index-of-batch-1"
+    m.feed({"adjacency_lists": adj1})                            # the same lists object: the cache stays valid
+    assert m.placeholders["message_index"] == "index-of-batch-1"
+    m.feed({"adjacency_lists": adj2})                            # another batch without an index of its own
+    assert m.placeholders["message_index"] is None
+    m.feed({"adjacency_lists": adj1, "message_index": "again"})
+    assert m.placeholders["message_index"] == "again"
+
+
+def test_unsupported_hidden_size_and_residual_count_fail_early(pkg):
+    ms = pkg.synthetic_qm9(12, mean_nodes=6, seed=2)
+    base = {"--quiet": True, "--device": "cpu", "train_data": None, "valid_data": ms}
+    with pytest.raises(ValueError, match="multiple of 4"):
+        pkg.SparseGGNNChemModel(dict(base, **{"--config": {"hidden_size": 30}}))
+    with pytest.raises(ValueError, match="residual"):
+        pkg.SparseGGNNChemModel(dict(base, **{"--config": {"residual_connections": {"4": [0, 1, 2]}}}))
+
+
+def test_dense_task_sample_ratios_mask_labels(pkg):
+    """chem_tensorflow_dense.py:153-158,180-189: per bucket, the labels of the examples beyond the sampled share
+    feed value 0 / mask 0 (advisor finding: the dense packer trained on every label)."""
+    ms = pkg.synthetic_qm9(96, mean_nodes=7, seed=5)
+    cfg = {"batch_size": 8, "task_sample_ratios": {"0": 0.25}}
+    m = pkg.DenseGGNNChemModel({"--quiet": True, "--device": "cpu", "train_data": ms, "valid_data": ms, "--config": cfg})
+    tr, va = m.train_data, m.valid_data
+    assert va["label_mask"].min() == 1.0                         # validation data are never masked
+    lm = tr["label_mask"]
+    for bucket in tr["bucketed"].values():
+        keep = int(len(bucket) * 0.25)
+        assert lm[np.asarray(bucket), 0].sum() == keep
+    total_masked = 0
+    for feed in m.make_minibatch_iterator(tr, is_training=True):
+        tm, tv = feed["target_mask"], feed["target_values"]
+        assert tm.shape == tv.shape and set(np.unique(tm.numpy())) <= {0.0, 1.0}
+        assert (tv[tm == 0] == 0).all()
+        total_masked += int((tm == 0).sum())
+    assert total_masked > 0
+
+
+def test_device_dataset_rejects_bond_outside_its_graph(pkg):
+    raw = [{"targets": [[0.0]], "graph": [[0, 1, 1]], "node_features": [[1, 0, 0, 0, 0]] * 2},
+           {"targets": [[0.0]], "graph": [[0, 1, 2]], "node_features": [[1, 0, 0, 0, 0]] * 2}]     # node 2 of a 2-node graph
+    ms = pkg.data.MoleculeSet.from_json(raw)
+    with pytest.raises(IndexError, match="graph 1"):
+        pkg.data_device.DeviceMoleculeSet(ms, "cpu")
+
+
+def _epoch_stats_worker(rank, world, port, ret):
+    import importlib
+    import types
+    pkg = importlib.import_module("gated-graph-neural-network-samples_amd")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    ctx = pkg.parallel.DataParallelContext.from_env(backend="gloo")
+    stub = types.SimpleNamespace(params={"task_ids": [0, 1], "task_sample_ratios": {}}, dist=ctx)
+    rng = np.random.default_rng(7)                                 # the same stream on both ranks: [step, rank, ...]
+    steps = 3
+    num = rng.uniform(1, 2, (steps, world, 2)); den = rng.integers(1, 9, (steps, world, 2)).astype(float)
+    ab = rng.uniform(1, 2, (steps, world, 2)); graphs = rng.integers(1, 9, (steps, world)).astype(float)
+    graphs[2, 1] = 0; num[2, 1] = 0; den[2, 1] = 0; ab[2, 1] = 0    # rank 1's last batch is an empty padding batch
+    stats = [torch.tensor(np.concatenate([num[s, rank], den[s, rank], ab[s, rank]])) for s in range(steps)]
+    loss, accs, total = pkg.chem_model.ChemModel._reduce_epoch_stats(stub, stats, list(graphs[:, rank]))
+    N, Dn, A, G = num.sum(1), den.sum(1), ab.sum(1), graphs.sum(1)
+    want_loss = float(((N / (Dn + 1e-7)).sum(1) * G).sum() / G.sum())
+    want_acc = ((A / (Dn + 1e-7)) * G[:, None]).sum(0) / G.sum()
+    ret[rank] = (abs(loss - want_loss), float(np.abs(accs - want_acc).max()), total == int(G.sum()), loss)
+    dist.destroy_process_group()
+
+
+def test_epoch_statistics_are_identical_on_every_rank_gloo(pkg):
+    """Advisor finding: under data parallelism every rank must derive the same epoch loss / MAE (they decide on the
+    best epoch and on early stopping; ranks that disagree hang the next all-reduce)."""
+    port = _free_port()
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_epoch_stats_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0][0] < 1e-12 and ret[0][1] < 1e-12 and ret[0][2] and ret[1][2]
+    assert ret[0][3] == ret[1][3]                                  # bit-identical on the two ranks
