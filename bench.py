@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- node-state updates/sec of the sparse GGNN propagation hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode forward|train]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -13,10 +13,24 @@ A "step" = compute_final_node_representations() over ONE such batch (inputs resi
 metric value = nodes * 8 / time, whole job (all ranks).  Multi-GPU: graphs are independent, so ranks get
 disjoint batches and the forward path has no collective ("scaling": "weak", per-GPU batch fixed).
 
+Timing: every resident batch is run once before anything is timed (whatever --warmup says), then W warm-up steps, then
+the K-step loop is timed `timed_repeats` times back to back inside ONE barrier/synchronize bracket -- as often as
+it takes to reach --min-time seconds (a 20-step loop is 25 ms, too short to be stable across boxes) -- and
+ms_per_step / value are taken over all `steps_timed` = K * timed_repeats steps.
+
 Also on the JSON line:
   roofline      -- the dominant kernel (by measured time): algorithmic flops (or bytes) per launch /
-                   its average launch duration, measured live with HIP events on the launch stream.
+                   its average launch duration, measured live with HIP events on the launch stream; `traffic` from
+                   the newest profiles/*_pmc_summary.json, only if it was recorded for the kernel sources in this tree.
   kernels       -- the same for every kernel of the path.
+  index_build_ms_per_batch, pack_ms_per_batch, end_to_end_fresh_batch
+                -- the work of chem_tensorflow_sparse.py:120-129 / 278-350 that the metric leaves outside the timed
+                   region (it is paid once per batch, at pack time) and the rate with it inside.
+  train         -- the full optimisation step (forward, backward, gradient all-reduce over RCCL when N > 1, per-variable
+                   clip, Adam) on the same batches: ms per step and the all-reduce's share (--mode train makes this
+                   the headline instead).
+  secondary     -- BASELINE.json configs[2] (dense, padded batch 256 x 29 vertices) and configs[4] (one graph,
+                   100k nodes / 1M edges, h = 256): throughput and per-kernel roofline fractions (rank 0, N = 1).
   cpu_baseline  -- the torch-CPU fp32 port of the reference op order (oracle/ggnn_oracle_torch.py),
                    timed on this host on rank 0 at N=1, on a bounded sample (one batch, few reps).
 """
@@ -24,6 +38,8 @@ from __future__ import annotations
 
 import argparse
 import gc
+import glob
+import hashlib
 import importlib
 import json
 import os
@@ -39,6 +55,7 @@ PKG = "gated-graph-neural-network-samples_amd"
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+HBM_COPY_GBPS = 6290.0
 
 
 def parse_args():
@@ -46,24 +63,29 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--mode", choices=("forward", "train"), default="forward",
+                    help="forward: the propagation (headline metric); train: the full optimisation step incl. the RCCL all-reduce")
+    ap.add_argument("--min-time", type=float, default=0.5, help="minimum duration of the timed region in seconds")
     ap.add_argument("--mean-nodes", type=float, default=18.0, help="mean atoms per molecule (18 = QM9 with H)")
     ap.add_argument("--batches", type=int, default=6, help="distinct resident batches to cycle through")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent batches are issued on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] / train legs")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--batch-size", type=int, default=0, help="override the reference's batch_size (100000 nodes); experiments only")
     return ap.parse_args()
 
 
+# ---- algorithmic work per launch -----------------------------------------------------------------------
 def kernel_model(name, V, M, D, T, R=None):
     """Algorithmic flops / bytes per launch -> (bound, work).  R = active (node,type) pairs."""
     if name == "msg_transform":
         return "mfma", 2.0 * V * D * T * D
     if name == "msg_transform_compact":
         return "mfma", 2.0 * R * D * D
-    if name == "gather_segment_sum":
-        return "hbm", float(M * D * 4 + M * 8 + V * D * 4)
+    if name in ("gather_segment_sum", "dense_aggregate"):
+        return "hbm", kernel_bytes(name, V, M, D, T, R)
     if name.startswith("gru_fused"):
         nx = int(name.split("nx=")[1].rstrip("]"))
         return "mfma", 6.0 * V * (nx + 1) * D * D
@@ -84,6 +106,8 @@ def kernel_bytes(name, V, M, D, T, R=None):
         return float(V * D * 4 + R * 4 + R * D * 4)          # states (each read once) + pair list + compact rows
     if name == "gather_segment_sum":
         return float(M * D * 4 + M * 8 + V * D * 4)
+    if name == "dense_aggregate":                            # adjacency [b,T,v,v] (= M floats here) + transformed rows + output
+        return float(M * 4 + V * T * D * 4 + V * D * 4)
     nx = int(name.split("nx=")[1].rstrip("]"))
     if name.startswith("gru_fused_gather"):                  # residual segments + h + h_out + gathered rows + slots
         return float((nx - 1 + 2) * V * D * 4 + M * D * 4 + M * 4 + V * 4 + V * T * 4)
@@ -94,6 +118,183 @@ def kernel_bytes(name, V, M, D, T, R=None):
     if name.startswith("gru_candidate"):
         return float((nx + 3 + 1) * V * D * 4)
     raise KeyError(name)
+
+
+def kernel_table(res, reps, V, M, D, T, R=None):
+    """HIP-event timings {name: [ms..]} -> per-kernel roofline records."""
+    kernels = {}
+    for name, times in res.items():
+        try:
+            bound, work = kernel_model(name, V, M, D, T, R)
+            by = kernel_bytes(name, V, M, D, T, R)
+        except (KeyError, IndexError, ValueError):
+            continue
+        avg_ms = float(np.mean(times))
+        if bound == "mfma":
+            ach, peak, unit = work / (avg_ms * 1e-3) / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBPS, "GB/s"
+        kernels[name] = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                         "avg_us": avg_ms * 1e3, "median_us": float(np.median(times)) * 1e3,
+                         "max_us": float(np.max(times)) * 1e3, "launches_per_step": len(times) / reps,
+                         "time_share": None, "traffic": None, "algorithmic_bytes": by,
+                         "hbm_frac": by / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    tot_ms = sum(float(np.sum(res[n])) for n in kernels)
+    for name in kernels:
+        kernels[name]["time_share"] = float(np.sum(res[name])) / tot_ms if tot_ms else None
+    return kernels, tot_ms
+
+
+# ---- HBM traffic: the committed PMC summary of THIS source tree, or nothing ---------------------------------------
+def csrc_sha1():
+    """Hash of the kernel sources: a PMC summary is only attached to kernels built from the same sources."""
+    h = hashlib.sha1()
+    for path in sorted(glob.glob(os.path.join(ROOT, PKG, "csrc", "*"))):
+        if path.endswith((".hip", ".hpp", ".h")):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def load_pmc(workload):
+    """Newest profiles/r*_pmc_summary*.json for `workload` ('bench' | 'large' | 'dense'), with the reason when unusable."""
+    suffix = {"bench": "_pmc_summary.json", "large": "_config5_pmc_summary.json", "dense": "_config3_pmc_summary.json"}[workload]
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*" + suffix))
+                   if workload != "bench" or "_config" not in os.path.basename(f))
+    if not files:
+        return None, None, "no profiles/*%s" % suffix
+    path = files[-1]
+    pmc = json.load(open(path))
+    meta = pmc.get("_meta") or {}
+    rel = os.path.relpath(path, ROOT)
+    if meta.get("csrc_sha1") != csrc_sha1():
+        msg = ("%s was recorded for other kernel sources (csrc sha1 %s, this tree %s): traffic NOT reported -- rerun "
+               "tools/profile_round.sh" % (rel, str(meta.get("csrc_sha1"))[:10], csrc_sha1()[:10]))
+        print("[bench] WARNING: " + msg, file=sys.stderr)
+        return None, rel, msg
+    return pmc, rel, None
+
+
+def pmc_key(pmc, name, D):
+    """bench kernel label -> key of tools/pmc_summary.py (short kernel name, template arguments for the fused GRUs)."""
+    if name in ("msg_transform_compact", "dense_aggregate"):
+        return next((k for k in pmc if k.startswith(name)), None)
+    if name == "msg_transform" or name.startswith("gru_gates") or name.startswith("gru_candidate"):
+        return None                                      # (all three are instances of ggnn_gemm_kernel: not separable by name)
+    if name == "gather_segment_sum":
+        return next((k for k in pmc if k.startswith("gather_segment_sum") and "attn" not in k), None)
+    if name.startswith("gru_fused"):                     # template args <D, NX, NW, SAVE, GATHER>
+        nx = name.split("nx=")[1].rstrip("]")
+        tail = "true>" if name.startswith("gru_fused_gather") else "false>"
+        return next((k for k in pmc if k.startswith("gru_fused<%d, %s," % (D, nx)) and k.endswith(tail) and k.count(",") == 4),
+                    None) or next((k for k in pmc if k.startswith("gru_panel<%d," % D)), None)
+    return None
+
+
+def attach_traffic(kernels, workload, D):
+    pmc, rel, err = load_pmc(workload)
+    missing = []
+    for name, rec in kernels.items():
+        key = pmc_key(pmc, name, D) if pmc else None
+        if key and key in pmc:
+            rec["traffic"] = pmc[key]["hbm_bytes_fetch_x2_plus_write"]
+            rec["traffic_source"] = rel
+            rec["mfma_util_pmc"] = pmc[key].get("mfma_util")
+        elif pmc is not None and pmc_key({}, name, D) is None and name not in ("msg_transform",) and not name.startswith(("gru_gates", "gru_candidate")):
+            missing.append(name)
+    if pmc is not None and missing:
+        print("[bench] WARNING: %s has no counters for %s (kernel set changed?)" % (rel, missing), file=sys.stderr)
+    return err
+
+
+def timed_loop(fn, warmup, steps, min_time=0.0, sync=torch.cuda.synchronize):
+    import gc as _gc
+    for i in range(warmup):
+        fn(i)
+    _gc.collect(); _gc.freeze(); _gc.disable()       # no 45 ms cyclic-GC pause inside the timed region
+    sync()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for i in range(steps):
+            fn(n + i)
+        n += steps
+        sync()
+        dt = time.perf_counter() - t0
+        if dt >= min_time:
+            break
+    _gc.enable()
+    return dt / n, n
+
+
+# ---- secondary workloads (rank 0, N = 1) ---------------------------------------------------------------------------
+def secondary_large(pkg, dev):
+    """BASELINE.json configs[4]: one graph, 100k nodes / 1M edges / 4 edge types, h = 256, one weight set, 8 steps."""
+    V, M, T, D = 100000, 1000000, 4, 256
+    adj_np, nin_np = pkg.synthetic_large_graph(V, M, T, seed=0)
+    raw = [{"targets": [[0.0]], "graph": [[0, t + 1, 1] for t in range(T)], "node_features": [[1, 0, 0, 0, 0]] * 2}]
+    cfg = {"hidden_size": D, "layer_timesteps": [8], "residual_connections": {}, "tie_fwd_bkwd": True}
+    model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": str(dev), "train_data": None, "valid_data": raw, "--config": cfg})
+    adj = [torch.from_numpy(a).to(dev) for a in adj_np]
+    index = pkg.ops.prepare_message_index(pkg.ops.build_message_index(adj, V), D)
+    feed = {"initial_node_representation": (torch.rand(V, D, device=dev) * 2 - 1), "adjacency_lists": adj,
+            "num_incoming_edges_per_type": torch.from_numpy(nin_np).to(dev), "message_index": index}
+
+    def step(i):
+        model.feed(feed)
+        with torch.no_grad():
+            model.compute_final_node_representations()
+    dt, n = timed_loop(step, 3, 10, 0.3)
+    with pkg.ops.kernel_timing() as kt:
+        for i in range(3):
+            step(i)
+    comp = getattr(index, "_compact", None)
+    R = comp.num_rows if comp is not None else None
+    kernels, tot_ms = kernel_table(kt.results(), 3, V, M, D, T, R)
+    err = attach_traffic(kernels, "large", D)
+    out = {"workload": "configs[4]: sparse GGNN forward, ONE graph: %d nodes / %d edges / %d edge types, h=%d, 8 steps" % (V, M, T, D),
+           "ms_per_step": dt * 1e3, "steps_timed": n, "node_state_updates_per_sec": V * 8 / dt,
+           "active_source_type_pairs": R, "kernels": kernels, "kernel_time_ms_per_step": tot_ms / 3}
+    k2 = kernels.get("gather_segment_sum")
+    if k2:
+        out["scatter_add"] = {"achieved_GBps": k2["achieved"], "frac_of_8TBps_spec": k2["frac"],
+                              "frac_of_6.29TBps_copy": k2["achieved"] / HBM_COPY_GBPS, "avg_us": k2["avg_us"],
+                              "algorithmic_bytes": k2["algorithmic_bytes"], "traffic": k2["traffic"]}
+    if err:
+        out["traffic_error"] = err
+    return out
+
+
+def secondary_dense(pkg, dev):
+    """BASELINE.json configs[2]: dense-adjacency GGNN, padded batch 256 x 29 vertices, h = 100, 4 timesteps."""
+    ms = pkg.synthetic_qm9(4000, mean_nodes=27, seed=0)
+    model = pkg.DenseGGNNChemModel({"--quiet": True, "--device": str(dev), "train_data": None, "valid_data": ms})
+    feeds = [f for f in model.make_minibatch_iterator(model.valid_data, False) if f["num_vertices"] == 29][:4]
+    if not feeds:
+        return {"error": "no full v=29 batch"}
+    for f in feeds:
+        f["initial_node_representation"] = (torch.rand_like(f["initial_node_representation"]) * 2 - 1)
+
+    def step(i):
+        model.feed(feeds[i % len(feeds)])
+        with torch.no_grad():
+            model.compute_final_node_representations()
+    dt, n = timed_loop(step, 5, 50, 0.3)
+    with pkg.ops.kernel_timing() as kt:
+        for i in range(6):
+            step(i)
+    b, v = feeds[0]["initial_node_representation"].shape[:2]
+    D, T = model.params["hidden_size"], model.num_edge_types
+    kernels, tot_ms = kernel_table(kt.results(), 6, b * v, b * T * v * v, D, T)
+    err = attach_traffic(kernels, "dense", D)
+    out = {"workload": "configs[2]: dense GGNN forward, padded batch %d x v=%d, h=%d, %d edge types, %d timesteps" % (
+               b, v, D, T, model.params["num_timesteps"]),
+           "ms_per_step": dt * 1e3, "steps_timed": n, "graphs_per_sec": b / dt,
+           "node_state_updates_per_sec": b * v * model.params["num_timesteps"] / dt,
+           "kernels": kernels, "kernel_time_ms_per_step": tot_ms / 6}
+    if err:
+        out["traffic_error"] = err
+    return out
 
 
 def main():
@@ -108,13 +309,17 @@ def main():
     # ---- data: enough QM9-shaped molecules for `batches` distinct ~100k-node batches per rank ------
     mols_per_batch = int(100000 / args.mean_nodes * 1.02) + 8
     ms = pkg.synthetic_qm9(mols_per_batch * args.batches, mean_nodes=args.mean_nodes, seed=1000 + rank)
-    model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": str(dev), "train_data": None, "valid_data": ms})
+    model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": str(dev), "train_data": None, "valid_data": ms, "dist": dist_ctx})
+    if world > 1:
+        dist_ctx.broadcast_(list(model.named_variables().values()))     # every rank starts from rank 0's weights
     params = model.params
     if args.batch_size:
         params["batch_size"] = args.batch_size
     D, T = params["hidden_size"], model.num_edge_types
     n_prop = sum(params["layer_timesteps"])
+    model.dist = None                       # (the iterator shards by rank; here every rank packs its OWN dataset)
     feeds = list(model.make_minibatch_iterator(model.valid_data, is_training=False))[:args.batches]
+    model.dist = dist_ctx
     rng = torch.Generator(device="cpu").manual_seed(1234 + rank)
     for f in feeds:   # random dense states: one-hot inputs are sparse and inflate clocks (DVFS)
         f["initial_node_representation"] = (torch.rand(f["initial_node_representation"].shape, generator=rng) * 2 - 1).to(dev)
@@ -126,8 +331,14 @@ def main():
     # the tail of one batch's kernel (a partially filled last wave of workgroups) is then back-filled by the
     # next batch's kernels.  Every step still runs the full 8-step forward of one batch; K steps are timed.
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+    train_feeds = []
+    for f in feeds:
+        tf = dict(f)
+        tf["edge_weight_dropout_keep_prob"] = params["edge_weight_dropout_keep_prob"]      # the reference's training default (0.8)
+        tf["out_layer_dropout_keep_prob"] = 1.0
+        train_feeds.append(tf)
 
-    def step(i, multi=True):
+    def fwd_step(i, multi=True):
         f = feeds[i % len(feeds)]
         if streams is None or not multi:
             model.feed(f)
@@ -136,103 +347,175 @@ def main():
             model.feed(f)
             return model.compute_final_node_representations()
 
-    with torch.no_grad():
-        if streams is not None:
-            for s in streams:
-                s.wait_stream(torch.cuda.current_stream())
-        for i in range(args.warmup):
-            step(i)
-        # One generation-2 pass of Python's cyclic garbage collector over the interpreter's long-lived objects
-        # (torch, numpy, the model) blocks the host for ~45 ms; the launch queue runs dry and a 70-140 ms timed
-        # region reads 20-40 % slow, depending on where the allocation counter happens to trip
-        # (tools/stream_jitter.py shows the single gap).  Nothing in the timed region creates reference cycles.
-        gc.collect()
-        gc.freeze()
-        gc.disable()
-        torch.cuda.synchronize()
-        dist_ctx.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        torch.cuda.synchronize()
-        dist_ctx.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        gc.enable()
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist_ctx.all_reduce_max_(el)
-    elapsed = float(el.item())
-    my_nodes = sum(nodes[i % len(feeds)] for i in range(args.steps))
-    my_graphs = sum(graphs[i % len(feeds)] for i in range(args.steps))
-    tot = torch.tensor([my_nodes, my_graphs], dtype=torch.float64, device=dev)
-    dist_ctx.all_reduce_sum_(tot)
-    total_nodes, total_graphs = float(tot[0].item()), float(tot[1].item())
+    def train_step(i, multi=True):
+        return model.train_batch(train_feeds[i % len(train_feeds)])
+
+    def timed_region(step, steps, warmup, min_time, no_grad):
+        """barrier + synchronize | `repeats` x K steps | synchronize + barrier; MAX over ranks.  The repeat count is
+        agreed between the ranks from a calibration pass (one untimed K-step loop)."""
+        ctx = torch.no_grad() if no_grad else torch.enable_grad()
+        with ctx:
+            if streams is not None:
+                for s in streams:
+                    s.wait_stream(torch.cuda.current_stream())
+            for i in range(len(feeds) * (len(streams) if streams else 1)):     # every resident batch, on every stream
+                step(i)
+            for i in range(warmup):
+                step(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):                                              # calibration (also warm-up)
+                step(i)
+            torch.cuda.synchronize()
+            cal = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist_ctx.all_reduce_max_(cal)
+            repeats = max(1, int(np.ceil(min_time / max(float(cal.item()), 1e-6))))
+            # One generation-2 pass of Python's cyclic garbage collector over the interpreter's long-lived objects
+            # (torch, numpy, the model) blocks the host for ~45 ms; the launch queue runs dry and a short timed
+            # region reads 20-40 % slow (tools/stream_jitter.py).  Nothing in the timed region creates reference cycles.
+            gc.collect()
+            gc.freeze()
+            gc.disable()
+            torch.cuda.synchronize()
+            dist_ctx.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(repeats):
+                for i in range(steps):
+                    step(i)
+            torch.cuda.synchronize()
+            dist_ctx.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            gc.enable()
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist_ctx.all_reduce_max_(el)
+        return float(el.item()), repeats
+
+    def totals(steps_timed):
+        my_nodes = sum(nodes[i % len(feeds)] for i in range(args.steps)) * (steps_timed // args.steps)
+        my_graphs = sum(graphs[i % len(feeds)] for i in range(args.steps)) * (steps_timed // args.steps)
+        tot = torch.tensor([my_nodes, my_graphs], dtype=torch.float64, device=dev)
+        dist_ctx.all_reduce_sum_(tot)
+        return float(tot[0].item()), float(tot[1].item())
+
+    headline_train = args.mode == "train"
+    elapsed, repeats = timed_region(train_step if headline_train else fwd_step, args.steps, args.warmup, args.min_time,
+                                    no_grad=not headline_train)
+    steps_timed = args.steps * repeats
+    total_nodes, total_graphs = totals(steps_timed)
     value = total_nodes * n_prop / elapsed
 
+    what = ("sparse GGNN TRAINING step (forward + backward + gradient all-reduce + per-variable clip + Adam)" if headline_train
+            else "sparse GGNN forward propagation")
     out = {
-        "metric": "node-state updates/sec on QM9-shaped graphs, h=100, 4 edge types",
+        "metric": "node-state updates/sec on QM9-shaped graphs, h=100, 4 edge types" + (" (training step)" if headline_train else ""),
         "value": value, "unit": "node-state updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / steps_timed * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "sparse GGNN forward propagation, full-QM9-sized synthetic batches (configs[1])",
-                   "hidden_size": D, "num_edge_types": T, "propagation_steps": n_prop,
+        "steps_timed": steps_timed, "timed_repeats": repeats, "timed_seconds": elapsed,
+        "config": {"workload": what + ", full-QM9-sized synthetic batches (configs[%d])" % (3 if world > 1 else 1),
+                   "mode": args.mode, "hidden_size": D, "num_edge_types": T, "propagation_steps": n_prop,
                    "layer_timesteps": params["layer_timesteps"], "residual_connections": params["residual_connections"],
                    "nodes_per_batch": int(np.mean(nodes)), "messages_per_batch": int(np.mean(msgs)),
                    "graphs_per_batch": int(np.mean(graphs)), "mean_nodes_per_graph": args.mean_nodes,
-                   "active_source_type_pairs_per_batch": None, "hip_streams": max(args.streams, 1),
-                   "batch_size_param": params["batch_size"], "parallelism": "dp%d (independent graph batches)" % world},
+                   "active_source_type_pairs_per_batch": None, "hip_streams": 1 if headline_train else max(args.streams, 1),
+                   "resident_batches": len(feeds), "batch_size_param": params["batch_size"],
+                   "parallelism": "dp%d (independent graph batches%s)" % (world, "; one flat fp32 gradient all-reduce per step" if headline_train else "")},
         "graphs_per_sec": total_graphs / elapsed,
     }
 
+    # ---- the other mode, short: forward runs get a `train` object, train runs a `forward` object (all ranks: it holds the collective)
+    if not args.no_secondary:
+        o_steps = max(4, min(args.steps, 12))
+        if headline_train:
+            el2, rep2 = timed_region(fwd_step, o_steps, 2, 0.2, no_grad=True)
+            n2 = sum(nodes[i % len(feeds)] for i in range(o_steps)) * rep2
+            t2 = torch.tensor([n2], dtype=torch.float64, device=dev); dist_ctx.all_reduce_sum_(t2)
+            out["forward"] = {"value": float(t2.item()) * n_prop / el2, "unit": "node-state updates/s", "ms_per_step": el2 / (o_steps * rep2) * 1e3,
+                              "steps_timed": o_steps * rep2}
+        else:
+            el2, rep2 = timed_region(train_step, o_steps, 2, 0.3, no_grad=False)
+            n2 = sum(nodes[i % len(feeds)] for i in range(o_steps)) * rep2
+            t2 = torch.tensor([n2], dtype=torch.float64, device=dev); dist_ctx.all_reduce_sum_(t2)
+            out["train"] = {"what": "forward + backward + flat gradient all-reduce (RCCL, N > 1) + per-variable clip + Adam, one batch per rank per step",
+                            "value": float(t2.item()) * n_prop / el2, "unit": "node-state updates/s",
+                            "ms_per_step": el2 / (o_steps * rep2) * 1e3, "steps_timed": o_steps * rep2, "n_gpus": world}
+    # the gradient all-reduce on its own (HIP events around DataParallelContext.reduce_gradients), all ranks take part
+    if world > 1 and (headline_train or not args.no_secondary):
+        variables = list(model.trainable_variables.values())
+        gbuf = [torch.zeros_like(v) for v in variables]
+        ev = []
+        for i in range(12):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); dist_ctx.reduce_gradients(variables, list(gbuf)); e.record()
+            ev.append((s, e))
+        torch.cuda.synchronize()
+        ar = [s.elapsed_time(e) * 1e3 for s, e in ev][2:]
+        rec = {"allreduce_us": float(np.mean(ar)), "allreduce_min_us": float(np.min(ar)),
+               "allreduce_bytes": int(sum(v.numel() for v in variables) * 4), "backend": "nccl (RCCL)"}
+        out.setdefault("train", {}).update(rec) if not headline_train else out.update({"collective": rec})
+
+    # ---- index prep / packing outside the timed region, and the rate with them inside (rank 0) ----------------------
+    if rank == 0 and not headline_train:
+        ops = pkg.ops
+        for warm in (True, False):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for f in feeds:
+                ops.prepare_message_index(ops.build_message_index(f["adjacency_lists"], f["initial_node_representation"].shape[0],
+                                                                  validate=False), D)
+            torch.cuda.synchronize()
+            idx_ms = (time.perf_counter() - t0) / len(feeds) * 1e3
+        dms = model.valid_data["molecules_dev"]
+        from importlib import import_module
+        dd = import_module(PKG + ".data_device")
+        list(dd.pack_batches_device(dms, params, T, None))                         # warm
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        packed = list(dd.pack_batches_device(dms, params, T, None))
+        torch.cuda.synchronize()
+        pack_ms = (time.perf_counter() - t0) / len(packed) * 1e3
+        del packed
+        pool = torch.rand((max(params["batch_size"], max(nodes)), D), device=dev) * 2 - 1     # dense random states, as above
+        with torch.no_grad():
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            nn = 0
+            for rep in range(2):
+                for fb in dd.pack_batches_device(dms, params, T, None):
+                    Vf = fb["initial_node_representation"].shape[0]
+                    fb["initial_node_representation"] = pool[:Vf]
+                    model.feed(fb)
+                    model.compute_final_node_representations()
+                    nn += Vf
+            torch.cuda.synchronize()
+            e2e = time.perf_counter() - t0
+        del pool
+        out["index_build_ms_per_batch"] = idx_ms
+        out["pack_ms_per_batch"] = pack_ms
+        out["end_to_end_fresh_batch"] = {
+            "value": nn * n_prop / e2e, "unit": "node-state updates/s",
+            "what": "every step packs a fresh ~100k-node batch on the GPU from graph ids (chem_tensorflow_sparse.py:278-350), builds its "
+                    "message index (:120-129: stable sort by target, source-pair compaction, one host sync) and runs the 8-step forward; "
+                    "one stream, %d batches" % (2 * len(feeds))}
+
     # ---- roofline leg: per-launch HIP-event timing of every kernel (rank 0) -----------------------------
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not headline_train:
         reps = max(4, min(args.steps, 12))
         with torch.no_grad(), pkg.ops.kernel_timing():
-            step(0, multi=False)              # untimed: the per-step entry points' first launches (one-off set-up)
+            fwd_step(0, multi=False)          # untimed: the per-step entry points' first launches (one-off set-up)
         torch.cuda.synchronize()
         with torch.no_grad(), pkg.ops.kernel_timing() as kt:
             for i in range(reps):
-                step(i, multi=False)          # single stream: launches must not overlap while they are timed
+                fwd_step(i, multi=False)      # single stream: launches must not overlap while they are timed
         res = kt.results()
         Vb, Mb = float(np.mean([nodes[i % len(feeds)] for i in range(reps)])), float(np.mean([msgs[i % len(feeds)] for i in range(reps)]))
         comps = [getattr(f["message_index"], "_compact", None) for f in feeds]
         Rb = float(np.mean([c.num_rows for c in comps])) if all(c is not None for c in comps) else None
-        kernels = {}
-        for name, times in res.items():
-            bound, work = kernel_model(name, Vb, Mb, D, T, Rb)
-            avg_ms = float(np.mean(times))
-            if bound == "mfma":
-                ach, peak, unit = work / (avg_ms * 1e-3) / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
-            else:
-                ach, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBPS, "GB/s"
-            kernels[name] = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                             "avg_us": avg_ms * 1e3, "median_us": float(np.median(times)) * 1e3,
-                             "max_us": float(np.max(times)) * 1e3, "launches_per_step": len(times) / reps,
-                             "time_share": None, "traffic": None,
-                             "algorithmic_bytes": kernel_bytes(name, Vb, Mb, D, T, Rb),
-                             "hbm_frac": kernel_bytes(name, Vb, Mb, D, T, Rb) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        tot_ms = sum(float(np.sum(t)) for t in res.values())
-        for name, times in res.items():
-            kernels[name]["time_share"] = float(np.sum(times)) / tot_ms
-        # HBM traffic per launch cannot be read from inside this process: it comes from the committed rocprofv3
-        # PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as MI355X_MICROARCH.md
-        # prescribes for gfx950), same workload, same kernels -- profiles/*_pmc_summary.json
-        pmc_file = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")
-        if os.path.exists(pmc_file):
-            pmc = json.load(open(pmc_file))
-            for name in kernels:
-                key = {"msg_transform_compact": "msg_transform_compact"}.get(name)
-                if name == "gather_segment_sum":
-                    key = next((k for k in pmc if k.startswith("gather_segment_sum") and "attn" not in k), None)
-                if key is None and name.startswith("gru_fused"):      # template args <D, NX, NW, SAVE, GATHER>
-                    nx = name.split("nx=")[1].rstrip("]")
-                    tail = "true>" if name.startswith("gru_fused_gather") else "false>"
-                    key = next((k for k in pmc if k.startswith("gru_fused<%d, %s," % (D, nx)) and k.endswith(tail)
-                                and k.count(",") == 4), None)
-                if key in pmc:
-                    kernels[name]["traffic"] = pmc[key]["hbm_bytes_fetch_x2_plus_write"]
-                    kernels[name]["traffic_source"] = "profiles/r01_final_pmc_summary.json"
+        kernels, tot_ms = kernel_table(res, reps, Vb, Mb, D, T, Rb)
+        # HBM traffic per launch cannot be read from inside this process: it comes from the committed rocprofv3 PMC
+        # passes of tools/profile_round.sh (separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950), same workload -- and only if that summary was recorded for the
+        # kernel sources of this tree (csrc sha1); otherwise traffic stays null and the reason is printed.
+        traffic_err = attach_traffic(kernels, "bench", D)
         # The edge-indexed scatter-add (chem_tensorflow_sparse.py:198-209) runs INSIDE the GRU launch on the timed path
         # (ggnn_gru_packed_gather_f32).  Its stand-alone kernel -- the one the training path, edge-bias layers and
         # non-fused hidden sizes use -- is timed here over all 8 timesteps of the same batches so that its HBM rate is
@@ -242,27 +525,36 @@ def main():
             try:
                 with torch.no_grad(), pkg.ops.kernel_timing() as kt2:
                     for i in range(min(reps, 4)):
-                        step(i, multi=False)
+                        fwd_step(i, multi=False)
             finally:
                 pkg.ops.FUSE_GATHER = saved
             t2 = kt2.results().get("gather_segment_sum")
             if t2:
-                avg_ms = float(np.mean(t2))
-                by = kernel_bytes("gather_segment_sum", Vb, Mb, D, T, Rb)
-                out["scatter_add"] = {"kernel": "gather_segment_sum", "bound": "hbm", "achieved": by / (avg_ms * 1e-3) / 1e9,
-                                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": by / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                      "avg_us": avg_ms * 1e3, "algorithmic_bytes": by, "in_timed_path": False,
-                                      "traffic": None}
-                if os.path.exists(pmc_file):       # (kernel variants: gather_segment_sum / gather_segment_sum_flat)
-                    key = next((k for k in pmc if k.startswith("gather_segment_sum") and "attn" not in k), None)
-                    if key:
-                        out["scatter_add"]["traffic"] = pmc[key]["hbm_bytes_fetch_x2_plus_write"]
-                        out["scatter_add"]["traffic_source"] = "profiles/r01_final_pmc_summary.json"
+                k2, _ = kernel_table({"gather_segment_sum": t2}, min(reps, 4), Vb, Mb, D, T, Rb)
+                attach_traffic(k2, "bench", D)
+                rec = k2["gather_segment_sum"]
+                out["scatter_add"] = {"kernel": "gather_segment_sum", "bound": "hbm", "achieved": rec["achieved"], "peak": HBM_PEAK_GBPS,
+                                      "unit": "GB/s", "frac": rec["frac"], "frac_of_6.29TBps_copy": rec["achieved"] / HBM_COPY_GBPS,
+                                      "avg_us": rec["avg_us"], "algorithmic_bytes": rec["algorithmic_bytes"],
+                                      "in_timed_path": False, "traffic": rec["traffic"], "traffic_source": rec.get("traffic_source")}
         dom = max(kernels, key=lambda k: kernels[k]["time_share"])
         out["roofline"] = dict(kernels[dom], kernel=dom)
+        if traffic_err:
+            out["roofline"]["traffic_error"] = traffic_err
         out["config"]["active_source_type_pairs_per_batch"] = None if Rb is None else int(Rb)
         out["kernels"] = kernels
         out["kernel_time_ms_per_step"] = tot_ms / reps
+
+    # ---- secondary configs (rank 0, N = 1) ----------------------------------------------------------------------------
+    if rank == 0 and world == 1 and not args.no_secondary and not headline_train:
+        sec = {}
+        for key, fn in (("config3_dense_b256", secondary_dense), ("config5_large_graph_h256", secondary_large)):
+            try:
+                sec[key] = fn(pkg, dev)
+            except Exception as exc:                                   # a secondary leg must never take the headline down
+                sec[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            torch.cuda.empty_cache()
+        out["secondary"] = sec
 
     # ---- CPU baseline leg: torch-CPU port of the reference op order, bounded sample (rank 0, N=1) ---------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -291,7 +583,8 @@ def main():
                                          "port of chem_tensorflow_sparse.py:117-218 in reference op order" % (nodes[0], msgs[0], args.cpu_reps),
                                "host_cpus": os.cpu_count(), "graphs_per_sec": graphs[0] / cpu_t,
                                "max_abs_diff_gpu_vs_cpu": float((got - ref).abs().max())}
-        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if not headline_train:
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
 
     if rank == 0:
         print(json.dumps(out))

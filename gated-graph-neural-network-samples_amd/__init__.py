@@ -21,7 +21,7 @@ for _m in _SUBMODULES:
 from .chem_model import ChemModel                                   # noqa: E402
 from .sparse_model import SparseGGNNChemModel, GGNNWeights          # noqa: E402
 from .dense_model import DenseGGNNChemModel                         # noqa: E402
-from .data import MoleculeSet, synthetic_qm9, pack_batches          # noqa: E402
+from .data import MoleculeSet, synthetic_qm9, synthetic_large_graph, pack_batches          # noqa: E402
 
 __all__ = ["ChemModel", "SparseGGNNChemModel", "DenseGGNNChemModel", "GGNNWeights", "MoleculeSet",
-           "synthetic_qm9", "pack_batches"]
+           "synthetic_qm9", "synthetic_large_graph", "pack_batches"]

@@ -258,7 +258,7 @@ class ChemModel(object):
         start_time = time.time()
         processed_graphs = 0
         steps = 0
-        sharded = self.dist is not None and self.dist.world_size > 1
+        sharded = self.dist is not None and self.dist.active
         shard_stats, shard_graphs = [], []
         for step, batch_data in enumerate(self.make_minibatch_iterator(data, is_training)):
             num_graphs = batch_data['num_graphs']

@@ -112,6 +112,33 @@ def _ranges(starts: np.ndarray, lengths: np.ndarray) -> np.ndarray:
     return base + np.arange(total, dtype=np.int64)
 
 
+def synthetic_large_graph(num_nodes: int = 100000, num_edges: int = 1000000, num_edge_types: int = 4, seed: int = 0,
+                          power_law: bool = False):
+    """BASELINE.json configs[4]: ONE large graph -- `num_edges` directed messages split uniformly
+    over `num_edge_types`, sources and targets uniform over `num_nodes` (or Zipf-distributed TARGETS with
+    power_law=True: a few hub nodes collect thousands of messages), not symmetric.  Returns the sparse model's feed
+    pieces as NumPy arrays: (adjacency_lists: T x int32 [E_t,2] sorted by (src,dst) like the reference's packer
+    (chem_tensorflow_sparse.py:265), num_incoming_edges_per_type: float32 [V,T])."""
+    rng = np.random.default_rng(seed)
+    V, M, T = int(num_nodes), int(num_edges), int(num_edge_types)
+    types = rng.integers(0, T, M)
+    src = rng.integers(0, V, M).astype(np.int32)
+    if power_law:
+        dst = (np.minimum(rng.zipf(1.6, M), V) - 1).astype(np.int32)
+        dst = rng.permutation(V).astype(np.int32)[dst]            # hubs are not the low node ids
+    else:
+        dst = rng.integers(0, V, M).astype(np.int32)
+    adjacency_lists = []
+    nin = np.zeros((V, T), np.float32)
+    for t in range(T):
+        sel = types == t
+        a = np.stack([src[sel], dst[sel]], axis=1).astype(np.int32).reshape(-1, 2)
+        a = a[np.lexsort((a[:, 1], a[:, 0]))]
+        nin[:, t] = np.bincount(a[:, 1], minlength=V).astype(np.float32)
+        adjacency_lists.append(np.ascontiguousarray(a))
+    return adjacency_lists, nin
+
+
 def synthetic_qm9(num_graphs: int, mean_nodes: float = 18.0, seed: int = 0, num_bond_types: int = 4,
                   annotation_size: int = 5, num_tasks: int = 1, max_degree: Optional[int] = 4) -> MoleculeSet:
     """Synthetic QM9-shaped molecules.

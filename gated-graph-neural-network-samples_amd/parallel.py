@@ -26,9 +26,19 @@ from .utils import SMALL_NUMBER
 
 
 class DataParallelContext:
-    def __init__(self, rank: int, world_size: int, device: torch.device, group=None):
+    def __init__(self, rank: int, world_size: int, device: torch.device, group=None, force_collectives: bool = False):
         self.rank, self.world_size, self.device, self.group = rank, world_size, device, group
+        # force_collectives (GGNN_FORCE_COLLECTIVES=1): issue the collectives even at world_size 1 -- a one-rank RCCL
+        # smoke test of the exact calls an N-GPU run makes (needs an initialised process group)
+        self.force_collectives = force_collectives
         self._flat: Optional[torch.Tensor] = None
+        self._views: List[torch.Tensor] = []
+        self._layout = None
+
+    @property
+    def active(self) -> bool:
+        """True when the training step has to reduce across ranks."""
+        return self.world_size > 1 or self.force_collectives
 
     @classmethod
     def from_env(cls, backend: Optional[str] = None) -> "DataParallelContext":
@@ -42,32 +52,33 @@ class DataParallelContext:
         device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
         if use_cuda:
             torch.cuda.set_device(device)
-        if world > 1 and not dist.is_initialized():
+        force = os.environ.get("GGNN_FORCE_COLLECTIVES", "0") != "0"
+        if (world > 1 or force) and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             backend = backend or ("nccl" if use_cuda else "gloo")
             kwargs = {"device_id": device} if (use_cuda and backend == "nccl") else {}
             dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
-        return cls(rank, world, device)
+        return cls(rank, world, device, force_collectives=force)
 
     # ---- collectives ------------------------------------------------------------------------------
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world_size > 1:
+        if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world_size > 1:
+        if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
 
     def barrier(self) -> None:
-        if self.world_size > 1:
+        if self.active:
             dist.barrier(group=self.group)
 
     def broadcast_(self, tensors: List[torch.Tensor], src: int = 0) -> None:
         """Make every rank start from rank-0's weights (one flat broadcast)."""
-        if self.world_size <= 1:
+        if not self.active:
             return
         flat = torch.cat([t.reshape(-1) for t in tensors])
         dist.broadcast(flat, src=src, group=self.group)
@@ -91,26 +102,26 @@ class DataParallelContext:
         return total
 
     def reduce_gradients(self, variables: List[torch.Tensor], grads: List[Optional[torch.Tensor]]) -> None:
-        """ONE sum all-reduce of one flat buffer with every gradient; results are scattered back in place.
-        A variable with no gradient on this rank (e.g. an empty padding batch) contributes zeros."""
-        n = sum(v.numel() for v in variables)
-        if self._flat is None or self._flat.numel() != n or self._flat.device != variables[0].device:
+        """ONE sum all-reduce of one flat buffer with every gradient.  The gradients are packed into the buffer with a
+        single multi-tensor copy (torch._foreach_copy_ onto persistent views of the buffer) and `grads[i]` is then
+        REPLACED by the view of the reduced buffer -- no copy back, no per-variable launches on a latency-bound step.
+        A variable with no gradient on this rank (e.g. an empty padding batch) contributes zeros.  The views are valid
+        until the next call."""
+        layout = tuple((v.data_ptr(), tuple(v.shape)) for v in variables)
+        if self._flat is None or self._layout != layout or self._flat.device != variables[0].device:
+            n = sum(v.numel() for v in variables)
             self._flat = torch.empty(n, dtype=torch.float32, device=variables[0].device)
-        flat = self._flat
-        off = 0
-        for v, g in zip(variables, grads):
-            k = v.numel()
-            if g is None:
-                flat[off:off + k].zero_()
-            else:
-                flat[off:off + k].copy_(g.reshape(-1))
-            off += k
-        self.all_reduce_sum_(flat)
-        off = 0
-        for i, v in enumerate(variables):
-            k = v.numel()
-            if grads[i] is None:
-                grads[i] = flat[off:off + k].view_as(v).clone()
-            else:
-                grads[i].copy_(flat[off:off + k].view_as(v))
-            off += k
+            self._views, off = [], 0
+            for v in variables:
+                self._views.append(self._flat[off:off + v.numel()].view(v.shape))
+                off += v.numel()
+            self._layout = layout
+        live_dst = [w for w, g in zip(self._views, grads) if g is not None]
+        live_src = [g for g in grads if g is not None]
+        if len(live_src) < len(grads):
+            self._flat.zero_()
+        if live_src:
+            torch._foreach_copy_(live_dst, live_src)
+        self.all_reduce_sum_(self._flat)
+        for i, w in enumerate(self._views):
+            grads[i] = w

@@ -114,7 +114,7 @@ def train_step(model, batch_data) -> torch.Tensor:
     try:
         loss = model.forward_batch(batch_data)
         dist = getattr(model, "dist", None)
-        if dist is not None and dist.world_size > 1:
+        if dist is not None and dist.active:
             loss_for_grad = dist.global_loss(model)
         else:
             loss_for_grad = loss
@@ -122,7 +122,7 @@ def train_step(model, batch_data) -> torch.Tensor:
     finally:
         model.training = False
     grads = [v.grad for v in variables]
-    if dist is not None and dist.world_size > 1:
+    if dist is not None and dist.active:
         dist.reduce_gradients(variables, grads)
         loss = loss_for_grad
     for v in variables:

@@ -61,7 +61,7 @@ def sparse_step(h, adjacency_lists, nin, edge_weights, cell, residual_states=(),
         msgs.append(h.index_select(0, src).matmul(edge_weights[t]))    # :161-164
         tgts.append(adj[:, 1].long())
         srcs.append(src)
-        types.append(torch.full((adj.shape[0],), t, dtype=torch.long))
+        types.append(torch.full((adj.shape[0],), t, dtype=torch.long, device=h.device))
     msgs = torch.cat(msgs, 0)                                          # :168
     tgts = torch.cat(tgts, 0)                                          # :128
     if attention_weights is not None:                                  # :170-196, written with per-target loops
@@ -73,7 +73,7 @@ def sparse_step(h, adjacency_lists, nin, edge_weights, cell, residual_states=(),
             e = torch.exp(scores[sel] - scores[sel].max())
             att[sel] = e / (e.sum() + SMALL_NUMBER)
         msgs = msgs * att[:, None]
-    incoming = torch.zeros(V, h.shape[1], dtype=h.dtype).index_add_(0, tgts, msgs)  # :198-200
+    incoming = torch.zeros(V, h.shape[1], dtype=h.dtype, device=h.device).index_add_(0, tgts, msgs)  # :198-200
     if edge_biases is not None:
         incoming = incoming + nin.matmul(edge_biases)                  # :202-204
     if avg:
@@ -106,7 +106,7 @@ def gated_regression(last_h, h0, graph_nodes_list, num_graphs, gate_W, gate_b, t
     """chem_tensorflow_sparse.py:220-231 with utils.MLP(hid_sizes=[]) = x@W+b (utils.py:64-70)."""
     gate = torch.sigmoid(torch.cat([last_h, h0], dim=-1).matmul(gate_W) + gate_b)
     gated = gate * (last_h.matmul(tr_W) + tr_b)
-    out = torch.zeros(num_graphs, 1, dtype=last_h.dtype).index_add_(0, graph_nodes_list.long(), gated)
+    out = torch.zeros(num_graphs, 1, dtype=last_h.dtype, device=last_h.device).index_add_(0, graph_nodes_list.long(), gated)
     return out[:, 0]
 
 

@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""Reduce the rocprofv3 PMC passes of tools/profile_round.sh to profiles/<round>_pmc_summary.json.
+"""Reduce the rocprofv3 PMC passes of tools/profile_round.sh to profiles/<round>[_configN]_pmc_summary.json.
 
-Input: a directory holding {fetch,write,mfma}_counter_collection.csv -- three SEPARATE --pmc passes of the same
-command (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE), as MI355X_MICROARCH.md prescribes.
+    python tools/pmc_summary.py <dir> <out.json> [prefix]
+
+Input: <dir>/<prefix>{fetch,write,mfma}_counter_collection.csv -- three SEPARATE --pmc passes of the same command
+(FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE), as MI355X_MICROARCH.md prescribes.
 Per ggnn kernel (averaged over its launches):
   hbm_bytes_fetch_x2_plus_write = 2 * FETCH_SIZE_KB * 1024 + WRITE_SIZE_KB * 1024     (gfx950: FETCH_SIZE is doubled)
   gpu_cycles = GRBM_GUI_ACTIVE / 8 XCDs;  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (gpu_cycles * 1024 SIMDs)
   avg_us from the dispatch timestamps of the mfma pass (counter collection serialises kernels).
+"_meta" records the sha1 of the kernel sources the passes were taken with: bench.py attaches `traffic` only when it
+matches the tree it runs from.
 """
 import csv
 import json
@@ -15,6 +19,9 @@ import re
 import sys
 from collections import defaultdict
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
 
 def short_name(kernel_name):
     m = re.search(r"ggnn::(\w+?)(?:_kernel)?(<[^(]*>)?\(", kernel_name) or re.search(r"(\w+?)(?:_kernel)?(<[^(]*>)?\(", kernel_name)
@@ -22,12 +29,14 @@ def short_name(kernel_name):
         return kernel_name
     base, targs = m.group(1), m.group(2) or ""
     base = base[5:] if base.startswith("ggnn_") else base
-    return base + (targs if base.startswith("gru_fused") else "")
+    return base + (targs if base.startswith(("gru_fused", "gru_panel", "gemm", "msg_transform_compact")) else "")
 
 
 def read_pass(path):
     per = defaultdict(lambda: defaultdict(list))      # kernel -> counter -> per-dispatch values
     dur = defaultdict(dict)                           # kernel -> dispatch -> ns
+    if not os.path.exists(path):
+        return per, dur
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             name = row["Kernel_Name"]
@@ -41,11 +50,14 @@ def read_pass(path):
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
-    fetch, _ = read_pass(os.path.join(src, "fetch_counter_collection.csv"))
-    write, _ = read_pass(os.path.join(src, "write_counter_collection.csv"))
-    mfma, dur = read_pass(os.path.join(src, "mfma_counter_collection.csv"))
+    prefix = sys.argv[3] if len(sys.argv) > 3 else ""
+    fetch, _ = read_pass(os.path.join(src, prefix + "fetch_counter_collection.csv"))
+    write, _ = read_pass(os.path.join(src, prefix + "write_counter_collection.csv"))
+    mfma, dur = read_pass(os.path.join(src, prefix + "mfma_counter_collection.csv"))
     mean = lambda xs: sum(xs) / len(xs) if xs else 0.0
-    out = {}
+    import bench
+    out = {"_meta": {"csrc_sha1": bench.csrc_sha1(), "prefix": prefix,
+                     "counters": "FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (three separate rocprofv3 --pmc passes)"}}
     for k in sorted(mfma):
         fkb, wkb = mean(fetch[k]["FETCH_SIZE"]), mean(write[k]["WRITE_SIZE"])
         cyc = mean(mfma[k]["GRBM_GUI_ACTIVE"]) / 8.0
@@ -57,8 +69,9 @@ def main():
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
     for k, v in out.items():
-        print("%-34s %8.1f us  hbm %7.1f MB  mfma_util %.3f  clk %.2f GHz" % (k, v["avg_us"], v["hbm_bytes_fetch_x2_plus_write"] / 1e6,
-                                                                            v["mfma_util"], v["clock_GHz"]))
+        if k != "_meta":
+            print("%-44s %8.1f us  hbm %7.1f MB  mfma_util %.3f  clk %.2f GHz" % (k, v["avg_us"], v["hbm_bytes_fetch_x2_plus_write"] / 1e6,
+                                                                                  v["mfma_util"], v["clock_GHz"]))
 
 
 if __name__ == "__main__":
