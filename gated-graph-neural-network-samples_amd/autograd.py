@@ -33,7 +33,7 @@ def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tens
                                        *residual_states)
     D = h.shape[1]
     # same choice as the native driver (ggnn_propagate.hip): segment sum gathered inside the GRU kernel
-    gather_in_gru = len(residual_states) + 1 <= int(ops.FUSE_GATHER) and ops.gru_is_fused(D) and edge_biases is None
+    gather_in_gru = len(residual_states) + 1 <= int(ops.FUSE_GATHER) and ops.gru_gather_fused(D) and edge_biases is None
     if USE_COMPACT_TRANSFORM and ops.compact_supported(D):
         # transform only the (node, type) pairs that emit a message; the pair list is built once per batch
         comp = getattr(index, "_compact", None)

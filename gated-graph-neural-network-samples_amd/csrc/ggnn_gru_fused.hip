@@ -34,7 +34,13 @@
 
 namespace ggnn {
 
+// large hidden sizes (multiples of 64 from 128): column-panel kernels, ggnn_panel.hip
+int gru_panel_supported(int D);
+int gru_panel_pack_floats(int D, int nx);
+int gru_panel_dispatch(const GruFusedArgs& a, int D, float* packed, hipStream_t st);
+
 int gru_pack_floats(int D, int nx) {
+    if (gru_panel_supported(D)) return gru_panel_pack_floats(D, nx);
     switch (D) {
         case 100: return 3 * (nx + 1) * StageCfg<100>::IMG;
         case 64: return 3 * (nx + 1) * StageCfg<64>::IMG;
@@ -600,9 +606,11 @@ static int dispatch_nx(const GruFusedArgs& a, float* packed, hipStream_t st) {
     }
 }
 
-int gru_fused_supported(int D) { return D == 100 || D == 64 || D == 32; }
+// 1: whole-block stage images, with a gather-fused variant; 2: column-panel kernel (no gather-fused variant); 0: none
+int gru_fused_supported(int D) { return (D == 100 || D == 64 || D == 32) ? 1 : (gru_panel_supported(D) ? 2 : 0); }
 
 int gru_fused_dispatch(const GruFusedArgs& a, int D, float* packed, hipStream_t st) {
+    if (gru_panel_supported(D)) return gru_panel_dispatch(a, D, packed, st);
     switch (D) {
         case 100: return dispatch_nx<100>(a, packed, st);
         case 64: return dispatch_nx<64>(a, packed, st);

@@ -169,7 +169,12 @@ static int launch_compact(const float* h, const float* W, const int* pair_node, 
     return GGNN_OK;
 }
 
+int gru_panel_supported(int D);      // ggnn_panel.hip: hidden sizes handled on column panels
+int transform_panel_dispatch(const float* h, const float* W, const int* pair_node, const int* row_off, int T, int V, int D,
+                             float* packed, float* Hc, hipStream_t st);
+
 static int stage_img_floats(int D) {
+    if (gru_panel_supported(D)) return D * D;            // NP panel images of D x 64
     switch (D) {
         case 100: return StageCfg<100>::IMG;
         case 64: return StageCfg<64>::IMG;
@@ -242,6 +247,7 @@ extern "C" int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* p
     TypeRows tr{};
     tr.T = T;                                   // all row counts zero: pack only
     hipStream_t st = (hipStream_t)stream;
+    if (gru_panel_supported(D)) return transform_panel_dispatch(nullptr, W, nullptr, tr.row_off, T, 0, D, packed, nullptr, st);
     switch (D) {
         case 100: return launch_compact<100>(nullptr, W, nullptr, tr, packed, nullptr, st);
         case 64: return launch_compact<64>(nullptr, W, nullptr, tr, packed, nullptr, st);
@@ -257,7 +263,7 @@ extern "C" int ggnn_msg_transform_compact_f32(const float* h, const float* W, co
     GGNN_CHECK_ARG(V >= 0 && D > 0 && D % 4 == 0 && T > 0 && T <= kMaxTypesC, "bad sizes V=%d D=%d T=%d", V, D, T);
     GGNN_CHECK_ARG(type_row_off, "null pointer");
     if (!ggnn_msg_transform_compact_supported(D))
-        return fail(GGNN_E_UNSUPPORTED, "compacted message transform supports hidden sizes 32, 64, 100 (got %d)", D);
+        return fail(GGNN_E_UNSUPPORTED, "compacted message transform supports hidden sizes 32, 64, 100, 128, 192, 256 (got %d)", D);
     TypeRows tr;
     tr.T = T;
     tr.num_nodes = V;
@@ -276,6 +282,7 @@ extern "C" int ggnn_msg_transform_compact_f32(const float* h, const float* W, co
         return fail(GGNN_E_WORKSPACE, "compact transform workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* packed = static_cast<float*>(ws);
+    if (gru_panel_supported(D)) return transform_panel_dispatch(h, W, pair_node, tr.row_off, T, V, D, packed, Hc, st);
     switch (D) {
         case 100: return launch_compact<100>(h, W, pair_node, tr, packed, Hc, st);
         case 64: return launch_compact<64>(h, W, pair_node, tr, packed, Hc, st);

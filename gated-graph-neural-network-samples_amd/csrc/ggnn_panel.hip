@@ -1,0 +1,438 @@
+// Register-chained kernels for LARGE hidden sizes (D a multiple of 64: 128, 192, 256 -- BASELINE config "100k nodes / 1M
+// edges, h = 256"): the fused GRU node update (chem_tensorflow_sparse.py:211-216) and the compacted per-edge-type message
+// transform (:160-164) on COLUMN PANELS of the weight blocks.
+//
+// Why panels.  The D = 100 kernels (ggnn_gru_fused.hip, ggnn_msg_compact.hip) keep one D x D weight block as a 48 KiB
+// k-interleaved image in LDS and a wave owns 16 rows x ALL D output columns of all three gates.  At D = 256 a block is
+// 256 KiB (LDS: 160 KiB per CU) and three gates x 16 column tiles are 192 accumulator registers.  Here a stage multiplies
+// the wave's 16 x D activation fragment by ONE 64-column panel of one weight block: the panel image is D x 64 floats
+// (64 KiB at D = 256; two of them form the LDS-DMA ring) and a stage's accumulators are 4 tiles = 16 registers.
+//
+// GRU pass of a wave over its 16 rows (NS = NX + 1 input segments x_0 .. x_{NX-1}, h; NP = D / 64 panels):
+//   phase R   for every segment s, every panel p:   acc_r[p] += seg_s x Wg[s rows, r columns of panel p]
+//             r = sigmoid(acc_r + bg_r);  rh = r * h   -- in activation-fragment layout (output tile nt == k chunk nt, the
+//             property the D = 100 kernel chains on), so r*h feeds the candidate stages from registers
+//   phase UC  for every panel p:   u_p = sum_s seg_s x Wg[s, u columns of p],  c_p = sum_s x_s x Wc[s, p] + rh x Wc[h rows, p]
+//             u = sigmoid(.), c = act(.), h'[:, panel p] = u h + (1 - u) c   -> stored; nothing but x, h is read and h' written
+// Only ONE activation fragment is resident besides r*h: the fragment of the next stage's segment is (re)loaded from
+// memory (L2 hits after the first touch) right after the wave's MFMA burst of the current stage, i.e. while the partner
+// wave of the SIMD owns the matrix pipe.  Per wave: r*h 64 + fragment 64 + accumulators 32 + weight operands 32 VGPRs.
+// Every product chain accumulates its segments in [x_0 | .. | h] order like the plain [x|h] Wg / [x|r*h] Wc products.
+//
+// The transform is the same stage loop without the chain: a persistent workgroup is bound to ONE (edge type, panel),
+// keeps that panel image in LDS and walks 16-row tiles of the type's active (source node, type) pairs.
+#include "ggnn_stage.hpp"
+#include <type_traits>
+
+namespace ggnn {
+
+template <int D>
+struct PanelCfg {
+    static_assert(D % 64 == 0, "panel kernels need a hidden size that is a multiple of 64");
+    static constexpr int PT = 4;                 // column tiles per panel
+    static constexpr int BN = 64;                // columns per panel
+    static constexpr int NP = D / BN;            // panels per D-column weight block
+    static constexpr int NC = D / 16;            // k chunks == column tiles of a gate
+    static constexpr int IMG = D * BN;           // floats per panel image
+    static constexpr int IMG_BYTES = IMG * 4;
+};
+
+// image[c][kq][n][e] = W[r0 + 16c + 4kq + e][c0 + n]   (n < 64): the k-interleaved layout of ggnn_stage.hpp
+template <int D>
+__device__ __forceinline__ void pack_panel_image(const float* __restrict__ W, int r0, int c0, int ldw, float* __restrict__ img,
+                                                 int first, int stride) {
+    using C = PanelCfg<D>;
+    for (int i = first; i < C::IMG; i += stride) {
+        const int e = i & 3, n = (i >> 2) % C::BN, ck = (i >> 2) / C::BN;
+        img[i] = W[(size_t)(r0 + 4 * ck + e) * ldw + c0 + n];
+    }
+}
+
+// acc[0..3] (+)= fragment x panel image: per k chunk 4 ds_read_b128 feed 16 MFMAs; one chunk of read-ahead
+template <int D, bool ZERO>
+__device__ __forceinline__ void panel_mma(f32x4 (&acc)[4], const Frag<D>& a, const float* img, int li, int kq) {
+    using C = PanelCfg<D>;
+    const f32x4* base = reinterpret_cast<const f32x4*>(img) + kq * C::BN + li;
+    f32x4 w[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[0][j] = base[j * 16];
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c) {
+        if (c + 1 < C::NC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[(c + 1) & 1][j] = base[(c + 1) * 4 * C::BN + j * 16];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 cin = (ZERO && c == 0 && e == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c & 1][j][e], a.v[c][e], cin, 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// LDS-DMA of `BYTES` (a multiple of NW KiB) from src to LDS dst by an NW-wave workgroup (see dma_stage_image)
+template <int BYTES, int NW>
+__device__ __forceinline__ void dma_block(const float* src, float* dst, int wave, int lane) {
+    constexpr int PER_WAVE = BYTES / (NW * 1024);
+    static_assert(BYTES % (NW * 1024) == 0, "block must split into whole KiB per wave");
+    char* d = reinterpret_cast<char*>(dst) + (size_t)wave * PER_WAVE * 1024;
+    const unsigned voff = (unsigned)lane * 16u;
+#pragma unroll
+    for (int i0 = 0; i0 < PER_WAVE; i0 += 4) {
+        const unsigned long long sb = reinterpret_cast<unsigned long long>(src) + (unsigned long long)wave * PER_WAVE * 1024 + (unsigned long long)i0 * 1024;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+        const char* s = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+        lds_void* dl = (lds_void*)(d + i0 * 1024);
+        if (i0 + 0 < PER_WAVE) __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 0, 0);
+        if (i0 + 1 < PER_WAVE) __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 1024, 0);
+        if (i0 + 2 < PER_WAVE) __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 2048, 0);
+        if (i0 + 3 < PER_WAVE) __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 3072, 0);
+    }
+}
+
+// ---- packed GRU weights: one image per stage, in stage order ---------------------------------------------------------------
+//   phase R :  (s, p)            s < NS, p < NP     Wg rows [sD, (s+1)D), columns [64p, 64p+64)
+//   phase UC:  p < NP:  for s < NX: U (Wg rows s, cols D + 64p ..), C (Wc rows s, cols 64p ..);  U (Wg rows h);  C (Wc rows h = r*h)
+__host__ __device__ constexpr int panel_gru_images(int D, int nx) { return 3 * (nx + 1) * (D / 64); }
+
+template <int D>
+__global__ void gru_panel_pack_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx, float* __restrict__ out) {
+    using C = PanelCfg<D>;
+    const int ns = nx + 1, NP = C::NP;
+    const int i = blockIdx.y;
+    const float* W; int r0, c0, ldw;
+    if (i < ns * NP) { W = Wg; r0 = (i / NP) * D; c0 = (i % NP) * C::BN; ldw = 2 * D; }
+    else {
+        const int j = i - ns * NP, p = j / (2 * ns), q = j % (2 * ns);          // q: U x_0, C x_0, .., U h, C rh
+        const int s = q / 2;
+        if (q % 2 == 0) { W = Wg; r0 = s * D; c0 = D + p * C::BN; ldw = 2 * D; }
+        else { W = Wc; r0 = s * D; c0 = p * C::BN; ldw = D; }
+    }
+    pack_panel_image<D>(W, r0, c0, ldw, out + (size_t)i * C::IMG, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+template <int D, int NX, int NW, bool SAVE>
+__global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a, const float* __restrict__ packed) {
+    using C = PanelCfg<D>;
+    constexpr int NP = C::NP, NC = C::NC, NS = NX + 1;
+    constexpr int NSTAGE = 3 * NS * NP;
+    constexpr int R_STAGES = NS * NP;
+    extern __shared__ __attribute__((aligned(16))) float lds_[];    // [biases | ring [2][IMG]]
+    constexpr int BIAS_FLOATS = (4 * D + 63) / 64 * 64;
+    float* bias_s = lds_;                      // [-log2e*bg (2D) | 2 log2e*bc (D) | bc (D)]
+    float* ring = lds_ + BIAS_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const bool late = wave >= NW / 2;          // (the two waves of a SIMD: w and w + NW/2; see ggnn_gru_fused.hip)
+
+    for (int i = tid; i < 4 * D; i += NW * 64)
+        bias_s[i] = i < 2 * D ? -kLog2e * a.bg[i] : (i < 3 * D ? 2.0f * kLog2e * a.bc[i - 2 * D] : a.bc[i - 3 * D]);
+
+    // tickets: full rounds of NW tiles per workgroup, then the rest spread thin over all workgroups (tail_w tiles each)
+    const int wt_total = (a.V + 15) / 16;
+    const int nb = gridDim.x;
+    const int full_tk = wt_total / (NW * nb) * nb;
+    const int rest = wt_total - full_tk * NW;
+    const int tail_w = (rest + nb - 1) / nb;
+    const int n_tk = full_tk + (tail_w ? (rest + tail_w - 1) / tail_w : 0);
+    auto tile_of = [&](int t) -> int {
+        if (t < full_tk) return t * NW + wave;
+        if (t >= n_tk) return -1;
+        const int tl = full_tk * NW + (t - full_tk) * tail_w + wave;
+        return (wave < tail_w && tl < wt_total) ? tl : -1;
+    };
+    auto row_of = [&](int t) -> int {          // clamped row of this lane in ticket t (always a valid row to read)
+        const int tile = tile_of(t);
+        const int r = (tile >= 0 ? tile : 0) * 16 + li;
+        return r < a.V ? r : a.V - 1;
+    };
+
+    int cur = 0;
+    dma_block<C::IMG_BYTES, NW>(packed, ring, wave, lane);
+    Frag<D> af;                                // the ONE resident activation fragment (segment of the current stage)
+    int tk = blockIdx.x;
+    if (tk < n_tk) load_frag<D>(af, a.x[0], row_of(tk), kq);
+    __syncthreads();
+
+    for (; tk < n_tk; tk += nb) {
+        const int tile = tile_of(tk);
+        const bool active = tile >= 0;                                  // wave-uniform
+        const int row = active ? tile * 16 + li : a.V;                  // (>= V: nothing is stored)
+        const int rowc = row < a.V ? row : a.V - 1;
+        const bool last_pass = tk + nb >= n_tk;
+        const int rown = last_pass ? 0 : row_of(tk + nb);
+
+        // The pass body exists twice: for a wave WITH a tile, and for a wave without one (thin tail tickets), which only takes
+        // part in the image DMA and the barriers.  (One body with `if (active)` around every MFMA block turns each stage into
+        // a diamond whose accumulator phis the register allocator does not coalesce: 296 instead of 230 registers at D = 256.)
+        auto run_pass = [&](auto active_c) {
+            constexpr bool ACT = decltype(active_c)::value;
+            // one stage: [late waves: DMA of the next image] MFMAs [early waves: DMA]; then `after()` (this wave's loads for
+            // the NEXT stage: they fly while the partner wave multiplies) and the barrier that publishes the next image
+            auto stage = [&](auto zero_c, f32x4 (&acc)[4], const Frag<D>& A, int img_idx, auto&& after) {
+                const int nidx = img_idx + 1 < NSTAGE ? img_idx + 1 : 0;
+                const bool more = (img_idx + 1 < NSTAGE) || !last_pass;
+                const float* nsrc = packed + (size_t)nidx * C::IMG;
+                float* ndst = ring + (cur ^ 1) * C::IMG;
+                if (late && more) dma_block<C::IMG_BYTES, NW>(nsrc, ndst, wave, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ACT) panel_mma<D, decltype(zero_c)::value>(acc, A, ring + cur * C::IMG, li, kq);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!late && more) dma_block<C::IMG_BYTES, NW>(nsrc, ndst, wave, lane);
+                if constexpr (ACT) after();
+                __syncthreads();
+                cur ^= 1;
+            };
+            auto nothing = [] {};
+
+            // ---- phase R: r columns, all panels, segment by segment ---------------------------------------------------
+            f32x4 acc_r[NP][4];
+#define GGNN_R_STAGE(S, P)                                                                                          \
+            if constexpr ((S) < NS && (P) < NP) {                                                                   \
+                auto next_seg = [&] {   /* after the last panel of a segment: fetch the next segment's fragment */   \
+                    if constexpr ((P) == NP - 1 && (S) + 1 < NS)                                                     \
+                        load_frag<D>(af, (S) + 1 < NX ? a.x[(S) + 1 < NX ? (S) + 1 : 0] : a.h, rowc, kq);          \
+                };                                                                                                  \
+                stage(std::integral_constant<bool, (S) == 0>{}, acc_r[(P) < NP ? (P) : 0], af, (S) * NP + (P), next_seg); \
+            }
+#define GGNN_R_SEG(S) GGNN_R_STAGE(S, 0) GGNN_R_STAGE(S, 1) GGNN_R_STAGE(S, 2) GGNN_R_STAGE(S, 3)
+            GGNN_R_SEG(0) GGNN_R_SEG(1) GGNN_R_SEG(2) GGNN_R_SEG(3)
+#undef GGNN_R_SEG
+#undef GGNN_R_STAGE
+            static_assert(NP <= 4 && NS <= 4, "stage macros cover up to 4 panels x 4 segments");
+
+            // ---- r = sigmoid(.), rh = r * h in activation-fragment layout (af holds h here) ---------------------------------
+            Frag<D> rh;
+            if constexpr (ACT) {
+#pragma unroll
+                for (int nt = 0; nt < NC; ++nt) {
+                    const int col = nt * 16 + 4 * kq;
+                    const f32x4 r = sigmoid4_scaled(acc_r[nt / 4][nt % 4], ld4(bias_s + col));
+                    if constexpr (SAVE) { if (row < a.V) st4_b(a.save_r, ((unsigned)row * D + col) * 4u, r); }
+                    rh.v[nt] = r * af.v[nt];
+                    __builtin_amdgcn_sched_barrier(0);      // one tile at a time: no 16-deep batch of bias reads in flight
+                }
+                load_frag<D>(af, a.x[0], rowc, kq);                     // first fragment of phase UC
+            }
+
+            // ---- phase UC: u and candidate columns, panel by panel (run-time loop: the panel only enters addresses) ----------
+#pragma unroll 1
+            for (int p = 0; p < NP; ++p) {
+                f32x4 acc_u[4], acc_c[4];
+                const int img0 = R_STAGES + p * 2 * NS;
+                const bool last_panel = p + 1 == NP;
+#define GGNN_X_STAGES(S)                                                                                            \
+                if constexpr ((S) < NX) {                                                                           \
+                    stage(std::integral_constant<bool, (S) == 0>{}, acc_u, af, img0 + 2 * (S), nothing);            \
+                    auto next_seg = [&] { load_frag<D>(af, (S) + 1 < NX ? a.x[(S) + 1 < NX ? (S) + 1 : 0] : a.h, rowc, kq); }; \
+                    stage(std::integral_constant<bool, (S) == 0>{}, acc_c, af, img0 + 2 * (S) + 1, next_seg);       \
+                }
+                GGNN_X_STAGES(0) GGNN_X_STAGES(1) GGNN_X_STAGES(2)
+#undef GGNN_X_STAGES
+                // h -> u columns; afterwards the fragment registers are free: the next panel's (or next pass's) x_0 goes there
+                auto after_h = [&] { load_frag<D>(af, a.x[0], last_panel ? rown : rowc, kq); };
+                stage(std::false_type{}, acc_u, af, img0 + 2 * NX, after_h);
+                stage(std::false_type{}, acc_c, rh, img0 + 2 * NX + 1, nothing);
+                if constexpr (ACT) {
+                    if (row < a.V) {
+                        // (the h columns of this panel are fetched here, not a stage ahead: 16 more live registers across the
+                        //  r*h stage; the ~0.5k clocks of L2 latency per 65k-clock panel are covered by the partner wave)
+                        f32x4 hcol[4];
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) hcol[nt] = ld4_b(a.h, ((unsigned)row * D + p * 64 + nt * 16 + 4 * kq) * 4u);
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const int col = p * 64 + nt * 16 + 4 * kq;
+                            const f32x4 u = sigmoid4_scaled(acc_u[nt], ld4(bias_s + D + col));
+                            f32x4 c;
+                            if (a.act == GGNN_ACT_TANH) {
+                                c = tanh4_scaled(acc_c[nt], ld4(bias_s + 2 * D + col));
+                            } else {
+                                c = acc_c[nt] + ld4(bias_s + 3 * D + col);
+                                c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
+                            }
+                            st4_b(a.h_out, ((unsigned)row * D + col) * 4u, u * hcol[nt] + (1.0f - u) * c);
+                            if constexpr (SAVE) {
+                                st4_b(a.save_u, ((unsigned)row * D + col) * 4u, u);
+                                st4_b(a.save_c, ((unsigned)row * D + col) * 4u, c);
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        if (active) run_pass(std::true_type{});
+        else run_pass(std::false_type{});
+    }
+}
+
+template <int D, int NX, bool SAVE>
+static int launch_gru_panel(const GruFusedArgs& a_in, float* packed, hipStream_t st) {
+    using C = PanelCfg<D>;
+    constexpr int NW = 8;
+    GruFusedArgs a = a_in;
+    if (a.Wg) {   // raw weights given: build the stage images first
+        hipLaunchKernelGGL((gru_panel_pack_kernel<D>), dim3(8, panel_gru_images(D, NX)), dim3(256), 0, st, a.Wg, a.Wc, NX, packed);
+        GGNN_CHECK_HIP(hipGetLastError());
+    }
+    if (a.h == nullptr) return GGNN_OK;   // pack-only call
+    if ((unsigned long long)a.V * D >= (1ULL << 30))
+        return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit byte offsets: V*D must be < 2^30 (V=%d, D=%d)", a.V, D);
+    const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)((4 * D + 63) / 64 * 64) * sizeof(float);
+    const int wt_total = (a.V + 15) / 16;
+    int nb = num_cus();
+    if (nb > wt_total) nb = wt_total;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_panel_kernel<D, NX, NW, SAVE>, lds, lds_ok));
+    hipLaunchKernelGGL((ggnn_gru_panel_kernel<D, NX, NW, SAVE>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+template <int D>
+static int dispatch_panel_nx(const GruFusedArgs& a, float* packed, hipStream_t st) {
+    const bool save = a.save_r || a.save_u || a.save_c;
+    if (save && !(a.save_r && a.save_u && a.save_c))
+        return fail(GGNN_E_INVALID, "save_r / save_u / save_c must be given together");
+    if (a.g_H) return fail(GGNN_E_UNSUPPORTED, "hidden size %d has no gather-fused GRU (use ggnn_gather_segment_sum_f32 + ggnn_gru_packed_f32)", D);
+    switch (a.nx) {
+        case 1: return save ? launch_gru_panel<D, 1, true>(a, packed, st) : launch_gru_panel<D, 1, false>(a, packed, st);
+        case 2: return save ? launch_gru_panel<D, 2, true>(a, packed, st) : launch_gru_panel<D, 2, false>(a, packed, st);
+        case 3: return save ? launch_gru_panel<D, 3, true>(a, packed, st) : launch_gru_panel<D, 3, false>(a, packed, st);
+        default: return fail(GGNN_E_INVALID, "nx %d outside 1..3", a.nx);
+    }
+}
+
+int gru_panel_supported(int D) { return D == 128 || D == 192 || D == 256; }
+
+int gru_panel_pack_floats(int D, int nx) { return gru_panel_supported(D) ? panel_gru_images(D, nx) * D * 64 : 0; }
+
+int gru_panel_dispatch(const GruFusedArgs& a, int D, float* packed, hipStream_t st) {
+    switch (D) {
+        case 128: return dispatch_panel_nx<128>(a, packed, st);
+        case 192: return dispatch_panel_nx<192>(a, packed, st);
+        case 256: return dispatch_panel_nx<256>(a, packed, st);
+        default: return fail(GGNN_E_UNSUPPORTED, "no panel GRU for hidden size %d", D);
+    }
+}
+
+// ---- compacted message transform on panels ------------------------------------------------------------------------------
+constexpr int kMaxTypesP = 64;
+struct PanelRows {
+    int row_off[kMaxTypesP + 1];       // compact rows of type t: row_off[t] .. row_off[t+1]-1
+    int wg_off[kMaxTypesP + 1];        // workgroups of type t (all its panels): wg_off[t] .. wg_off[t+1]-1, a multiple of NP each
+    int T;
+};
+
+// workgroup (type t, panel p, j-th of the type's workgroups on that panel): keeps image (t, p) in LDS and walks 16-row tiles
+// j*NW + wave, + stride, ... of the type's active pairs; the rows of tile k+1 are fetched under the MFMAs of tile k.
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void msg_transform_panel_kernel(const float* __restrict__ h, const int* __restrict__ pair_node,
+                                                                      PanelRows pr, const float* __restrict__ packed,
+                                                                      float* __restrict__ Hc) {
+    using C = PanelCfg<D>;
+    constexpr int NP = C::NP;
+    extern __shared__ __attribute__((aligned(16))) float img[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    int t = 0;
+    while (t + 1 < pr.T && (int)blockIdx.x >= pr.wg_off[t + 1]) ++t;
+    const int wg_in_type = (int)blockIdx.x - pr.wg_off[t];
+    const int per_panel = (pr.wg_off[t + 1] - pr.wg_off[t]) / NP;       // workgroups of this type on each panel
+    const int p = wg_in_type / per_panel, j = wg_in_type % per_panel;
+    const int row_beg = pr.row_off[t], row_end = pr.row_off[t + 1];
+    const int n_wt = (row_end - row_beg + 15) / 16;
+    const int stride = per_panel * NW;
+    int idx = j * NW + wave;
+
+    auto row_of = [&](int i) { const int r = row_beg + i * 16 + li; return r < row_end ? r : row_end - 1; };
+    Frag<D> a, an;
+    int node_0 = 0, node_n = 0;
+    if (idx < n_wt) node_0 = pair_node[row_of(idx)];
+    if (idx + stride < n_wt) node_n = pair_node[row_of(idx + stride)];
+    dma_block<C::IMG_BYTES, NW>(packed + (size_t)(t * NP + p) * C::IMG, img, wave, lane);
+    if (idx < n_wt) load_frag<D>(a, h, node_0, kq);
+    __syncthreads();
+
+    while (idx < n_wt) {
+        const int idx_n = idx + stride;
+        if (idx_n < n_wt) load_frag<D>(an, h, node_n, kq);
+        if (idx_n + stride < n_wt) node_n = pair_node[row_of(idx_n + stride)];
+        f32x4 acc[4];
+        __builtin_amdgcn_sched_barrier(0);
+        panel_mma<D, true>(acc, a, img, li, kq);
+        const int r = row_beg + idx * 16 + li;
+        if (r < row_end) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) st4_b(Hc, ((unsigned)r * (unsigned)D + p * 64 + nt * 16 + 4 * kq) * 4u, acc[nt]);
+        }
+        a = an;
+        idx = idx_n;
+    }
+}
+
+template <int D>
+__global__ void edge_weight_panel_pack_kernel(const float* __restrict__ W, float* __restrict__ out) {
+    using C = PanelCfg<D>;
+    const int t = blockIdx.y / C::NP, p = blockIdx.y % C::NP;
+    pack_panel_image<D>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * C::IMG,
+                        blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+template <int D>
+static int launch_transform_panel(const float* h, const float* W, const int* pair_node, const int* row_off, int T, int V,
+                                  float* packed, float* Hc, hipStream_t st) {
+    using C = PanelCfg<D>;
+    constexpr int NW = 8, NP = C::NP;
+    if (W) {
+        hipLaunchKernelGGL((edge_weight_panel_pack_kernel<D>), dim3(8, T * NP), dim3(256), 0, st, W, packed);
+        GGNN_CHECK_HIP(hipGetLastError());
+    }
+    const int R = row_off[T];
+    if (R == 0 || h == nullptr) return GGNN_OK;
+    if ((unsigned long long)R * D >= (1ULL << 30) || (unsigned long long)V * D >= (1ULL << 30))
+        return fail(GGNN_E_UNSUPPORTED, "compacted transform indexes with 32-bit byte offsets: rows*D and V*D must be < 2^30");
+    // one workgroup per CU (64 KiB image + ~176 VGPRs per wave); every type gets workgroups in proportion to its rows,
+    // the same number on each of its NP panels, at least one per panel, no more than it has 8-tile rounds
+    PanelRows pr{};
+    pr.T = T;
+    const int budget = num_cus() / NP > 0 ? num_cus() / NP : 1;          // workgroups per panel, all types together
+    pr.wg_off[0] = 0;
+    for (int t = 0; t < T; ++t) {
+        pr.row_off[t] = row_off[t];
+        const long long rows = row_off[t + 1] - row_off[t];
+        long long n = rows * budget / R;
+        const long long rounds = (rows + 16 * NW - 1) / (16 * NW);
+        if (n > rounds) n = rounds;
+        if (rows > 0 && n < 1) n = 1;
+        pr.wg_off[t + 1] = pr.wg_off[t] + (int)n * NP;
+    }
+    pr.row_off[T] = R;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (C::IMG_BYTES > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&msg_transform_panel_kernel<D, NW>, C::IMG_BYTES, lds_ok));
+    hipLaunchKernelGGL((msg_transform_panel_kernel<D, NW>), dim3(pr.wg_off[T]), dim3(NW * 64), C::IMG_BYTES, st, h, pair_node, pr,
+                       (const float*)packed, Hc);
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+int transform_panel_dispatch(const float* h, const float* W, const int* pair_node, const int* row_off, int T, int V, int D,
+                             float* packed, float* Hc, hipStream_t st) {
+    if (T > kMaxTypesP) return fail(GGNN_E_UNSUPPORTED, "more than %d edge types", kMaxTypesP);
+    switch (D) {
+        case 128: return launch_transform_panel<128>(h, W, pair_node, row_off, T, V, packed, Hc, st);
+        case 192: return launch_transform_panel<192>(h, W, pair_node, row_off, T, V, packed, Hc, st);
+        case 256: return launch_transform_panel<256>(h, W, pair_node, row_off, T, V, packed, Hc, st);
+        default: return fail(GGNN_E_UNSUPPORTED, "no panel transform for hidden size %d", D);
+    }
+}
+
+}  // namespace ggnn

@@ -87,7 +87,7 @@ extern "C" int ggnn_sparse_propagate_f32(
         const bool packed_gru = gru_packed && gru_packed[l] && ggnn_gru_is_fused(D);
         // fuse_gather = the largest number of concatenated GRU inputs (residuals + messages) for which the segment sum
         // is gathered inside the GRU kernel; 0 = never.
-        const bool gather_in_gru = fuse_gather > 0 && nx <= fuse_gather && packed_gru && bias_l == nullptr &&
+        const bool gather_in_gru = fuse_gather > 0 && nx <= fuse_gather && packed_gru && ggnn_gru_is_fused(D) == 1 && bias_l == nullptr &&
                                    (unsigned long long)V * T * D < (1ULL << 30);      // (its 32-bit byte offsets)
         for (int s = 0; s < steps; ++s) {          // :153
             int rc;

@@ -371,6 +371,12 @@ def gru_is_fused(D: int) -> bool:
     return bool(_lib.load().ggnn_gru_is_fused(D))
 
 
+def gru_gather_fused(D: int) -> bool:
+    """True when the fused GRU of this hidden size has the variant that gathers the segment sum inside the kernel
+    (ggnn_gru_is_fused == 1: the whole-block kernels; the column-panel kernels of D = 128/192/256 report 2)."""
+    return _lib.load().ggnn_gru_is_fused(D) == 1
+
+
 def build_compact_sources(index: MessageIndex) -> CompactSources:
     """Enumerate the (node, type) pairs that emit at least one message and re-target the segment-sum's
     gather rows at them.  index: the by-target MessageIndex of the batch (build_message_index)."""

@@ -14,7 +14,9 @@
  *   - return 0 on success, <0 on error (GGNN_E_*); ggnn_last_error() gives a thread-local message.
  *     Nothing throws or aborts across the ABI.
  *   - fp32 data, int32 indices (chem_tensorflow_sparse.py:65-71), row-major, rows 16-byte aligned,
- *     D % 4 == 0.  Supported hidden sizes D: multiples of 100, 64 or 32 (GGNN_E_UNSUPPORTED else).
+ *     D % 4 == 0.  Supported hidden sizes D: multiples of 100, 64 or 32 (GGNN_E_UNSUPPORTED else).  Fused single-launch
+ *     kernels exist for D = 32, 64, 100 (whole weight blocks as LDS stage images) and D = 128, 192, 256 (64-column
+ *     panels of the weight blocks, ggnn_panel.hip); other sizes run the generic tiled GEMM kernels.
  *   - E_t = 0 and nodes with zero in-degree are valid (chem_tensorflow_sparse.py:346-347).
  */
 #ifndef GGNN_HIP_H
@@ -167,8 +169,10 @@ int ggnn_cudnn_gru_f32(const float* const* x_segs, int nx, const float* h, const
                        const float* Wcx, const float* bcx, const float* Wch, const float* bch, float* h_out,
                        void* ws, size_t ws_bytes, int V, int D, ggnn_stream_t stream);
 
-/* 1 if ggnn_gru_f32 runs as ONE fused launch for this hidden size (gates -> r*h -> candidate -> blend
- * chained in registers; D in {32, 64, 100}); 0 if it runs as the two launches below (ws is then used). */
+/* Non-zero if ggnn_gru_f32 runs as ONE fused launch for this hidden size (gates -> r*h -> candidate -> blend chained in
+ * registers): 1 for D in {32, 64, 100} (whole-block stage images; ggnn_gru_packed_gather_f32 exists for these),
+ * 2 for D in {128, 192, 256} (column-panel kernel, ggnn_panel.hip; no gather-fused variant);
+ * 0 if it runs as the two launches below (ws is then used). */
 int ggnn_gru_is_fused(int D);
 
 /* Pre-packed weights (inference: weights are constant across batches).  The fused GRU and the compacted

@@ -44,8 +44,10 @@ def test_argument_validation_without_gpu(pkg):
     off = (ctypes.c_int64 * 2)(0, 5)
     assert lib.ggnn_build_target_csr(None, off, 1, 10, 7, None, None, None, None, None, 0, None) == -1  # type_off[T] != M
     assert lib.ggnn_gru_workspace_bytes(1000, 100) >= 2 * 1000 * 100 * 4      # un-fused scratch (+ packed weight images)
-    assert lib.ggnn_gru_workspace_bytes(1000, 256) == 2 * 1000 * 256 * 4      # no fused path at D=256
-    assert lib.ggnn_gru_is_fused(100) == 1 and lib.ggnn_gru_is_fused(256) == 0
+    assert lib.ggnn_gru_workspace_bytes(1000, 200) == 2 * 1000 * 200 * 4      # no fused path at D=200: r*h and u only
+    assert lib.ggnn_gru_is_fused(100) == 1 and lib.ggnn_gru_is_fused(256) == 2 and lib.ggnn_gru_is_fused(200) == 0
+    assert lib.ggnn_gru_packed_bytes(256, 1) == 3 * 2 * 256 * 256 * 4          # column-panel images of the three gates
+    assert lib.ggnn_msg_transform_compact_supported(256) == 1 and lib.ggnn_msg_transform_compact_supported(200) == 0
     assert lib.ggnn_csr_workspace_bytes(0, 10) > 0
 
 

@@ -27,7 +27,7 @@ def _free_port():
 
 
 def _dataset(pkg):
-    return pkg.synthetic_qm9(60, mean_nodes=14, seed=21)
+    return pkg.synthetic_qm9(110, mean_nodes=14, seed=21)
 
 
 def _rank_worker(rank, world, port, backend, ret):
