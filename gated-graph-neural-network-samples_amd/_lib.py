@@ -36,6 +36,9 @@ SYMBOLS = {
     "ggnn_unsorted_segment_sum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "ggnn_gated_readout_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_int, c_int, c_void_p]),
+    "ggnn_readout_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ggnn_readout_loss_fwd_f32": (c_int, [c_void_p] * 15 + [c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
+    "ggnn_readout_loss_bwd_f32": (c_int, [c_void_p] * 14 + [c_int] + [c_void_p] * 4 + [c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
     "ggnn_gru_workspace_bytes": (c_size_t, [c_int, c_int]),
     "ggnn_gru_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -78,3 +78,41 @@ class _SegmentSumRows(torch.autograd.Function):
 
 def segment_sum_rows(data: torch.Tensor, ids: torch.Tensor, num_segments: int) -> torch.Tensor:
     return _SegmentSumRows.apply(data, ids, num_segments)
+
+
+class _ReadoutLoss(torch.autograd.Function):
+    """gated_regression + the masked loss sums of one task as ONE differentiable unit on the fused HIP kernels
+    (ggnn_readout_loss_{fwd,bwd}_f32; chem_tensorflow_sparse.py:220-231, chem_tensorflow.py:158-170): no [V,2D] concat,
+    no per-node intermediates, deterministic segmented sums.  Returns (out [G], sum 0.5 diff^2, sum |diff|, sum mask)."""
+
+    @staticmethod
+    def forward(ctx, last_h, h0, graph_nodes_list, graph_ptr, node_mask, num_graphs, gate_W, gate_b, transform_W, transform_b,
+                target, mask):
+        last_h = last_h.contiguous()
+        gW, tW = gate_W.reshape(-1).contiguous(), transform_W.reshape(-1).contiguous()
+        out, gate, val, stats = ops.readout_loss_fwd(last_h, h0, graph_nodes_list, graph_ptr, node_mask, num_graphs, gW,
+                                                     gate_b.reshape(-1), tW, transform_b.reshape(-1), target, mask)
+        ctx.save_for_backward(last_h, h0, graph_nodes_list, node_mask, gW, tW, gate, val, out, target, mask)
+        ctx.num_graphs = int(num_graphs)
+        ctx.shapes = (gate_W.shape, gate_b.shape, transform_W.shape, transform_b.shape)
+        num, ab, ms = stats[0], stats[1], stats[2]
+        ctx.mark_non_differentiable(ms)
+        return out, num, ab, ms
+
+    @staticmethod
+    def backward(ctx, d_out, d_num, d_abs, d_ms):
+        last_h, h0, gnl, node_mask, gW, tW, gate, val, out, target, mask = ctx.saved_tensors
+        zero = None
+        if d_num is not None or d_abs is not None:
+            zero = torch.zeros((), dtype=torch.float32, device=last_h.device)
+        d_stats = None if zero is None else torch.stack([zero if d_num is None else d_num.reshape(()),
+                                                         zero if d_abs is None else d_abs.reshape(())]).contiguous()
+        d_h, dgW, dgb, dtW, dtb = ops.readout_loss_bwd(last_h, h0, gnl, node_mask, ctx.num_graphs, gW, tW, gate, val, out, target, mask,
+                                                       None if d_out is None else d_out.contiguous(), d_stats)
+        sg, sgb, st, stb = ctx.shapes
+        return (d_h, None, None, None, None, None, dgW.reshape(sg), dgb.reshape(sgb), dtW.reshape(st), dtb.reshape(stb), None, None)
+
+
+def readout_loss(last_h, h0, graph_nodes_list, graph_ptr, node_mask, num_graphs, gate_W, gate_b, transform_W, transform_b, target, mask):
+    return _ReadoutLoss.apply(last_h, h0, graph_nodes_list, graph_ptr, node_mask, num_graphs, gate_W, gate_b, transform_W, transform_b,
+                              target, mask)

@@ -183,21 +183,31 @@ class ChemModel(object):
             final = torch.zeros_like(self.placeholders['initial_node_representation'])   # :147
         self.ops['final_node_representations'] = final
         self.ops['losses'] = []
+        fused_readout = getattr(self, 'gated_regression_with_loss', None)
         for (internal_id, task_id) in enumerate(self.params['task_ids']):
-            computed_values = self.gated_regression(final, self.weights['regression_gate_task%i' % task_id],
-                                                    self.weights['regression_transform_task%i' % task_id])
-            diff = computed_values - self.placeholders['target_values'][internal_id, :]      # :161
+            gate_mlp = self.weights['regression_gate_task%i' % task_id]
+            transform_mlp = self.weights['regression_transform_task%i' % task_id]
+            task_target_values = self.placeholders['target_values'][internal_id, :]
             task_target_mask = self.placeholders['target_mask'][internal_id, :]
-            task_target_num = task_target_mask.sum() + SMALL_NUMBER                           # :163
-            diff = diff * task_target_mask                                                    # :164
-            self.ops['accuracy_task%i' % task_id] = diff.abs().sum() / task_target_num       # :165
-            task_loss = (0.5 * diff * diff).sum() / task_target_num                           # :166
+            # models with a fused readout + loss kernel (one forward and one backward launch group on the GPU) return the
+            # prediction together with the three masked sums of :161-166; None -> the op-by-op form below
+            fused = fused_readout(final, gate_mlp, transform_mlp, task_target_values, task_target_mask) if fused_readout else None
+            if fused is not None:
+                computed_values, loss_num, abs_sum, mask_sum = fused
+            else:
+                computed_values = self.gated_regression(final, gate_mlp, transform_mlp)
+                diff = computed_values - task_target_values                                   # :161
+                diff = diff * task_target_mask                                                # :164
+                loss_num, abs_sum, mask_sum = (0.5 * diff * diff).sum(), diff.abs().sum(), task_target_mask.sum()
+            task_target_num = mask_sum + SMALL_NUMBER                                         # :163
+            self.ops['accuracy_task%i' % task_id] = abs_sum / task_target_num                 # :165
+            task_loss = loss_num / task_target_num                                            # :166
             # :168 looks the ratio up with an int key although configs carry str keys -> never applied
             task_loss = task_loss * (1.0 / (self.params['task_sample_ratios'].get(task_id) or 1.0))
             self.ops['losses'].append(task_loss)
-            self.ops['loss_numerator_task%i' % task_id] = (0.5 * diff * diff).sum()
-            self.ops['abs_error_sum_task%i' % task_id] = diff.abs().sum()
-            self.ops['loss_denominator_task%i' % task_id] = task_target_mask.sum()
+            self.ops['loss_numerator_task%i' % task_id] = loss_num
+            self.ops['abs_error_sum_task%i' % task_id] = abs_sum
+            self.ops['loss_denominator_task%i' % task_id] = mask_sum
         self.ops['loss'] = torch.stack(self.ops['losses']).sum()                              # :170
         return self.ops['loss']
 
@@ -214,7 +224,7 @@ class ChemModel(object):
         self.placeholders.update(batch_data)
 
     DERIVED_PLACEHOLDERS = {'adjacency_lists': ('message_index',), 'adjacency_matrix': ('_sparse_form',),
-                            'graph_nodes_list': ('graph_ptr',)}
+                            'graph_nodes_list': ('graph_ptr', 'graph_nodes_sorted')}
 
     def make_train_step(self):
         """chem_tensorflow.py:172-193: Adam(lr) on all trainable variables (minus graph_model/* when

@@ -116,6 +116,7 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
         'adjacency_lists': adjacency,
         'num_incoming_edges_per_type': nin,
         'graph_nodes_list': gnl,
+        'graph_ptr': torch.cat([offs, offs.new_full((1,), V)]).to(torch.int32),       # first node of every graph (+ V)
         'target_values': tv,
         'target_mask': tm,
         'num_graphs': G,

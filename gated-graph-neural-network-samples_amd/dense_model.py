@@ -138,6 +138,30 @@ class DenseGGNNChemModel(ChemModel):
             h = tf_dropout(h, keep_s)
         return h.reshape(b, v, h_dim)
 
+    def gated_regression_with_loss(self, last_h, regression_gate, regression_transform, target_values, target_mask):
+        """chem_tensorflow_dense.py:119-129 + chem_tensorflow.py:161-166 on the fused readout kernels: graph g owns the
+        consecutive rows g*v .. g*v+v-1 of the flattened [b*v, h] states, padding vertices are switched off by node_mask."""
+        from .autograd import readout_loss
+        ph = self.placeholders
+        h_dim = self.params['hidden_size']
+        g, t = regression_gate.params, regression_transform.params
+        if not last_h.is_cuda or h_dim > 256 or len(g["weights"]) != 1 or len(t["weights"]) != 1:
+            return None
+        b, v = last_h.shape[0], int(ph['num_vertices'])
+        key = (b, v, str(last_h.device))
+        cached = getattr(self, '_readout_index', None)
+        if cached is None or cached[0] != key:
+            gnl = torch.arange(b, dtype=torch.int32, device=last_h.device).repeat_interleave(v).contiguous()
+            gptr = (torch.arange(b + 1, dtype=torch.int32, device=last_h.device) * v).contiguous()
+            self._readout_index = cached = (key, gnl, gptr)
+        keep = float(ph.get('out_layer_dropout_keep_prob', 1.0))
+        out, num, ab, ms = readout_loss(last_h.reshape(-1, h_dim), ph['initial_node_representation'].reshape(-1, h_dim).contiguous(),
+                                        cached[1], cached[2], ph['node_mask'].reshape(-1).contiguous(), b,
+                                        tf_dropout(g["weights"][0], keep), g["biases"][0], tf_dropout(t["weights"][0], keep),
+                                        t["biases"][0], target_values.contiguous(), target_mask.contiguous())
+        self.output = out
+        return out, num, ab, ms
+
     def gated_regression(self, last_h, regression_gate, regression_transform):
         """chem_tensorflow_dense.py:119-129."""
         ph = self.placeholders

@@ -693,6 +693,54 @@ def gated_readout(last_h: torch.Tensor, h0: torch.Tensor, graph_nodes_list: torc
     return out
 
 
+def readout_loss_fwd(last_h: torch.Tensor, h0: torch.Tensor, graph_nodes_list: torch.Tensor, graph_ptr: Optional[torch.Tensor],
+                     node_mask: Optional[torch.Tensor], num_graphs: int, gate_W: torch.Tensor, gate_b: torch.Tensor,
+                     transform_W: torch.Tensor, transform_b: torch.Tensor, target: Optional[torch.Tensor],
+                     mask: Optional[torch.Tensor]):
+    """Fused gated_regression + masked loss sums (chem_tensorflow_sparse.py:220-231, chem_tensorflow.py:158-170), forward:
+    -> (out [G], node_gate [V], node_val [V], stats [3] = (sum 0.5 diff^2, sum |diff|, sum mask) or None without target).
+    graph_nodes_list must be non-decreasing (batcher output); deterministic."""
+    lib = _lib.load()
+    _req(last_h, torch.float32, "last_h"); _req(h0, torch.float32, "h0"); _req(graph_nodes_list, torch.int32, "graph_nodes_list")
+    V, D = last_h.shape
+    G = int(num_graphs)
+    dev = last_h.device
+    out = torch.empty(G, dtype=torch.float32, device=dev)
+    gate = torch.empty(max(V, 1), dtype=torch.float32, device=dev)
+    val = torch.empty(max(V, 1), dtype=torch.float32, device=dev)
+    stats = torch.empty(3, dtype=torch.float32, device=dev) if target is not None else None
+    ws_bytes = lib.ggnn_readout_workspace_bytes(V, D, G)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    for n, t in (("gate_W", gate_W), ("gate_b", gate_b), ("transform_W", transform_W), ("transform_b", transform_b)):
+        _req(t, torch.float32, n)
+    _launch("readout_loss_fwd", lambda: lib.ggnn_readout_loss_fwd_f32(
+        _ptr(last_h), _ptr(h0), _ptr(graph_nodes_list), _ptr(graph_ptr), _ptr(node_mask), _ptr(gate_W), _ptr(gate_b), _ptr(transform_W),
+        _ptr(transform_b), _ptr(target), _ptr(mask), _ptr(out), _ptr(gate), _ptr(val), _ptr(stats), _ptr(ws), ws_bytes, V, D, G, _stream()))
+    return out, gate, val, stats
+
+
+def readout_loss_bwd(last_h, h0, graph_nodes_list, node_mask, num_graphs, gate_W, transform_W, gate, val, out, target, mask,
+                     d_out: Optional[torch.Tensor], d_stats: Optional[torch.Tensor], d_last_h: Optional[torch.Tensor] = None):
+    """Backward of readout_loss_fwd: -> (d_last_h [V,D], d_gate_W [2D], d_gate_b [1], d_transform_W [D], d_transform_b [1]).
+    d_last_h given: the gradient is ADDED to it (further tasks of a multi-task model)."""
+    lib = _lib.load()
+    V, D = last_h.shape
+    G = int(num_graphs)
+    dev = last_h.device
+    accumulate = d_last_h is not None
+    if d_last_h is None:
+        d_last_h = torch.empty_like(last_h) if V and G else torch.zeros_like(last_h)
+    dgW = torch.empty(2 * D, dtype=torch.float32, device=dev); dgb = torch.empty(1, dtype=torch.float32, device=dev)
+    dtW = torch.empty(D, dtype=torch.float32, device=dev); dtb = torch.empty(1, dtype=torch.float32, device=dev)
+    ws_bytes = lib.ggnn_readout_workspace_bytes(V, D, G)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _launch("readout_loss_bwd", lambda: lib.ggnn_readout_loss_bwd_f32(
+        _ptr(last_h), _ptr(h0), _ptr(graph_nodes_list), _ptr(node_mask), _ptr(gate_W), _ptr(transform_W), _ptr(gate), _ptr(val), _ptr(out),
+        _ptr(target), _ptr(mask), _ptr(d_out), _ptr(d_stats), _ptr(d_last_h), 1 if accumulate else 0, _ptr(dgW), _ptr(dgb), _ptr(dtW),
+        _ptr(dtb), _ptr(ws), ws_bytes, V, D, G, _stream()))
+    return d_last_h, dgW, dgb, dtW, dtb
+
+
 # ---- the remaining switches of the same function: attention, RNN cell, cudnn-compatible GRU cell ------------------
 def gather_segment_sum_attn(H: torch.Tensor, h: torch.Tensor, index: MessageIndex, type_factors: torch.Tensor,
                             num_incoming_edges_per_type: Optional[torch.Tensor], edge_biases: Optional[torch.Tensor],

@@ -274,16 +274,53 @@ class SparseGGNNChemModel(ChemModel):
                                     gru_packed, act)
         return outs[-1]
 
+    def _graph_nodes_sorted(self) -> bool:
+        """The fused readout sums a graph's nodes as one segment: graph_nodes_list must be non-decreasing.  Batches of this
+        package's packers say so ('graph_nodes_sorted'); a foreign feed is checked once per list object (one sync)."""
+        ph = self.placeholders
+        if ph.get('graph_nodes_sorted') is not None:
+            return bool(ph['graph_nodes_sorted'])
+        gnl = ph['graph_nodes_list']
+        cached = getattr(self, '_gnl_checked', None)
+        if cached is None or cached[0] is not gnl:
+            ok = bool(gnl.numel() < 2 or bool((gnl[1:] >= gnl[:-1]).all().item()))
+            self._gnl_checked = cached = (gnl, ok)
+        return cached[1]
+
+    def gated_regression_with_loss(self, last_h, regression_gate, regression_transform, target_values, target_mask):
+        """gated_regression (chem_tensorflow_sparse.py:220-231) and the masked sums of chem_tensorflow.py:161-166 in one
+        fused, differentiable, deterministic unit (autograd.readout_loss).  None when the fused kernels do not apply."""
+        from .autograd import readout_loss
+        if not last_h.is_cuda or self.params['hidden_size'] > 256 or not self._graph_nodes_sorted():
+            return None
+        keep = float(self.placeholders.get('out_layer_dropout_keep_prob', 1.0))
+        g, t = regression_gate.params, regression_transform.params
+        if len(g["weights"]) != 1 or len(t["weights"]) != 1:
+            return None
+        ph = self.placeholders
+        out, num, ab, ms = readout_loss(last_h, ph['initial_node_representation'], ph['graph_nodes_list'], ph.get('graph_ptr'), None,
+                                        ph['num_graphs'], tf_dropout(g["weights"][0], keep), g["biases"][0],
+                                        tf_dropout(t["weights"][0], keep), t["biases"][0],          # utils.py:68 dropout on W
+                                        target_values.contiguous(), target_mask.contiguous())
+        self.output = out
+        return out, num, ab, ms
+
     def gated_regression(self, last_h, regression_gate, regression_transform):
         """chem_tensorflow_sparse.py:220-231."""
         from .autograd import segment_sum_rows
         keep = float(self.placeholders.get('out_layer_dropout_keep_prob', 1.0))
         if not (self.training and torch.is_grad_enabled()) and keep >= 1.0 and last_h.is_cuda:
-            # inference: one fused HIP pass (no [V,2D] concat, no per-node intermediates)
+            # inference: one fused HIP pass (no [V,2D] concat, no per-node intermediates); deterministic segmented sum for
+            # batcher output, the atomic form only for an unsorted graph_nodes_list
             g, t = regression_gate.params, regression_transform.params
-            output = ops.gated_readout(last_h.contiguous(), self.placeholders['initial_node_representation'],
-                                       self.placeholders['graph_nodes_list'], self.placeholders['num_graphs'],
-                                       g["weights"][0], g["biases"][0], t["weights"][0], t["biases"][0])
+            ph = self.placeholders
+            if self._graph_nodes_sorted() and self.params['hidden_size'] <= 256:
+                output = ops.readout_loss_fwd(last_h.contiguous(), ph['initial_node_representation'], ph['graph_nodes_list'],
+                                              ph.get('graph_ptr'), None, ph['num_graphs'], g["weights"][0].reshape(-1),
+                                              g["biases"][0], t["weights"][0].reshape(-1), t["biases"][0], None, None)[0]
+            else:
+                output = ops.gated_readout(last_h.contiguous(), ph['initial_node_representation'], ph['graph_nodes_list'],
+                                           ph['num_graphs'], g["weights"][0], g["biases"][0], t["weights"][0], t["biases"][0])
             self.output = output
             return output
         gate_input = torch.cat([last_h, self.placeholders['initial_node_representation']], dim=-1)   # [v x 2h]
@@ -327,6 +364,7 @@ class SparseGGNNChemModel(ChemModel):
             'adjacency_lists': adjacency,
             'num_incoming_edges_per_type': t(b.num_incoming_edges_per_type),
             'graph_nodes_list': t(b.graph_nodes_list),
+            'graph_ptr': t(np.concatenate([[0], np.cumsum(np.bincount(b.graph_nodes_list, minlength=b.num_graphs))]).astype(np.int32)),
             'target_values': t(b.target_values),
             'target_mask': t(b.target_mask),
             'num_graphs': b.num_graphs,

@@ -137,10 +137,43 @@ int ggnn_unsorted_segment_sum_f32(const float* data, const int32_t* ids, float* 
 /* ---- (a-R) fused graph-level readout: chem_tensorflow_sparse.py:220-231 + utils.py:39-70 -------------
  * out[g] = sum_{v in graph g} sigmoid([hT[v] | h0[v]] . gate_W + gate_b) * (hT[v] . transform_W + transform_b)
  *   hT, h0 [V,D]; graph_nodes_list [V] int32 (:71, :304); gate_W [2D] (the [2D,1] MLP weight), transform_W [D];
- *   gate_b, transform_b DEVICE [1]; out [num_graphs] (zero-filled by the call).  fp32 atomics (one add per node). */
+ *   gate_b, transform_b DEVICE [1]; out [num_graphs] (zero-filled by the call).  fp32 atomics (one add per node): the
+ *   form for an UNSORTED graph_nodes_list; the models use ggnn_readout_loss_fwd_f32 (deterministic) for batcher output. */
 int ggnn_gated_readout_f32(const float* hT, const float* h0, const int32_t* graph_nodes_list, const float* gate_W,
                            const float* gate_b, const float* transform_W, const float* transform_b, float* out, int V,
                            int D, int num_graphs, ggnn_stream_t stream);
+
+/* ---- (f-2) fused readout + masked loss, forward and backward ------------------------------------------------------------
+ * chem_tensorflow_sparse.py:220-231 (gated_regression; dense: chem_tensorflow_dense.py:119-129 with node_mask) +
+ * chem_tensorflow.py:158-170 (masked loss / MAE of one task) + utils.py:39-70 (MLP with hid_sizes = []).
+ * DETERMINISTIC and atomics-free: graph_nodes_list must be NON-DECREASING (the reference batchers append graph after
+ * graph, :297-304), so out[g] is a segmented sum in node order; all cross-block reductions run in a fixed order.
+ *
+ * ggnn_readout_loss_fwd_f32
+ *   hT, h0 [V,D]; graph_nodes_list [V] int32 sorted; graph_ptr [G+1] int32 or NULL (first node of every graph; NULL: found by
+ *   binary search); node_mask [V] or NULL (dense model: 0 for padding vertices); gate_W [2D], transform_W [D]; gate_b,
+ *   transform_b DEVICE [1]; target, mask [G] or NULL (this task's row of target_values / target_mask)
+ *   out [G]:  out[g] = sum_{v in g} sigmoid([hT|h0][v] . gate_W + gate_b) (hT[v] . transform_W + transform_b) (node_mask[v])
+ *   node_gate, node_val [V]: the per-node gate and value, kept for the backward pass
+ *   stats DEVICE [3] or NULL: sum_g 0.5 diff_g^2, sum_g |diff_g|, sum_g mask_g with diff = (out - target) mask   (:161-166; the
+ *   caller divides by (sum mask + 1e-7) -- under data parallelism by the ALL-REDUCED mask count)
+ *   ws: ggnn_readout_workspace_bytes(V, D, G) bytes.
+ * ggnn_readout_loss_bwd_f32
+ *   d_out [G] or NULL (gradient w.r.t. out), d_stats DEVICE [2] or NULL (gradients w.r.t. stats[0] and stats[1]);
+ *   d_hT [V,D] written (accumulate = 0) or added to (accumulate != 0: second and later tasks);
+ *   d_gate_W [2D], d_gate_b [1], d_transform_W [D], d_transform_b [1] written.  D <= 256. */
+size_t ggnn_readout_workspace_bytes(int V, int D, int num_graphs);
+int ggnn_readout_loss_fwd_f32(const float* hT, const float* h0, const int32_t* graph_nodes_list, const int32_t* graph_ptr,
+                              const float* node_mask, const float* gate_W, const float* gate_b, const float* transform_W,
+                              const float* transform_b, const float* target, const float* mask, float* out,
+                              float* node_gate, float* node_val, float* stats, void* ws, size_t ws_bytes, int V, int D,
+                              int num_graphs, ggnn_stream_t stream);
+int ggnn_readout_loss_bwd_f32(const float* hT, const float* h0, const int32_t* graph_nodes_list, const float* node_mask,
+                              const float* gate_W, const float* transform_W, const float* node_gate, const float* node_val,
+                              const float* out, const float* target, const float* mask, const float* d_out,
+                              const float* d_stats, float* d_hT, int accumulate, float* d_gate_W, float* d_gate_b,
+                              float* d_transform_W, float* d_transform_b, void* ws, size_t ws_bytes, int V, int D,
+                              int num_graphs, ggnn_stream_t stream);
 
 /* ---- (a-8, a-G) residual concat + GRU node update: chem_tensorflow_sparse.py:211-216 -----------
  * TF-1.3 GRUCell: [r|u] = sigmoid([x|h] Wg + bg); c = act([x | r*h] Wc + bc); h' = u*h + (1-u)*c
