@@ -1,21 +1,27 @@
 """Backward pass of one propagation timestep (what TF autodiff derives from
-chem_tensorflow_sparse.py:153-216 via optimizer.compute_gradients, chem_tensorflow.py:184).
+chem_tensorflow_sparse.py:153-216 via optimizer.compute_gradients, chem_tensorflow.py:184) -- every launch a
+hand-written HIP kernel of libggnn_hip.so; torch only allocates the buffers.
 
-Forward runs on the hand-written HIP kernels and saves r, u, c.  Backward:
-  * GRU gate algebra: two fused HIP element-wise passes (ggnn_gru_bwd_stage{1,2}_f32);
-  * d(gather/segment-sum) = the SAME HIP gather/segment-sum kernel driven by the transpose index
-    (messages bucketed by (src,type), gathering d_incoming[dst]) -- atomics-free and deterministic;
-  * optionally (USE_COMPACT_TRANSFORM) the message transform runs in its compacted form in both directions (active
-    (node,type) pairs only): the transpose gather lands on compact rows, dHc W_t^T is the forward kernel on
-    transposed weights, the per-node sum over types is one more segment sum;
-  * dX = dY W^T runs on the package's own FP32-MFMA GEMM (ggnn_gemm_f32 on the transposed weights; ~2.5x the vendor
-    BLAS at these skinny shapes: M = 1e5, K and N = 100..400);
-  * the weight gradients dW = X^T dY -- plain tall-skinny library GEMMs -- go to the vendor BLAS through torch,
-    batched along the 1e5-long reduction (tn_matmul).
+Forward (training) = the inference kernels: compacted message transform on the active (node, type) pairs, stand-alone
+segment sum (its result is a saved operand of the weight gradients), fused GRU in its r/u/c-saving form.
+
+Backward, per timestep (nx = residual inputs + 1, K = (nx+1) D):
+  1. ggnn_gru_bwd_stage1_f32      g, h, r, u, c -> dpc, dpu (= dpg[:, D:]), dh = g*u, r*h           (one element-wise pass)
+  2. ggnn_xty_f32                 dWc = [x.. | incoming | r*h]^T dpc        (segment pointers: no [V,K] concat)
+     ggnn_colsum_f32              dbc
+  3. ggnn_gru_bwd_dx_cand_f32     dpc Wc^T with the stage-2 algebra in the epilogue: dx (x part), dh += drh*r, dpr -> dpg[:, :D]
+  4. ggnn_xty_f32 / ggnn_colsum_f32   dWg = [x.. | incoming | h]^T dpg, dbg
+  5. ggnn_gru_bwd_dx_gates_f32    dpg Wg^T: dx += (residual columns), d_incoming = (dx + .) / (deg + 1e-7), dh += (h columns)
+  6. ggnn_gather_segment_sum_f32 on the transpose index: dHc[r] = sum of d_incoming[dst] over the messages leaving pair r
+  7. ggnn_msg_transform_compact_f32 on W^T: Z = dHc W_t^T;  ggnn_gather_segment_sum_acc_f32: dh[v] += sum_t Z[row(v,t)]
+  8. ggnn_xty_f32 (row-gathered, one batch per edge type): dW_t = h[pair_node[rows_t]]^T dHc[rows_t]
+No vendor-BLAS call and no torch arithmetic kernel is left on this path (hidden sizes without a compacted transform keep the
+dense-form fallback at the end of this file).
 """
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
@@ -23,17 +29,12 @@ from . import _lib, ops
 from ._lib import check
 from .utils import SMALL_NUMBER, tn_matmul
 
-# Training forward/backward on the compacted message transform (GGNN_TRAIN_COMPACT=1) or on the dense [V, T*D] form
-# (default).  The compacted form does 3.3x fewer transform flops in both directions, but its backward needs two more
-# segment sums, a row gather and per-type weight-gradient products; measured on MI355X at QM9 shapes the training
-# step is 12.4 ms compacted vs 12.1 ms dense, so dense stays the default (inference always uses the compacted form).
-USE_COMPACT_TRANSFORM = os.environ.get("GGNN_TRAIN_COMPACT", "0") != "0"
+# Training forward/backward on the compacted message transform (default wherever the hidden size has one) or on the dense
+# [V, T*D] form (GGNN_TRAIN_COMPACT=0; always for other hidden sizes).
+USE_COMPACT_TRANSFORM = os.environ.get("GGNN_TRAIN_COMPACT", "1") != "0"
 
-
-# Weight gradients X^T dY: vendor BLAS batched along the rows (utils.tn_matmul; default) or the package's row-split TN
-# kernel ggnn_gemm_tn_f32 (GGNN_TN_KERNEL=1).  Measured on MI355X at V = 1e5: [V,400]^T [V,200] 195 us (82 TF) batched
-# BLAS vs 297 us (54 TF) own kernel; [V,200]^T [V,100] 89 vs 138 us -- the own kernel (deterministic, tested) is not
-# yet competitive, so the library product keeps this plain GEMM.
+# Dense-form fallback only: weight gradients X^T dY on the vendor BLAS batched along the rows (utils.tn_matmul) or on the
+# package's first row-split kernel ggnn_gemm_tn_f32 (GGNN_TN_KERNEL=1).
 USE_TN_KERNEL = os.environ.get("GGNN_TN_KERNEL", "0") != "0"
 
 
@@ -52,21 +53,47 @@ def _source_index(index: "ops.MessageIndex", num_nodes: int) -> "ops.MessageInde
     return src_index
 
 
+class _TransposeCache:
+    """W^T (contiguous) per weight tensor version: the backward of every timestep of a layer multiplies by the same
+    transposed weights, so the transpose copy is made once per layer and optimisation step."""
+
+    def __init__(self):
+        self._t = {}
+
+    def get(self, W: torch.Tensor, dims=(0, 1)) -> torch.Tensor:
+        key = (id(W), W._version, dims)
+        hit = self._t.get(key)
+        if hit is not None and hit[0]() is W:
+            return hit[1]
+        if len(self._t) > 256:
+            self._t.clear()
+        Wt = W.transpose(*dims).contiguous()
+        self._t[key] = (weakref.ref(W), Wt)
+        return Wt
+
+
+_TRANSPOSED = _TransposeCache()
+
+
 class PropagationStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, index, nin, edge_weights, edge_biases, use_avg, activation, Wg, bg, Wc, bc, *residuals):
         h = h.contiguous()
-        edge_weights = edge_weights.contiguous()
+        D = h.shape[1]
         ctx.comp = None
-        if USE_COMPACT_TRANSFORM and ops.compact_supported(h.shape[1]):
+        if USE_COMPACT_TRANSFORM and ops.compact_supported(D) and D <= 104:
             # transform only the (node, type) pairs that emit a message (~1.2 V rows instead of T V)
+            from .autograd import _PACKED
             comp = getattr(index, "_compact", None)
             if comp is None:
                 comp = index._compact = ops.build_compact_sources(index)
             ctx.comp = comp
-            H = ops.msg_transform_compact(h, edge_weights, comp)
+            ew = edge_weights if edge_weights.is_contiguous() else edge_weights.contiguous()
+            H = ops.msg_transform_compact_packed(h, _PACKED.edge(ew), ew.shape[0], comp)
             incoming = ops.gather_segment_sum_compact(H, index, comp, nin, edge_biases, use_avg)
+            edge_weights = ew
         else:
+            edge_weights = edge_weights.contiguous()
             H = ops.msg_transform(h, edge_weights)
             incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
         del H
@@ -78,6 +105,8 @@ class PropagationStepFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.comp is None:
+            return _backward_dense_form(ctx, g)
         lib = _lib.load()
         h, nin, W, Wg, Wc, incoming, r, u, c, *residuals = ctx.saved_tensors
         V, D = h.shape
@@ -85,61 +114,97 @@ class PropagationStepFn(torch.autograd.Function):
         nx = len(residuals) + 1
         K = (nx + 1) * D
         g = g.contiguous()
+        dev = h.device
         st = torch.cuda.current_stream().cuda_stream
         act = ops.ACT_IDS[ctx.activation]
+        xs = list(residuals) + [incoming]
 
-        # ---- GRU blend and candidate:  h' = u*h + (1-u)*c,  c = act([x | r*h] Wc + bc)
-        a_c = torch.empty((V, K), dtype=torch.float32, device=h.device)        # [x_0 | .. | incoming | r*h]
-        for i, x in enumerate(list(residuals) + [incoming]):
-            a_c[:, i * D:(i + 1) * D] = x
+        # ---- 1. GRU blend and candidate:  h' = u*h + (1-u)*c,  c = act([x | r*h] Wc + bc)
         dpc = torch.empty_like(h)
-        dpg = torch.empty((V, 2 * D), dtype=torch.float32, device=h.device)    # [d pre-r | d pre-u]
+        dpg = torch.empty((V, 2 * D), dtype=torch.float32, device=dev)         # [d pre-r | d pre-u]
         dh = torch.empty_like(h)
-        check(lib.ggnn_gru_bwd_stage1_f32(g.data_ptr(), h.data_ptr(), r.data_ptr(), u.data_ptr(), c.data_ptr(), act,
-                                          dpc.data_ptr(), dpg.data_ptr(), dh.data_ptr(), a_c.data_ptr(), K, nx * D, V, D, st))
-        dWc = _tn(a_c, dpc)
-        dbc = dpc.sum(0)
-        dxrh = ops.gemm([dpc], Wc.t().contiguous())                            # [V, (nx+1)D] = dpc Wc^T
-        # ---- gates: [r|u] = sigmoid([x | h] Wg + bg)
-        drh = dxrh[:, nx * D:]
-        check(lib.ggnn_gru_bwd_stage2_f32(drh.data_ptr(), K, h.data_ptr(), r.data_ptr(), dh.data_ptr(), dpg.data_ptr(), V, D, st))
-        a_c[:, nx * D:] = h                                                    # reuse the buffer as [x | h]
-        dWg = _tn(a_c, dpg)
-        dbg = dpg.sum(0)
-        dxh = ops.gemm([dpg[:, :D], dpg[:, D:]], Wg.t().contiguous())           # [V, (nx+1)D] = dpg Wg^T
-        dh += dxh[:, nx * D:]
-        dx = dxrh[:, :nx * D] + dxh[:, :nx * D]
+        rh = torch.empty_like(h)
+        ops._launch("gru_bwd_stage1", lambda: lib.ggnn_gru_bwd_stage1_f32(
+            g.data_ptr(), h.data_ptr(), r.data_ptr(), u.data_ptr(), c.data_ptr(), act, dpc.data_ptr(), dpg.data_ptr(),
+            dh.data_ptr(), rh.data_ptr(), D, 0, V, D, st))
+        # ---- 2. candidate weights
+        dWc = ops.xty(xs + [rh], dpc)
+        dbc = ops.colsum(dpc)
+        # ---- 3. dpc Wc^T; gates pre-activation gradients ([r|u] = sigmoid([x | h] Wg + bg))
+        dx = torch.empty((V, nx * D), dtype=torch.float32, device=dev)
+        ops._launch("gru_bwd_dx_cand[nx=%d]" % nx, lambda: lib.ggnn_gru_bwd_dx_cand_f32(
+            dpc.data_ptr(), _TRANSPOSED.get(Wc).data_ptr(), h.data_ptr(), r.data_ptr(), dx.data_ptr(), dh.data_ptr(), dpg.data_ptr(),
+            nx, V, D, st))
+        # ---- 4. gate weights
+        dWg = ops.xty(xs + [h], dpg)
+        dbg = ops.colsum(dpg)
+        # ---- 5. dpg Wg^T; mean aggregation (chem_tensorflow_sparse.py:206-209)
+        dinc = torch.empty_like(h)
+        ops._launch("gru_bwd_dx_gates[nx=%d]" % nx, lambda: lib.ggnn_gru_bwd_dx_gates_f32(
+            dpg.data_ptr(), _TRANSPOSED.get(Wg).data_ptr(), dx.data_ptr(), dinc.data_ptr(), nin.data_ptr(), T, 1 if ctx.use_avg else 0,
+            dh.data_ptr(), nx, V, D, st))
         d_res = [dx[:, i * D:(i + 1) * D] for i in range(nx - 1)]
-        dinc = dx[:, (nx - 1) * D:]
+        dbias = None
+        if ctx.has_bias:                                                       # :202-204  incoming += nin @ edge_biases
+            dbias = ops.xty([dinc], nin).t().contiguous()                      # (dinc^T nin)^T = nin^T dinc   [T, D]
 
-        # ---- mean / bias / segment sum (chem_tensorflow_sparse.py:198-209)
-        if ctx.use_avg:
-            dinc = dinc / (nin.sum(dim=-1, keepdim=True) + SMALL_NUMBER)
-        dinc = dinc.contiguous()
-        dbias = nin.t().matmul(dinc) if ctx.has_bias else None
-        if ctx.comp is not None:
-            # ---- compacted transform Hc[r] = h[node(r)] W_type(r): its backward on the same R rows
-            comp = ctx.comp
-            bwd = ops.compact_backward(ctx.index, comp)
-            R = comp.num_rows
+        # ---- 6.-8. segment sum and compacted transform  Hc[r] = h[node(r)] W_type(r)  on the same R rows
+        comp = ctx.comp
+        bwd = ops.compact_backward(ctx.index, comp)
+        R = comp.num_rows
+        if R:
+            from .autograd import _PACKED
+            dHc = ops.segment_sum_rows_by_index(dinc, bwd.rows_index)                          # [R,D], transpose gather
+            Z = ops.msg_transform_compact_packed(dHc, _PACKED.edge(_TRANSPOSED.get(W, (1, 2))), T, bwd.identity)   # dHc W_t^T
+            ops.segment_sum_rows_acc(Z[:R], bwd.node_index, dh)                              # sum over a node's types
+            dW = ops.xty([h], dHc, x_rows=comp.pair_node, row_off=comp.type_row_off)           # [T, D, D]
+        else:
             dW = torch.zeros_like(W)
-            if R:
-                dHc = ops.segment_sum_rows_by_index(dinc, bwd.rows_index)                      # [R,D], transpose gather
-                Z = ops.msg_transform_compact(dHc, W.transpose(1, 2).contiguous(), bwd.identity)   # dHc W_t^T, same kernel
-                dh += ops.segment_sum_rows_by_index(Z[:R], bwd.node_index)                   # sum over a node's types
-                hg = h.index_select(0, comp.pair_node[:R].long())
-                for t in range(T):
-                    a, b = comp.type_row_off[t], comp.type_row_off[t + 1]
-                    if b > a:
-                        dW[t] = tn_matmul(hg[a:b], dHc[a:b], chunk=512)    # (rare types have only a few thousand rows)
-            return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, *d_res)
-        dH = ops.segment_sum_rows_by_index(dinc, _source_index(ctx.index, V)).view(V, T * D)
-
-        # ---- message transform H = h [W_0 | .. | W_{T-1}]
-        WT = W.transpose(1, 2).reshape(T * D, D).contiguous()                  # rows t*D..: W_t^T
-        for t0 in range(0, T, 4):                                              # (the GEMM takes <= 4 K segments)
-            t1 = min(t0 + 4, T)
-            dh += ops.gemm([dH[:, t * D:(t + 1) * D] for t in range(t0, t1)], WT[t0 * D:t1 * D])
-        dW = _tn(h, dH).view(D, T, D).transpose(0, 1)
-
         return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, *d_res)
+
+
+def _backward_dense_form(ctx, g):
+    """Hidden sizes without a compacted transform (or GGNN_TRAIN_COMPACT=0): the dense [V, T*D] message transform; its
+    weight gradients are plain tall-skinny products on the vendor BLAS (utils.tn_matmul)."""
+    lib = _lib.load()
+    h, nin, W, Wg, Wc, incoming, r, u, c, *residuals = ctx.saved_tensors
+    V, D = h.shape
+    T = W.shape[0]
+    nx = len(residuals) + 1
+    K = (nx + 1) * D
+    g = g.contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    act = ops.ACT_IDS[ctx.activation]
+
+    a_c = torch.empty((V, K), dtype=torch.float32, device=h.device)        # [x_0 | .. | incoming | r*h]
+    for i, x in enumerate(list(residuals) + [incoming]):
+        a_c[:, i * D:(i + 1) * D] = x
+    dpc = torch.empty_like(h)
+    dpg = torch.empty((V, 2 * D), dtype=torch.float32, device=h.device)    # [d pre-r | d pre-u]
+    dh = torch.empty_like(h)
+    check(lib.ggnn_gru_bwd_stage1_f32(g.data_ptr(), h.data_ptr(), r.data_ptr(), u.data_ptr(), c.data_ptr(), act,
+                                      dpc.data_ptr(), dpg.data_ptr(), dh.data_ptr(), a_c.data_ptr(), K, nx * D, V, D, st))
+    dWc = _tn(a_c, dpc)
+    dbc = dpc.sum(0)
+    dxrh = ops.gemm([dpc], Wc.t().contiguous())                            # [V, (nx+1)D] = dpc Wc^T
+    drh = dxrh[:, nx * D:]
+    check(lib.ggnn_gru_bwd_stage2_f32(drh.data_ptr(), K, h.data_ptr(), r.data_ptr(), dh.data_ptr(), dpg.data_ptr(), V, D, st))
+    a_c[:, nx * D:] = h                                                    # reuse the buffer as [x | h]
+    dWg = _tn(a_c, dpg)
+    dbg = dpg.sum(0)
+    dxh = ops.gemm([dpg[:, :D], dpg[:, D:]], Wg.t().contiguous())           # [V, (nx+1)D] = dpg Wg^T
+    dh += dxh[:, nx * D:]
+    dx = dxrh[:, :nx * D] + dxh[:, :nx * D]
+    d_res = [dx[:, i * D:(i + 1) * D] for i in range(nx - 1)]
+    dinc = dx[:, (nx - 1) * D:]
+    if ctx.use_avg:
+        dinc = dinc / (nin.sum(dim=-1, keepdim=True) + SMALL_NUMBER)
+    dinc = dinc.contiguous()
+    dbias = nin.t().matmul(dinc) if ctx.has_bias else None
+    dH = ops.segment_sum_rows_by_index(dinc, _source_index(ctx.index, V)).view(V, T * D)
+    WT = W.transpose(1, 2).reshape(T * D, D).contiguous()                  # rows t*D..: W_t^T
+    for t0 in range(0, T, 4):                                              # (the GEMM takes <= 4 K segments)
+        t1 = min(t0 + 4, T)
+        dh += ops.gemm([dH[:, t * D:(t + 1) * D] for t in range(t0, t1)], WT[t0 * D:t1 * D])
+    dW = _tn(h, dH).view(D, T, D).transpose(0, 1)
+    return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, *d_res)

@@ -286,3 +286,38 @@ extern "C" int ggnn_gru_packed_gather_f32(const float* const* x_segs, int nx, co
     a.tickets = tile_counter;
     return gru_fused_dispatch(a, D, const_cast<float*>(packed), (hipStream_t)stream);
 }
+
+// ---- backward dX products with fused GRU gate algebra (epilogues in ggnn_gemm.hpp) ------------------------------------------
+// WcT: Wc^T [D, (nx+1) D] row-major; dpc [V,D].  dx [V, nx*D] written; dh [V,D] += drh*r; dpg[:, 0:D] = drh*h*r*(1-r).
+extern "C" int ggnn_gru_bwd_dx_cand_f32(const float* dpc, const float* WcT, const float* h, const float* r, float* dx, float* dh,
+                                        float* dpg, int nx, int V, int D, ggnn_stream_t stream) {
+    if (int rc = check_common(V, D)) return rc;
+    GGNN_CHECK_ARG(nx >= 1 && nx <= 3, "nx %d outside 1..3", nx);
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(dpc && WcT && h && r && dx && dh && dpg, "null pointer");
+    GGNN_CHECK_ARG(aligned16(dpc) && aligned16(WcT) && aligned16(h) && aligned16(r) && aligned16(dx) && aligned16(dh) && aligned16(dpg),
+                   "pointers must be 16-byte aligned");
+    const int K = (nx + 1) * D;
+    GemmOperands g{};
+    g.A[0] = dpc; g.lda[0] = D; g.nseg = 1; g.D = D; g.M = V;
+    g.B = WcT; g.ldb = K; g.b_blk_cols = K; g.b_blk_stride = 0; g.N = K;
+    EpiBwdCand e{dx, nx * D, nx * D, h, r, dh, dpg, D};
+    return dispatch_gemm(g, e, (hipStream_t)stream);
+}
+
+// WgT: Wg^T [2D, (nx+1) D]; dpg [V,2D].  dx[:, residual columns] += ; dinc [V,D] = (dx[:, last segment] + Q) (/ (deg + 1e-7));
+// dh += Q[:, h columns].
+extern "C" int ggnn_gru_bwd_dx_gates_f32(const float* dpg, const float* WgT, float* dx, float* dinc, const float* nin, int T,
+                                         int use_avg, float* dh, int nx, int V, int D, ggnn_stream_t stream) {
+    if (int rc = check_common(V, D)) return rc;
+    GGNN_CHECK_ARG(nx >= 1 && nx <= 3, "nx %d outside 1..3", nx);
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(dpg && WgT && dx && dinc && dh && (!use_avg || nin), "null pointer");
+    GGNN_CHECK_ARG(aligned16(dpg) && aligned16(WgT) && aligned16(dx) && aligned16(dinc) && aligned16(dh), "pointers must be 16-byte aligned");
+    const int K = (nx + 1) * D;
+    GemmOperands g{};
+    g.A[0] = dpg; g.lda[0] = 2 * D; g.A[1] = dpg + D; g.lda[1] = 2 * D; g.nseg = 2; g.D = D; g.M = V;
+    g.B = WgT; g.ldb = K; g.b_blk_cols = K; g.b_blk_stride = 0; g.N = K;
+    EpiBwdGates e{dx, nx * D, nx * D, (nx - 1) * D, dinc, nin, T, use_avg, dh, D};
+    return dispatch_gemm(g, e, (hipStream_t)stream);
+}

@@ -136,6 +136,48 @@ struct EpiCudnnCand {
     }
 };
 
+// ---- dX = dY W^T with the GRU gate algebra in the epilogue ------------------------------------------------------------------
+// Candidate:  P = dpc Wc^T  [V, (nx+1) D].  Columns [0, nx*D): dx (the x part, stored; the gates pass adds to it).
+//             Columns [nx*D, (nx+1)*D): drh ->  dh += drh * r ;  dpr = drh * h * r (1 - r) -> dpg[:, 0:D]          (stage 2)
+struct EpiBwdCand {
+    float* dx; int ld_dx; int xcols;                        // xcols = nx * D
+    const float* h; const float* r; float* dh; float* dpg; int D;
+    __device__ __forceinline__ void operator()(int row, int col, f32x4 v) const {
+        if (col < xcols) { st4(dx + (size_t)row * ld_dx + col, v); return; }
+        const int c = col - xcols;
+        const size_t o = (size_t)row * D + c;
+        const f32x4 hv = ld4(h + o), rv = ld4(r + o);
+        st4(dh + o, ld4(dh + o) + v * rv);
+        st4(dpg + (size_t)row * 2 * D + c, v * hv * rv * (1.0f - rv));
+    }
+};
+
+// Gates:  Q = dpg Wg^T  [V, (nx+1) D].  Columns of the residual inputs: dx += Q.  Columns of the aggregated messages (the
+//         LAST x segment): d_incoming = (dx + Q) * inv_deg[row] (mean aggregation, chem_tensorflow_sparse.py:206-209) -> dinc.
+//         Columns of h: dh += Q.
+struct EpiBwdGates {
+    float* dx; int ld_dx; int xcols; int inc0;              // inc0 = (nx-1)*D: first column of the aggregated-messages segment
+    float* dinc; const float* nin; int T; int use_avg;
+    float* dh; int D;
+    __device__ __forceinline__ void operator()(int row, int col, f32x4 v) const {
+        if (col >= xcols) {
+            const size_t o = (size_t)row * D + (col - xcols);
+            st4(dh + o, ld4(dh + o) + v);
+            return;
+        }
+        const f32x4 t = ld4(dx + (size_t)row * ld_dx + col) + v;
+        if (col < inc0) { st4(dx + (size_t)row * ld_dx + col, t); return; }
+        f32x4 o = t;
+        if (use_avg) {
+            float deg = 0.f;
+            for (int k = 0; k < T; ++k) deg += nin[(size_t)row * T + k];
+            o = t / (deg + 1e-7f);
+        }
+        st4(dinc + (size_t)row * D + (col - inc0), o);
+    }
+};
+
+
 struct GruFusedArgs {
     const float* x[3];
     int nx;

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void gated_readout_kernel(const float* __restr
 //             final kernel: the block partials summed in block order -> d_gate_W [2D], d_gate_b, d_transform_W [D], d_transform_b
 constexpr int kReadoutLanes = 16;               // lanes per node
 constexpr int kReadoutMaxSlots = 4;             // float4 column slots per lane: D <= 16 * 4 * 4 = 256
-constexpr int kReadoutBwdBlocks = 512;
+constexpr int kReadoutBwdBlocks = 256;
 
 __global__ __launch_bounds__(256) void readout_node_kernel(const float* __restrict__ hT, const float* __restrict__ h0,
                                                            const float* __restrict__ Wg, const float* __restrict__ bgp,
@@ -225,8 +225,14 @@ __global__ void readout_bwd_final_kernel(const float* __restrict__ partials, int
     const int W = 3 * D + 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * W + i];
+    float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // eight independent chains, fixed combination order
+    int b = 0;
+    for (; b + 8 <= nblocks; b += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] += partials[(size_t)(b + q) * W + i];
+    }
+    for (int q = 0; b < nblocks; ++b, ++q) c[q] += partials[(size_t)b * W + i];
+    const float s = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
     if (i < 2 * D) d_gate_W[i] = s;
     else if (i < 3 * D) d_transform_W[i - 2 * D] = s;
     else if (i == 3 * D) d_gate_b[0] = s;

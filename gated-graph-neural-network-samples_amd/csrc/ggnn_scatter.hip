@@ -84,7 +84,7 @@ template <int LPR>
 __global__ __launch_bounds__(256) void gather_segment_sum_kernel(
         const float* __restrict__ H, const int* __restrict__ row_ptr, const int* __restrict__ gidx,
         const float* __restrict__ nin, const float* __restrict__ bias, int use_avg, float* __restrict__ out,
-        int V, int D, int T) {
+        int V, int D, int T, int accumulate) {
     constexpr int NODES = 256 / LPR;
     const int l = threadIdx.x % LPR;
     int v = blockIdx.x * NODES + threadIdx.x / LPR;
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void gather_segment_sum_kernel(
                 acc += b;
             }
             if (use_avg) acc = acc / den;                     // :206-209
+            if (accumulate) acc += *reinterpret_cast<const f32x4*>(out + (size_t)v * D + 4 * c4);
             *reinterpret_cast<f32x4*>(out + (size_t)v * D + 4 * c4) = acc;
         }
     }
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void gather_segment_sum_kernel(
 __global__ __launch_bounds__(256) void gather_segment_sum_flat_kernel(
         const float* __restrict__ H, const int* __restrict__ row_ptr, const int* __restrict__ gidx,
         const float* __restrict__ nin, const float* __restrict__ bias, int use_avg, float* __restrict__ out,
-        long long total4, int D, int T) {
+        long long total4, int D, int T, int accumulate) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total4) return;
     const int D4 = D >> 2;
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(256) void gather_segment_sum_flat_kernel(
         if (bias) acc += b;
         if (use_avg) acc = acc / (deg + 1e-7f);
     }
+    if (accumulate) acc += *reinterpret_cast<const f32x4*>(out + (size_t)v * D + 4 * c4);
     *reinterpret_cast<f32x4*>(out + (size_t)v * D + 4 * c4) = acc;
 }
 
@@ -308,9 +310,9 @@ extern "C" int ggnn_build_source_csr(const int32_t* adj, const int64_t* type_off
     return build_csr(adj, type_off, T, V, M, 1, row_ptr, gather_row, msg_perm, err_flag, ws, ws_bytes, stream);
 }
 
-extern "C" int ggnn_gather_segment_sum_f32(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row,
-                                           const float* nin, const float* bias, int use_avg, float* out, int V,
-                                           int D, int T, ggnn_stream_t stream) {
+static int gather_segment_sum_impl(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row,
+                                   const float* nin, const float* bias, int use_avg, float* out, int V,
+                                   int D, int T, int accumulate, ggnn_stream_t stream) {
     GGNN_CHECK_ARG(V >= 0 && D > 0 && D % 4 == 0 && T > 0, "bad sizes V=%d D=%d T=%d", V, D, T);
     if (V == 0) return GGNN_OK;
     GGNN_CHECK_ARG(Hrows && row_ptr && out, "null pointer");
@@ -326,19 +328,31 @@ extern "C" int ggnn_gather_segment_sum_f32(const float* Hrows, const int32_t* ro
     if (flat) {
         const long long total4 = (long long)V * D4;
         hipLaunchKernelGGL(gather_segment_sum_flat_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, Hrows,
-                           row_ptr, gather_row, nin, bias, use_avg, out, total4, D, T);
+                           row_ptr, gather_row, nin, bias, use_avg, out, total4, D, T, accumulate);
     } else if (D4 <= 16) {
         hipLaunchKernelGGL(gather_segment_sum_kernel<16>, dim3((V + 15) / 16), dim3(256), 0, st, Hrows, row_ptr,
-                           gather_row, nin, bias, use_avg, out, V, D, T);
+                           gather_row, nin, bias, use_avg, out, V, D, T, accumulate);
     } else if (D4 <= 32) {
         hipLaunchKernelGGL(gather_segment_sum_kernel<32>, dim3((V + 7) / 8), dim3(256), 0, st, Hrows, row_ptr,
-                           gather_row, nin, bias, use_avg, out, V, D, T);
+                           gather_row, nin, bias, use_avg, out, V, D, T, accumulate);
     } else {
         hipLaunchKernelGGL(gather_segment_sum_kernel<64>, dim3((V + 3) / 4), dim3(256), 0, st, Hrows, row_ptr,
-                           gather_row, nin, bias, use_avg, out, V, D, T);
+                           gather_row, nin, bias, use_avg, out, V, D, T, accumulate);
     }
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
+}
+
+extern "C" int ggnn_gather_segment_sum_f32(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row,
+                                           const float* nin, const float* bias, int use_avg, float* out, int V,
+                                           int D, int T, ggnn_stream_t stream) {
+    return gather_segment_sum_impl(Hrows, row_ptr, gather_row, nin, bias, use_avg, out, V, D, T, 0, stream);
+}
+
+// out[v] += sum of the gathered rows (backward pass: several gradient contributions meet in one [V,D] tensor)
+extern "C" int ggnn_gather_segment_sum_acc_f32(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row, float* out,
+                                               int V, int D, ggnn_stream_t stream) {
+    return gather_segment_sum_impl(Hrows, row_ptr, gather_row, nullptr, nullptr, 0, out, V, D, 1, 1, stream);
 }
 
 extern "C" int ggnn_gather_segment_sum_attn_f32(const float* Hrows, const float* h, const int32_t* row_ptr,

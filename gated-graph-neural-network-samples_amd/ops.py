@@ -298,6 +298,60 @@ def gemm_tn(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def xty(x_segs: Sequence[torch.Tensor], dy: torch.Tensor, x_rows: Optional[torch.Tensor] = None,
+        row_off: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """Weight-gradient product  concat(x_segs, dim=1)^T @ dy  on ggnn_xty_f32 (no concat materialised; deterministic).
+    x_segs: [M', Dseg] float32 tensors with unit column stride (any row stride: column slices are fine); dy [M, N], N <= 208.
+    x_rows (int32 [M]): row r of the X operand is x_segs[.][x_rows[r]] (edge-weight gradients on compact rows).
+    row_off (host ints [B+1]): B independent products over the row ranges -> [B, K, N]; default one product -> [K, N]."""
+    lib = _lib.load()
+    nseg = len(x_segs)
+    Dseg = x_segs[0].shape[1]
+    for i, x in enumerate(x_segs):
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != Dseg or (x.shape[0] > 1 and x.stride(1) != 1):
+            raise TypeError("x_segs[%d] must be a [M, %d] float32 CUDA/HIP tensor with unit column stride" % (i, Dseg))
+    if not dy.is_cuda or dy.dtype != torch.float32 or dy.dim() != 2 or (dy.shape[0] > 1 and dy.stride(1) != 1):
+        raise TypeError("dy must be a 2-D float32 CUDA/HIP tensor with unit column stride")
+    M, N = dy.shape
+    K = nseg * Dseg
+    batched = row_off is not None
+    offs = [0, M] if row_off is None else [int(o) for o in row_off]
+    B = len(offs) - 1
+    out = torch.empty((B, K, N), dtype=torch.float32, device=dy.device)
+    m_max = max([offs[b + 1] - offs[b] for b in range(B)] + [0])
+    ws_bytes = lib.ggnn_xty_workspace_bytes(m_max, K, N, B)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+    segs = (ctypes.c_void_p * nseg)(*[x.data_ptr() for x in x_segs])
+    ldx = (ctypes.c_int32 * nseg)(*[(x.stride(0) if x.shape[0] > 1 else Dseg) for x in x_segs])
+    ro = (ctypes.c_int32 * (B + 1))(*offs)
+    ldy = dy.stride(0) if M > 1 else N
+    if x_rows is not None:
+        _req(x_rows, torch.int32, "x_rows")
+    _launch("xty[K=%d,N=%d%s]" % (K, N, ",x%d" % B if batched else ""), lambda: lib.ggnn_xty_f32(
+        segs, nseg, Dseg, ldx, _ptr(x_rows), _ptr(dy), ldy, _ptr(out), K, N, ro, B, _ptr(ws), ws_bytes, _stream()))
+    return out if batched else out[0]
+
+
+def colsum(dy: torch.Tensor) -> torch.Tensor:
+    """Deterministic column sums of a [M, N] float32 matrix (bias gradients)."""
+    lib = _lib.load()
+    M, N = dy.shape
+    out = torch.empty(N, dtype=torch.float32, device=dy.device)
+    ws_bytes = lib.ggnn_colsum_workspace_bytes(N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+    _launch("colsum[N=%d]" % N, lambda: lib.ggnn_colsum_f32(_ptr(dy), dy.stride(0) if M > 1 else N, M, N, _ptr(out), _ptr(ws), ws_bytes, _stream()))
+    return out
+
+
+def segment_sum_rows_acc(rows: torch.Tensor, index, out: torch.Tensor) -> torch.Tensor:
+    """out[s,:] += sum of rows[index.gather_row[slot],:] over the slots of segment s (ggnn_gather_segment_sum_acc_f32)."""
+    lib = _lib.load()
+    _req(rows, torch.float32, "rows"); _req(out, torch.float32, "out")
+    _launch("gather_segment_sum_acc", lambda: lib.ggnn_gather_segment_sum_acc_f32(
+        _ptr(rows), _ptr(index.row_ptr), _ptr(index.gather_row), _ptr(out), index.num_nodes, rows.shape[1], _stream()))
+    return out
+
+
 def unsorted_segment_sum(data: torch.Tensor, segment_ids: torch.Tensor, num_segments: int) -> torch.Tensor:
     """tf.unsorted_segment_sum (fp32 atomics; any id order).  data [M,D] or [M], ids [M] int32."""
     lib = _lib.load()

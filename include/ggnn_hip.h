@@ -307,6 +307,34 @@ size_t ggnn_gemm_tn_workspace_bytes(int M, int K, int N);
 int ggnn_gemm_tn_f32(const float* A, int lda, const float* B, int ldb, float* C, int M, int K, int N, void* ws,
                      size_t ws_bytes, ggnn_stream_t stream);
 
+/* ---- (a-B) backward GEMMs of one propagation timestep, hand-written (ggnn_bwd_gemm.hip) ---------------------------------------
+ * What TF autodiff derives from chem_tensorflow_sparse.py:160-164, 211-216 through compute_gradients (chem_tensorflow.py:184).
+ *
+ * ggnn_xty_f32: C[b] = X[rows of batch b]^T Y[rows of batch b]   -- every weight gradient (dW = X^T dY).
+ *   X is given as nseg <= 4 column segments of Dseg columns each (HOST arrays x_segs / ldx: pointers and row strides), so the
+ *   [residuals | incoming | h] operand of the GRU kernels is never concatenated; x_rows (device int32, or NULL) gathers the X
+ *   rows (edge-weight gradients: X row of compact row r = h[pair_node[r]]); row_off HOST [nbatch+1] splits the rows into batches
+ *   with one [K,N] output each (one per edge type).  K = nseg * Dseg, N <= 208, N % 4 == 0.  Deterministic (fixed-order split
+ *   reduction).  ws: ggnn_xty_workspace_bytes(largest batch, K, N, nbatch).
+ * ggnn_colsum_f32: out[n] = sum_v Y[v, n]  (bias gradients), deterministic.
+ * ggnn_gru_bwd_dx_cand_f32:  P = dpc Wc^T (WcT = Wc^T, [D, (nx+1)D] row-major):  dx [V, nx*D] = P[:, x columns];
+ *   dh += P[:, h columns] * r;  dpg[:, 0:D] = P[:, h columns] * h * r * (1 - r)       (the stage-2 algebra, fused)
+ * ggnn_gru_bwd_dx_gates_f32: Q = dpg Wg^T (WgT [2D, (nx+1)D]):  dx[:, residual columns] += Q;
+ *   dinc [V,D] = (dx[:, last segment] + Q) (/ (sum_t nin + 1e-7) with use_avg, chem_tensorflow_sparse.py:206-209);  dh += Q[:, h columns]
+ * ggnn_gather_segment_sum_acc_f32: out[v] += sum of the gathered rows (several gradient contributions meet in one tensor). */
+size_t ggnn_xty_workspace_bytes(int M_max, int K, int N, int nbatch);
+int ggnn_xty_f32(const float* const* x_segs, int nseg, int Dseg, const int32_t* ldx, const int32_t* x_rows, const float* Y,
+                 int ldy, float* C, int K, int N, const int32_t* row_off, int nbatch, void* ws, size_t ws_bytes,
+                 ggnn_stream_t stream);
+size_t ggnn_colsum_workspace_bytes(int N);
+int ggnn_colsum_f32(const float* Y, int ldy, int M, int N, float* out, void* ws, size_t ws_bytes, ggnn_stream_t stream);
+int ggnn_gru_bwd_dx_cand_f32(const float* dpc, const float* WcT, const float* h, const float* r, float* dx, float* dh,
+                             float* dpg, int nx, int V, int D, ggnn_stream_t stream);
+int ggnn_gru_bwd_dx_gates_f32(const float* dpg, const float* WgT, float* dx, float* dinc, const float* nin, int T,
+                              int use_avg, float* dh, int nx, int V, int D, ggnn_stream_t stream);
+int ggnn_gather_segment_sum_acc_f32(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row, float* out,
+                                    int V, int D, ggnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
