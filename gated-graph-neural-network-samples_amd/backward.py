@@ -119,31 +119,17 @@ class PropagationStepFn(torch.autograd.Function):
         act = ops.ACT_IDS[ctx.activation]
         xs = list(residuals) + [incoming]
 
-        # ---- 1. GRU blend and candidate:  h' = u*h + (1-u)*c,  c = act([x | r*h] Wc + bc)
-        dpc = torch.empty_like(h)
-        dpg = torch.empty((V, 2 * D), dtype=torch.float32, device=dev)         # [d pre-r | d pre-u]
-        dh = torch.empty_like(h)
-        rh = torch.empty_like(h)
-        ops._launch("gru_bwd_stage1", lambda: lib.ggnn_gru_bwd_stage1_f32(
-            g.data_ptr(), h.data_ptr(), r.data_ptr(), u.data_ptr(), c.data_ptr(), act, dpc.data_ptr(), dpg.data_ptr(),
-            dh.data_ptr(), rh.data_ptr(), D, 0, V, D, st))
-        # ---- 2. candidate weights
-        dWc = ops.xty(xs + [rh], dpc)
-        dbc = ops.colsum(dpc)
-        # ---- 3. dpc Wc^T; gates pre-activation gradients ([r|u] = sigmoid([x | h] Wg + bg))
-        dx = torch.empty((V, nx * D), dtype=torch.float32, device=dev)
-        ops._launch("gru_bwd_dx_cand[nx=%d]" % nx, lambda: lib.ggnn_gru_bwd_dx_cand_f32(
-            dpc.data_ptr(), _TRANSPOSED.get(Wc).data_ptr(), h.data_ptr(), r.data_ptr(), dx.data_ptr(), dh.data_ptr(), dpg.data_ptr(),
-            nx, V, D, st))
-        # ---- 4. gate weights
-        dWg = ops.xty(xs + [h], dpg)
-        dbg = ops.colsum(dpg)
-        # ---- 5. dpg Wg^T; mean aggregation (chem_tensorflow_sparse.py:206-209)
-        dinc = torch.empty_like(h)
-        ops._launch("gru_bwd_dx_gates[nx=%d]" % nx, lambda: lib.ggnn_gru_bwd_dx_gates_f32(
-            dpg.data_ptr(), _TRANSPOSED.get(Wg).data_ptr(), dx.data_ptr(), dinc.data_ptr(), nin.data_ptr(), T, 1 if ctx.use_avg else 0,
-            dh.data_ptr(), nx, V, D, st))
-        d_res = [dx[:, i * D:(i + 1) * D] for i in range(nx - 1)]
+        if ops.gru_bwd_is_fused(D):
+            # ---- 1.-5. in ONE launch: gate algebra, dX products, mean aggregation; dpc / dpg / r*h written for the dW products
+            from .autograd import _PACKED
+            dpc, dpg, rh, dh, dxs = ops.gru_bwd_fused(g, h, r, u, c, _PACKED.gru_bwd(Wg, Wc, nx, D), nin, ctx.use_avg, nx, ctx.activation)
+            dinc = dxs[-1]
+            d_res = dxs[:-1]
+            Kx = (nx + 1) * D
+            wc = ops.xty(xs + [rh], dpc, ones_row=True); dWc, dbc = wc[:Kx], wc[Kx]      # bias gradient = the ones row
+            wg = ops.xty(xs + [h], dpg, ones_row=True); dWg, dbg = wg[:Kx], wg[Kx]
+        else:
+            dpc, dpg, dh, dinc, d_res, dWc, dbc, dWg, dbg = _gru_backward_unfused(lib, g, h, r, u, c, Wg, Wc, nin, xs, nx, T, act, ctx.use_avg, st)
         dbias = None
         if ctx.has_bias:                                                       # :202-204  incoming += nin @ edge_biases
             dbias = ops.xty([dinc], nin).t().contiguous()                      # (dinc^T nin)^T = nin^T dinc   [T, D]
@@ -161,6 +147,37 @@ class PropagationStepFn(torch.autograd.Function):
         else:
             dW = torch.zeros_like(W)
         return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, *d_res)
+
+
+def _gru_backward_unfused(lib, g, h, r, u, c, Wg, Wc, nin, xs, nx, T, act, use_avg, st):
+    """Steps 1-5 as separate launches (hidden sizes without the fused backward kernel)."""
+    V, D = h.shape
+    dev = h.device
+    # ---- 1. GRU blend and candidate:  h' = u*h + (1-u)*c,  c = act([x | r*h] Wc + bc)
+    dpc = torch.empty_like(h)
+    dpg = torch.empty((V, 2 * D), dtype=torch.float32, device=dev)         # [d pre-r | d pre-u]
+    dh = torch.empty_like(h)
+    rh = torch.empty_like(h)
+    ops._launch("gru_bwd_stage1", lambda: lib.ggnn_gru_bwd_stage1_f32(
+        g.data_ptr(), h.data_ptr(), r.data_ptr(), u.data_ptr(), c.data_ptr(), act, dpc.data_ptr(), dpg.data_ptr(),
+        dh.data_ptr(), rh.data_ptr(), D, 0, V, D, st))
+    # ---- 2. candidate weights (+ bias: the ones row of the same product)
+    Kx = (nx + 1) * D
+    wc = ops.xty(xs + [rh], dpc, ones_row=True); dWc, dbc = wc[:Kx], wc[Kx]
+    # ---- 3. dpc Wc^T; gates pre-activation gradients ([r|u] = sigmoid([x | h] Wg + bg))
+    dx = torch.empty((V, nx * D), dtype=torch.float32, device=dev)
+    ops._launch("gru_bwd_dx_cand[nx=%d]" % nx, lambda: lib.ggnn_gru_bwd_dx_cand_f32(
+        dpc.data_ptr(), _TRANSPOSED.get(Wc).data_ptr(), h.data_ptr(), r.data_ptr(), dx.data_ptr(), dh.data_ptr(), dpg.data_ptr(),
+        nx, V, D, st))
+    # ---- 4. gate weights
+    wg = ops.xty(xs + [h], dpg, ones_row=True); dWg, dbg = wg[:Kx], wg[Kx]
+    # ---- 5. dpg Wg^T; mean aggregation (chem_tensorflow_sparse.py:206-209)
+    dinc = torch.empty_like(h)
+    ops._launch("gru_bwd_dx_gates[nx=%d]" % nx, lambda: lib.ggnn_gru_bwd_dx_gates_f32(
+        dpg.data_ptr(), _TRANSPOSED.get(Wg).data_ptr(), dx.data_ptr(), dinc.data_ptr(), nin.data_ptr(), T, 1 if use_avg else 0,
+        dh.data_ptr(), nx, V, D, st))
+    d_res = [dx[:, i * D:(i + 1) * D] for i in range(nx - 1)]
+    return dpc, dpg, dh, dinc, d_res, dWc, dbc, dWg, dbg
 
 
 def _backward_dense_form(ctx, g):

@@ -29,6 +29,7 @@ struct XtyArgs {
     const float* Y; int ldy;                                // dY(v, n)
     float* part;                                            // partial products [batch][split][K][N]
     int K, N, nbatch, splits;
+    int Kout;                                               // K, or K + 1: row K of the product is 1^T dY (column sums = bias gradient)
     int row_off[kXtyMaxBatch + 1];                          // batch b owns rows row_off[b] .. row_off[b+1]-1
     int kb_tiles;                                           // 16-column tiles of X per workgroup
     int pitch_x, pitch_y;                                   // LDS row pitches in floats
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(MT >= 2 ? 512 : 832) void xty_kernel(XtyArgs a) {
     const int px = a.pitch_x, py = a.pitch_y;
     float* sx = slab;
     float* sy = slab + 2 * kXtyRows * px;
-    float* out = a.part + ((size_t)batch * a.splits + split) * a.K * a.N;
+    float* out = a.part + ((size_t)batch * a.splits + split) * a.Kout * a.N;
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(MT >= 2 ? 512 : 832) void xty_kernel(XtyArgs a) {
         };
 
         const int ktile0 = wave * MT;                                 // this wave's first X tile inside the workgroup's block
-        const bool wave_on = ktile0 < a.kb_tiles && kcol0 + ktile0 * 16 < a.K;
+        const bool wave_on = ktile0 < a.kb_tiles && kcol0 + ktile0 * 16 < a.Kout;
         int buf = 0;
         fetch_rows(r_beg);
         issue(0, r_beg);
@@ -174,7 +175,10 @@ __global__ __launch_bounds__(MT >= 2 ? 512 : 832) void xty_kernel(XtyArgs a) {
                     const bool row_ok = 4 * s + kq < nvalid;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        const float xv = row_ok ? xa[s & 1][mt] : 0.f;
+                        float xv = xa[s & 1][mt];
+                        // the "ones" column K of X (Kout == K + 1): its row of the product is the column sum of dY
+                        if (a.Kout > a.K && kcol0 + (ktile0 + mt) * 16 + li == a.K) xv = 1.0f;
+                        xv = row_ok ? xv : 0.f;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, yb[s & 1][nt], acc[mt][nt], 0, 0, 0);
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(MT >= 2 ? 512 : 832) void xty_kernel(XtyArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int k = k0 + 4 * kq + e;
-                            if (k < a.K) out[(size_t)k * a.N + n] = acc[mt][nt][e];
+                            if (k < a.Kout) out[(size_t)k * a.N + n] = acc[mt][nt][e];
                         }
                     }
                 }
@@ -228,9 +232,9 @@ __global__ void xty_reduce_kernel(const float* __restrict__ part, float* __restr
 
 struct XtyPlan { int mt, nt, nw, kb_tiles, kblocks, splits; size_t lds; };
 
-static XtyPlan xty_plan(int M_max, int K, int N, int nbatch) {
+static XtyPlan xty_plan(int M_max, int Kout, int N, int nbatch) {
     XtyPlan p{};
-    const int ktiles = (K + 15) / 16;
+    const int ktiles = (Kout + 15) / 16;
     p.nt = N <= 112 ? 7 : 13;
     p.mt = N <= 112 ? 2 : 1;
     const int max_w = p.mt >= 2 ? 8 : 13;                            // waves per workgroup (register budget: launch bounds)
@@ -264,8 +268,8 @@ static int launch_xty(const XtyArgs& a, const XtyPlan& p, float* C, hipStream_t 
     if (p.lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&xty_kernel<MT, NT, GATHER>, p.lds, lds_ok));
     hipLaunchKernelGGL((xty_kernel<MT, NT, GATHER>), dim3(p.kblocks, p.splits, a.nbatch), dim3(p.nw * 64), p.lds, st, a);
     GGNN_CHECK_HIP(hipGetLastError());
-    const long long total = (long long)a.K * a.N * a.nbatch;
-    hipLaunchKernelGGL(xty_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)a.part, C, a.K * a.N,
+    const long long total = (long long)a.Kout * a.N * a.nbatch;
+    hipLaunchKernelGGL(xty_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)a.part, C, a.Kout * a.N,
                        p.splits, a.nbatch);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
@@ -314,13 +318,14 @@ using namespace ggnn;
 
 extern "C" size_t ggnn_xty_workspace_bytes(int M_max, int K, int N, int nbatch) {
     if (M_max <= 0 || K <= 0 || N <= 0 || nbatch <= 0) return 256;
-    const XtyPlan p = xty_plan(M_max, K, N, nbatch);
-    return (size_t)p.splits * nbatch * K * N * sizeof(float) + 256;
+    const XtyPlan p = xty_plan(M_max, K + 1, N, nbatch);             // (sized for the ones-row form)
+    return (size_t)p.splits * nbatch * (K + 1) * N * sizeof(float) + 256;
 }
 
 extern "C" int ggnn_xty_f32(const float* const* x_segs, int nseg, int Dseg, const int32_t* ldx, const int32_t* x_rows,
-                            const float* Y, int ldy, float* C, int K, int N, const int32_t* row_off, int nbatch, void* ws,
-                            size_t ws_bytes, ggnn_stream_t stream) {
+                            const float* Y, int ldy, float* C, int K, int N, int ones_row, const int32_t* row_off, int nbatch,
+                            void* ws, size_t ws_bytes, ggnn_stream_t stream) {
+    const int Kout = ones_row ? K + 1 : K;
     GGNN_CHECK_ARG(nseg >= 1 && nseg <= 4 && Dseg > 0 && Dseg % 4 == 0 && K == nseg * Dseg, "X is nseg <= 4 segments of Dseg columns (K = %d, nseg = %d, Dseg = %d)", K, nseg, Dseg);
     GGNN_CHECK_ARG(N > 0 && N % 4 == 0 && N <= 208, "N = %d must be a multiple of 4, <= 208", N);
     GGNN_CHECK_ARG(nbatch >= 1 && nbatch <= kXtyMaxBatch && row_off && C && ldx, "bad batch description");
@@ -333,7 +338,7 @@ extern "C" int ggnn_xty_f32(const float* const* x_segs, int nseg, int Dseg, cons
         if (b) { GGNN_CHECK_ARG(row_off[b] >= row_off[b - 1], "row_off not monotone"); m_max = row_off[b] - row_off[b - 1] > m_max ? row_off[b] - row_off[b - 1] : m_max; }
     }
     if (m_max == 0) {
-        GGNN_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)nbatch * K * N * sizeof(float), st));
+        GGNN_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)nbatch * Kout * N * sizeof(float), st));
         return GGNN_OK;
     }
     GGNN_CHECK_ARG(x_segs && Y && ws && aligned16(Y) && aligned16(ws), "null or misaligned pointer");
@@ -342,7 +347,8 @@ extern "C" int ggnn_xty_f32(const float* const* x_segs, int nseg, int Dseg, cons
         a.X[s] = x_segs[s]; a.ldx[s] = ldx[s];
     }
     if (ws_bytes < ggnn_xty_workspace_bytes(m_max, K, N, nbatch)) return fail(GGNN_E_WORKSPACE, "xty workspace too small");
-    const XtyPlan p = xty_plan(m_max, K, N, nbatch);
+    const XtyPlan p = xty_plan(m_max, Kout, N, nbatch);
+    a.Kout = Kout;
     a.nseg = nseg; a.Dseg = Dseg; a.x_rows = x_rows; a.Y = Y; a.ldy = ldy; a.part = static_cast<float*>(ws);
     a.K = K; a.N = N; a.nbatch = nbatch; a.splits = p.splits; a.kb_tiles = p.kb_tiles;
     a.pitch_x = xty_pitch(p.kb_tiles * 16); a.pitch_y = xty_pitch(p.nt * 16);

@@ -1,0 +1,377 @@
+// Backward of the GRU node update (TF autodiff of GRUCell, chem_tensorflow_sparse.py:211-216 through
+// chem_tensorflow.py:184) as ONE launch -- the mirror image of ggnn_gru_fused.hip:
+//
+//   given g = dL/dh' and the saved h, r, u, c of the forward pass
+//     dpc = g (1-u) act'(c)        dpu = g (h-c) u (1-u)                                (element-wise, in registers)
+//     drh = dpc Wc^T[h rows]       dpr = drh h r (1-r)                                  (GEMM -> epilogue -> next operand)
+//     dh  = g u + drh r + dpr Wg_r^T[h rows] + dpu Wg_u^T[h rows]
+//     dx_s = dpc Wc^T[x_s rows] + dpr Wg_r^T[x_s rows] + dpu Wg_u^T[x_s rows]           s = 0 .. nx-1
+//     d_incoming = dx_{nx-1} / (sum_t nin + 1e-7)                                       (mean aggregation, :206-209)
+//   and, for the weight-gradient products that follow (ggnn_xty_f32), dpc, [dpr | dpu] and r*h are written once.
+//
+// Like the forward kernel it chains through registers: a wave owns 16 rows; dpc / dpr / dpu live as activation fragments
+// (lane (row, kq) holds columns 16c + 4kq + e), the D x D blocks of Wc^T / Wg^T stream through a 2-deep LDS-DMA ring as
+// k-interleaved stage images (ggnn_stage.hpp), and because output tile nt of the MFMA core IS activation chunk c = nt, drh
+// comes out of its GEMM stage already in the layout the next stages consume (only the D % 16 remainder column needs
+// cross-lane reads).  3 (nx + 1) stages per 16-row tile -- the same MFMA count as the forward pass -- replace the five
+// launches of the first backward (element-wise stage 1, two dX GEMMs with epilogues, two passes of stage-2 algebra) and the
+// [V,K] intermediates between them.
+//
+// Stage order per tile:   h block of Wc^T (-> drh, dpr);  h blocks of Wg_r^T, Wg_u^T (-> dh);
+//                         then per x segment: Wc^T, Wg_r^T, Wg_u^T blocks (-> dx_s)
+#include "ggnn_stage.hpp"
+#include <type_traits>
+
+namespace ggnn {
+
+struct GruBwdArgs {
+    const float* g; const float* h; const float* r; const float* u; const float* c;
+    float* dpc; float* dpg; float* rh; float* dh;
+    float* dx[3];                       // nx outputs [V,D]; the last one is d_incoming (scaled when use_avg)
+    const float* nin; int T; int use_avg;
+    int nx; int V; int act;
+};
+
+// image i of the packed backward weights (image[k][n] = B(k, n) with out[:, n] = sum_k A[:, k] B(k, n)):
+//   0: Wc^T h block      B(k,n) = Wc[nx*D + n][k]
+//   1: Wg_r^T h block    B(k,n) = Wg[nx*D + n][k]          2: Wg_u^T h block   B(k,n) = Wg[nx*D + n][D + k]
+//   3 + 3s + {0,1,2}: the same three for x segment s (rows s*D + n)
+template <int D>
+__global__ void gru_bwd_pack_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx, float* __restrict__ out) {
+    using C = StageCfg<D>;
+    const int i = blockIdx.y;
+    const int seg = i < 3 ? nx : (i - 3) / 3, which = i < 3 ? i : (i - 3) % 3;
+    const float* W = which == 0 ? Wc : Wg;
+    const int ldw = which == 0 ? D : 2 * D;
+    const int c0 = which == 2 ? D : 0;
+    float* img = out + (size_t)i * C::IMG;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < C::IMG; j += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        int k = -1, n = 0;
+        if (j < C::MAIN) {
+            const int e = j & 3; n = (j >> 2) % C::BN; const int ck = (j >> 2) / C::BN;
+            k = 4 * ck + e;
+        } else if (j < C::MAIN + C::REM) {
+            const int jj = j - C::MAIN;
+            n = jj % C::BN; k = 16 * C::NC + jj / C::BN;
+        }
+        if (k >= 0 && n < D) v = W[(size_t)(seg * D + n) * ldw + c0 + k];          // transposed read
+        img[j] = v;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void store_frag(float* base, int row, int kq, const Frag<D>& f) {
+    constexpr int NC = StageCfg<D>::NC, NR = StageCfg<D>::NR;
+    const unsigned ob = ((unsigned)row * (unsigned)D + 4u * (unsigned)kq) * 4u;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) st4_b(base, ob + 64u * c, f.v[c]);
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + ((unsigned)row * (unsigned)D + 16u * NC + 4u * q + (unsigned)kq) * 4u) = f.r[q];
+}
+
+template <int D, int NX, int NW, bool PREFETCH, int RING>
+__global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs a, const float* __restrict__ packed) {
+    using C = StageCfg<D>;
+    constexpr int NT = C::NT, NC = C::NC, NR = C::NR;
+    constexpr int NSTAGE = 3 * (NX + 1);
+    extern __shared__ __attribute__((aligned(16))) float ring[];    // [2][IMG]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const bool late = wave >= NW / 2;
+
+    // static tickets: full rounds of NW tiles per workgroup, then the rest spread thin (tail_w tiles per workgroup)
+    const int wt_total = (a.V + 15) / 16;
+    const int nb = gridDim.x;
+    const int full_tk = wt_total / (NW * nb) * nb;
+    const int rest = wt_total - full_tk * NW;
+    const int tail_w = (rest + nb - 1) / nb;
+    const int n_tk = full_tk + (tail_w ? (rest + tail_w - 1) / tail_w : 0);
+    auto tile_of = [&](int t) -> int {
+        if (t < full_tk) return t * NW + wave;
+        if (t >= n_tk) return -1;
+        const int tl = full_tk * NW + (t - full_tk) * tail_w + wave;
+        return (wave < tail_w && tl < wt_total) ? tl : -1;
+    };
+
+    // Raw inputs of a tile (g, u, c, h, r as activation fragments).  They are fetched one pass AHEAD -- at the start of the
+    // last stage of the previous pass, when only dpu of the current tile is still live -- so that no pass starts with an
+    // exposed load phase; the first tile's are fetched before the loop.
+    struct Raw { Frag<D> g, u, c, h, r; };
+    auto fetch_raw = [&](Raw& x, int t, int part) {           // part 0: g, u, c, h;  part 1: r
+        const int tile = tile_of(t);
+        const int r0 = (tile >= 0 ? tile : 0) * 16 + li;
+        const int rc = r0 < a.V ? r0 : a.V - 1;
+        if (part == 0) {
+            load_frag<D>(x.g, a.g, rc, kq); load_frag<D>(x.u, a.u, rc, kq); load_frag<D>(x.c, a.c, rc, kq);
+            load_frag<D>(x.h, a.h, rc, kq);
+        } else {
+            load_frag<D>(x.r, a.r, rc, kq);
+        }
+    };
+    // value of accumulator-layout tile NC (the D % 16 remainder columns 16NC .. +3, held by the kq == 0 lanes) from a fragment:
+    // column 16NC + e is the remainder element of lane (li, kq' = e)
+    auto rem_tile = [&](const Frag<D>& f) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (NR > 0) {
+            v.x = __shfl(f.r[0], li); v.y = __shfl(f.r[0], li + 16); v.z = __shfl(f.r[0], li + 32); v.w = __shfl(f.r[0], li + 48);
+        }
+        return v;
+    };
+    static_assert(NR <= 1, "remainder handling covers D % 16 in {0, 4}");
+
+    int cur = 0;
+    if constexpr (RING == 2) dma_stage_image<D, NW>(packed, ring, wave, lane);
+    Raw raw;
+    if (PREFETCH && (int)blockIdx.x < n_tk) { fetch_raw(raw, blockIdx.x, 0); fetch_raw(raw, blockIdx.x, 1); }
+    __syncthreads();
+
+    // A wave has tiles in a PREFIX of its workgroup's passes (full tickets, then possibly a thin tail ticket), so the passes run
+    // as two loops -- with a tile, without -- instead of one loop with a branch: the prefetched raw fragments are carried from
+    // pass to pass, and a diamond in the loop body would put 125 registers through phi copies.
+    int tk = blockIdx.x;
+    auto run_pass = [&](auto active_c) {
+        const int tile = tile_of(tk);
+        const bool last_pass = tk + nb >= n_tk;
+        {
+            constexpr bool ACT = decltype(active_c)::value;      // (two pass bodies instead of a branch per stage: ggnn_panel.hip)
+            const int row = (ACT ? tile : 0) * 16 + li;
+            const bool row_ok = ACT && row < a.V;
+
+            auto stage = [&](auto zero_c, f32x4 (&acc)[NT], const Frag<D>& A, int img_idx, auto&& before, auto&& after) {
+                const int nidx = img_idx + 1 < NSTAGE ? img_idx + 1 : 0;
+                const bool more = (img_idx + 1 < NSTAGE) || !last_pass;
+                const float* nsrc = packed + (size_t)nidx * C::IMG;
+                float* ndst = ring + (cur ^ 1) * C::IMG;
+                before();
+                if constexpr (RING == 1) {
+                    // one image in LDS (two of these 4-wave workgroups share a CU and run out of phase: the DMA wait and the
+                    // load / epilogue phases of one are covered by the MFMAs of the other)
+                    __syncthreads();                                   // the previous stage's image has been consumed
+                    dma_stage_image<D, NW>(packed + (size_t)img_idx * C::IMG, ring, wave, lane);
+                    __syncthreads();                                   // (vmcnt(0) + barrier: landed)
+                    if constexpr (ACT) stage_mma<D, NoHook, NT, decltype(zero_c)::value>(acc, A, ring, li, kq);
+                    after();
+                } else {
+                    if (late && more) dma_stage_image<D, NW>(nsrc, ndst, wave, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (ACT) stage_mma<D, NoHook, NT, decltype(zero_c)::value>(acc, A, ring + cur * C::IMG, li, kq);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!late && more) dma_stage_image<D, NW>(nsrc, ndst, wave, lane);
+                    after();
+                    __syncthreads();
+                    cur ^= 1;
+                }
+            };
+            auto nothing = [] {};
+
+            // ---- element-wise head, in place on the raw fragments: g -> dpc, c -> dpu, u -> g*u, h -> h*r*(1-r) (r stays) ----------
+            Frag<D> dpc, dpu, gu, rf, hrr, dpr;
+            if constexpr (ACT) {
+                if constexpr (!PREFETCH) { fetch_raw(raw, tk, 0); fetch_raw(raw, tk, 1); }
+                auto dact = [&](float cv) { return a.act == GGNN_ACT_TANH ? 1.0f - cv * cv : (cv > 0.f ? 1.0f : 0.f); };
+                const unsigned os = ((unsigned)row * (unsigned)D + 4u * (unsigned)kq) * 4u;
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) {
+                    const f32x4 gv = raw.g.v[cc], uv = raw.u.v[cc], cv = raw.c.v[cc], hv = raw.h.v[cc], rv = raw.r.v[cc];
+                    const f32x4 omu = 1.0f - uv;
+                    const f32x4 da = {dact(cv.x), dact(cv.y), dact(cv.z), dact(cv.w)};
+                    dpc.v[cc] = gv * omu * da;
+                    dpu.v[cc] = gv * (hv - cv) * uv * omu;
+                    gu.v[cc] = gv * uv;
+                    rf.v[cc] = rv;
+                    hrr.v[cc] = hv * rv * (1.0f - rv);
+                    if (row_ok) {
+                        st4_b(a.dpc, os + 64u * cc, dpc.v[cc]);
+                        st4_b(a.rh, os + 64u * cc, rv * hv);         // the last segment of the [x | r*h] operand of dWc
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const float gv = raw.g.r[q], uv = raw.u.r[q], cv = raw.c.r[q], hv = raw.h.r[q], rv = raw.r.r[q];
+                    const float omu = 1.0f - uv;
+                    dpc.r[q] = gv * omu * dact(cv);
+                    dpu.r[q] = gv * (hv - cv) * uv * omu;
+                    gu.r[q] = gv * uv; rf.r[q] = rv; hrr.r[q] = hv * rv * (1.0f - rv);
+                    if (row_ok) {
+                        const unsigned o2 = ((unsigned)row * (unsigned)D + 16u * NC + 4u * q + (unsigned)kq) * 4u;
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(a.dpc) + o2) = dpc.r[q];
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(a.rh) + o2) = rv * hv;
+                    }
+                }
+            }
+
+            // ---- stage 0: drh = dpc Wc^T[h block]; dpr = drh h r (1-r); dh_part = drh r  (accumulator layout) ----------------
+            f32x4 acc[NT];
+            stage(std::true_type{}, acc, dpc, 0, nothing, nothing);
+            if constexpr (ACT) {
+                // accumulator tile nt == fragment chunk nt (same lanes, same columns); the remainder tile through rem_tile().
+                // dpr goes to its fragment, and the accumulator is re-used as the START value of the dh stages:
+                // acc = drh*r + g*u, onto which stages 1, 2 add dpr Wg_r^T + dpu Wg_u^T
+#pragma unroll
+                for (int nt = 0; nt < NC; ++nt) {
+                    dpr.v[nt] = acc[nt] * hrr.v[nt];
+                    acc[nt] = acc[nt] * rf.v[nt] + gu.v[nt];
+                }
+                if constexpr (NR > 0) {
+                    // remainder column 16NC + kq of dpr lives in tile NC of lane (li, kq' = 0), element kq
+                    const f32x4 dprt = acc[NT - 1] * rem_tile(hrr);
+                    const float t0 = __shfl(dprt.x, li), t1 = __shfl(dprt.y, li), t2 = __shfl(dprt.z, li), t3 = __shfl(dprt.w, li);
+                    dpr.r[0] = kq == 0 ? t0 : (kq == 1 ? t1 : (kq == 2 ? t2 : t3));
+                    acc[NT - 1] = acc[NT - 1] * rem_tile(rf) + rem_tile(gu);
+                }
+                if (row_ok) {                                               // dpg = [dpr | dpu], row stride 2D
+                    constexpr unsigned RS = 2u * D * 4u;
+                    const unsigned ob = (unsigned)row * RS + 16u * (unsigned)kq;
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        st4_b(a.dpg, ob + 64u * cc, dpr.v[cc]);
+                        st4_b(a.dpg, ob + D * 4u + 64u * cc, dpu.v[cc]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) {
+                        const unsigned o1 = (unsigned)row * RS + (16u * NC + 4u * q + (unsigned)kq) * 4u;
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(a.dpg) + o1) = dpr.r[q];
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(a.dpg) + o1 + D * 4u) = dpu.r[q];
+                    }
+                }
+            }
+
+            // ---- stages 1, 2: the h blocks of Wg^T -> dh = g u + drh r + dpr Wg_r^T + dpu Wg_u^T ------------------------------------
+            stage(std::false_type{}, acc, dpr, 1, nothing, nothing);
+            stage(std::false_type{}, acc, dpu, 2, nothing, nothing);
+            if constexpr (ACT) {
+                if (row_ok) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int col = nt * 16 + 4 * kq;
+                        if (col < D) st4_b(a.dh, ((unsigned)row * D + col) * 4u, acc[nt]);
+                    }
+                }
+            }
+
+            // ---- x segments: dx_s = dpc Wc^T + dpr Wg_r^T + dpu Wg_u^T; the LAST stage starts with the next tile's raw fetch -------
+            // (g, u, c, h before the burst of the last stage -- dpc, dpr are dead by then; r after it, when dpu is dead too:
+            //  all five at once overflow the register file by ~60 values)
+            auto fetch_next_a = [&] { if (PREFETCH && ACT && !last_pass) fetch_raw(raw, tk + nb, 0); };
+            auto fetch_next_b = [&] { if (PREFETCH && ACT && !last_pass) fetch_raw(raw, tk + nb, 1); };
+#define GGNN_BWD_SEG(S)                                                                                             \
+            if constexpr ((S) < NX) {                                                                               \
+                stage(std::true_type{}, acc, dpc, 3 + 3 * (S), nothing, nothing);                                   \
+                stage(std::false_type{}, acc, dpr, 4 + 3 * (S), nothing, nothing);                                  \
+                if constexpr ((S) == NX - 1) stage(std::false_type{}, acc, dpu, 5 + 3 * (S), fetch_next_a, fetch_next_b); \
+                else stage(std::false_type{}, acc, dpu, 5 + 3 * (S), nothing, nothing);                             \
+                if constexpr (ACT) {                                                                                \
+                    if (row_ok) {                                                                                   \
+                        float den = 1.0f;                                                                           \
+                        if ((S) == NX - 1 && a.use_avg) {                                                           \
+                            float deg = 0.f;                                                                        \
+                            for (int t = 0; t < a.T; ++t) deg += a.nin[(size_t)row * a.T + t];                      \
+                            den = deg + 1e-7f;                                                                      \
+                        }                                                                                           \
+                        _Pragma("unroll")                                                                           \
+                        for (int nt = 0; nt < NT; ++nt) {                                                           \
+                            const int col = nt * 16 + 4 * kq;                                                       \
+                            if (col < D) {                                                                          \
+                                f32x4 v = acc[nt];                                                                  \
+                                if ((S) == NX - 1 && a.use_avg) v = v / den;                                        \
+                                st4_b(a.dx[(S)], ((unsigned)row * D + col) * 4u, v);                                \
+                            }                                                                                       \
+                        }                                                                                           \
+                    }                                                                                               \
+                }                                                                                                   \
+            }
+            GGNN_BWD_SEG(0) GGNN_BWD_SEG(1) GGNN_BWD_SEG(2)
+#undef GGNN_BWD_SEG
+        }
+    };
+    for (; tk < n_tk && tile_of(tk) >= 0; tk += nb) run_pass(std::true_type{});
+    for (; tk < n_tk; tk += nb) run_pass(std::false_type{});
+}
+
+template <int D, int NX, int NW, bool PREFETCH, int RING>
+static int launch_gru_bwd_variant(const GruBwdArgs& a, const float* packed, hipStream_t st) {
+    using C = StageCfg<D>;
+    const size_t lds = (size_t)RING * C::IMG_BYTES;
+    const int wt_total = (a.V + 15) / 16;
+    int nb = num_cus() * (RING == 1 ? 2 : 1);                  // single-image form: two 4-wave workgroups per CU
+    if (nb > wt_total) nb = wt_total;
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (lds > 64 * 1024) GGNN_CHECK_HIP((allow_dynamic_lds(&ggnn_gru_bwd_fused_kernel<D, NX, NW, PREFETCH, RING>, lds, lds_ok)));
+    hipLaunchKernelGGL((ggnn_gru_bwd_fused_kernel<D, NX, NW, PREFETCH, RING>), dim3(nb), dim3(NW * 64), lds, st, a, packed);
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+template <int D, int NX>
+static int launch_gru_bwd(const GruBwdArgs& a, const float* Wg, const float* Wc, float* packed, hipStream_t st) {
+    if (Wg) {
+        hipLaunchKernelGGL((gru_bwd_pack_kernel<D>), dim3(8, 3 * (NX + 1)), dim3(256), 0, st, Wg, Wc, NX, packed);
+        GGNN_CHECK_HIP(hipGetLastError());
+    }
+    if (a.g == nullptr || a.V == 0) return GGNN_OK;
+    if ((unsigned long long)a.V * 2 * D >= (1ULL << 30))
+        return fail(GGNN_E_UNSUPPORTED, "fused GRU backward indexes with 32-bit byte offsets: V*2D must be < 2^30 (V=%d, D=%d)", a.V, D);
+    // GGNN_BWD_FORM: 0 = one 8-wave workgroup per CU, 2-image ring, inputs fetched at the top of a pass;
+    //                1 = the same with the next tile's inputs prefetched under the last stage;
+    //                2 = two 4-wave workgroups per CU, one image each
+    static const int form = [] { const char* e = getenv("GGNN_BWD_FORM"); return e ? atoi(e) : 0; }();
+    if (form == 1) return launch_gru_bwd_variant<D, NX, 8, true, 2>(a, packed, st);
+    if (form == 2) return launch_gru_bwd_variant<D, NX, 4, false, 1>(a, packed, st);
+    return launch_gru_bwd_variant<D, NX, 8, false, 2>(a, packed, st);
+}
+
+template <int D>
+static int dispatch_gru_bwd(const GruBwdArgs& a, const float* Wg, const float* Wc, float* packed, hipStream_t st) {
+    switch (a.nx) {
+        case 1: return launch_gru_bwd<D, 1>(a, Wg, Wc, packed, st);
+        case 2: return launch_gru_bwd<D, 2>(a, Wg, Wc, packed, st);
+        case 3: return launch_gru_bwd<D, 3>(a, Wg, Wc, packed, st);
+        default: return fail(GGNN_E_INVALID, "nx %d outside 1..3", a.nx);
+    }
+}
+
+}  // namespace ggnn
+
+using namespace ggnn;
+
+extern "C" int ggnn_gru_bwd_is_fused(int D) { return D == 100 || D == 64 || D == 32; }
+
+extern "C" size_t ggnn_gru_bwd_packed_bytes(int D, int nx) {
+    size_t img = 0;
+    switch (D) {
+        case 100: img = StageCfg<100>::IMG; break;
+        case 64: img = StageCfg<64>::IMG; break;
+        case 32: img = StageCfg<32>::IMG; break;
+        default: return 0;
+    }
+    return (size_t)3 * (nx + 1) * img * sizeof(float);
+}
+
+// Wg / Wc given: (re)build the packed transposed-block images into `packed` first; g == NULL: pack only.
+extern "C" int ggnn_gru_bwd_fused_f32(const float* g, const float* h, const float* r, const float* u, const float* c, const float* Wg,
+                                      const float* Wc, float* packed, float* dpc, float* dpg, float* rh, float* dh,
+                                      float* const* dx, const float* nin, int T, int use_avg, int nx, int V, int D, int act,
+                                      ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(V >= 0 && nx >= 1 && nx <= 3, "bad sizes V=%d nx=%d", V, nx);
+    if (!ggnn_gru_bwd_is_fused(D)) return fail(GGNN_E_UNSUPPORTED, "no fused GRU backward for hidden size %d", D);
+    GGNN_CHECK_ARG(act == GGNN_ACT_TANH || act == GGNN_ACT_RELU, "unknown activation %d", act);
+    GGNN_CHECK_ARG(packed && aligned16(packed) && (!Wg || Wc), "packed weights missing");
+    GruBwdArgs a{};
+    a.nx = nx; a.V = V; a.act = act; a.T = T; a.use_avg = use_avg; a.nin = nin;
+    if (g) {
+        GGNN_CHECK_ARG(h && r && u && c && dpc && dpg && rh && dh && dx && (!use_avg || nin), "null pointer");
+        GGNN_CHECK_ARG(aligned16(g) && aligned16(h) && aligned16(r) && aligned16(u) && aligned16(c) && aligned16(dpc) && aligned16(dpg) &&
+                       aligned16(rh) && aligned16(dh), "pointers must be 16-byte aligned");
+        a.g = g; a.h = h; a.r = r; a.u = u; a.c = c; a.dpc = dpc; a.dpg = dpg; a.rh = rh; a.dh = dh;
+        for (int s = 0; s < nx; ++s) { GGNN_CHECK_ARG(dx[s] && aligned16(dx[s]), "dx[%d] null or misaligned", s); a.dx[s] = dx[s]; }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 100: return dispatch_gru_bwd<100>(a, Wg, Wc, packed, st);
+        case 64: return dispatch_gru_bwd<64>(a, Wg, Wc, packed, st);
+        default: return dispatch_gru_bwd<32>(a, Wg, Wc, packed, st);
+    }
+}

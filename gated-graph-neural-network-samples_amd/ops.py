@@ -299,11 +299,12 @@ def gemm_tn(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
 
 
 def xty(x_segs: Sequence[torch.Tensor], dy: torch.Tensor, x_rows: Optional[torch.Tensor] = None,
-        row_off: Optional[Sequence[int]] = None) -> torch.Tensor:
+        row_off: Optional[Sequence[int]] = None, ones_row: bool = False) -> torch.Tensor:
     """Weight-gradient product  concat(x_segs, dim=1)^T @ dy  on ggnn_xty_f32 (no concat materialised; deterministic).
     x_segs: [M', Dseg] float32 tensors with unit column stride (any row stride: column slices are fine); dy [M, N], N <= 208.
     x_rows (int32 [M]): row r of the X operand is x_segs[.][x_rows[r]] (edge-weight gradients on compact rows).
-    row_off (host ints [B+1]): B independent products over the row ranges -> [B, K, N]; default one product -> [K, N]."""
+    row_off (host ints [B+1]): B independent products over the row ranges -> [B, K, N]; default one product -> [K, N].
+    ones_row: the result has K + 1 rows, the last one the column sums of dy (the bias gradient next to the weight gradient)."""
     lib = _lib.load()
     nseg = len(x_segs)
     Dseg = x_segs[0].shape[1]
@@ -317,7 +318,8 @@ def xty(x_segs: Sequence[torch.Tensor], dy: torch.Tensor, x_rows: Optional[torch
     batched = row_off is not None
     offs = [0, M] if row_off is None else [int(o) for o in row_off]
     B = len(offs) - 1
-    out = torch.empty((B, K, N), dtype=torch.float32, device=dy.device)
+    Kout = K + 1 if ones_row else K
+    out = torch.empty((B, Kout, N), dtype=torch.float32, device=dy.device)
     m_max = max([offs[b + 1] - offs[b] for b in range(B)] + [0])
     ws_bytes = lib.ggnn_xty_workspace_bytes(m_max, K, N, B)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
@@ -328,7 +330,7 @@ def xty(x_segs: Sequence[torch.Tensor], dy: torch.Tensor, x_rows: Optional[torch
     if x_rows is not None:
         _req(x_rows, torch.int32, "x_rows")
     _launch("xty[K=%d,N=%d%s]" % (K, N, ",x%d" % B if batched else ""), lambda: lib.ggnn_xty_f32(
-        segs, nseg, Dseg, ldx, _ptr(x_rows), _ptr(dy), ldy, _ptr(out), K, N, ro, B, _ptr(ws), ws_bytes, _stream()))
+        segs, nseg, Dseg, ldx, _ptr(x_rows), _ptr(dy), ldy, _ptr(out), K, N, 1 if ones_row else 0, ro, B, _ptr(ws), ws_bytes, _stream()))
     return out if batched else out[0]
 
 
@@ -350,6 +352,27 @@ def segment_sum_rows_acc(rows: torch.Tensor, index, out: torch.Tensor) -> torch.
     _launch("gather_segment_sum_acc", lambda: lib.ggnn_gather_segment_sum_acc_f32(
         _ptr(rows), _ptr(index.row_ptr), _ptr(index.gather_row), _ptr(out), index.num_nodes, rows.shape[1], _stream()))
     return out
+
+
+def gru_bwd_is_fused(D: int) -> bool:
+    return bool(_lib.load().ggnn_gru_bwd_is_fused(D))
+
+
+def gru_bwd_fused(g, h, r, u, c, packed, nin, use_avg: bool, nx: int, activation: str):
+    """The GRU backward of one timestep in one launch (ggnn_gru_bwd_fused_f32) -> (dpc, dpg, rh, dh, [dx_0 .. dx_{nx-1}]);
+    the last dx is d_incoming (already divided by the in-degree for mean aggregation)."""
+    lib = _lib.load()
+    V, D = h.shape
+    T = nin.shape[1] if nin is not None else 1
+    dev = h.device
+    dpc = torch.empty_like(h); rh = torch.empty_like(h); dh = torch.empty_like(h)
+    dpg = torch.empty((V, 2 * D), dtype=torch.float32, device=dev)
+    dx = [torch.empty_like(h) for _ in range(nx)]
+    dxp = (ctypes.c_void_p * nx)(*[t.data_ptr() for t in dx])
+    _launch("gru_bwd_fused[nx=%d]" % nx, lambda: lib.ggnn_gru_bwd_fused_f32(
+        _ptr(g), _ptr(h), _ptr(r), _ptr(u), _ptr(c), None, None, _ptr(packed), _ptr(dpc), _ptr(dpg), _ptr(rh), _ptr(dh), dxp,
+        _ptr(nin), T, 1 if use_avg else 0, nx, V, D, ACT_IDS[activation.lower()], _stream()))
+    return dpc, dpg, rh, dh, dx
 
 
 def unsorted_segment_sum(data: torch.Tensor, segment_ids: torch.Tensor, num_segments: int) -> torch.Tensor:
@@ -607,6 +630,21 @@ class PackedWeights:
             check(lib.ggnn_gru_pack_weights_f32(_ptr(Wg), _ptr(Wc), nx, D, _ptr(packed), _stream()))
             torch.cuda.current_stream().synchronize()    # rare (once per weight version); other streams may read it next
             hit = self._store(self._gru, key, (Wg, Wc), packed)
+        return hit
+
+    def gru_bwd(self, Wg: torch.Tensor, Wc: torch.Tensor, nx: int, D: int) -> torch.Tensor:
+        """Transposed-block stage images of the fused GRU backward (ggnn_gru_bwd_fused_f32), once per weight version."""
+        lib = _lib.load()
+        if not hasattr(self, "_gru_bwd"):
+            self._gru_bwd = {}
+        key = self._key(Wg, Wc)
+        hit = self._lookup(self._gru_bwd, key, (Wg, Wc))
+        if hit is None:
+            _req(Wg, torch.float32, "Wg"); _req(Wc, torch.float32, "Wc")
+            packed = torch.empty(lib.ggnn_gru_bwd_packed_bytes(D, nx) // 4, dtype=torch.float32, device=Wg.device)
+            check(lib.ggnn_gru_bwd_fused_f32(None, None, None, None, None, _ptr(Wg), _ptr(Wc), _ptr(packed), None, None, None, None,
+                                             None, None, 0, 0, nx, 0, D, 0, _stream()))
+            hit = self._store(self._gru_bwd, key, (Wg, Wc), packed)
         return hit
 
     def edge(self, W: torch.Tensor) -> torch.Tensor:

@@ -315,7 +315,8 @@ int ggnn_gemm_tn_f32(const float* A, int lda, const float* B, int ldb, float* C,
  *   [residuals | incoming | h] operand of the GRU kernels is never concatenated; x_rows (device int32, or NULL) gathers the X
  *   rows (edge-weight gradients: X row of compact row r = h[pair_node[r]]); row_off HOST [nbatch+1] splits the rows into batches
  *   with one [K,N] output each (one per edge type).  K = nseg * Dseg, N <= 208, N % 4 == 0.  Deterministic (fixed-order split
- *   reduction).  ws: ggnn_xty_workspace_bytes(largest batch, K, N, nbatch).
+ *   reduction).  ones_row != 0: X gets a virtual column of ones, i.e. C is [K+1, N] per batch and its last row is the column
+ *   sum of Y -- the bias gradient comes out of the same pass.  ws: ggnn_xty_workspace_bytes(largest batch, K, N, nbatch).
  * ggnn_colsum_f32: out[n] = sum_v Y[v, n]  (bias gradients), deterministic.
  * ggnn_gru_bwd_dx_cand_f32:  P = dpc Wc^T (WcT = Wc^T, [D, (nx+1)D] row-major):  dx [V, nx*D] = P[:, x columns];
  *   dh += P[:, h columns] * r;  dpg[:, 0:D] = P[:, h columns] * h * r * (1 - r)       (the stage-2 algebra, fused)
@@ -324,7 +325,7 @@ int ggnn_gemm_tn_f32(const float* A, int lda, const float* B, int ldb, float* C,
  * ggnn_gather_segment_sum_acc_f32: out[v] += sum of the gathered rows (several gradient contributions meet in one tensor). */
 size_t ggnn_xty_workspace_bytes(int M_max, int K, int N, int nbatch);
 int ggnn_xty_f32(const float* const* x_segs, int nseg, int Dseg, const int32_t* ldx, const int32_t* x_rows, const float* Y,
-                 int ldy, float* C, int K, int N, const int32_t* row_off, int nbatch, void* ws, size_t ws_bytes,
+                 int ldy, float* C, int K, int N, int ones_row, const int32_t* row_off, int nbatch, void* ws, size_t ws_bytes,
                  ggnn_stream_t stream);
 size_t ggnn_colsum_workspace_bytes(int N);
 int ggnn_colsum_f32(const float* Y, int ldy, int M, int N, float* out, void* ws, size_t ws_bytes, ggnn_stream_t stream);
@@ -334,6 +335,21 @@ int ggnn_gru_bwd_dx_gates_f32(const float* dpg, const float* WgT, float* dx, flo
                               int use_avg, float* dh, int nx, int V, int D, ggnn_stream_t stream);
 int ggnn_gather_segment_sum_acc_f32(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row, float* out,
                                     int V, int D, ggnn_stream_t stream);
+
+/* The whole GRU backward of a timestep in ONE launch (D in {32, 64, 100}; ggnn_gru_bwd_fused.hip) -- the mirror image of the
+ * fused forward kernel: from g = dL/dh' and the saved h, r, u, c it computes, chained through registers,
+ *   dpc = g (1-u) act'(c);  dpu = g (h-c) u (1-u);  drh = dpc Wc^T[h rows];  dpr = drh h r (1-r);
+ *   dh  = g u + drh r + [dpr|dpu] Wg^T[h rows];   dx[s] = dpc Wc^T[x_s rows] + [dpr|dpu] Wg^T[x_s rows]   (s < nx)
+ *   dx[nx-1] is divided by (sum_t nin + 1e-7) when use_avg (d_incoming of the mean aggregation, chem_tensorflow_sparse.py:206-209)
+ * and writes dpc [V,D], dpg = [dpr|dpu] [V,2D] and rh = r*h [V,D] for the weight-gradient products (ggnn_xty_f32).
+ *   Wg [(nx+1)D, 2D], Wc [(nx+1)D, D] or NULL: with weights given, their transposed-block stage images are (re)built into
+ *   `packed` (ggnn_gru_bwd_packed_bytes(D, nx) bytes) first; NULL: `packed` holds them already.  g == NULL: pack only.
+ *   dx: HOST array of nx device pointers [V,D]. */
+int ggnn_gru_bwd_is_fused(int D);
+size_t ggnn_gru_bwd_packed_bytes(int D, int nx);
+int ggnn_gru_bwd_fused_f32(const float* g, const float* h, const float* r, const float* u, const float* c, const float* Wg,
+                           const float* Wc, float* packed, float* dpc, float* dpg, float* rh, float* dh, float* const* dx,
+                           const float* nin, int T, int use_avg, int nx, int V, int D, int act, ggnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -607,6 +607,9 @@ def test_xty_weight_gradient_product(pkg, cuda, M, nseg, Dseg, N):
     assert got.shape == (nseg * Dseg, N)
     assert np.all(np.abs(got.cpu().numpy() - want) <= bound)
     assert torch.equal(got, pkg.ops.xty(dxs, dy))
+    both = pkg.ops.xty(dxs, dy, ones_row=True)                   # weight gradient + bias gradient (column sums) in one pass
+    assert both.shape == (nseg * Dseg + 1, N) and np.all(np.abs(both[:-1].cpu().numpy() - want) <= bound)
+    np.testing.assert_allclose(both[-1].cpu().numpy(), wide[:, 4:4 + N].astype(np.float64).sum(0), atol=1e-3 + 4e-7 * M, rtol=1e-5)
 
 
 def test_xty_row_gathered_batches_and_colsum(pkg, cuda):

@@ -54,11 +54,14 @@ def _oracle_loss_and_grads(oracle_torch, model, layers, feed):
 @pytest.mark.parametrize("config", [{}, {"use_edge_bias": True, "graph_rnn_activation": "relu"},
                                     {"use_edge_msg_avg_aggregation": False, "hidden_size": 64,
                                      "layer_timesteps": [2, 1], "residual_connections": {"1": [0]}}])
-@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("compact", [False, True, "unfused-gru-backward"])
 def test_gradients_match_oracle_autograd(pkg, oracle, oracle_torch, cuda, config, compact, monkeypatch):
     """compact: the message transform (forward AND backward) on the active (node,type) pairs only vs the dense
-    [V, T*D] form -- both must reproduce the oracle's autograd gradients."""
-    monkeypatch.setattr(pkg.backward, "USE_COMPACT_TRANSFORM", compact)
+    [V, T*D] form; "unfused-gru-backward": the compacted form with the GRU backward as separate launches instead of the
+    single fused kernel -- all must reproduce the oracle's autograd gradients."""
+    monkeypatch.setattr(pkg.backward, "USE_COMPACT_TRANSFORM", bool(compact))
+    if compact == "unfused-gru-backward":
+        monkeypatch.setattr(pkg.ops, "gru_bwd_is_fused", lambda D: False)
     model, layers, feed = _setup(pkg, oracle, config)
     want_loss, want = _oracle_loss_and_grads(oracle_torch, model, layers, feed)
     variables = model.trainable_variables
