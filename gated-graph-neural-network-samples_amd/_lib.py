@@ -33,6 +33,9 @@ SYMBOLS = {
                                                c_int, c_int, c_int, c_void_p]),
     "ggnn_gather_segment_sum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                             c_int, c_int, c_int, c_void_p]),
+    "ggnn_build_slot_heads": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ggnn_gather_segment_sum_heads_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                                  c_int, c_int, c_int, c_int, c_void_p]),
     "ggnn_unsorted_segment_sum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "ggnn_gated_readout_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_int, c_int, c_void_p]),

@@ -255,6 +255,8 @@ static XtyPlan xty_plan(int M_max, int Kout, int N, int nbatch) {
     const int by_lds = (int)((size_t)160 * 1024 / p.lds);
     if (per_cu > by_lds) per_cu = by_lds;
     if (per_cu < 1) per_cu = 1;
+    static const int per_cu_env = [] { const char* e = getenv("GGNN_XTY_PER_CU"); return e ? atoi(e) : 0; }();   // (experiments)
+    if (per_cu_env > 0) per_cu = per_cu_env;
     int target = per_cu * num_cus() / (p.kblocks * nbatch);
     if (target < 1) target = 1;
     const int max_s = (M_max + 4 * kXtyRows - 1) / (4 * kXtyRows);    // at least 4 slabs per split

@@ -173,6 +173,59 @@ __global__ __launch_bounds__(256) void gather_segment_sum_flat_kernel(
     *reinterpret_cast<f32x4*>(out + (size_t)v * D + 4 * c4) = acc;
 }
 
+// Slot heads: the gather rows of the first FOUR message slots of every node in one 16-byte record (-1 = no such slot).
+// The CSR walk is a chain of three dependent loads per lane (row_ptr -> slot index -> source row); with the head record the
+// slot indices of a node arrive with ONE load that does not depend on row_ptr, so a lane has its (up to) four source rows in
+// flight after a single round trip -- at QM9 shapes (no atom has more than 4 bonds) the slot list is never touched at all.
+__global__ void slot_heads_kernel(const int* __restrict__ row_ptr, const int* __restrict__ gidx, int V, int4* __restrict__ heads) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const int beg = row_ptr[v], n = row_ptr[v + 1] - beg;
+    int4 h;
+    h.x = n > 0 ? gidx[beg] : -1; h.y = n > 1 ? gidx[beg + 1] : -1;
+    h.z = n > 2 ? gidx[beg + 2] : -1; h.w = n > 3 ? gidx[beg + 3] : -1;
+    heads[v] = h;
+}
+
+// One lane per (node, float4 column), slot heads: same sums, same order, same epilogue as gather_segment_sum_flat_kernel.
+__global__ __launch_bounds__(256) void gather_segment_sum_heads_kernel(
+        const float* __restrict__ H, const int* __restrict__ row_ptr, const int* __restrict__ gidx, const int4* __restrict__ heads,
+        const float* __restrict__ nin, const float* __restrict__ bias, int use_avg, float* __restrict__ out,
+        long long total4, int D, int T, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int D4 = D >> 2;
+    const int v = (int)(i / D4);
+    const int c4 = (int)(i - (long long)v * D4);
+    const int4 hd = heads[v];
+    const int beg = row_ptr[v], end = row_ptr[v + 1];           // (independent of the head record: only the tail loop needs them)
+    const float* hcol = H + 4 * c4;
+    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0, r3 = r0;
+    if (hd.x >= 0) r0 = *reinterpret_cast<const f32x4*>(hcol + (size_t)hd.x * D);
+    if (hd.y >= 0) r1 = *reinterpret_cast<const f32x4*>(hcol + (size_t)hd.y * D);
+    if (hd.z >= 0) r2 = *reinterpret_cast<const f32x4*>(hcol + (size_t)hd.z * D);
+    if (hd.w >= 0) r3 = *reinterpret_cast<const f32x4*>(hcol + (size_t)hd.w * D);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc += r0;                                                  // slot order = reference accumulation order
+    if (hd.y >= 0) acc += r1;
+    if (hd.z >= 0) acc += r2;
+    if (hd.w >= 0) acc += r3;
+    for (int e = beg + 4; e < end; ++e) acc += *reinterpret_cast<const f32x4*>(hcol + (size_t)gidx[e] * D);
+    if (bias || use_avg) {
+        float deg = 0.f;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) {
+            const float n = nin[(size_t)v * T + t];
+            deg += n;
+            if (bias) b += n * *reinterpret_cast<const f32x4*>(bias + (size_t)t * D + 4 * c4);
+        }
+        if (bias) acc += b;
+        if (use_avg) acc = acc / (deg + 1e-7f);
+    }
+    if (accumulate) acc += *reinterpret_cast<const f32x4*>(out + (size_t)v * D + 4 * c4);
+    *reinterpret_cast<f32x4*>(out + (size_t)v * D + 4 * c4) = acc;
+}
+
 // ---- propagation attention (chem_tensorflow_sparse.py:147-149, 170-196) fused into the segment sum ---------
 // score_m = <h[src_m], h[tgt_m]> * factor[type_m]; a_m = softmax over the messages INTO each target (max-shifted,
 // denominator + 1e-7); incoming[v] = sum_m a_m * msg_m.  One sub-wave per target: pass 1 finds the max score,
@@ -312,7 +365,7 @@ extern "C" int ggnn_build_source_csr(const int32_t* adj, const int64_t* type_off
 
 static int gather_segment_sum_impl(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row,
                                    const float* nin, const float* bias, int use_avg, float* out, int V,
-                                   int D, int T, int accumulate, ggnn_stream_t stream) {
+                                   int D, int T, int accumulate, ggnn_stream_t stream, const int32_t* heads = nullptr) {
     GGNN_CHECK_ARG(V >= 0 && D > 0 && D % 4 == 0 && T > 0, "bad sizes V=%d D=%d T=%d", V, D, T);
     if (V == 0) return GGNN_OK;
     GGNN_CHECK_ARG(Hrows && row_ptr && out, "null pointer");
@@ -325,7 +378,11 @@ static int gather_segment_sum_impl(const float* Hrows, const int32_t* row_ptr, c
     static int flat_env = -2;
     if (flat_env == -2) { const char* e = getenv("GGNN_K2_FLAT"); flat_env = e ? atoi(e) : -1; }
     const bool flat = flat_env >= 0 ? flat_env != 0 : (D4 < 64 && (64 % D4) != 0);
-    if (flat) {
+    if (heads) {
+        const long long total4 = (long long)V * D4;
+        hipLaunchKernelGGL(gather_segment_sum_heads_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, Hrows, row_ptr,
+                           gather_row, reinterpret_cast<const int4*>(heads), nin, bias, use_avg, out, total4, D, T, accumulate);
+    } else if (flat) {
         const long long total4 = (long long)V * D4;
         hipLaunchKernelGGL(gather_segment_sum_flat_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, Hrows,
                            row_ptr, gather_row, nin, bias, use_avg, out, total4, D, T, accumulate);
@@ -394,4 +451,24 @@ extern "C" int ggnn_unsorted_segment_sum_f32(const float* data, const int32_t* i
                        ids, out, total, D, num_segments);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
+}
+
+// Slot heads of a by-target (or by-source) index: heads[v] = the first four entries of gather_row[row_ptr[v] .. row_ptr[v+1]) (-1 padded).
+extern "C" int ggnn_build_slot_heads(const int32_t* row_ptr, const int32_t* gather_row, int32_t* heads, int V, ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(V >= 0, "negative V");
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(row_ptr && heads && aligned16(heads), "null or misaligned pointer");
+    hipLaunchKernelGGL(slot_heads_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, row_ptr, gather_row, V,
+                       reinterpret_cast<int4*>(heads));
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+// ggnn_gather_segment_sum_f32 with the slot heads of the index (ggnn_build_slot_heads): identical results, one dependent
+// load level less per lane.
+extern "C" int ggnn_gather_segment_sum_heads_f32(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row,
+                                                 const int32_t* heads, const float* nin, const float* bias, int use_avg, float* out,
+                                                 int V, int D, int T, int accumulate, ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(heads && aligned16(heads), "heads null or misaligned");
+    return gather_segment_sum_impl(Hrows, row_ptr, gather_row, nin, bias, use_avg, out, V, D, T, accumulate, stream, heads);
 }

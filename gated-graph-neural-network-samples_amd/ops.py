@@ -151,6 +151,38 @@ def build_source_index(adjacency_lists: Sequence[torch.Tensor], num_nodes: int) 
     return _build_index(adjacency_lists, num_nodes, False, by_source=True)
 
 
+USE_SLOT_HEADS = os.environ.get("GGNN_SLOT_HEADS", "1") != "0"
+
+
+def slot_heads(owner, row_ptr: torch.Tensor, gather_row: torch.Tensor, num_segments: int) -> Optional[torch.Tensor]:
+    """[num_segments, 4] int32 gather rows of the first four slots of every segment (-1 padded), built once per index and
+    cached on `owner` (ggnn_build_slot_heads): the segment-sum kernels then need one dependent load level less."""
+    if not USE_SLOT_HEADS or num_segments == 0:
+        return None
+    cached = getattr(owner, "_slot_heads", None)
+    if cached is not None and cached[0] is gather_row:
+        return cached[1]
+    lib = _lib.load()
+    heads = torch.empty((num_segments, 4), dtype=torch.int32, device=row_ptr.device)
+    check(lib.ggnn_build_slot_heads(_ptr(row_ptr), _ptr(gather_row), _ptr(heads), num_segments, _stream()))
+    owner._slot_heads = (gather_row, heads)
+    return heads
+
+
+def _segment_sum(name, Hrows, row_ptr, gather_row, heads, nin, bias, use_avg, out, V, D, T, accumulate=False):
+    lib = _lib.load()
+    if heads is not None:
+        _launch(name, lambda: lib.ggnn_gather_segment_sum_heads_f32(
+            _ptr(Hrows), _ptr(row_ptr), _ptr(gather_row), _ptr(heads), _ptr(nin), _ptr(bias), 1 if use_avg else 0, _ptr(out), V, D, T,
+            1 if accumulate else 0, _stream()))
+    elif accumulate:
+        _launch(name, lambda: lib.ggnn_gather_segment_sum_acc_f32(_ptr(Hrows), _ptr(row_ptr), _ptr(gather_row), _ptr(out), V, D, _stream()))
+    else:
+        _launch(name, lambda: lib.ggnn_gather_segment_sum_f32(_ptr(Hrows), _ptr(row_ptr), _ptr(gather_row), _ptr(nin), _ptr(bias),
+                                                              1 if use_avg else 0, _ptr(out), V, D, T, _stream()))
+    return out
+
+
 def msg_transform(h: torch.Tensor, edge_weights: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """H[v, t*D:(t+1)*D] = h[v] @ edge_weights[t]   (chem_tensorflow_sparse.py:160-164, all types
     in one FP32-MFMA GEMM).  h [V,D], edge_weights [T,D,D] -> H [V, T*D]."""
@@ -194,10 +226,8 @@ def gather_segment_sum(H: torch.Tensor, index: MessageIndex, num_incoming_edges_
         out = torch.empty((V, D), dtype=torch.float32, device=H.device)
     else:
         _req(out, torch.float32, "out")
-    _launch("gather_segment_sum", lambda: lib.ggnn_gather_segment_sum_f32(
-        _ptr(H), _ptr(index.row_ptr), _ptr(index.gather_row), _ptr(nin), _ptr(edge_biases), 1 if use_avg else 0,
-        _ptr(out), V, D, T, _stream()))
-    return out
+    return _segment_sum("gather_segment_sum", H, index.row_ptr, index.gather_row, slot_heads(index, index.row_ptr, index.gather_row, V),
+                        nin, edge_biases, use_avg, out, V, D, T)
 
 
 def gru_workspace(V: int, D: int, device) -> torch.Tensor:
@@ -349,9 +379,9 @@ def segment_sum_rows_acc(rows: torch.Tensor, index, out: torch.Tensor) -> torch.
     """out[s,:] += sum of rows[index.gather_row[slot],:] over the slots of segment s (ggnn_gather_segment_sum_acc_f32)."""
     lib = _lib.load()
     _req(rows, torch.float32, "rows"); _req(out, torch.float32, "out")
-    _launch("gather_segment_sum_acc", lambda: lib.ggnn_gather_segment_sum_acc_f32(
-        _ptr(rows), _ptr(index.row_ptr), _ptr(index.gather_row), _ptr(out), index.num_nodes, rows.shape[1], _stream()))
-    return out
+    return _segment_sum("gather_segment_sum_acc", rows, index.row_ptr, index.gather_row,
+                        slot_heads(index, index.row_ptr, index.gather_row, index.num_nodes), None, None, False, out, index.num_nodes,
+                        rows.shape[1], 1, accumulate=True)
 
 
 def gru_bwd_is_fused(D: int) -> bool:
@@ -396,9 +426,8 @@ def segment_sum_rows_by_index(rows: torch.Tensor, index: MessageIndex, out: Opti
     nseg = index.num_nodes
     if out is None:
         out = torch.empty((nseg, D), dtype=torch.float32, device=rows.device)
-    _launch("gather_segment_sum_bwd", lambda: lib.ggnn_gather_segment_sum_f32(
-        _ptr(rows), _ptr(index.row_ptr), _ptr(index.gather_row), None, None, 0, _ptr(out), nseg, D, 1, _stream()))
-    return out
+    return _segment_sum("gather_segment_sum_bwd", rows, index.row_ptr, index.gather_row,
+                        slot_heads(index, index.row_ptr, index.gather_row, nseg), None, None, False, out, nseg, D, 1)
 
 
 def dense_aggregate(adjacency: torch.Tensor, Hm: torch.Tensor, edge_biases: Optional[torch.Tensor],
@@ -483,6 +512,7 @@ def prepare_message_index(index: MessageIndex, hidden_size: int, compact: bool =
     compacted message transform for the hidden sizes that have one."""
     if compact and index.num_messages and compact_supported(hidden_size) and getattr(index, "_compact", None) is None:
         index._compact = build_compact_sources(index)
+        slot_heads(index._compact, index.row_ptr, index._compact.gather_row, index.num_nodes)
     return index
 
 
@@ -571,10 +601,8 @@ def gather_segment_sum_compact(Hc: torch.Tensor, index: MessageIndex, comp: Comp
         _req(edge_biases, torch.float32, "edge_biases")
     if out is None:
         out = torch.empty((V, D), dtype=torch.float32, device=Hc.device)
-    _launch("gather_segment_sum", lambda: lib.ggnn_gather_segment_sum_f32(
-        _ptr(Hc), _ptr(index.row_ptr), _ptr(comp.gather_row), _ptr(nin), _ptr(edge_biases), 1 if use_avg else 0,
-        _ptr(out), V, D, T, _stream()))
-    return out
+    return _segment_sum("gather_segment_sum", Hc, index.row_ptr, comp.gather_row, slot_heads(comp, index.row_ptr, comp.gather_row, V),
+                        nin, edge_biases, use_avg, out, V, D, T)
 
 
 # ---- pre-packed weights (inference) ---------------------------------------------------------------------

@@ -128,6 +128,15 @@ int ggnn_gather_segment_sum_attn_f32(const float* Hrows, const float* h, const i
                                      const float* type_factors, const float* nin, const float* bias, int use_avg,
                                      float* out, int V, int D, int T, ggnn_stream_t stream);
 
+/* Slot heads: heads[v] (int32 [V,4], 16-byte aligned) = the gather rows of the first four message slots of node v (-1 = no such
+ * slot), built once per batch from (row_ptr, gather_row).  ggnn_gather_segment_sum_heads_f32 is ggnn_gather_segment_sum_f32 with
+ * them (bit-identical results): the slot indices of a node arrive with one load that does not depend on row_ptr, so a lane has
+ * its source rows in flight after ONE round trip instead of two; accumulate != 0 adds to `out` instead of overwriting it. */
+int ggnn_build_slot_heads(const int32_t* row_ptr, const int32_t* gather_row, int32_t* heads, int V, ggnn_stream_t stream);
+int ggnn_gather_segment_sum_heads_f32(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row, const int32_t* heads,
+                                      const float* nin, const float* bias, int use_avg, float* out, int V, int D, int T,
+                                      int accumulate, ggnn_stream_t stream);
+
 /* tf.unsorted_segment_sum in its general form (chem_tensorflow_sparse.py:198-200, 226-228):
  * out[ids[m],:] += data[m,:] with out zero-filled first; fp32 atomics, any id order.  Used for the
  * readout's per-graph sum and available for un-bucketed message lists. */

@@ -630,3 +630,21 @@ def test_xty_row_gathered_batches_and_colsum(pkg, cuda):
     cs = pkg.ops.colsum(dev(y, cuda))
     np.testing.assert_allclose(cs.cpu().numpy(), y.astype(np.float64).sum(0), atol=2e-3, rtol=1e-5)
     assert torch.equal(cs, pkg.ops.colsum(dev(y, cuda)))
+
+
+@pytest.mark.parametrize("V,M,D,T", [(3000, 9000, 100, 4), (400, 9000, 100, 3), (100000, 200000, 100, 4), (5000, 20000, 256, 4)])
+def test_slot_heads_segment_sum_is_bit_identical(pkg, cuda, V, M, D, T, monkeypatch):
+    """The slot-head form of the segment sum (first four slot indices of a node in one 16-byte record) computes exactly the
+    sums of the CSR walk: same slot order, same adds -- including nodes with more than four slots and empty nodes."""
+    rng = np.random.default_rng(V + M)
+    h, adj, nin = random_graph_batch(rng, V, M, T, D, sorted_src=True)
+    H = dev(rng.uniform(-1, 1, (V, T * D)).astype(np.float32), cuda)
+    nd = dev(nin, cuda)
+    bias = dev(rng.uniform(-1, 1, (T, D)).astype(np.float32), cuda)
+    index = pkg.ops.build_message_index([dev(a, cuda) for a in adj], V)
+    monkeypatch.setattr(pkg.ops, "USE_SLOT_HEADS", True)
+    a = pkg.ops.gather_segment_sum(H, index, nd, bias, True)
+    assert getattr(index, "_slot_heads", None) is not None
+    monkeypatch.setattr(pkg.ops, "USE_SLOT_HEADS", False)
+    b = pkg.ops.gather_segment_sum(H, index, nd, bias, True)
+    assert torch.equal(a, b)

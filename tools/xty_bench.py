@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Micro-benchmark of ggnn_xty_f32 (the weight-gradient product of the backward pass) at the training step's shapes, next to
+the vendor BLAS on the same operands:  python tools/xty_bench.py"""
+import importlib, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("gated-graph-neural-network-samples_amd")
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+
+V = 99986
+for (nseg, N) in ((2, 200), (3, 200), (4, 200), (2, 100), (3, 100), (4, 100)):
+    xs = [torch.rand(V, 100, device=dev) for _ in range(nseg)]
+    dy = torch.rand(V, N, device=dev)
+    t = timeit(lambda: pkg.ops.xty(xs, dy, ones_row=True))
+    xc = torch.cat(xs, 1)
+    tb = timeit(lambda: pkg.utils.tn_matmul(xc, dy))
+    gf = 2.0 * V * nseg * 100 * N / 1e9
+    print("K=%d N=%d: xty %.1f us (%.1f TF)   batched BLAS %.1f us (%.1f TF)" % (nseg * 100, N, t, gf / t * 1e-3 * 1e3 / 1e3 * 1e3 / 1e3 * 1e3 if False else gf / (t * 1e-6) / 1e3, tb, gf / (tb * 1e-6) / 1e3))
+R, T = 122638, 4
+h = torch.rand(V, 100, device=dev); dHc = torch.rand(R, 100, device=dev)
+rows = torch.randint(0, V, (R,), device=dev, dtype=torch.int32).sort()[0].contiguous()
+off = [0, 36000, 70000, 95000, R]
+t = timeit(lambda: pkg.ops.xty([h], dHc, x_rows=rows, row_off=off))
+print("edge weights (gathered, 4 batches, R=%d): %.1f us (%.1f TF)" % (R, t, 2.0 * R * 1e4 / (t * 1e-6) / 1e12))
+t = timeit(lambda: pkg.ops.xty([dHc], dHc, row_off=off))
+print("same without the row gather: %.1f us" % t)
