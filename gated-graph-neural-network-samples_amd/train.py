@@ -18,9 +18,97 @@ class TFAdam:
     def __init__(self, variables: List[torch.Tensor], lr=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8):
         self.vars = variables
         self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, epsilon
-        self.m = [torch.zeros_like(v) for v in variables]
-        self.v = [torch.zeros_like(v) for v in variables]
         self.t = 0
+        self._flat = None
+        if variables and all(v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() and v.data_ptr() % 16 == 0 for v in variables):
+            self._make_flat()
+        else:                                                   # CPU tensors (host-side tests): per-variable torch slots
+            self.m = [torch.zeros_like(v) for v in variables]
+            self.v = [torch.zeros_like(v) for v in variables]
+
+    # ---- fused path (GPU): gradients and Adam slots live in flat buffers, clip + Adam are two HIP launches for all variables ----
+    def _make_flat(self) -> None:
+        from . import _lib
+        lib = _lib.load()
+        B = lib.ggnn_optim_block_floats()
+        dev = self.vars[0].device
+        first, block_var = [0], []
+        for i, v in enumerate(self.vars):
+            nb = (v.numel() + B - 1) // B
+            block_var += [i] * nb
+            first.append(first[-1] + nb)
+        nblocks = first[-1]
+        i32 = lambda xs: torch.tensor(xs, dtype=torch.int32, device=dev)
+        f = {"B": B, "nblocks": nblocks, "block_var": i32(block_var), "var_first": i32(first),
+             "var_numel": i32([v.numel() for v in self.vars]),
+             "p_ptr": torch.tensor([v.data_ptr() for v in self.vars], dtype=torch.int64, device=dev),
+             "p_ptr_host": [v.data_ptr() for v in self.vars],
+             "g": torch.zeros(nblocks * B, dtype=torch.float32, device=dev),
+             "m": torch.zeros(nblocks * B, dtype=torch.float32, device=dev),
+             "v": torch.zeros(nblocks * B, dtype=torch.float32, device=dev),
+             "partial": torch.empty(nblocks, dtype=torch.float32, device=dev),
+             "active_host": None, "active": torch.ones(len(self.vars), dtype=torch.int32, device=dev)}
+        view = lambda buf, i, v: buf[first[i] * B:first[i] * B + v.numel()].view(v.shape)
+        self.m = [view(f["m"], i, v) for i, v in enumerate(self.vars)]
+        self.v = [view(f["v"], i, v) for i, v in enumerate(self.vars)]
+        f["g_views"] = [view(f["g"], i, v) for i, v in enumerate(self.vars)]
+        self._flat = f
+
+    @property
+    def fused(self) -> bool:
+        return self._flat is not None
+
+    @torch.no_grad()
+    def load_gradients(self, grads: List[torch.Tensor]) -> torch.Tensor:
+        """Pack this step's gradients into the flat gradient buffer (ONE multi-tensor copy; variables without a gradient keep
+        zeros and are marked inactive) and return the buffer -- the operand of the data-parallel all-reduce."""
+        f = self._flat
+        mask = [0 if g is None else 1 for g in grads]
+        if mask != f["active_host"]:
+            if 0 in mask:
+                f["g"].zero_()
+            f["active"].copy_(torch.tensor(mask, dtype=torch.int32), non_blocking=False)
+            f["active_host"] = mask
+        elif 0 in mask:
+            for w, g in zip(f["g_views"], grads):
+                if g is None:
+                    w.zero_()
+        dst = [w for w, g in zip(f["g_views"], grads) if g is not None]
+        src = [g.reshape(w.shape) for w, g in zip(f["g_views"], grads) if g is not None]
+        if src:
+            torch._foreach_copy_(dst, src)
+        return f["g"]
+
+    def mark_all_active(self) -> None:
+        """After a data-parallel all-reduce every variable has a (possibly zero) reduced gradient on every rank."""
+        f = self._flat
+        mask = [1] * len(self.vars)
+        if mask != f["active_host"]:
+            f["active"].fill_(1)
+            f["active_host"] = mask
+
+    @torch.no_grad()
+    def clip_and_apply(self, clip_norm: float) -> None:
+        """Per-variable clip_by_norm (chem_tensorflow.py:186-190) + the Adam update on the packed gradients: two launches."""
+        from . import _lib
+        f = self._flat
+        if [v.data_ptr() for v in self.vars] != f["p_ptr_host"]:
+            raise RuntimeError("a trainable variable was re-allocated after the optimizer was built")
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        lib = _lib.load()
+        _lib.check(lib.ggnn_clip_adam_f32(f["p_ptr"].data_ptr(), f["var_numel"].data_ptr(), f["g"].data_ptr(), f["m"].data_ptr(),
+                                          f["v"].data_ptr(), f["partial"].data_ptr(), f["block_var"].data_ptr(),
+                                          f["var_first"].data_ptr(), f["active"].data_ptr(), f["nblocks"], float(clip_norm or 0.0),
+                                          lr_t, self.b1, self.b2, self.eps, torch.cuda.current_stream().cuda_stream))
+        # The kernel wrote the weights through raw pointers: bump their version counters, which the caches of packed LDS
+        # weight images (ops.PackedWeights) and of transposed weights are keyed on.
+        bump = getattr(torch.autograd.graph, "increment_version", None)
+        if bump is not None:
+            for v in self.vars:
+                bump(v)
+        else:
+            torch._foreach_add_(self.vars, 0.0)
 
     @torch.no_grad()
     def apply_gradients(self, grads: List[torch.Tensor]) -> None:
@@ -122,13 +210,24 @@ def train_step(model, batch_data) -> torch.Tensor:
     finally:
         model.training = False
     grads = [v.grad for v in variables]
-    if dist is not None and dist.active:
-        dist.reduce_gradients(variables, grads)
-        loss = loss_for_grad
+    opt = model.optimizer
     for v in variables:
         v.requires_grad_(False)
-    clip_by_norm_(grads, model.params['clamp_gradient_norm'])
-    model.optimizer.apply_gradients(grads)
+    if opt.fused and len(opt.vars) == len(variables) and all(a is b for a, b in zip(opt.vars, variables)):
+        # GPU: one multi-tensor copy packs the gradients, ONE all-reduce of the flat buffer under data parallelism, then
+        # per-variable clip + Adam in two launches for all variables (ggnn_clip_adam_f32)
+        flat = opt.load_gradients(grads)
+        if dist is not None and dist.active:
+            dist.all_reduce_sum_(flat)
+            opt.mark_all_active()
+            loss = loss_for_grad
+        opt.clip_and_apply(model.params['clamp_gradient_norm'])
+    else:
+        if dist is not None and dist.active:
+            dist.reduce_gradients(variables, grads)
+            loss = loss_for_grad
+        clip_by_norm_(grads, model.params['clamp_gradient_norm'])
+        opt.apply_gradients(grads)
     for v in variables:
         v.grad = None
     return loss.detach()

@@ -360,6 +360,18 @@ int ggnn_gru_bwd_fused_f32(const float* g, const float* h, const float* r, const
                            const float* Wc, float* packed, float* dpc, float* dpg, float* rh, float* dh, float* const* dx,
                            const float* nin, int T, int use_avg, int nx, int V, int D, int act, ggnn_stream_t stream);
 
+/* ---- optimiser: per-variable clip_by_norm + TF-1.3 Adam for ALL variables in two launches (chem_tensorflow.py:183-191) --------
+ * grads / m / v are FLAT buffers of nblocks * ggnn_optim_block_floats() floats in which every variable starts on a block
+ * boundary (padding zero); param_ptrs: DEVICE array [nvars] of the variables' base pointers (each 16-byte aligned; the
+ * parameters stay in the model's tensors), var_numel [nvars] their element counts; block_var [nblocks]: variable of each block; var_first [nvars+1]: first block of each variable;
+ * var_active [nvars]: 0 = the variable has no gradient this step (left untouched, like a None gradient); partial: nblocks floats.
+ *   g <- g * clip / max(||g||_2, clip) per variable (clip_norm <= 0: no clipping);
+ *   m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;  p <- p - lr_t m / (sqrt(v) + eps)      (lr_t = lr sqrt(1-b2^t) / (1-b1^t), host) */
+int ggnn_optim_block_floats(void);
+int ggnn_clip_adam_f32(float* const* param_ptrs, const int32_t* var_numel, const float* grads, float* m, float* v, float* partial,
+                       const int32_t* block_var, const int32_t* var_first, const int32_t* var_active, int nblocks, float clip_norm,
+                       float lr_t, float beta1, float beta2, float epsilon, ggnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
