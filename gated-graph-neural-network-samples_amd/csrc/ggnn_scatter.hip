@@ -378,7 +378,7 @@ static int gather_segment_sum_impl(const float* Hrows, const int32_t* row_ptr, c
     static int flat_env = -2;
     if (flat_env == -2) { const char* e = getenv("GGNN_K2_FLAT"); flat_env = e ? atoi(e) : -1; }
     const bool flat = flat_env >= 0 ? flat_env != 0 : (D4 < 64 && (64 % D4) != 0);
-    if (heads) {
+    if (heads && flat) {   // (the sub-wave kernels keep their own slot-index broadcast: at D = 256 / in-degree 10 they measure 155 vs 179 us)
         const long long total4 = (long long)V * D4;
         hipLaunchKernelGGL(gather_segment_sum_heads_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, Hrows, row_ptr,
                            gather_row, reinterpret_cast<const int4*>(heads), nin, bias, use_avg, out, total4, D, T, accumulate);

@@ -92,13 +92,19 @@ class DenseGGNNChemModel(ChemModel):
         keep_s = float(ph.get('graph_state_keep_prob', 1.0))
         bias = self.weights['edge_biases'].reshape(self.num_edge_types, h_dim) if self.params['use_edge_bias'] else None
         cell = self.weights['node_gru']
+        # the GRU's LDS weight images are packed once per weight version (the one cell is shared by all timesteps, :101-102)
+        from .autograd import _PACKED
+        packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, 1, h_dim) if ops.gru_is_fused(h_dim) else None
         for i in range(self.params['num_timesteps']):                  # :100
             # :104 a fresh weight-dropout mask per (timestep, edge type)
             W = tf_dropout(self.weights['edge_weights'], keep_w).contiguous()
             Hm = ops.msg_transform(h, W)                               # :104-106 for all edge types
             acts = ops.dense_aggregate(A, Hm, bias)                    # :107-112
-            h = ops.gru([acts], h, cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias,
-                        "tanh")                                        # :115
+            if packed is not None:
+                h = ops.gru_packed([acts], h, packed, cell.gates_bias, cell.candidate_bias, "tanh")      # :115
+            else:
+                h = ops.gru([acts], h, cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias,
+                            "tanh")                                    # :115
             h = tf_dropout(h, keep_s)
         return h.reshape(b, v, h_dim)                                  # :116
 
