@@ -36,6 +36,9 @@ SYMBOLS = {
     "ggnn_build_slot_heads": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ggnn_gather_segment_sum_heads_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                                   c_int, c_int, c_int, c_int, c_void_p]),
+    "ggnn_attn_bwd_target_f32": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "ggnn_weighted_segment_sum_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p]),
+    "ggnn_range_sum_f32": (c_int, [c_void_p, POINTER(c_int64), c_int, c_void_p, c_void_p]),
     "ggnn_unsorted_segment_sum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "ggnn_gated_readout_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_int, c_int, c_void_p]),
@@ -83,6 +86,11 @@ SYMBOLS = {
     "ggnn_gru_bwd_dx_cand_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
     "ggnn_gru_bwd_dx_gates_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ggnn_gather_segment_sum_acc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ggnn_bwd_dx_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ggnn_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "ggnn_cudnn_gru_train_f32": (c_int, [POINTER(c_void_p), c_int] + [c_void_p] * 9 + [c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "ggnn_cudnn_gru_bwd_stage_f32": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p]),
     "ggnn_gru_bwd_is_fused": (c_int, [c_int]),
     "ggnn_gru_bwd_packed_bytes": (c_size_t, [c_int, c_int]),
     "ggnn_gru_bwd_fused_f32": (c_int, [c_void_p] * 12 + [POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

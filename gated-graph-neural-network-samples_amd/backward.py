@@ -135,18 +135,29 @@ class PropagationStepFn(torch.autograd.Function):
             dbias = ops.xty([dinc], nin).t().contiguous()                      # (dinc^T nin)^T = nin^T dinc   [T, D]
 
         # ---- 6.-8. segment sum and compacted transform  Hc[r] = h[node(r)] W_type(r)  on the same R rows
-        comp = ctx.comp
-        bwd = ops.compact_backward(ctx.index, comp)
-        R = comp.num_rows
-        if R:
-            from .autograd import _PACKED
-            dHc = ops.segment_sum_rows_by_index(dinc, bwd.rows_index)                          # [R,D], transpose gather
-            Z = ops.msg_transform_compact_packed(dHc, _PACKED.edge(_TRANSPOSED.get(W, (1, 2))), T, bwd.identity)   # dHc W_t^T
-            ops.segment_sum_rows_acc(Z[:R], bwd.node_index, dh)                              # sum over a node's types
-            dW = ops.xty([h], dHc, x_rows=comp.pair_node, row_off=comp.type_row_off)           # [T, D, D]
-        else:
-            dW = torch.zeros_like(W)
+        dW = transform_backward(ctx.index, ctx.comp, h, W, dinc, dh)
         return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, *d_res)
+
+
+def transform_backward(index, comp, h, W, dinc, dh, message_weights=None):
+    """Backward of  incoming[v] = sum over the messages into v of (w_m *) h[src_m] W_type(m)  given dinc = dL/d incoming:
+    adds the state gradient to `dh` in place and returns dW [T,D,D].  On the compact (source node, type) rows whatever form
+    the forward transform had:  dHc[r] = sum over the messages leaving pair r of (w_m *) dinc[dst_m]  (transpose gather),
+    Z = dHc W_t^T (the compacted transform kernel on W^T),  dh[v] += sum_t Z[row(v,t)],  dW_t = h[pair_node[rows_t]]^T dHc[rows_t].
+    message_weights: per-message weights w (by message id; the attention coefficients) or None."""
+    from .autograd import _PACKED
+    T = W.shape[0]
+    bwd = ops.compact_backward(index, comp)
+    R = comp.num_rows
+    if not R:
+        return torch.zeros_like(W)
+    if message_weights is None:
+        dHc = ops.segment_sum_rows_by_index(dinc, bwd.rows_index)                              # [R,D], transpose gather
+    else:
+        dHc = ops.weighted_segment_sum(dinc, bwd.rows_index, bwd.rows_index.msg, message_weights)
+    Z = ops.msg_transform_compact_packed(dHc, _PACKED.edge(_TRANSPOSED.get(W, (1, 2))), T, bwd.identity)       # dHc W_t^T
+    ops.segment_sum_rows_acc(Z[:R], bwd.node_index, dh)                                      # sum over a node's types
+    return ops.xty([h], dHc, x_rows=comp.pair_node, row_off=comp.type_row_off)                 # [T, D, D]
 
 
 def _gru_backward_unfused(lib, g, h, r, u, c, Wg, Wc, nin, xs, nx, T, act, use_avg, st):

@@ -231,9 +231,9 @@ extern "C" size_t ggnn_cudnn_gru_workspace_bytes(int V, int D) {
     return V < 0 || D <= 0 ? 0 : (size_t)4 * V * D * sizeof(float);
 }
 
-extern "C" int ggnn_cudnn_gru_f32(const float* const* x_segs, int nx, const float* h, const float* Wg, const float* bg,
-                                  const float* Wcx, const float* bcx, const float* Wch, const float* bch, float* h_out,
-                                  void* ws, size_t ws_bytes, int V, int D, ggnn_stream_t stream) {
+static int cudnn_gru_impl(const float* const* x_segs, int nx, const float* h, const float* Wg, const float* bg,
+                          const float* Wcx, const float* bcx, const float* Wch, const float* bch, float* h_out,
+                          void* ws, size_t ws_bytes, int V, int D, float* save_c, ggnn_stream_t stream) {
     if (int rc = gru_args_check(x_segs, nx, h, V, D)) return rc;
     if (V == 0) return GGNN_OK;
     GGNN_CHECK_ARG(Wg && bg && Wcx && bcx && Wch && bch && h_out && ws && h_out != h, "null pointer or h_out aliases h");
@@ -256,8 +256,47 @@ extern "C" int ggnn_cudnn_gru_f32(const float* const* x_segs, int nx, const floa
     for (int s = 0; s < nx; ++s) { g.A[s] = x_segs[s]; g.lda[s] = D; }
     g.nseg = nx; g.D = D; g.M = V;
     g.B = Wcx; g.ldb = D; g.b_blk_cols = D; g.b_blk_stride = 0; g.N = D;
-    EpiCudnnCand e{bcx, r, hc, h, u, h_out, D};
+    EpiCudnnCand e{bcx, r, hc, h, u, h_out, D, save_c};
     return dispatch_gemm(g, e, st);
+}
+
+extern "C" int ggnn_cudnn_gru_f32(const float* const* x_segs, int nx, const float* h, const float* Wg, const float* bg,
+                                  const float* Wcx, const float* bcx, const float* Wch, const float* bch, float* h_out,
+                                  void* ws, size_t ws_bytes, int V, int D, ggnn_stream_t stream) {
+    return cudnn_gru_impl(x_segs, nx, h, Wg, bg, Wcx, bcx, Wch, bch, h_out, ws, ws_bytes, V, D, nullptr, stream);
+}
+
+// Training form: also keeps the candidate c; after the call ws holds [r*h | u | r | h Wch + bch] ([V,D] each) for the backward pass.
+extern "C" int ggnn_cudnn_gru_train_f32(const float* const* x_segs, int nx, const float* h, const float* Wg, const float* bg,
+                                        const float* Wcx, const float* bcx, const float* Wch, const float* bch, float* h_out,
+                                        float* save_c, void* ws, size_t ws_bytes, int V, int D, ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(save_c && aligned16(save_c), "save_c null or misaligned");
+    return cudnn_gru_impl(x_segs, nx, h, Wg, bg, Wcx, bcx, Wch, bch, h_out, ws, ws_bytes, V, D, save_c, stream);
+}
+
+// General dX product of the backward pass with its epilogue (EpiBwdDx): Q = dY WT, dY [V, nseg_y * D] given as nseg_y column
+// segments of one row-major matrix (row stride ldy), WT [nseg_y * D, K] row-major.  Columns [0, xcols) of Q are the x segments
+// (xcols = nx * D; with split_inc the last D of them are the aggregated messages -> dinc, divided by the in-degree with
+// use_avg; without it all of them go to dx); columns
+// [xcols, K) (K == xcols + D, or K == xcols: no h block) -> dh.  acc_dx / acc_dh: add to the existing dx / dh instead of writing.
+extern "C" int ggnn_bwd_dx_f32(const float* dY, int ldy, int nseg_y, const float* WT, int K, float* dx, int xcols, int split_inc,
+                               float* dinc, const float* nin, int T, int use_avg, float* dh, int acc_dx, int acc_dh, int V, int D,
+                               ggnn_stream_t stream) {
+    if (int rc = check_common(V, D)) return rc;
+    GGNN_CHECK_ARG(nseg_y >= 1 && nseg_y <= 4 && ldy >= nseg_y * D && ldy % 4 == 0, "bad dY layout");
+    GGNN_CHECK_ARG(xcols >= 0 && xcols % D == 0 && (K == xcols || K == xcols + D) && K > 0, "K / xcols mismatch");
+    if (V == 0) return GGNN_OK;
+    const bool inc = split_inc && xcols > 0;
+    GGNN_CHECK_ARG(dY && WT && (K == xcols || dh) && (!inc || dinc) && ((inc && xcols <= D && !acc_dx) || xcols == 0 || dx) &&
+                   (!(inc && use_avg) || nin), "null pointer");
+    GGNN_CHECK_ARG(aligned16(dY) && aligned16(WT), "pointers must be 16-byte aligned");
+    GemmOperands g{};
+    for (int s = 0; s < nseg_y; ++s) { g.A[s] = dY + (size_t)s * D; g.lda[s] = ldy; }
+    g.nseg = nseg_y; g.D = D; g.M = V;
+    g.B = WT; g.ldb = K; g.b_blk_cols = K; g.b_blk_stride = 0; g.N = K;
+    const int inc0 = inc ? xcols - D : xcols;                // first column of the aggregated-messages segment (xcols: none)
+    EpiBwdDx e{dx, xcols > 0 ? xcols : 4, xcols, inc0, dinc, nin, T, use_avg, dh, D, acc_dx, acc_dh};   // dx: [V, xcols]
+    return dispatch_gemm(g, e, (hipStream_t)stream);
 }
 
 // GRU with the segment sum fused in: the aggregated-messages input (the LAST x segment) is not passed but gathered

@@ -126,13 +126,14 @@ struct EpiBiasAct {
 // CudnnCompatibleGRUCell candidate (chem_tensorflow_sparse.py:105-108):
 //   c = tanh(x Wcx + bcx + r * (h Wch + bch)); h' = u*h + (1-u)*c     (hc = h Wch + bch precomputed)
 struct EpiCudnnCand {
-    const float* bcx; const float* r; const float* hc; const float* h; const float* u; float* h_out; int D;
+    const float* bcx; const float* r; const float* hc; const float* h; const float* u; float* h_out; int D; float* save_c;
     __device__ __forceinline__ void operator()(int row, int col, f32x4 v) const {
         const size_t o = (size_t)row * D + col;
         f32x4 c = v + ld4(bcx + col) + ld4(r + o) * ld4(hc + o);
         c.x = tanh_f(c.x); c.y = tanh_f(c.y); c.z = tanh_f(c.z); c.w = tanh_f(c.w);
         const f32x4 uv = ld4(u + o);
         st4(h_out + o, uv * ld4(h + o) + (1.0f - uv) * c);
+        if (save_c) st4(save_c + o, c);
     }
 };
 
@@ -177,6 +178,30 @@ struct EpiBwdGates {
     }
 };
 
+
+// General dX epilogue of the backward pass: Q = dY W^T with columns [x_0 .. x_{nx-1} | h] (the h block may be absent):
+//   residual columns -> dx (= or +=), the LAST x segment -> dinc = (acc_dx ? dx + Q : Q) (/ (sum_t nin + 1e-7)), h columns -> dh (= or +=)
+struct EpiBwdDx {
+    float* dx; int ld_dx; int xcols; int inc0;
+    float* dinc; const float* nin; int T; int use_avg;
+    float* dh; int D; int acc_dx; int acc_dh;
+    __device__ __forceinline__ void operator()(int row, int col, f32x4 v) const {
+        if (col >= xcols) {
+            const size_t o = (size_t)row * D + (col - xcols);
+            st4(dh + o, acc_dh ? ld4(dh + o) + v : v);
+            return;
+        }
+        f32x4 t = v;
+        if (acc_dx) t = t + ld4(dx + (size_t)row * ld_dx + col);
+        if (col < inc0) { st4(dx + (size_t)row * ld_dx + col, t); return; }
+        if (use_avg) {
+            float deg = 0.f;
+            for (int k = 0; k < T; ++k) deg += nin[(size_t)row * T + k];
+            t = t / (deg + 1e-7f);
+        }
+        st4(dinc + (size_t)row * D + (col - inc0), t);
+    }
+};
 
 struct GruFusedArgs {
     const float* x[3];

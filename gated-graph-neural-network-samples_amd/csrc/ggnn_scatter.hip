@@ -282,6 +282,112 @@ __global__ __launch_bounds__(256) void gather_segment_sum_attn_kernel(
     }
 }
 
+// ---- backward of the propagation attention (what TF autodiff derives from chem_tensorflow_sparse.py:170-196) ----------------
+// Forward, per target v over its message slots e (g_e = src_e*T + t_e):  p_e = <h[src_e], h[v]>,  s_e = p_e f[t_e],
+//   a_e = exp(s_e - max) / (sum_k exp(s_k - max) + 1e-7),   att[v] = sum_e a_e H[g_e].
+// Given d = dL/d att [V,D]:   da_e = <H[g_e], d[v]>,   ds_e = a_e (da_e - sum_k a_k da_k)
+//   target side (this kernel):   dh[v] (+)= sum_e ds_e f[t_e] h[src_e]
+//   per message (written by ORIGINAL message id m = msg_perm[slot], the order the by-source index refers to):
+//       coef_a[m] = a_e            -> dH[g_e]   += a_e d[v]                 (weighted transpose gather, below)
+//       coef_s[m] = ds_e f[t_e]    -> dh[src_e] += ds_e f[t_e] h[v]         (weighted gather by source node, below)
+//       dfac[m]   = ds_e p_e       -> df[t]      = sum over the messages of type t  (range reduction, below)
+// One sub-wave per target, the scores recomputed in every pass (no [M] temporaries beyond the three outputs).
+template <int LPR>
+__global__ __launch_bounds__(256) void attn_bwd_target_kernel(
+        const float* __restrict__ H, const float* __restrict__ h, const float* __restrict__ d, const int* __restrict__ row_ptr,
+        const int* __restrict__ gidx, const int* __restrict__ msg_perm, const float* __restrict__ factors,
+        float* __restrict__ coef_a, float* __restrict__ coef_s, float* __restrict__ dfac, float* __restrict__ dh, int accumulate,
+        int V, int D, int T) {
+    constexpr int NODES = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    int v = blockIdx.x * NODES + threadIdx.x / LPR;
+    const bool live = v < V;
+    v = live ? v : V - 1;
+    const int beg = row_ptr[v], end = live ? row_ptr[v + 1] : beg;
+    const int D4 = D >> 2;
+    const bool col_ok = l < D4;
+    const int c4 = col_ok ? l : 0;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 hv = col_ok ? *reinterpret_cast<const f32x4*>(h + (size_t)v * D + 4 * c4) : zero;
+    const f32x4 dv = col_ok ? *reinterpret_cast<const f32x4*>(d + (size_t)v * D + 4 * c4) : zero;
+    auto dot = [&](f32x4 a, f32x4 b) {
+        float part = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) part += __shfl_xor(part, off, LPR);
+        return part;
+    };
+    auto hsrc = [&](int g) { return col_ok ? *reinterpret_cast<const f32x4*>(h + (size_t)(g / T) * D + 4 * c4) : zero; };
+    float m = -3.402823466e+38f;
+    for (int e = beg; e < end; ++e) { const int g = gidx[e]; m = fmaxf(m, dot(hsrc(g), hv) * factors[g % T]); }
+    float S = 0.f;
+    for (int e = beg; e < end; ++e) { const int g = gidx[e]; S += expf(dot(hsrc(g), hv) * factors[g % T] - m); }
+    const float inv = 1.0f / (S + 1e-7f);
+    float t1 = 0.f;
+    for (int e = beg; e < end; ++e) {
+        const int g = gidx[e];
+        const float a = expf(dot(hsrc(g), hv) * factors[g % T] - m) * inv;
+        const f32x4 Hg = col_ok ? *reinterpret_cast<const f32x4*>(H + (size_t)g * D + 4 * c4) : zero;
+        t1 += a * dot(Hg, dv);
+    }
+    f32x4 acc = zero;
+    for (int e = beg; e < end; ++e) {
+        const int g = gidx[e];
+        const f32x4 hs = hsrc(g);
+        const float f = factors[g % T];
+        const float p = dot(hs, hv);
+        const float a = expf(p * f - m) * inv;
+        const f32x4 Hg = col_ok ? *reinterpret_cast<const f32x4*>(H + (size_t)g * D + 4 * c4) : zero;
+        const float ds = a * (dot(Hg, dv) - t1);
+        acc += (ds * f) * hs;
+        if (l == 0) {
+            const int mid = msg_perm[e];
+            coef_a[mid] = a; coef_s[mid] = ds * f; dfac[mid] = ds * p;
+        }
+    }
+    if (col_ok && live) {
+        float* o = dh + (size_t)v * D + 4 * c4;
+        if (accumulate) acc += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = acc;
+    }
+}
+
+// out[seg] (+)= sum over the slots of seg of w[wid[slot]] * rows[gidx[slot]]   (slot order; one sub-wave per segment)
+template <int LPR>
+__global__ __launch_bounds__(256) void weighted_segment_sum_kernel(
+        const float* __restrict__ rows, const int* __restrict__ row_ptr, const int* __restrict__ gidx, const int* __restrict__ wid,
+        const float* __restrict__ w, float* __restrict__ out, int accumulate, int nseg, int D) {
+    constexpr int SEGS = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int sgm = blockIdx.x * SEGS + threadIdx.x / LPR;
+    if (sgm >= nseg) return;
+    const int beg = row_ptr[sgm], end = row_ptr[sgm + 1];
+    const int D4 = D >> 2;
+    for (int c4 = l; c4 < D4; c4 += LPR) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int e = beg; e < end; ++e)
+            acc += w[wid[e]] * *reinterpret_cast<const f32x4*>(rows + (size_t)gidx[e] * D + 4 * c4);
+        float* o = out + (size_t)sgm * D + 4 * c4;
+        if (accumulate) acc += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = acc;
+    }
+}
+
+// out[b] = sum of values[off[b] .. off[b+1])   (one block per range, fixed-order tree: deterministic)
+struct RangeOffsets { long long off[kMaxTypes + 1]; };
+__global__ __launch_bounds__(256) void range_sum_kernel(const float* __restrict__ values, RangeOffsets ro, float* __restrict__ out) {
+    __shared__ float red[256];
+    const long long beg = ro.off[blockIdx.x], end = ro.off[blockIdx.x + 1];
+    float s = 0.f;
+    for (long long i = beg + threadIdx.x; i < end; i += 256) s += values[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
 __global__ void unsorted_segment_sum_kernel(const float* __restrict__ data, const int* __restrict__ ids,
                                             float* out, long long total, int D, int num_segments) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -471,4 +577,59 @@ extern "C" int ggnn_gather_segment_sum_heads_f32(const float* Hrows, const int32
                                                  int V, int D, int T, int accumulate, ggnn_stream_t stream) {
     GGNN_CHECK_ARG(heads && aligned16(heads), "heads null or misaligned");
     return gather_segment_sum_impl(Hrows, row_ptr, gather_row, nin, bias, use_avg, out, V, D, T, accumulate, stream, heads);
+}
+
+// ---- propagation-attention backward (see attn_bwd_target_kernel) ----------------------------------------------------------
+extern "C" int ggnn_attn_bwd_target_f32(const float* Hrows, const float* h, const float* d_att, const int32_t* row_ptr,
+                                        const int32_t* gather_row, const int32_t* msg_perm, const float* type_factors,
+                                        float* coef_a, float* coef_s, float* dfac, float* dh, int accumulate, int V, int D, int T,
+                                        ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(V >= 0 && D > 0 && D % 4 == 0 && T > 0, "bad sizes V=%d D=%d T=%d", V, D, T);
+    if (D > 256) return fail(GGNN_E_UNSUPPORTED, "propagation attention supports hidden sizes up to 256 (got %d)", D);
+    if (V == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(Hrows && h && d_att && row_ptr && type_factors && dh, "null pointer");
+    GGNN_CHECK_ARG(aligned16(Hrows) && aligned16(h) && aligned16(d_att) && aligned16(dh), "pointers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int D4 = D / 4;
+#define GGNN_ATTN_BWD(LPR, NODES)                                                                                     \
+    hipLaunchKernelGGL(attn_bwd_target_kernel<LPR>, dim3((V + NODES - 1) / NODES), dim3(256), 0, st, Hrows, h, d_att, row_ptr,   \
+                       gather_row, msg_perm, type_factors, coef_a, coef_s, dfac, dh, accumulate, V, D, T)
+    if (D4 <= 16) GGNN_ATTN_BWD(16, 16);
+    else if (D4 <= 32) GGNN_ATTN_BWD(32, 8);
+    else GGNN_ATTN_BWD(64, 4);
+#undef GGNN_ATTN_BWD
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+extern "C" int ggnn_weighted_segment_sum_f32(const float* rows, const int32_t* row_ptr, const int32_t* gather_row,
+                                             const int32_t* weight_id, const float* weights, float* out, int accumulate,
+                                             int num_segments, int D, ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(num_segments >= 0 && D > 0 && D % 4 == 0, "bad sizes");
+    if (num_segments == 0) return GGNN_OK;
+    GGNN_CHECK_ARG(rows && row_ptr && out && aligned16(rows) && aligned16(out), "null or misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int D4 = D / 4;
+    if (D4 <= 16)
+        hipLaunchKernelGGL(weighted_segment_sum_kernel<16>, dim3((num_segments + 15) / 16), dim3(256), 0, st, rows, row_ptr, gather_row,
+                           weight_id, weights, out, accumulate, num_segments, D);
+    else if (D4 <= 32)
+        hipLaunchKernelGGL(weighted_segment_sum_kernel<32>, dim3((num_segments + 7) / 8), dim3(256), 0, st, rows, row_ptr, gather_row,
+                           weight_id, weights, out, accumulate, num_segments, D);
+    else
+        hipLaunchKernelGGL(weighted_segment_sum_kernel<64>, dim3((num_segments + 3) / 4), dim3(256), 0, st, rows, row_ptr, gather_row,
+                           weight_id, weights, out, accumulate, num_segments, D);
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+extern "C" int ggnn_range_sum_f32(const float* values, const int64_t* range_off, int num_ranges, float* out, ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(num_ranges >= 0 && num_ranges <= kMaxTypes && range_off && out, "bad ranges");
+    if (num_ranges == 0) return GGNN_OK;
+    RangeOffsets ro;
+    for (int b = 0; b <= num_ranges; ++b) { ro.off[b] = range_off[b]; GGNN_CHECK_ARG(b == 0 || range_off[b] >= range_off[b - 1], "ranges not monotone"); }
+    GGNN_CHECK_ARG(values || ro.off[num_ranges] == ro.off[0], "null pointer");
+    hipLaunchKernelGGL(range_sum_kernel, dim3(num_ranges), dim3(256), 0, (hipStream_t)stream, values, ro, out);
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
 }

@@ -405,6 +405,95 @@ def gru_bwd_fused(g, h, r, u, c, packed, nin, use_avg: bool, nx: int, activation
     return dpc, dpg, rh, dh, dx
 
 
+def weighted_segment_sum(rows: torch.Tensor, index: "SegmentIndex", weight_id: torch.Tensor, weights: torch.Tensor,
+                         out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """out[s] (+)= sum over the slots of segment s of weights[weight_id[slot]] * rows[index.gather_row[slot]]."""
+    lib = _lib.load()
+    _req(rows, torch.float32, "rows"); _req(weights, torch.float32, "weights"); _req(weight_id, torch.int32, "weight_id")
+    D = rows.shape[1]
+    nseg = index.num_nodes
+    if out is None:
+        out = torch.empty((nseg, D), dtype=torch.float32, device=rows.device)
+    _launch("weighted_segment_sum", lambda: lib.ggnn_weighted_segment_sum_f32(
+        _ptr(rows), _ptr(index.row_ptr), _ptr(index.gather_row), _ptr(weight_id), _ptr(weights), _ptr(out), 1 if accumulate else 0,
+        nseg, D, _stream()))
+    return out
+
+
+def attn_backward_target(H: torch.Tensor, h: torch.Tensor, d_att: torch.Tensor, index: MessageIndex, type_factors: torch.Tensor,
+                         dh: torch.Tensor):
+    """Target-side pass of the propagation-attention backward (ggnn_attn_bwd_target_f32): adds sum_e ds_e f_t h[src_e] to dh[v]
+    and returns the per-message (coef_a, coef_s, dfac), indexed by message id."""
+    lib = _lib.load()
+    V, D = h.shape
+    T, M = index.num_edge_types, index.num_messages
+    dev = h.device
+    ca = torch.empty(max(M, 1), dtype=torch.float32, device=dev); cs = torch.empty_like(ca); df = torch.empty_like(ca)
+    _launch("attn_bwd_target", lambda: lib.ggnn_attn_bwd_target_f32(
+        _ptr(H), _ptr(h), _ptr(d_att), _ptr(index.row_ptr), _ptr(index.gather_row), _ptr(index.msg_perm), _ptr(type_factors), _ptr(ca),
+        _ptr(cs), _ptr(df), _ptr(dh), 1, V, D, T, _stream()))
+    return ca, cs, df
+
+
+def range_sum(values: torch.Tensor, offsets: Sequence[int]) -> torch.Tensor:
+    """out[b] = sum(values[offsets[b]:offsets[b+1]]), deterministic (ggnn_range_sum_f32)."""
+    lib = _lib.load()
+    B = len(offsets) - 1
+    out = torch.empty(B, dtype=torch.float32, device=values.device)
+    off = (ctypes.c_int64 * (B + 1))(*[int(o) for o in offsets])
+    check(lib.ggnn_range_sum_f32(_ptr(values), off, B, _ptr(out), _stream()))
+    return out
+
+
+def bwd_dx(dY: torch.Tensor, nseg_y: int, WT: torch.Tensor, xcols: int, split_inc: bool, dx: Optional[torch.Tensor],
+           dinc: Optional[torch.Tensor], nin: Optional[torch.Tensor], use_avg: bool, dh: Optional[torch.Tensor], acc_dx: bool,
+           acc_dh: bool, D: int) -> None:
+    """Q = dY WT with the backward epilogue of ggnn_bwd_dx_f32 (x columns -> dx / dinc, h columns -> dh)."""
+    lib = _lib.load()
+    V = dY.shape[0]
+    K = WT.shape[1]
+    T = nin.shape[1] if nin is not None else 1
+    _launch("bwd_dx[K=%d]" % K, lambda: lib.ggnn_bwd_dx_f32(
+        _ptr(dY), dY.stride(0) if V > 1 else dY.shape[1], nseg_y, _ptr(WT), K, _ptr(dx), xcols, 1 if split_inc else 0, _ptr(dinc),
+        _ptr(nin), T, 1 if use_avg else 0, _ptr(dh), 1 if acc_dx else 0, 1 if acc_dh else 0, V, D, _stream()))
+
+
+def act_bwd(g: torch.Tensor, out: torch.Tensor, activation: str) -> torch.Tensor:
+    """dP = g * act'(out) (BasicRNNCell backward)."""
+    lib = _lib.load()
+    V, D = out.shape
+    dP = torch.empty_like(out)
+    _launch("act_bwd", lambda: lib.ggnn_act_bwd_f32(_ptr(g), _ptr(out), ACT_IDS[activation.lower()], _ptr(dP), V, D, _stream()))
+    return dP
+
+
+def cudnn_gru_train(x_segs: Sequence[torch.Tensor], h: torch.Tensor, Wg, bg, Wcx, bcx, Wch, bch):
+    """ops.cudnn_gru that keeps what the backward pass needs: -> (h', r, u, c, hc)."""
+    lib = _lib.load()
+    V, D = h.shape
+    nx = len(x_segs)
+    out = torch.empty_like(h); c = torch.empty_like(h)
+    ws_bytes = lib.ggnn_cudnn_gru_workspace_bytes(V, D)
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=h.device)
+    segs = (ctypes.c_void_p * nx)(*[_req(x, torch.float32, "x").data_ptr() for x in x_segs])
+    _launch("cudnn_gru[nx=%d]" % nx, lambda: lib.ggnn_cudnn_gru_train_f32(segs, nx, _ptr(h), _ptr(Wg), _ptr(bg), _ptr(Wcx), _ptr(bcx),
+                                                                          _ptr(Wch), _ptr(bch), _ptr(out), _ptr(c), _ptr(ws), ws_bytes,
+                                                                          V, D, _stream()))
+    n = V * D
+    return out, ws[2 * n:3 * n].view(V, D), ws[n:2 * n].view(V, D), c, ws[3 * n:4 * n].view(V, D)
+
+
+def cudnn_gru_bwd_stage(g, h, r, u, c, hc):
+    """Element-wise part of the CudnnCompatibleGRUCell backward -> (dpc, dpg = [dpr|dpu], dh = g*u, dhc)."""
+    lib = _lib.load()
+    V, D = h.shape
+    dpc = torch.empty_like(h); dh = torch.empty_like(h); dhc = torch.empty_like(h)
+    dpg = torch.empty((V, 2 * D), dtype=torch.float32, device=h.device)
+    _launch("cudnn_gru_bwd_stage", lambda: lib.ggnn_cudnn_gru_bwd_stage_f32(_ptr(g), _ptr(h), _ptr(r), _ptr(u), _ptr(c), _ptr(hc),
+                                                                             _ptr(dpc), _ptr(dpg), _ptr(dh), _ptr(dhc), V, D, _stream()))
+    return dpc, dpg, dh, dhc
+
+
 def unsorted_segment_sum(data: torch.Tensor, segment_ids: torch.Tensor, num_segments: int) -> torch.Tensor:
     """tf.unsorted_segment_sum (fp32 atomics; any id order).  data [M,D] or [M], ids [M] int32."""
     lib = _lib.load()
@@ -519,8 +608,9 @@ def prepare_message_index(index: MessageIndex, hidden_size: int, compact: bool =
 class SegmentIndex:
     """row_ptr / gather_row pair for segment_sum_rows_by_index (the fields of MessageIndex that kernel reads)."""
 
-    def __init__(self, row_ptr: torch.Tensor, gather_row: torch.Tensor, num_nodes: int):
+    def __init__(self, row_ptr: torch.Tensor, gather_row: torch.Tensor, num_nodes: int, msg: Optional[torch.Tensor] = None):
         self.row_ptr, self.gather_row, self.num_nodes = row_ptr, gather_row, num_nodes
+        self.msg = msg                     # slot -> original message id (for per-message weights), where known
 
 
 class CompactBackward:
@@ -551,7 +641,9 @@ class CompactBackward:
         rp_c = torch.zeros(R + 1, dtype=torch.int32, device=dev)
         rp_c[1:] = ends.to(torch.int32)
         slots = torch.repeat_interleave(start - (ends - length), length, output_size=M) + torch.arange(M, device=dev)
-        self.rows_index = SegmentIndex(rp_c, src.gather_row[slots].contiguous(), R)
+        self.rows_index = SegmentIndex(rp_c, src.gather_row[slots].contiguous(), R, src.msg_perm[slots].contiguous())
+        # messages leaving a NODE (all its types: the by-(src,type) segments of a node are consecutive)
+        self.source_node_index = SegmentIndex(src.row_ptr[::T].contiguous(), src.gather_row, V, src.msg_perm)
         order = torch.sort(pn, stable=True)[1]                          # rows by node, type ascending inside a node
         rp_n = torch.zeros(V + 1, dtype=torch.int32, device=dev)
         rp_n[1:] = torch.cumsum(torch.bincount(pn, minlength=V), 0).to(torch.int32)

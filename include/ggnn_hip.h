@@ -137,6 +137,21 @@ int ggnn_gather_segment_sum_heads_f32(const float* Hrows, const int32_t* row_ptr
                                       const float* nin, const float* bias, int use_avg, float* out, int V, int D, int T,
                                       int accumulate, ggnn_stream_t stream);
 
+/* Backward of the propagation attention (TF autodiff of chem_tensorflow_sparse.py:170-196), three kernels:
+ * ggnn_attn_bwd_target_f32: per target node (by-target index: row_ptr, gather_row = src*T+type, msg_perm = slot -> message id),
+ *   from d_att = dL/d(attention-weighted sum) [V,D]: the target-side state gradient dh[v] (+)= sum_e ds_e f_t h[src_e], and per
+ *   MESSAGE (indexed by message id): coef_a = softmax weight a_e, coef_s = ds_e f_t, dfac = ds_e <h_src, h_tgt>;
+ * ggnn_weighted_segment_sum_f32: out[seg] (+)= sum_slots weights[weight_id[slot]] * rows[gather_row[slot]] -- with the by-source
+ *   index it is dH[src,type] = sum a_e d_att[dst] (weights = coef_a) and dh[src] += sum ds_e f_t h[dst] (weights = coef_s);
+ * ggnn_range_sum_f32: out[b] = sum values[range_off[b] .. range_off[b+1]) (HOST offsets; d attention factor of type t: messages are
+ *   type-major).  All deterministic. */
+int ggnn_attn_bwd_target_f32(const float* Hrows, const float* h, const float* d_att, const int32_t* row_ptr,
+                             const int32_t* gather_row, const int32_t* msg_perm, const float* type_factors, float* coef_a,
+                             float* coef_s, float* dfac, float* dh, int accumulate, int V, int D, int T, ggnn_stream_t stream);
+int ggnn_weighted_segment_sum_f32(const float* rows, const int32_t* row_ptr, const int32_t* gather_row, const int32_t* weight_id,
+                                  const float* weights, float* out, int accumulate, int num_segments, int D, ggnn_stream_t stream);
+int ggnn_range_sum_f32(const float* values, const int64_t* range_off, int num_ranges, float* out, ggnn_stream_t stream);
+
 /* tf.unsorted_segment_sum in its general form (chem_tensorflow_sparse.py:198-200, 226-228):
  * out[ids[m],:] += data[m,:] with out zero-filled first; fp32 atomics, any id order.  Used for the
  * readout's per-graph sum and available for un-bucketed message lists. */
@@ -344,6 +359,23 @@ int ggnn_gru_bwd_dx_gates_f32(const float* dpg, const float* WgT, float* dx, flo
                               int use_avg, float* dh, int nx, int V, int D, ggnn_stream_t stream);
 int ggnn_gather_segment_sum_acc_f32(const float* Hrows, const int32_t* row_ptr, const int32_t* gather_row, float* out,
                                     int V, int D, ggnn_stream_t stream);
+
+/* Backward building blocks of the other two cell types (chem_tensorflow_sparse.py:105-110) and of any product dX = dY W^T:
+ * ggnn_bwd_dx_f32: Q = dY WT with dY [V, nseg_y*D] (column segments of one matrix, row stride ldy) and WT [nseg_y*D, K];
+ *   columns [0, xcols) of Q are the x segments (dx is [V, xcols]: written or added to; with split_inc the LAST D of them are
+ *   the aggregated messages and go to dinc [V,D] = (acc_dx ? dx + Q : Q), divided by (sum_t nin + 1e-7) with use_avg);
+ *   columns [xcols, K) (K == xcols + D; or K == xcols: no h block) -> dh (written, or added to with acc_dh).
+ * ggnn_act_bwd_f32: dP = g * act'(out) for out = act(P)   (BasicRNNCell).
+ * ggnn_cudnn_gru_train_f32: ggnn_cudnn_gru_f32 that also keeps the candidate c; afterwards ws holds [r*h | u | r | hc] ([V,D] each).
+ * ggnn_cudnn_gru_bwd_stage_f32: dpc = g(1-u)(1-c^2); dpg = [dpc hc r(1-r) | g(h-c)u(1-u)]; dh = g u; dhc = dpc r. */
+int ggnn_bwd_dx_f32(const float* dY, int ldy, int nseg_y, const float* WT, int K, float* dx, int xcols, int split_inc, float* dinc,
+                    const float* nin, int T, int use_avg, float* dh, int acc_dx, int acc_dh, int V, int D, ggnn_stream_t stream);
+int ggnn_act_bwd_f32(const float* g, const float* out, int act, float* dP, int V, int D, ggnn_stream_t stream);
+int ggnn_cudnn_gru_train_f32(const float* const* x_segs, int nx, const float* h, const float* Wg, const float* bg,
+                             const float* Wcx, const float* bcx, const float* Wch, const float* bch, float* h_out,
+                             float* save_c, void* ws, size_t ws_bytes, int V, int D, ggnn_stream_t stream);
+int ggnn_cudnn_gru_bwd_stage_f32(const float* g, const float* h, const float* r, const float* u, const float* c, const float* hc,
+                                 float* dpc, float* dpg, float* dh, float* dhc, int V, int D, ggnn_stream_t stream);
 
 /* The whole GRU backward of a timestep in ONE launch (D in {32, 64, 100}; ggnn_gru_bwd_fused.hip) -- the mirror image of the
  * fused forward kernel: from g = dL/dh' and the saved h, r, u, c it computes, chained through registers,

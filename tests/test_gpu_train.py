@@ -111,3 +111,38 @@ def test_training_reduces_loss(pkg, oracle, cuda):
         model.run_epoch("train", model.train_data, True)
     l1 = model.run_epoch("valid", model.valid_data, False)[0]
     assert np.isfinite(l1) and l1 < l0
+
+
+@pytest.mark.parametrize("config", [
+    {"use_propagation_attention": True},
+    {"use_propagation_attention": True, "use_edge_bias": True, "use_edge_msg_avg_aggregation": False, "hidden_size": 64},
+    {"graph_rnn_cell": "RNN", "graph_rnn_activation": "ReLU"},
+    {"graph_rnn_cell": "RNN", "use_edge_bias": True, "layer_timesteps": [2, 1], "residual_connections": {"1": [0]}},
+    {"graph_rnn_cell": "CudnnCompatibleGRUCell"},
+    {"graph_rnn_cell": "CudnnCompatibleGRUCell", "use_propagation_attention": True, "layer_timesteps": [1, 2],
+     "residual_connections": {"1": [0]}},
+], ids=["attention", "attention-bias-sum-h64", "rnn-relu", "rnn-bias-residual", "cudnn-gru", "cudnn-gru-attention-residual"])
+def test_variant_hip_backward_equals_autograd_of_torch_restatement(pkg, oracle, cuda, config, monkeypatch):
+    """The non-default switches (attention, BasicRNNCell, CudnnCompatibleGRUCell): the hand-written HIP backward against torch
+    autograd of the timestep restated in differentiable torch ops (variants._step_torch, the test oracle)."""
+    from importlib import import_module
+    variants = import_module(pkg.__name__ + ".variants")
+    grads = {}
+    for mode in (False, True):
+        monkeypatch.setattr(variants, "TORCH_BACKWARD", mode)
+        model, layers, feed = _setup(pkg, oracle, config, n=80, seed=4)
+        variables = model.trainable_variables
+        for v in variables.values():
+            v.requires_grad_(True); v.grad = None
+        model.training = True
+        loss = model.forward_batch(feed)
+        loss.backward()
+        model.training = False
+        grads[mode] = {k: v.grad.detach().double().cpu() for k, v in variables.items()}
+        grads[(mode, "loss")] = float(loss)
+    assert abs(grads[(False, "loss")] - grads[(True, "loss")]) <= 1e-6 * max(1.0, abs(grads[(True, "loss")]))
+    for name, want in grads[True].items():
+        got = grads[False][name]
+        scale = float(want.abs().max()) + 1e-12
+        err = float((got - want).abs().max())
+        assert err <= 3e-4 * scale + 1e-7, (name, err, scale)
