@@ -74,6 +74,44 @@ __device__ __forceinline__ void panel_mma(f32x4 (&acc)[4], const Frag<D>& a, con
     }
 }
 
+// The same product with the panel image read straight from GLOBAL memory (L2-resident) instead of LDS, three chunks of
+// read-ahead: the cooperative tail pass, where every wave multiplies by a DIFFERENT panel at the same time (the ring holds one
+// image per stage).  Same k order per output element as panel_mma.
+template <int D, bool ZERO>
+__device__ __forceinline__ void panel_mma_global(f32x4 (&acc)[4], const Frag<D>& a, const float* __restrict__ gimg, int li, int kq) {
+    using C = PanelCfg<D>;
+    // wave-uniform image base in scalar registers + ONE 32-bit per-lane byte offset; the chunk advances the scalar base and the
+    // tile is an instruction immediate (per-lane 64-bit addresses for the 64 loads of a stage get hoisted out of the pass loop
+    // by the compiler -- hundreds of register pairs, i.e. kilobytes of scratch)
+    const unsigned long long gb = reinterpret_cast<unsigned long long>(gimg);
+    const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gb), ghi = __builtin_amdgcn_readfirstlane((unsigned)(gb >> 32));
+    const float* sbase = reinterpret_cast<const float*>(((unsigned long long)ghi << 32) | glo);
+    const unsigned voff = (unsigned)(kq * C::BN + li) * 16u;
+    auto chunk = [&](int c, int j) { return ld4_b(sbase + (size_t)c * 4 * C::BN * 4, voff + 256u * j); };
+    constexpr int AHEAD = 3;
+    f32x4 w[AHEAD + 1][4];
+#pragma unroll
+    for (int c = 0; c < AHEAD && c < C::NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[c][j] = chunk(c, j);
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c) {
+        if (c + AHEAD < C::NC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[(c + AHEAD) % (AHEAD + 1)][j] = chunk(c + AHEAD, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 cin = (ZERO && c == 0 && e == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c % (AHEAD + 1)][j][e], a.v[c][e], cin, 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // LDS-DMA of `BYTES` (a multiple of NW KiB) from src to LDS dst by an NW-wave workgroup (see dma_stage_image)
 template <int BYTES, int NW>
 __device__ __forceinline__ void dma_block(const float* src, float* dst, int wave, int lane) {
@@ -142,9 +180,15 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
     const int rest = wt_total - full_tk * NW;
     const int tail_w = (rest + nb - 1) / nb;
     const int n_tk = full_tk + (tail_w ? (rest + tail_w - 1) / tail_w : 0);
+    // One-tile tail tickets (tail_w == 1, the usual case) are worked COOPERATIVELY: wave p < NP takes panel p of the tile (phase R
+    // for its 64 columns, r*h exchanged through LDS, then phase UC for its panel), weights straight from the images in L2 --
+    // 3 NS stages on each of NP waves instead of 3 NS NP stages on one wave while seven idle.
+    const bool coop_tail = (tail_w == 1) && (NP <= NW);
+    const int n_main = coop_tail ? full_tk : n_tk;              // tickets [n_main, n_tk) are cooperative tail passes
     auto tile_of = [&](int t) -> int {
         if (t < full_tk) return t * NW + wave;
         if (t >= n_tk) return -1;
+        if (coop_tail) return full_tk * NW + (t - full_tk);     // (every wave: the same tile)
         const int tl = full_tk * NW + (t - full_tk) * tail_w + wave;
         return (wave < tail_w && tl < wt_total) ? tl : -1;
     };
@@ -158,15 +202,15 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
     dma_block<C::IMG_BYTES, NW>(packed, ring, wave, lane);
     Frag<D> af;                                // the ONE resident activation fragment (segment of the current stage)
     int tk = blockIdx.x;
-    if (tk < n_tk) load_frag<D>(af, a.x[0], row_of(tk), kq);
+    if (tk < n_main) load_frag<D>(af, a.x[0], row_of(tk), kq);
     __syncthreads();
 
-    for (; tk < n_tk; tk += nb) {
+    for (; tk < n_main; tk += nb) {
         const int tile = tile_of(tk);
         const bool active = tile >= 0;                                  // wave-uniform
         const int row = active ? tile * 16 + li : a.V;                  // (>= V: nothing is stored)
         const int rowc = row < a.V ? row : a.V - 1;
-        const bool last_pass = tk + nb >= n_tk;
+        const bool last_pass = tk + nb >= n_main;             // (of the passes that use the ring)
         const int rown = last_pass ? 0 : row_of(tk + nb);
 
         // The pass body exists twice: for a wave WITH a tile, and for a wave without one (thin tail tickets), which only takes
@@ -270,6 +314,77 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
         };
         if (active) run_pass(std::true_type{});
         else run_pass(std::false_type{});
+    }
+
+    // ---- cooperative tail passes (the ring is idle from here on; its first bytes carry the r*h exchange block) ---------------
+    constexpr int RHP = D + 4;                                  // row pitch of the exchange block [16][RHP]
+    for (; tk < n_tk; tk += nb) {
+        const int tile = tile_of(tk);                           // the same tile for every wave
+        const int row = tile * 16 + li;
+        const int rowc = row < a.V ? row : a.V - 1;
+        const int p = wave;                                     // this wave's panel
+        const bool on = p < NP;
+        float* rh_x = ring;
+        auto gimg = [&](int img_idx) { return packed + (size_t)img_idx * C::IMG; };
+        Frag<D> rh;
+        f32x4 accr[4];
+        if (on) {
+            // phase R for the panel's 64 columns: segments in order, h last
+#define GGNN_CR_STAGE(S)                                                                                            \
+            if constexpr ((S) < NS) {                                                                               \
+                load_frag<D>(af, (S) < NX ? a.x[(S) < NX ? (S) : 0] : a.h, rowc, kq);                               \
+                panel_mma_global<D, (S) == 0>(accr, af, gimg((S) * NP + p), li, kq);                                \
+            }
+            GGNN_CR_STAGE(0) GGNN_CR_STAGE(1) GGNN_CR_STAGE(2) GGNN_CR_STAGE(3)
+#undef GGNN_CR_STAGE
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int col = p * 64 + nt * 16 + 4 * kq;
+                const f32x4 r = sigmoid4_scaled(accr[nt], ld4(bias_s + col));
+                const f32x4 hv = ld4_b(a.h, ((unsigned)rowc * D + col) * 4u);
+                if constexpr (SAVE) { if (row < a.V) st4_b(a.save_r, ((unsigned)row * D + col) * 4u, r); }
+                *reinterpret_cast<f32x4*>(rh_x + li * RHP + col) = r * hv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) rh.v[c] = *reinterpret_cast<const f32x4*>(rh_x + li * RHP + 16 * c + 4 * kq);
+        __syncthreads();                                        // (the block is rewritten by the next cooperative pass)
+        if (on) {
+            f32x4 acc_u[4], acc_c[4];
+            const int img0 = R_STAGES + p * 2 * NS;
+#define GGNN_CX_STAGES(S)                                                                                           \
+            if constexpr ((S) < NX) {                                                                               \
+                load_frag<D>(af, a.x[(S)], rowc, kq);                                                               \
+                panel_mma_global<D, (S) == 0>(acc_u, af, gimg(img0 + 2 * (S)), li, kq);                             \
+                panel_mma_global<D, (S) == 0>(acc_c, af, gimg(img0 + 2 * (S) + 1), li, kq);                         \
+            }
+            GGNN_CX_STAGES(0) GGNN_CX_STAGES(1) GGNN_CX_STAGES(2)
+#undef GGNN_CX_STAGES
+            load_frag<D>(af, a.h, rowc, kq);
+            panel_mma_global<D, false>(acc_u, af, gimg(img0 + 2 * NX), li, kq);
+            panel_mma_global<D, false>(acc_c, rh, gimg(img0 + 2 * NX + 1), li, kq);
+            if (row < a.V) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int col = p * 64 + nt * 16 + 4 * kq;
+                    const f32x4 hcol = ld4_b(a.h, ((unsigned)row * D + col) * 4u);
+                    const f32x4 u = sigmoid4_scaled(acc_u[nt], ld4(bias_s + D + col));
+                    f32x4 c;
+                    if (a.act == GGNN_ACT_TANH) {
+                        c = tanh4_scaled(acc_c[nt], ld4(bias_s + 2 * D + col));
+                    } else {
+                        c = acc_c[nt] + ld4(bias_s + 3 * D + col);
+                        c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
+                    }
+                    st4_b(a.h_out, ((unsigned)row * D + col) * 4u, u * hcol + (1.0f - u) * c);
+                    if constexpr (SAVE) {
+                        st4_b(a.save_u, ((unsigned)row * D + col) * 4u, u);
+                        st4_b(a.save_c, ((unsigned)row * D + col) * 4u, c);
+                    }
+                }
+            }
+        }
     }
 }
 
