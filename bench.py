@@ -178,7 +178,8 @@ def load_pmc(workload):
 def pmc_key(pmc, name, D):
     """bench kernel label -> key of tools/pmc_summary.py (short kernel name, template arguments for the fused GRUs)."""
     if name in ("msg_transform_compact", "dense_aggregate"):
-        return next((k for k in pmc if k.startswith(name)), None)
+        return next((k for k in pmc if k.startswith(name)), None) or \
+            (next((k for k in pmc if k.startswith("msg_transform_panel")), None) if name == "msg_transform_compact" else None)
     if name == "msg_transform" or name.startswith("gru_gates") or name.startswith("gru_candidate"):
         return None                                      # (all three are instances of ggnn_gemm_kernel: not separable by name)
     if name == "gather_segment_sum":
@@ -347,7 +348,15 @@ def main():
             model.feed(f)
             return model.compute_final_node_representations()
 
+    dbg_steps = os.environ.get("GGNN_BENCH_DEBUG", "0") != "0"
+
     def train_step(i, multi=True):
+        if dbg_steps:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r = model.train_batch(train_feeds[i % len(train_feeds)])
+            torch.cuda.synchronize()
+            print("[rank %d] train step %d: %.2f ms" % (rank, i, (time.perf_counter() - t0) * 1e3), file=sys.stderr)
+            return r
         return model.train_batch(train_feeds[i % len(train_feeds)])
 
     def timed_region(step, steps, warmup, min_time, no_grad):
