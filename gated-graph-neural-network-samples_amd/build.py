@@ -36,15 +36,42 @@ def needs_build() -> bool:
     return any(os.path.getmtime(s) > t for s in _deps())
 
 
+def _headers():
+    root = os.path.dirname(HERE)
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(root, "include", "*.h"))
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile every csrc/*.hip to an object (in parallel, only those older than their source or any header) and link them."""
     if not force and not needs_build():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found; cannot build libggnn_hip.so")
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-I", os.path.join(os.path.dirname(HERE), "include")]
+    newest_header = max([os.path.getmtime(h) for h in _headers()] + [0.0])
+    jobs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header)
+        jobs.append((src, obj, stale))
+
+    def compile_one(job):
+        src, obj, stale = job
+        if stale:
+            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print("[ggnn build] " + " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, jobs))
     tmp = OUT + ".tmp"
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
-           "-I", os.path.join(os.path.dirname(HERE), "include")] + sources() + ["-o", tmp]
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", tmp]
     if verbose:
         print("[ggnn build] " + " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
