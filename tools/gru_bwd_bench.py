@@ -1,0 +1,30 @@
+"""Stand-alone timing of the fused GRU backward (config-2 shape) for each GGNN_BWD_FORM, with a cross-form equality check.
+   python tools/gru_bwd_bench.py [forms...]"""
+import importlib, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("gated-graph-neural-network-samples_amd")
+V, D, nx, T = 99990, 100, 1, 4
+dev = "cuda:0"
+torch.manual_seed(0)
+r = lambda *s: torch.rand(*s, device=dev) * 2 - 1
+g, h, c = r(V, D), r(V, D), r(V, D)
+rr, u = torch.rand(V, D, device=dev), torch.rand(V, D, device=dev)
+Wg, Wc = r((nx + 1) * D, 2 * D) * 0.2, r((nx + 1) * D, D) * 0.2
+nin = torch.ones(V, T, device=dev)
+packed = pkg.ops.PackedWeights().gru_bwd(Wg, Wc, nx, D)
+run = lambda: pkg.ops.gru_bwd_fused(g, h, rr, u, c, packed, nin, True, nx, "tanh")
+forms = sys.argv[1:] or ["0", "3"]
+ref = None
+for f in forms:
+    os.environ["GGNN_BWD_FORM"] = f
+    for _ in range(5): out = run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): out = run()
+    e1.record(); torch.cuda.synchronize()
+    flat = [o for o in (out if isinstance(out, (tuple, list)) else [out]) if torch.is_tensor(o)]
+    flat += [x for o in out if isinstance(o, (tuple, list)) for x in o if torch.is_tensor(x)]
+    if ref is None: ref = [x.clone() for x in flat]
+    same = all(torch.equal(a, b) for a, b in zip(ref, flat))
+    print("form %s: %.1f us  bit-equal to form %s: %s" % (f, e0.elapsed_time(e1) * 20, forms[0], same), flush=True)
