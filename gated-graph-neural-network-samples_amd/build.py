@@ -52,6 +52,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-I", os.path.join(os.path.dirname(HERE), "include")]
+    flags += os.environ.get("GGNN_EXTRA_HIPCC_FLAGS", "").split()      # e.g. -DGGNN_XTY_TIMELINE=1 for tools/xty_timeline.py (then --force)
     newest_header = max([os.path.getmtime(h) for h in _headers()] + [0.0])
     jobs = []
     for src in sources():

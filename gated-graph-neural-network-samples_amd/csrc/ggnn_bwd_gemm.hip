@@ -11,28 +11,44 @@
 //                     that neither the [V,K] product nor r*h / dpr round-trip through HBM as separate passes.
 //
 // ggnn_xty_f32 design (FP32 MFMA 16x16x4, 157 TF peak):  the contraction runs over ROWS, so both operands are needed as
-// "4 consecutive rows x 16 consecutive columns" fragments.  Row slabs (32 rows) of X and dY are brought into LDS by LDS-DMA
+// "4 consecutive rows x 16 consecutive columns" fragments.  Row slabs (32 or 64 rows) of X and dY are brought into LDS by LDS-DMA
 // (global_load_lds, no staging registers, two slabs in flight) in their global row-major layout, with a row pitch == 16 or 48
-// (mod 64 floats) so that the four rows a ds_read_b32 operand fetch touches sit in disjoint banks.  Wave w of a workgroup owns
-// MT 16-column tiles of X (rows of dW) x ALL N columns (NT tiles): MT + NT operand reads feed MT*NT MFMAs per 4-row step.
+// (mod 64 floats) so that the four rows a ds_read_b32 operand fetch touches sit in disjoint banks.
+// A workgroup is 16 waves, one per (SIMD s, group i): the <= 16 column tiles of X (rows of dW) and the <= 16 column tiles of dY
+// are each cut into 4 groups of <= 4 tiles, and wave 4*i + s multiplies X group i with dY group (i + s) % 4 -- every (X group,
+// dY group) pair exactly once, and each SIMD gets one wave of every X group and of every dY group, so the MFMA load of the four
+// SIMDs differs by at most one tile product (13 x 13 tiles: 43/42/42/42; the earlier one-wave-per-X-tile layout: 52/39/39/39).
+// A wave reads MT + NT <= 8 operand registers for MT * NT <= 16 MFMAs per 4-row step.
 #include "ggnn_gemm.hpp"
 #include "ggnn_stage.hpp"
 
 namespace ggnn {
 
-constexpr int kXtyRows = 32;                   // rows per LDS slab
 constexpr int kXtyMaxBatch = 64;
+constexpr int kXtyWaves = 16;
+constexpr int kXtyMaxI = 4;                    // decoded DMA instructions per wave, operand and slab
+#ifndef GGNN_XTY_TIMELINE
+#define GGNN_XTY_TIMELINE 0
+#endif
+
+// 16-byte DMA sources that are not operand data: the chunk of X that holds the "ones" column K (Kout == K + 1: row K of the
+// product is then the column sum of dY, the bias gradient), and the X chunks of slab rows past the end of a workgroup's row range
+// (zeros: those rows then add nothing, whatever dY row the clamped address fetched) -- so the MFMA loop needs no masking at all.
+__device__ const float kXtyOnesChunk[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+__device__ const float kXtyZeroChunk[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
 struct XtyArgs {
     const float* X[4]; int ldx[4]; int nseg; int Dseg;     // X(v, k) = X[k / Dseg][row(v) * ldx + k % Dseg]
     const int* x_rows;                                      // optional: row(v) = x_rows[v]
     const float* Y; int ldy;                                // dY(v, n)
-    float* part;                                            // partial products [batch][split][K][N]
-    int K, N, nbatch, splits;
+    float* part;                                            // partial products [workgroup row][Kout][N]
+    int K, N, nbatch;
     int Kout;                                               // K, or K + 1: row K of the product is 1^T dY (column sums = bias gradient)
     int row_off[kXtyMaxBatch + 1];                          // batch b owns rows row_off[b] .. row_off[b+1]-1
-    int kb_tiles;                                           // 16-column tiles of X per workgroup
+    int wg_off[kXtyMaxBatch + 1];                           // ... and is worked by workgroup rows (blockIdx.y) wg_off[b] .. wg_off[b+1]-1
+    int kb_tiles, n_tiles;                                  // 16-column tiles of X per workgroup (blockIdx.x = K block); of dY
     int pitch_x, pitch_y;                                   // LDS row pitches in floats
+    unsigned long long* tdbg;                               // (debug) s_memtime stamps of workgroup (0,0): tools/xty_timeline.py
 };
 
 static inline int xty_pitch(int width) {                    // smallest pitch >= width, a multiple of 16, == 16 or 48 (mod 64)
@@ -41,165 +57,204 @@ static inline int xty_pitch(int width) {                    // smallest pitch >=
     return p;
 }
 
-// Slab loader: a slab is a linear run of 16-byte chunks (row-major, `cpr` chunks per row); DMA instruction j of a wave moves
-// chunks [64*(j*nw + wave), +64).  chunk -> (row in slab, segment, column in segment) is fixed per lane, so it is decoded once
-// and kept packed: bits 0-15 column within the segment, 16-17 segment, 18-23 row in slab, 31 = padding chunk.
-__host__ __device__ constexpr int xty_max_instr(int mt) { return mt >= 2 ? 8 : 4; }   // decoded DMA instructions per wave and slab
+// group g of 4 over n tiles: tiles [off, off + cnt)
+__host__ __device__ inline void xty_group(int n, int g, int& off, int& cnt) {
+    const int base = n >> 2, rem = n & 3;
+    cnt = base + (g < rem ? 1 : 0);
+    off = g * base + (g < rem ? g : rem);
+}
 
-template <int MT, int NT, bool GATHER>
-__global__ __launch_bounds__(MT >= 2 ? 512 : 832) void xty_kernel(XtyArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float slab[];     // [2][kXtyRows][pitch_x] | [2][kXtyRows][pitch_y]
+// Slab loader: a slab is a linear run of 16-byte chunks (row-major, `cpr` chunks per row); DMA instruction j of a wave moves
+// chunks [64*(j*16 + wave), +64).  chunk -> (row in slab, segment, column in segment) is fixed per lane, so it is decoded once
+// and kept packed: bits 0-15 column within the segment, 16-17 segment, 18-24 row in slab, 31 = padding chunk.
+template <bool GATHER, int ROWS, int MTM, int NTM>   // MTM / NTM: tiles of the largest X / dY group (the others have one less or as many)
+__global__ __launch_bounds__(kXtyWaves * 64) void xty_kernel(XtyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float slab[];     // [2][ROWS][pitch_x] | [2][ROWS][pitch_y]
+    constexpr int nw = kXtyWaves;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = blockDim.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int batch = blockIdx.z, split = blockIdx.y;
+    int batch = 0;
+    while (batch + 1 < a.nbatch && (int)blockIdx.y >= a.wg_off[batch + 1]) ++batch;
+    const int split = (int)blockIdx.y - a.wg_off[batch], splits = a.wg_off[batch + 1] - a.wg_off[batch];
     const int rb = a.row_off[batch], re = a.row_off[batch + 1];
-    int rows_per = (re - rb + a.splits - 1) / a.splits;
-    rows_per = (rows_per + kXtyRows - 1) / kXtyRows * kXtyRows;
+    int rows_per = (re - rb + splits - 1) / splits;
+    rows_per = (rows_per + ROWS - 1) / ROWS * ROWS;
     const int r_beg = rb + split * rows_per;
     const int r_end = min(re, r_beg + rows_per);
     const int kcol0 = blockIdx.x * a.kb_tiles * 16;                  // first X column of this workgroup
     const int px = a.pitch_x, py = a.pitch_y;
     float* sx = slab;
-    float* sy = slab + 2 * kXtyRows * px;
-    float* out = a.part + ((size_t)batch * a.splits + split) * a.Kout * a.N;
+    float* sy = slab + 2 * ROWS * px;
+    float* out = a.part + (size_t)blockIdx.y * a.Kout * a.N;
 
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this wave's tile groups
+    int kt0, my_mt, nt0, my_nt;
+    xty_group(a.kb_tiles, wave >> 2, kt0, my_mt);
+    xty_group(a.n_tiles, ((wave >> 2) + (wave & 3)) & 3, nt0, my_nt);
 
-    if (r_beg < r_end) {
-        // ---- per-lane decode of the DMA chunks -----------------------------------------------------------------------
-        constexpr int MAXI = xty_max_instr(MT);
-        const int cprx = px / 4, cpry = py / 4;
-        const int nix = kXtyRows * cprx / 64, niy = kXtyRows * cpry / 64;      // 1-KiB instructions per slab
-        unsigned mx[MAXI], my[MAXI];
+    // stamps of waves 0 and 15 of workgroup (0,0): [which][0] start, [1] first slab landed, [2+i] slab i consumed, [62] loop done, [63] stored
+    int stamp_i = 2;
+#if GGNN_XTY_TIMELINE          // (build with -DGGNN_XTY_TIMELINE=1 for tools/xty_timeline.py: the stamps cost scalar registers in the hot loop)
+#define GGNN_XT(K) if (a.tdbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == nw - 1) && (K) < 64) \
+        a.tdbg[(wave ? 64 : 0) + (K)] = __builtin_amdgcn_s_memtime();
+#else
+#define GGNN_XT(K)
+#endif
+    GGNN_XT(0)
+
+    // ---- per-lane decode of the DMA chunks ---------------------------------------------------------------------------
+    constexpr int MAXI = kXtyMaxI;
+    const int cprx = px / 4, cpry = py / 4;
+    const int nix = ROWS * cprx / 64, niy = ROWS * cpry / 64;      // 1-KiB instructions per slab
+    unsigned mx[MAXI], my[MAXI];
 #pragma unroll
-        for (int j = 0; j < MAXI; ++j) {
-            const int ix = j * nw + wave;
-            mx[j] = 0x80000000u; my[j] = 0x80000000u;
-            if (ix < nix) {
-                const int c = ix * 64 + lane, row = c / cprx, q = c - row * cprx;
-                int col = kcol0 + 4 * q;
-                if (!(4 * q < a.kb_tiles * 16 && col < a.K)) col = 0;            // padding chunk: any valid address
-                const int seg = col / a.Dseg, within = col - seg * a.Dseg;
-                mx[j] = (unsigned)within | ((unsigned)seg << 16) | ((unsigned)row << 18);
-            }
-            if (ix < niy) {
-                const int c = ix * 64 + lane, row = c / cpry, q = c - row * cpry;
-                my[j] = (unsigned)(4 * q < a.N ? 4 * q : 0) | ((unsigned)row << 18);
-            }
+    for (int j = 0; j < MAXI; ++j) {
+        const int ix = j * nw + wave;
+        mx[j] = 0x80000000u; my[j] = 0x80000000u;
+        if (ix < nix) {
+            const int c = ix * 64 + lane, row = c / cprx, q = c - row * cprx;
+            int col = kcol0 + 4 * q;
+            const bool ones = a.Kout > a.K && col == a.K && 4 * q < a.kb_tiles * 16;      // the chunk [1 0 0 0] of the ones column
+            if (!(4 * q < a.kb_tiles * 16 && col < a.K)) col = 0;            // padding chunk: any valid address
+            const int seg = col / a.Dseg, within = col - seg * a.Dseg;
+            mx[j] = (unsigned)within | ((unsigned)seg << 16) | ((unsigned)row << 18) | (ones ? 0x40000000u : 0u);
         }
-        // X row of slab row r (row gather for the edge-weight gradients); clamped rows are masked out in the products
-        auto xrow = [&](int r0, unsigned m) -> int {
-            int r = r0 + (int)((m >> 18) & 63u); r = r < r_end ? r : r_end - 1;
-            return r;
-        };
-        int rid[GATHER ? MAXI : 1];                                     // (GATHER) X rows of the NEXT slab to be issued
-        auto fetch_rows = [&](int r0) {
-            if constexpr (GATHER) {
-#pragma unroll
-                for (int j = 0; j < MAXI; ++j) rid[j] = (mx[j] >> 31) ? 0 : a.x_rows[xrow(r0 < r_end ? r0 : r_beg, mx[j])];
-            }
-        };
-        // segment bases / strides as VALUES in scalar registers (readfirstlane: otherwise the compiler selects the ADDRESS
-        // of the kernel argument and loads through it, see below)
-        auto sgpr_ptr = [](const float* p) {
-            const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-            return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
-        };
-        const float* X0 = sgpr_ptr(a.X[0]); const float* X1 = sgpr_ptr(a.X[1]);
-        const float* X2 = sgpr_ptr(a.X[2]); const float* X3 = sgpr_ptr(a.X[3]);
-        const int L0 = __builtin_amdgcn_readfirstlane(a.ldx[0]), L1 = __builtin_amdgcn_readfirstlane(a.ldx[1]);
-        const int L2 = __builtin_amdgcn_readfirstlane(a.ldx[2]), L3 = __builtin_amdgcn_readfirstlane(a.ldx[3]);
-        auto issue = [&](int buf, int r0) {                             // uses rid[] (fetched one slab ahead)
-#pragma unroll
-            for (int j = 0; j < MAXI; ++j) {
-                if (!(mx[j] >> 31)) {
-                    const unsigned m = mx[j];
-                    // (the segment is a per-lane value: select base and stride with compares -- indexing the kernel-argument
-                    //  arrays with it makes the compiler spill them to memory, and the loads that fetch them back sit in the
-                    //  same in-order queue as the DMA: every slab instruction then waited for the previous one)
-                    const int seg = (int)((m >> 16) & 3u);
-                    const float* xb = seg == 0 ? X0 : (seg == 1 ? X1 : (seg == 2 ? X2 : X3));
-                    const int xl = seg == 0 ? L0 : (seg == 1 ? L1 : (seg == 2 ? L2 : L3));
-                    const int xr = GATHER ? rid[GATHER ? j : 0] : xrow(r0, m);
-                    const float* src = xb + (size_t)xr * xl + (m & 0xFFFFu);
-                    float* dst = sx + buf * kXtyRows * px + (size_t)(j * nw + wave) * 256;      // 1 KiB = 256 floats per instruction
-                    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < MAXI; ++j) {
-                if (!(my[j] >> 31)) {
-                    const unsigned m = my[j];
-                    int r = r0 + (int)((m >> 18) & 63u); r = r < r_end ? r : r_end - 1;
-                    const float* src = a.Y + (size_t)r * a.ldy + (m & 0xFFFFu);
-                    float* dst = sy + buf * kXtyRows * py + (size_t)(j * nw + wave) * 256;
-                    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
-                }
-            }
-        };
-
-        const int ktile0 = wave * MT;                                 // this wave's first X tile inside the workgroup's block
-        const bool wave_on = ktile0 < a.kb_tiles && kcol0 + ktile0 * 16 < a.Kout;
-        int buf = 0;
-        fetch_rows(r_beg);
-        issue(0, r_beg);
-        fetch_rows(r_beg + kXtyRows);
-        __syncthreads();                                              // (vmcnt(0) + barrier: slab 0 has landed)
-        for (int r0 = r_beg; r0 < r_end; r0 += kXtyRows) {
-            if (r0 + kXtyRows < r_end) { issue(buf ^ 1, r0 + kXtyRows); fetch_rows(r0 + 2 * kXtyRows); }
-            if (wave_on) {
-                const float* bx = sx + buf * kXtyRows * px + ktile0 * 16 + li;
-                const float* by = sy + buf * kXtyRows * py + li;
-                const int nvalid = r_end - r0;                        // rows of this slab that exist (>= kXtyRows: all)
-                float xa[2][MT], yb[2][NT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) xa[0][mt] = bx[kq * px + mt * 16];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) yb[0][nt] = by[kq * py + nt * 16];
-#pragma unroll
-                for (int s = 0; s < kXtyRows / 4; ++s) {
-                    if (s + 1 < kXtyRows / 4) {
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) xa[(s + 1) & 1][mt] = bx[(4 * (s + 1) + kq) * px + mt * 16];
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) yb[(s + 1) & 1][nt] = by[(4 * (s + 1) + kq) * py + nt * 16];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    const bool row_ok = 4 * s + kq < nvalid;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        float xv = xa[s & 1][mt];
-                        // the "ones" column K of X (Kout == K + 1): its row of the product is the column sum of dY
-                        if (a.Kout > a.K && kcol0 + (ktile0 + mt) * 16 + li == a.K) xv = 1.0f;
-                        xv = row_ok ? xv : 0.f;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, yb[s & 1][nt], acc[mt][nt], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __syncthreads();                                          // slab[buf] consumed by all waves, slab[buf^1] landed
-            buf ^= 1;
+        if (ix < niy) {
+            const int c = ix * 64 + lane, row = c / cpry, q = c - row * cpry;
+            my[j] = (unsigned)(4 * q < a.N ? 4 * q : 0) | ((unsigned)row << 18);
         }
     }
-    // accumulator tile (mt, nt): lane (li, kq) holds dW[k0 + 4*kq + e][16*nt + li], e = 0..3
-    const int ktile0 = wave * MT;
-    if (ktile0 < a.kb_tiles) {
+    // X row of slab row r (row gather for the edge-weight gradients); rows past the range are clamped here and zeroed in issue()
+    auto xrow = [&](int r0, unsigned m) -> int {
+        int r = r0 + (int)((m >> 18) & 127u); r = r < r_end ? r : r_end - 1;
+        return r;
+    };
+    int rid[GATHER ? MAXI : 1];                                     // (GATHER) X rows of the NEXT slab to be issued
+    auto fetch_rows = [&](int r0) {
+        if constexpr (GATHER) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int k0 = kcol0 + (ktile0 + mt) * 16;
-            if ((ktile0 + mt) < a.kb_tiles) {
+            for (int j = 0; j < MAXI; ++j) rid[j] = (mx[j] >> 31) ? 0 : a.x_rows[xrow(r0 < r_end ? r0 : r_beg, mx[j])];
+        }
+    };
+    // segment bases / strides as VALUES in scalar registers (readfirstlane: otherwise the compiler selects the ADDRESS
+    // of the kernel argument and loads through it, see below)
+    auto sgpr_ptr = [](const float* p) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
+    const float* X0 = sgpr_ptr(a.X[0]); const float* X1 = sgpr_ptr(a.X[1]);
+    const float* X2 = sgpr_ptr(a.X[2]); const float* X3 = sgpr_ptr(a.X[3]);
+    const int L0 = __builtin_amdgcn_readfirstlane(a.ldx[0]), L1 = __builtin_amdgcn_readfirstlane(a.ldx[1]);
+    const int L2 = __builtin_amdgcn_readfirstlane(a.ldx[2]), L3 = __builtin_amdgcn_readfirstlane(a.ldx[3]);
+    const float* Yb = sgpr_ptr(a.Y);
+    const int ldy = __builtin_amdgcn_readfirstlane(a.ldy);
+    auto issue = [&](int buf, int r0) {                             // uses rid[] (fetched one slab ahead)
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) {
+            if (!(mx[j] >> 31)) {
+                const unsigned m = mx[j];
+                // (the segment is a per-lane value: select base and stride with compares -- indexing the kernel-argument
+                //  arrays with it makes the compiler spill them to memory, and the loads that fetch them back sit in the
+                //  same in-order queue as the DMA: every slab instruction then waited for the previous one)
+                const int seg = (int)((m >> 16) & 3u);
+                const float* xb = seg == 0 ? X0 : (seg == 1 ? X1 : (seg == 2 ? X2 : X3));
+                const int xl = seg == 0 ? L0 : (seg == 1 ? L1 : (seg == 2 ? L2 : L3));
+                const int xr = GATHER ? rid[GATHER ? j : 0] : xrow(r0, m);
+                const float* src = xb + (size_t)xr * xl + (m & 0xFFFFu);
+                if (m & 0x40000000u) src = kXtyOnesChunk;
+                if (r0 + (int)((m >> 18) & 127u) >= r_end) src = kXtyZeroChunk;
+                float* dst = sx + buf * ROWS * px + (size_t)(j * nw + wave) * 256;      // 1 KiB = 256 floats per instruction
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) {
+            if (!(my[j] >> 31)) {
+                const unsigned m = my[j];
+                int r = r0 + (int)((m >> 18) & 127u); r = r < r_end ? r : r_end - 1;
+                const float* src = Yb + (size_t)r * ldy + (m & 0xFFFFu);
+                float* dst = sy + buf * ROWS * py + (size_t)(j * nw + wave) * 256;
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+            }
+        }
+    };
+
+    // The whole slab loop is instantiated per (tiles of X, tiles of dY) of a wave -- MTM or MTM-1, NTM or NTM-1, or none -- and
+    // selected ONCE: with run-time tile counts the compiler cannot count the outstanding LDS reads (s_waitcnt lgkmcnt(0) at every
+    // step) and branches around every MFMA, which left the matrix pipe idle a quarter of the time; with the selection inside the
+    // loop the accumulators pass through phi copies at every iteration and spill.
+    auto run = [&](auto mt_c, auto nt_c) {
+        constexpr int MT = decltype(mt_c)::value, NT = decltype(nt_c)::value;
+        constexpr bool ON = MT > 0 && NT > 0;
+        f32x4 acc[ON ? MT : 1][ON ? NT : 1];
+#pragma unroll
+        for (int mt = 0; mt < (ON ? MT : 1); ++mt)
+#pragma unroll
+            for (int nt = 0; nt < (ON ? NT : 1); ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int cls = wave >> 2;
+        if (r_beg < r_end) {
+            int buf = 0;
+            fetch_rows(r_beg);
+            issue(0, r_beg);
+            fetch_rows(r_beg + ROWS);
+            __syncthreads();                                              // (vmcnt(0) + barrier: slab 0 has landed)
+            GGNN_XT(1)
+            for (int r0 = r_beg; r0 < r_end; r0 += ROWS) {
+                // The DMA of the next slab is issued from INSIDE the MFMA steps, staggered: the four waves of a SIMD (waves c, c+4,
+                // c+8, c+12 -> classes 0..3) issue their share at step 0, 1, 2, 3 (x2 with 64-row slabs), so that at any moment at
+                // most one wave of a SIMD is computing addresses instead of feeding the matrix pipe.  (All sixteen waves issuing at
+                // the top of the slab left the pipe idle for ~2k of 15k clocks; the last class still has half the slab to land.)
+                const bool has_next = r0 + ROWS < r_end;
+                if (has_next && !ON) { issue(buf ^ 1, r0 + ROWS); fetch_rows(r0 + 2 * ROWS); }
+                if (stamp_i < 22) { GGNN_XT(20 + stamp_i) }          // [22+i] slab i: top of the slab
+                if constexpr (ON) {
+                    // MT x NT tile products per 4-row step, operands of step s+1 read under the MFMAs of step s
+                    const float* bx = sx + buf * ROWS * px + kt0 * 16 + li;
+                    const float* by = sy + buf * ROWS * py + nt0 * 16 + li;
+                    float xa[2][MT], yb[2][NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) xa[0][mt] = bx[kq * px + mt * 16];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) yb[0][nt] = by[kq * py + nt * 16];
+#pragma unroll
+                    for (int s = 0; s < ROWS / 4; ++s) {
+                        if (s + 1 < ROWS / 4) {
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) xa[(s + 1) & 1][mt] = bx[(4 * (s + 1) + kq) * px + mt * 16];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) yb[(s + 1) & 1][nt] = by[(4 * (s + 1) + kq) * py + nt * 16];
+                        }
+                        if (s % (ROWS / 32) == 0 && s / (ROWS / 32) < 4) {
+                            if (has_next && cls == s / (ROWS / 32)) { issue(buf ^ 1, r0 + ROWS); fetch_rows(r0 + 2 * ROWS); }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s & 1][mt], yb[s & 1][nt], acc[mt][nt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (stamp_i < 22) { GGNN_XT(40 + stamp_i) }          // [42+i] slab i: MFMAs issued
+                __syncthreads();                                          // slab[buf] consumed by all waves, slab[buf^1] landed
+                buf ^= 1;
+                if (stamp_i < 22) { GGNN_XT(stamp_i) }
+                ++stamp_i;
+            }
+        }
+        GGNN_XT(62)
+        // accumulator tile (mt, nt): lane (li, kq) holds dW[k0 + 4*kq + e][16*(nt0+nt) + li], e = 0..3  (a workgroup without rows
+        // still writes its zeros: the reduction adds every workgroup row)
+        if constexpr (ON) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int k0 = kcol0 + (kt0 + mt) * 16;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int n = 16 * nt + li;
+                    const int n = 16 * (nt0 + nt) + li;
                     if (n < a.N) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -210,17 +265,31 @@ __global__ __launch_bounds__(MT >= 2 ? 512 : 832) void xty_kernel(XtyArgs a) {
                 }
             }
         }
-    }
+        GGNN_XT(63)
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IM = std::integral_constant<int, MTM>; using IM1 = std::integral_constant<int, MTM - 1>;
+    using IN = std::integral_constant<int, NTM>; using IN1 = std::integral_constant<int, NTM - 1>;
+    // (the last K block can be short of whole groups: a wave whose X group is empty or smaller than MTM - 1 has no tiles there --
+    //  the host plan keeps that from happening for groups that do hold output rows, see xty_plan)
+    if (my_mt == MTM && my_nt == NTM) run(IM{}, IN{});
+    else if (my_mt == MTM - 1 && my_nt == NTM) run(IM1{}, IN{});
+    else if (my_mt == MTM && my_nt == NTM - 1) run(IM{}, IN1{});
+    else if (my_mt == MTM - 1 && my_nt == NTM - 1) run(IM1{}, IN1{});
+    else run(I0{}, I0{});
+#undef GGNN_XT
 }
 
-// C[b][i] = sum over the splits of part[b][s][i], in split order
-__global__ void xty_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, int KN, int S, int nbatch) {
+// C[b][i] = sum over the workgroup rows of batch b of part[row][i], in row order
+struct XtyReduceArgs { int wg_off[kXtyMaxBatch + 1]; };
+__global__ void xty_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, int KN, int nbatch, XtyReduceArgs ra) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)KN * nbatch) return;
     const int b = (int)(i / KN), j = (int)(i - (long long)b * KN);
-    // eight independent chains (split p goes to chain p % 8), combined pairwise: a fixed order with 1/8 of the dependent loads
+    // eight independent chains (row p goes to chain p % 8), combined pairwise: a fixed order with 1/8 of the dependent loads
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* src = part + (size_t)b * S * KN + j;
+    const int S = ra.wg_off[b + 1] - ra.wg_off[b];
+    const float* src = part + (size_t)ra.wg_off[b] * KN + j;
     int p = 0;
     for (; p + 8 <= S; p += 8) {
 #pragma unroll
@@ -230,49 +299,54 @@ __global__ void xty_reduce_kernel(const float* __restrict__ part, float* __restr
     C[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
-struct XtyPlan { int mt, nt, nw, kb_tiles, kblocks, splits; size_t lds; };
+struct XtyPlan { int rows, kb_tiles, n_tiles, kblocks, px, py, wg_rows; size_t lds; int wg_off[kXtyMaxBatch + 1]; };
 
-static XtyPlan xty_plan(int M_max, int Kout, int N, int nbatch) {
+// Workgroup rows (one 16-wave workgroup per CU and K block) are dealt to the batches in proportion to their row counts, at least
+// one per non-empty batch and at most one per 4 slabs of rows; an empty batch gets none (its product is the empty sum, 0).
+static XtyPlan xty_plan(const int* row_off, int nbatch, int Kout, int N) {
     XtyPlan p{};
     const int ktiles = (Kout + 15) / 16;
-    p.nt = N <= 112 ? 7 : 13;
-    p.mt = N <= 112 ? 2 : 1;
-    const int max_w = p.mt >= 2 ? 8 : 13;                            // waves per workgroup (register budget: launch bounds)
-    int tiles_per_wg = max_w * p.mt;
-    p.kblocks = (ktiles + tiles_per_wg - 1) / tiles_per_wg;
-    int px, py;
-    for (;; ++p.kblocks) {                                          // more (narrower) K blocks until a wave's share of the slab
-        p.kb_tiles = (ktiles + p.kblocks - 1) / p.kblocks;          // DMA fits its decoded instructions
-        p.nw = (p.kb_tiles + p.mt - 1) / p.mt;
-        px = xty_pitch(p.kb_tiles * 16); py = xty_pitch(p.nt * 16);
-        const int ix = kXtyRows * px * 4 / 1024, iy = kXtyRows * py * 4 / 1024;
-        if (((ix + p.nw - 1) / p.nw <= xty_max_instr(p.mt) && (iy + p.nw - 1) / p.nw <= xty_max_instr(p.mt)) || p.kb_tiles == 1) break;
-    }
-    // every DMA instruction moves a whole KiB: kXtyRows * pitch * 4 is a multiple of 1024 because pitch % 16 == 0 and 32 rows
-    p.lds = (size_t)2 * kXtyRows * (px + py) * sizeof(float);
-    // workgroups per CU: as many as registers (mt = 2: 3 waves per SIMD = 12 waves; mt = 1: 16 waves) and LDS allow
-    int per_cu = (p.mt >= 2 ? 12 : 16) / p.nw;
-    const int by_lds = (int)((size_t)160 * 1024 / p.lds);
-    if (per_cu > by_lds) per_cu = by_lds;
-    if (per_cu < 1) per_cu = 1;
-    static const int per_cu_env = [] { const char* e = getenv("GGNN_XTY_PER_CU"); return e ? atoi(e) : 0; }();   // (experiments)
-    if (per_cu_env > 0) per_cu = per_cu_env;
-    int target = per_cu * num_cus() / (p.kblocks * nbatch);
+    p.kblocks = (ktiles + 15) / 16;
+    p.kb_tiles = (ktiles + p.kblocks - 1) / p.kblocks;
+    p.n_tiles = (N + 15) / 16;
+    p.px = xty_pitch(p.kb_tiles * 16); p.py = xty_pitch(p.n_tiles * 16);
+    // 64-row slabs when two of them fit the 160 KiB of LDS (half the barriers, and a slab's MFMA time then covers the latency of the
+    // next slab's DMA also for the narrow edge-weight products), else 32
+    const int mtm = (p.kb_tiles + 3) / 4, ntm = (p.n_tiles + 3) / 4;
+    p.rows = (size_t)2 * 64 * (p.px + p.py) * sizeof(float) <= (size_t)160 * 1024 && mtm + ntm <= 6 ? 64 : 32;
+    static const int rows_env = [] { const char* e = getenv("GGNN_XTY_ROWS"); return e ? atoi(e) : 0; }();   // (experiments)
+    if (rows_env == 32) p.rows = 32;
+    p.lds = (size_t)2 * p.rows * (p.px + p.py) * sizeof(float);
+    long long total = 0;
+    for (int b = 0; b < nbatch; ++b) total += row_off[b + 1] - row_off[b];
+    int target = num_cus() / p.kblocks;
     if (target < 1) target = 1;
-    const int max_s = (M_max + 4 * kXtyRows - 1) / (4 * kXtyRows);    // at least 4 slabs per split
-    p.splits = target < max_s ? target : (max_s > 0 ? max_s : 1);
+    p.wg_off[0] = 0;
+    for (int b = 0; b < nbatch; ++b) {
+        const long long m = row_off[b + 1] - row_off[b];
+        long long w = total > 0 ? (long long)target * m / total : 0;
+        const long long cap = (m + 4 * p.rows - 1) / (4 * p.rows);
+        if (w > cap) w = cap;
+        if (w < 1 && m > 0) w = 1;
+        p.wg_off[b + 1] = p.wg_off[b] + (int)w;
+    }
+    p.wg_rows = p.wg_off[nbatch];
     return p;
 }
 
-template <int MT, int NT, bool GATHER>
+template <bool GATHER, int ROWS, int MTM, int NTM>
 static int launch_xty(const XtyArgs& a, const XtyPlan& p, float* C, hipStream_t st) {
     static std::atomic<unsigned long long> lds_ok{0};
-    if (p.lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&xty_kernel<MT, NT, GATHER>, p.lds, lds_ok));
-    hipLaunchKernelGGL((xty_kernel<MT, NT, GATHER>), dim3(p.kblocks, p.splits, a.nbatch), dim3(p.nw * 64), p.lds, st, a);
-    GGNN_CHECK_HIP(hipGetLastError());
+    if (p.wg_rows > 0) {
+        if (p.lds > 64 * 1024) GGNN_CHECK_HIP((allow_dynamic_lds(&xty_kernel<GATHER, ROWS, MTM, NTM>, p.lds, lds_ok)));
+        hipLaunchKernelGGL((xty_kernel<GATHER, ROWS, MTM, NTM>), dim3(p.kblocks, p.wg_rows), dim3(kXtyWaves * 64), p.lds, st, a);
+        GGNN_CHECK_HIP(hipGetLastError());
+    }
+    XtyReduceArgs ra;
+    for (int b = 0; b <= kXtyMaxBatch; ++b) ra.wg_off[b] = a.wg_off[b <= a.nbatch ? b : a.nbatch];
     const long long total = (long long)a.Kout * a.N * a.nbatch;
     hipLaunchKernelGGL(xty_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)a.part, C, a.Kout * a.N,
-                       p.splits, a.nbatch);
+                       a.nbatch, ra);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
@@ -320,8 +394,8 @@ using namespace ggnn;
 
 extern "C" size_t ggnn_xty_workspace_bytes(int M_max, int K, int N, int nbatch) {
     if (M_max <= 0 || K <= 0 || N <= 0 || nbatch <= 0) return 256;
-    const XtyPlan p = xty_plan(M_max, K + 1, N, nbatch);             // (sized for the ones-row form)
-    return (size_t)p.splits * nbatch * (K + 1) * N * sizeof(float) + 256;
+    // workgroup rows: <= one per CU and K block, plus the one-per-non-empty-batch minimum (sized for the ones-row form)
+    return (size_t)(num_cus() + nbatch) * (K + 1) * N * sizeof(float) + 256;
 }
 
 extern "C" int ggnn_xty_f32(const float* const* x_segs, int nseg, int Dseg, const int32_t* ldx, const int32_t* x_rows,
@@ -329,7 +403,7 @@ extern "C" int ggnn_xty_f32(const float* const* x_segs, int nseg, int Dseg, cons
                             void* ws, size_t ws_bytes, ggnn_stream_t stream) {
     const int Kout = ones_row ? K + 1 : K;
     GGNN_CHECK_ARG(nseg >= 1 && nseg <= 4 && Dseg > 0 && Dseg % 4 == 0 && K == nseg * Dseg, "X is nseg <= 4 segments of Dseg columns (K = %d, nseg = %d, Dseg = %d)", K, nseg, Dseg);
-    GGNN_CHECK_ARG(N > 0 && N % 4 == 0 && N <= 208, "N = %d must be a multiple of 4, <= 208", N);
+    GGNN_CHECK_ARG(N > 0 && N % 4 == 0 && N <= 256, "N = %d must be a multiple of 4, <= 256", N);
     GGNN_CHECK_ARG(nbatch >= 1 && nbatch <= kXtyMaxBatch && row_off && C && ldx, "bad batch description");
     GGNN_CHECK_ARG(ldy >= N && ldy % 4 == 0, "ldy %d", ldy);
     hipStream_t st = (hipStream_t)stream;
@@ -349,16 +423,30 @@ extern "C" int ggnn_xty_f32(const float* const* x_segs, int nseg, int Dseg, cons
         a.X[s] = x_segs[s]; a.ldx[s] = ldx[s];
     }
     if (ws_bytes < ggnn_xty_workspace_bytes(m_max, K, N, nbatch)) return fail(GGNN_E_WORKSPACE, "xty workspace too small");
-    const XtyPlan p = xty_plan(m_max, Kout, N, nbatch);
+    const XtyPlan p = xty_plan(row_off, nbatch, Kout, N);
     a.Kout = Kout;
     a.nseg = nseg; a.Dseg = Dseg; a.x_rows = x_rows; a.Y = Y; a.ldy = ldy; a.part = static_cast<float*>(ws);
-    a.K = K; a.N = N; a.nbatch = nbatch; a.splits = p.splits; a.kb_tiles = p.kb_tiles;
-    a.pitch_x = xty_pitch(p.kb_tiles * 16); a.pitch_y = xty_pitch(p.nt * 16);
-    const int px_kib = kXtyRows * a.pitch_x * 4 / 1024, py_kib = kXtyRows * a.pitch_y * 4 / 1024;
-    if ((px_kib + p.nw - 1) / p.nw > xty_max_instr(p.mt) || (py_kib + p.nw - 1) / p.nw > xty_max_instr(p.mt))
-        return fail(GGNN_E_UNSUPPORTED, "xty: slab too wide for %d waves (K=%d N=%d)", p.nw, K, N);
-    if (p.nt == 7) return x_rows ? launch_xty<2, 7, true>(a, p, C, st) : launch_xty<2, 7, false>(a, p, C, st);
-    return x_rows ? launch_xty<1, 13, true>(a, p, C, st) : launch_xty<1, 13, false>(a, p, C, st);
+    a.K = K; a.N = N; a.nbatch = nbatch; a.kb_tiles = p.kb_tiles; a.n_tiles = p.n_tiles;
+    a.pitch_x = p.px; a.pitch_y = p.py;
+    for (int b = 0; b <= kXtyMaxBatch; ++b) a.wg_off[b] = p.wg_off[b <= nbatch ? b : nbatch];
+    { const char* e = getenv("GGNN_XTY_TPTR"); a.tdbg = e ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
+    if ((p.rows * p.px / 256 + kXtyWaves - 1) / kXtyWaves > kXtyMaxI || (p.rows * p.py / 256 + kXtyWaves - 1) / kXtyWaves > kXtyMaxI)
+        return fail(GGNN_E_UNSUPPORTED, "xty: slab too wide (K=%d N=%d)", K, N);
+    const int mtm = (p.kb_tiles + 3) / 4, ntm = (p.n_tiles + 3) / 4;
+    const bool g = x_rows != nullptr;
+#define GGNN_XTY_CASE(G, R, M, Nn) if (g == G && p.rows == R && mtm == M && ntm == Nn) return launch_xty<G, R, M, Nn>(a, p, C, st);
+#define GGNN_XTY_ROW32(M) GGNN_XTY_CASE(false, 32, M, 1) GGNN_XTY_CASE(false, 32, M, 2) GGNN_XTY_CASE(false, 32, M, 3) GGNN_XTY_CASE(false, 32, M, 4)
+    GGNN_XTY_ROW32(1) GGNN_XTY_ROW32(2) GGNN_XTY_ROW32(3) GGNN_XTY_ROW32(4)
+    // 64-row slabs exist for the group shapes whose two slabs can fit the LDS (xty_plan picks them when they do)
+    GGNN_XTY_CASE(false, 64, 1, 1) GGNN_XTY_CASE(false, 64, 1, 2) GGNN_XTY_CASE(false, 64, 1, 3) GGNN_XTY_CASE(false, 64, 1, 4)
+    GGNN_XTY_CASE(false, 64, 2, 1) GGNN_XTY_CASE(false, 64, 2, 2) GGNN_XTY_CASE(false, 64, 2, 3) GGNN_XTY_CASE(false, 64, 2, 4)
+    GGNN_XTY_CASE(false, 64, 3, 1) GGNN_XTY_CASE(false, 64, 3, 2) GGNN_XTY_CASE(false, 64, 3, 3)
+    GGNN_XTY_CASE(false, 64, 4, 1) GGNN_XTY_CASE(false, 64, 4, 2)
+    // row-gathered X: one segment of <= 128 columns (edge-weight gradients)
+    GGNN_XTY_CASE(true, 64, 1, 1) GGNN_XTY_CASE(true, 64, 1, 2) GGNN_XTY_CASE(true, 64, 2, 1) GGNN_XTY_CASE(true, 64, 2, 2)
+#undef GGNN_XTY_ROW32
+#undef GGNN_XTY_CASE
+    return fail(GGNN_E_UNSUPPORTED, "xty: no kernel for %d x %d tile groups (K=%d N=%d)", mtm, ntm, K, N);
 }
 
 extern "C" size_t ggnn_colsum_workspace_bytes(int N) { return (size_t)kColsumBlocks * (N > 0 ? N : 1) * sizeof(float) + 256; }

@@ -20,7 +20,7 @@ def timeit(fn, n=20):
 
 
 V = 99986
-for (nseg, N) in ((2, 200), (3, 200), (4, 200), (2, 100), (3, 100), (4, 100)):
+for (nseg, N) in ((2, 200), (2, 100)):
     xs = [torch.rand(V, 100, device=dev) for _ in range(nseg)]
     dy = torch.rand(V, N, device=dev)
     t = timeit(lambda: pkg.ops.xty(xs, dy, ones_row=True))
