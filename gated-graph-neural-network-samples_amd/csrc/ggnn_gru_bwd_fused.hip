@@ -307,237 +307,11 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
     for (; tk < n_tk; tk += nb) run_pass(std::false_type{});
 }
 
-// ---- the pipelined form -------------------------------------------------------------------------------------------------------
-// The timeline of the form above (tools/gru_bwd_timeline.py) shows why it takes 190 us for 96 us of MFMA work: all workgroups run
-// the same phase at the same time, so the GPU alternates between a load phase in which every CU fetches its five input
-// fragments at once (24-42k clocks per pass: 67 MB at HBM speed), MFMA stages with an idle memory system, and store bursts.  Here
-// the memory operations of a pass are spread UNDER the MFMA stages instead:
-//   * g, u, c of the NEXT tile are fetched at the start of the last three stages (one array each: the registers of dpc's dead
-//     neighbours g*u, r, h*r*(1-r) are free by then), so a pass starts with dpc = g (1-u) act'(c) already computable;
-//   * h and r are fetched at the start of stage 0 and first used in its epilogue (dpu, h r (1-r), r*h);
-//   * every store is issued in front of an MFMA stage (dpc before stage 0, r*h and [dpr|dpu] before stage 1, dh before stage 3,
-//     dx before the next pass's stage 0).
-template <int D, int NX, int NW>
-__global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_pipe_kernel(GruBwdArgs a, const float* __restrict__ packed) {
-    using C = StageCfg<D>;
-    constexpr int NT = C::NT, NC = C::NC, NR = C::NR;
-    constexpr int NSTAGE = 3 * (NX + 1);
-    extern __shared__ __attribute__((aligned(16))) float ring[];    // [2][IMG]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, kq = lane >> 4;
-    const bool late = wave >= NW / 2;
-    static_assert(NR <= 1, "remainder handling covers D % 16 in {0, 4}");
-
-    const int wt_total = (a.V + 15) / 16;
-    const int nb = gridDim.x;
-    const int full_tk = wt_total / (NW * nb) * nb;
-    const int rest = wt_total - full_tk * NW;
-    const int tail_w = (rest + nb - 1) / nb;
-    const int n_tk = full_tk + (tail_w ? (rest + tail_w - 1) / tail_w : 0);
-    auto tile_of = [&](int t) -> int {
-        if (t < full_tk) return t * NW + wave;
-        if (t >= n_tk) return -1;
-        const int tl = full_tk * NW + (t - full_tk) * tail_w + wave;
-        return (wave < tail_w && tl < wt_total) ? tl : -1;
-    };
-    auto rowc_of = [&](int t) -> int {
-        const int tile = tile_of(t);
-        const int r0 = (tile >= 0 ? tile : 0) * 16 + li;
-        return r0 < a.V ? r0 : a.V - 1;
-    };
-    auto rem_tile = [&](const Frag<D>& f) -> f32x4 {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (NR > 0) {
-            v.x = __shfl(f.r[0], li); v.y = __shfl(f.r[0], li + 16); v.z = __shfl(f.r[0], li + 32); v.w = __shfl(f.r[0], li + 48);
-        }
-        return v;
-    };
-
-    int cur = 0;
-    dma_stage_image<D, NW>(packed, ring, wave, lane);
-    Frag<D> gq, uq, cq;                                     // g, u, c of the tile about to be processed (fetched a pass ahead)
-    int tk = blockIdx.x;
-    if (tk < n_tk) { const int rc = rowc_of(tk); load_frag<D>(gq, a.g, rc, kq); load_frag<D>(uq, a.u, rc, kq); load_frag<D>(cq, a.c, rc, kq); }
-    __syncthreads();
-
-    int pass_no = 0;
-    auto run_pass = [&](auto active_c) {
-        constexpr bool ACT = decltype(active_c)::value;
-        const int tile = tile_of(tk);
-        GGNN_BT(0)
-        const bool last_pass = tk + nb >= n_tk;
-        const int row = (ACT ? tile : 0) * 16 + li;
-        const int rowc = row < a.V ? row : a.V - 1;
-        const bool row_ok = ACT && row < a.V;
-        const int rown = last_pass ? 0 : rowc_of(tk + nb);
-
-        auto stage = [&](auto zero_c, f32x4 (&acc)[NT], const Frag<D>& A, int img_idx, auto&& before) {
-            const int nidx = img_idx + 1 < NSTAGE ? img_idx + 1 : 0;
-            const bool more = (img_idx + 1 < NSTAGE) || !last_pass;
-            const float* nsrc = packed + (size_t)nidx * C::IMG;
-            float* ndst = ring + (cur ^ 1) * C::IMG;
-            if constexpr (ACT) before();
-            if (late && more) dma_stage_image<D, NW>(nsrc, ndst, wave, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ACT) stage_mma<D, NoHook, NT, decltype(zero_c)::value>(acc, A, ring + cur * C::IMG, li, kq);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!late && more) dma_stage_image<D, NW>(nsrc, ndst, wave, lane);
-            __syncthreads();
-            cur ^= 1;
-        };
-        auto nothing = [] {};
-
-        // ---- head, registers only: dpc = g (1-u) act'(c);  gu = g u;  q = g u (1-u)  (dpu = q (h - c) once h is here) -----------
-        Frag<D> dpc, dpu, dpr, gu, cc_;
-        if constexpr (ACT) {
-            auto dact = [&](float cv) { return a.act == GGNN_ACT_TANH ? 1.0f - cv * cv : (cv > 0.f ? 1.0f : 0.f); };
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const f32x4 gv = gq.v[c], uv = uq.v[c], cv = cq.v[c];
-                const f32x4 omu = 1.0f - uv;
-                const f32x4 da = {dact(cv.x), dact(cv.y), dact(cv.z), dact(cv.w)};
-                dpc.v[c] = gv * omu * da;
-                gu.v[c] = gv * uv;
-                dpu.v[c] = gu.v[c] * omu;                       // (q; completed in the stage-0 epilogue)
-                cc_.v[c] = cv;
-            }
-#pragma unroll
-            for (int q = 0; q < NR; ++q) {
-                const float gv = gq.r[q], uv = uq.r[q], cv = cq.r[q];
-                const float omu = 1.0f - uv;
-                dpc.r[q] = gv * omu * dact(cv);
-                gu.r[q] = gv * uv; dpu.r[q] = gu.r[q] * omu; cc_.r[q] = cv;
-            }
-            if (row_ok) store_frag<D>(a.dpc, row, kq, dpc);
-        }
-        GGNN_BT(1)
-
-        // ---- stage 0 (h, r fetched under it): drh = dpc Wc^T[h block] -------------------------------------------------------------
-        Frag<D> hf, rf;
-        f32x4 acc[NT];
-        stage(std::true_type{}, acc, dpc, 0, [&] { load_frag<D>(hf, a.h, rowc, kq); load_frag<D>(rf, a.r, rowc, kq); });
-        GGNN_BT(2)
-        if constexpr (ACT) {
-            // dpu = q (h - c);  r*h stored;  hrr = h r (1-r) (in place of h)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                dpu.v[c] = dpu.v[c] * (hf.v[c] - cc_.v[c]);
-                cc_.v[c] = rf.v[c] * hf.v[c];                   // r*h
-                hf.v[c] = cc_.v[c] * (1.0f - rf.v[c]);          // h r (1-r)
-            }
-#pragma unroll
-            for (int q = 0; q < NR; ++q) {
-                dpu.r[q] = dpu.r[q] * (hf.r[q] - cc_.r[q]);
-                cc_.r[q] = rf.r[q] * hf.r[q];
-                hf.r[q] = cc_.r[q] * (1.0f - rf.r[q]);
-            }
-            if (row_ok) store_frag<D>(a.rh, row, kq, cc_);
-            // accumulator tile nt == fragment chunk nt; the remainder tile through rem_tile()
-#pragma unroll
-            for (int nt = 0; nt < NC; ++nt) {
-                dpr.v[nt] = acc[nt] * hf.v[nt];
-                acc[nt] = acc[nt] * rf.v[nt] + gu.v[nt];        // start value of the dh stages: drh r + g u
-            }
-            if constexpr (NR > 0) {
-                const f32x4 dprt = acc[NT - 1] * rem_tile(hf);
-                const float t0 = __shfl(dprt.x, li), t1 = __shfl(dprt.y, li), t2 = __shfl(dprt.z, li), t3 = __shfl(dprt.w, li);
-                dpr.r[0] = kq == 0 ? t0 : (kq == 1 ? t1 : (kq == 2 ? t2 : t3));
-                acc[NT - 1] = acc[NT - 1] * rem_tile(rf) + rem_tile(gu);
-            }
-            if (row_ok) {                                               // dpg = [dpr | dpu], row stride 2D
-                constexpr unsigned RS = 2u * D * 4u;
-                const unsigned ob = (unsigned)row * RS + 16u * (unsigned)kq;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    st4_b(a.dpg, ob + 64u * c, dpr.v[c]);
-                    st4_b(a.dpg, ob + D * 4u + 64u * c, dpu.v[c]);
-                }
-#pragma unroll
-                for (int q = 0; q < NR; ++q) {
-                    const unsigned o1 = (unsigned)row * RS + (16u * NC + 4u * q + (unsigned)kq) * 4u;
-                    *reinterpret_cast<float*>(reinterpret_cast<char*>(a.dpg) + o1) = dpr.r[q];
-                    *reinterpret_cast<float*>(reinterpret_cast<char*>(a.dpg) + o1 + D * 4u) = dpu.r[q];
-                }
-            }
-        }
-        // ---- stages 1, 2: dh ------------------------------------------------------------------------------------------------------
-        GGNN_BT(3)
-        stage(std::false_type{}, acc, dpr, 1, nothing);
-        GGNN_BT(4)
-        stage(std::false_type{}, acc, dpu, 2, nothing);
-        GGNN_BT(5)
-        if constexpr (ACT) {
-            if (row_ok) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int col = nt * 16 + 4 * kq;
-                    if (col < D) st4_b(a.dh, ((unsigned)row * D + col) * 4u, acc[nt]);
-                }
-            }
-        }
-        GGNN_BT(6)
-        // ---- x segments; the last three stages each start with one array of the NEXT tile -----------------------------------------------
-        auto fetch_g = [&] { if (!last_pass) load_frag<D>(gq, a.g, rown, kq); };
-        auto fetch_u = [&] { if (!last_pass) load_frag<D>(uq, a.u, rown, kq); };
-        auto fetch_c = [&] { if (!last_pass) load_frag<D>(cq, a.c, rown, kq); };
-#define GGNN_BWD_SEGP(S)                                                                                            \
-        if constexpr ((S) < NX) {                                                                                   \
-            if constexpr ((S) == NX - 1) {                                                                          \
-                stage(std::true_type{}, acc, dpc, 3 + 3 * (S), fetch_g);                                            \
-                GGNN_BT(8)                                                                                          \
-                stage(std::false_type{}, acc, dpr, 4 + 3 * (S), fetch_u);                                           \
-                GGNN_BT(9)                                                                                          \
-                stage(std::false_type{}, acc, dpu, 5 + 3 * (S), fetch_c);                                           \
-                GGNN_BT(10)                                                                                         \
-            } else {                                                                                                \
-                stage(std::true_type{}, acc, dpc, 3 + 3 * (S), nothing);                                            \
-                stage(std::false_type{}, acc, dpr, 4 + 3 * (S), nothing);                                           \
-                stage(std::false_type{}, acc, dpu, 5 + 3 * (S), nothing);                                           \
-            }                                                                                                       \
-            if constexpr (ACT) {                                                                                    \
-                if (row_ok) {                                                                                       \
-                    float den = 1.0f;                                                                               \
-                    if ((S) == NX - 1 && a.use_avg) {                                                               \
-                        float deg = 0.f;                                                                            \
-                        for (int t = 0; t < a.T; ++t) deg += a.nin[(size_t)row * a.T + t];                          \
-                        den = deg + 1e-7f;                                                                          \
-                    }                                                                                               \
-                    _Pragma("unroll")                                                                               \
-                    for (int nt = 0; nt < NT; ++nt) {                                                               \
-                        const int col = nt * 16 + 4 * kq;                                                           \
-                        if (col < D) {                                                                              \
-                            f32x4 v = acc[nt];                                                                      \
-                            if ((S) == NX - 1 && a.use_avg) v = v / den;                                            \
-                            st4_b(a.dx[(S)], ((unsigned)row * D + col) * 4u, v);                                    \
-                        }                                                                                           \
-                    }                                                                                               \
-                }                                                                                                   \
-            }                                                                                                       \
-        }
-        GGNN_BWD_SEGP(0) GGNN_BWD_SEGP(1) GGNN_BWD_SEGP(2)
-#undef GGNN_BWD_SEGP
-        GGNN_BT(7)
-        ++pass_no;
-    };
-    for (; tk < n_tk && tile_of(tk) >= 0; tk += nb) run_pass(std::true_type{});
-    for (; tk < n_tk; tk += nb) run_pass(std::false_type{});
-}
-
-template <int D, int NX>
-static int launch_gru_bwd_pipe(const GruBwdArgs& a, const float* packed, hipStream_t st) {
-    using C = StageCfg<D>;
-    constexpr int NW = 8;
-    const size_t lds = (size_t)2 * C::IMG_BYTES;
-    const int wt_total = (a.V + 15) / 16;
-    int nb = num_cus();
-    if (nb > wt_total) nb = wt_total;
-    static std::atomic<unsigned long long> lds_ok{0};
-    if (lds > 64 * 1024) GGNN_CHECK_HIP((allow_dynamic_lds(&ggnn_gru_bwd_pipe_kernel<D, NX, NW>, lds, lds_ok)));
-    hipLaunchKernelGGL((ggnn_gru_bwd_pipe_kernel<D, NX, NW>), dim3(nb), dim3(NW * 64), lds, st, a, packed);
-    GGNN_CHECK_HIP(hipGetLastError());
-    return GGNN_OK;
-}
+// (A "pipelined" form -- g, u, c of the next tile fetched under the last three stages, h and r under stage 0, every store issued in
+//  front of a stage -- was measured at 211 us against 201 us for the kernel above: 100 B of scratch, and the waits only move to where
+//  the data is needed.  The exposed load phase is bandwidth, not latency: 8 waves x 5 fragments = 280 KB per CU and pass at the CU's
+//  share of HBM (6 TB/s / 256 CUs = 10 B/clock) is 28k clocks; hiding it takes a full pass of prefetch distance, i.e. 125 more
+//  registers per wave or 256 KB of LDS per CU.  tools/gru_bwd_timeline.py, tools/gru_bwd_bench.py)
 
 template <int D, int NX, int NW, bool PREFETCH, int RING>
 static int launch_gru_bwd_variant(const GruBwdArgs& a, const float* packed, hipStream_t st) {
@@ -564,9 +338,8 @@ static int launch_gru_bwd(const GruBwdArgs& a, const float* Wg, const float* Wc,
         return fail(GGNN_E_UNSUPPORTED, "fused GRU backward indexes with 32-bit byte offsets: V*2D must be < 2^30 (V=%d, D=%d)", a.V, D);
     // GGNN_BWD_FORM: 0 = one 8-wave workgroup per CU, 2-image ring, inputs fetched at the top of a pass;
     //                1 = the same with the next tile's inputs prefetched under the last stage;
-    //                2 = two 4-wave workgroups per CU, one image each;  3 = the pipelined kernel (memory operations under the stages)
+    //                2 = two 4-wave workgroups per CU, one image each
     const int form = [] { const char* e = getenv("GGNN_BWD_FORM"); return e ? atoi(e) : 0; }();   // (read per call: tools/gru_bwd_bench.py)
-    if (form == 3) return launch_gru_bwd_pipe<D, NX>(a, packed, st);
     if (form == 1) return launch_gru_bwd_variant<D, NX, 8, true, 2>(a, packed, st);
     if (form == 2) return launch_gru_bwd_variant<D, NX, 4, false, 1>(a, packed, st);
     return launch_gru_bwd_variant<D, NX, 8, false, 2>(a, packed, st);
@@ -617,6 +390,12 @@ extern "C" int ggnn_gru_bwd_fused_f32(const float* g, const float* h, const floa
                        aligned16(rh) && aligned16(dh), "pointers must be 16-byte aligned");
         a.g = g; a.h = h; a.r = r; a.u = u; a.c = c; a.dpc = dpc; a.dpg = dpg; a.rh = rh; a.dh = dh;
         for (int s = 0; s < nx; ++s) { GGNN_CHECK_ARG(dx[s] && aligned16(dx[s]), "dx[%d] null or misaligned", s); a.dx[s] = dx[s]; }
+        // (experiments, tools/gru_bwd_bench.py: wrong results on purpose) bit 0: every [V,D] output aliases dpc; bit 1: every input aliases g
+        if (const char* e = getenv("GGNN_BWD_ALIAS")) {
+            const int m = atoi(e);
+            if (m & 1) { a.rh = a.dpc; a.dh = a.dpc; for (int s = 0; s < nx; ++s) a.dx[s] = a.dpc; }
+            if (m & 2) { a.h = a.g; a.r = a.g; a.u = a.g; a.c = a.g; }
+        }
     }
     hipStream_t st = (hipStream_t)stream;
     switch (D) {

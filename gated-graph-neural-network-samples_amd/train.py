@@ -59,19 +59,38 @@ class TFAdam:
         return self._flat is not None
 
     @torch.no_grad()
-    def load_gradients(self, grads: List[torch.Tensor]) -> torch.Tensor:
+    def sink_targets(self) -> Dict[int, torch.Tensor]:
+        """{variable address: its view of the flat gradient buffer}: where backward.weight_gradient_sink accumulates."""
+        return {v.data_ptr(): w for v, w in zip(self.vars, self._flat["g_views"])}
+
+    @torch.no_grad()
+    def zero_gradient_views(self, ptrs=None) -> None:
+        views = [w for v, w in zip(self.vars, self._flat["g_views"]) if ptrs is None or v.data_ptr() in ptrs]
+        if views:
+            torch._foreach_zero_(views)
+
+    @torch.no_grad()
+    def load_gradients(self, grads: List[torch.Tensor], in_place=()) -> torch.Tensor:
         """Pack this step's gradients into the flat gradient buffer (ONE multi-tensor copy; variables without a gradient keep
-        zeros and are marked inactive) and return the buffer -- the operand of the data-parallel all-reduce."""
+        zeros and are marked inactive) and return the buffer -- the operand of the data-parallel all-reduce.
+        in_place: addresses of variables whose gradient was accumulated straight into their view of the buffer (the
+        weight-gradient sink of the propagation steps); an autograd gradient for such a variable is ADDED to it."""
         f = self._flat
-        mask = [0 if g is None else 1 for g in grads]
+        mask = [0 if (g is None and v.data_ptr() not in in_place) else 1 for g, v in zip(grads, self.vars)]
+        if in_place:
+            extra = [(w, g) for w, g, v in zip(f["g_views"], grads, self.vars) if g is not None and v.data_ptr() in in_place]
+            for w, g in extra:
+                w.add_(g.reshape(w.shape))
+            grads = [None if v.data_ptr() in in_place else g for g, v in zip(grads, self.vars)]
+            keep = [v.data_ptr() in in_place for v in self.vars]
+        else:
+            keep = [False] * len(self.vars)
         if mask != f["active_host"]:
-            if 0 in mask:
-                f["g"].zero_()
             f["active"].copy_(torch.tensor(mask, dtype=torch.int32), non_blocking=False)
             f["active_host"] = mask
-        elif 0 in mask:
-            for w, g in zip(f["g_views"], grads):
-                if g is None:
+        if 0 in mask:
+            for w, g, k in zip(f["g_views"], grads, keep):
+                if g is None and not k:
                     w.zero_()
         dst = [w for w, g in zip(f["g_views"], grads) if g is not None]
         src = [g.reshape(w.shape) for w, g in zip(f["g_views"], grads) if g is not None]
@@ -199,6 +218,9 @@ def train_step(model, batch_data) -> torch.Tensor:
         v.requires_grad_(True)
         v.grad = None
     model.training = True
+    opt = model.optimizer
+    fused = opt.fused and len(opt.vars) == len(variables) and all(a is b for a, b in zip(opt.vars, variables))
+    in_place = ()
     try:
         loss = model.forward_batch(batch_data)
         dist = getattr(model, "dist", None)
@@ -206,17 +228,27 @@ def train_step(model, batch_data) -> torch.Tensor:
             loss_for_grad = dist.global_loss(model)
         else:
             loss_for_grad = loss
-        loss_for_grad.backward()
+        if fused:
+            # the propagation steps add their weight gradients straight into the flat gradient buffer, on a side stream
+            # (backward.weight_gradient_sink); everything else arrives through autograd and is packed below
+            from .backward import weight_gradient_sink
+            opt.zero_gradient_views()
+            with weight_gradient_sink(opt.sink_targets()) as sink:
+                loss_for_grad.backward()
+            if sink is not None:
+                torch.cuda.current_stream().wait_stream(sink.stream)
+                in_place = frozenset(sink.used)
+        else:
+            loss_for_grad.backward()
     finally:
         model.training = False
     grads = [v.grad for v in variables]
-    opt = model.optimizer
     for v in variables:
         v.requires_grad_(False)
-    if opt.fused and len(opt.vars) == len(variables) and all(a is b for a, b in zip(opt.vars, variables)):
+    if fused:
         # GPU: one multi-tensor copy packs the gradients, ONE all-reduce of the flat buffer under data parallelism, then
         # per-variable clip + Adam in two launches for all variables (ggnn_clip_adam_f32)
-        flat = opt.load_gradients(grads)
+        flat = opt.load_gradients(grads, in_place)
         if dist is not None and dist.active:
             dist.all_reduce_sum_(flat)
             opt.mark_all_active()

@@ -13,7 +13,7 @@ Wg, Wc = r((nx + 1) * D, 2 * D) * 0.2, r((nx + 1) * D, D) * 0.2
 nin = torch.ones(V, T, device=dev)
 packed = pkg.ops.PackedWeights().gru_bwd(Wg, Wc, nx, D)
 run = lambda: pkg.ops.gru_bwd_fused(g, h, rr, u, c, packed, nin, True, nx, "tanh")
-forms = sys.argv[1:] or ["0", "3"]
+forms = sys.argv[1:] or ["0", "1", "2"]
 ref = None
 for f in forms:
     os.environ["GGNN_BWD_FORM"] = f
