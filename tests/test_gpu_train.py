@@ -101,6 +101,26 @@ def test_train_step_matches_restated_tf_adam(pkg, oracle, oracle_torch, cuda):
         assert float((got - want).abs().max()) < 5e-6, name
 
 
+@pytest.mark.parametrize("config", [{"use_edge_bias": True}, {"layer_timesteps": [2, 1, 2], "residual_connections": {"1": [0], "2": [0, 1]}}])
+def test_side_stream_weight_gradients_are_bit_identical(pkg, oracle, cuda, config, monkeypatch):
+    """The fused training step adds the weight gradients of the propagation steps into the optimizer's flat gradient buffer
+    on a second stream (backward.weight_gradient_sink) instead of returning them to autograd: three steps from the same
+    weights give the same weights, bit for bit, with the sink switched off."""
+    results = []
+    for side in (True, False):
+        monkeypatch.setattr(pkg.backward, "USE_WGRAD_STREAM", side)
+        model, layers, feed = _setup(pkg, oracle, config, n=300, seed=4)
+        feed = dict(feed); feed["out_layer_dropout_keep_prob"] = 1.0
+        for _ in range(3):
+            model.train_batch(feed)
+        torch.cuda.synchronize()
+        results.append({k: v.detach().clone() for k, v in model.trainable_variables.items()})
+        if side:
+            assert pkg.backward._SINK.stream is not None and pkg.backward._SINK.targets is None
+    for k in results[0]:
+        assert torch.equal(results[0][k], results[1][k]), k
+
+
 def test_training_reduces_loss(pkg, oracle, cuda):
     ms = pkg.synthetic_qm9(400, mean_nodes=9, seed=3)
     model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms,
