@@ -546,6 +546,21 @@ def main():
                                       "unit": "GB/s", "frac": rec["frac"], "frac_of_6.29TBps_copy": rec["achieved"] / HBM_COPY_GBPS,
                                       "avg_us": rec["avg_us"], "algorithmic_bytes": rec["algorithmic_bytes"],
                                       "in_timed_path": False, "traffic": rec["traffic"], "traffic_source": rec.get("traffic_source")}
+                # the yardstick at THIS size: a device-to-device copy moving the same number of bytes (half read, half written),
+                # timed the same way -- a 25 us launch never reaches the 6.29 TB/s of a GB-sized copy (ramp-up and drain are ~3 us)
+                nfl = int(rec["algorithmic_bytes"] / 8)
+                src_c, dst_c = torch.empty(nfl, device=dev), torch.empty(nfl, device=dev)
+                for _ in range(3):
+                    dst_c.copy_(src_c)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    dst_c.copy_(src_c)
+                e1.record(); torch.cuda.synchronize()
+                copy_us = e0.elapsed_time(e1) * 1e3 / 20
+                out["scatter_add"]["copy_same_bytes_us"] = copy_us
+                out["scatter_add"]["frac_of_copy_same_bytes"] = copy_us / rec["avg_us"]
+                del src_c, dst_c
         dom = max(kernels, key=lambda k: kernels[k]["time_share"])
         out["roofline"] = dict(kernels[dom], kernel=dom)
         if traffic_err:

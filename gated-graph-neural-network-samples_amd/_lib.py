@@ -81,6 +81,8 @@ SYMBOLS = {
     "ggnn_xty_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ggnn_xty_f32": (c_int, [POINTER(c_void_p), c_int, c_int, POINTER(c_int32), c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                              c_int, POINTER(c_int32), c_int, c_void_p, c_size_t, c_void_p]),
+    "ggnn_xty_acc_f32": (c_int, [POINTER(c_void_p), c_int, c_int, POINTER(c_int32), c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                 c_int, c_int, c_int, c_int, POINTER(c_int32), c_int, c_void_p, c_size_t, c_void_p]),
     "ggnn_colsum_workspace_bytes": (c_size_t, [c_int]),
     "ggnn_colsum_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ggnn_gru_bwd_dx_cand_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),

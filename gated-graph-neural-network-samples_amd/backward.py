@@ -68,6 +68,9 @@ class _WeightGradSink:
         target.add_(value.view_as(target))
         self.used.add(ptr)
 
+    def mark(self, *ptrs):
+        self.used.update(ptrs)
+
 
 _SINK = _WeightGradSink()
 
@@ -197,11 +200,10 @@ class PropagationStepFn(torch.autograd.Function):
             sW, sb, sWg, sbg, sWc, sbc = ctx.var_shapes
             tg = [_SINK.target(p_, s_) for p_, s_ in ((pWg, sWg), (pbg, sbg), (pWc, sWc), (pbc, sbc))]
             if all(t is not None for t in tg):
-                def gru_weight_products():
-                    wc = ops.xty(xs + [rh], dpc, ones_row=True)                            # bias gradient = the ones row
-                    _SINK.add(pWc, tg[2], wc[:Kx]); _SINK.add(pbc, tg[3], wc[Kx])
-                    wg = ops.xty(xs + [h], dpg, ones_row=True)
-                    _SINK.add(pWg, tg[0], wg[:Kx]); _SINK.add(pbg, tg[1], wg[Kx])
+                def gru_weight_products():             # (the reduction kernel adds into the gradient buffers; bias = the ones row)
+                    ops.xty(xs + [rh], dpc, ones_row=True, add_to=tg[2], add_bias_to=tg[3])
+                    ops.xty(xs + [h], dpg, ones_row=True, add_to=tg[0], add_bias_to=tg[1])
+                    _SINK.mark(pWg, pbg, pWc, pbc)
                 _on_side_stream(xs + [rh, h, dpc, dpg], gru_weight_products)
                 dWc = dbc = dWg = dbg = None
             else:
@@ -244,7 +246,10 @@ def transform_backward(index, comp, h, W, dinc, dh, message_weights=None, sink=N
     Z = ops.msg_transform_compact_packed(dHc, _PACKED.edge(_TRANSPOSED.get(W, (1, 2))), T, bwd.identity)       # dHc W_t^T
     ops.segment_sum_rows_acc(Z[:R], bwd.node_index, dh)                                      # sum over a node's types
     if sink is not None:
-        _on_side_stream([h, dHc], lambda: _SINK.add(sink[0], sink[1], ops.xty([h], dHc, x_rows=comp.pair_node, row_off=comp.type_row_off)))
+        def edge_weight_products():
+            ops.xty([h], dHc, x_rows=comp.pair_node, row_off=comp.type_row_off, add_to=sink[1])
+            _SINK.mark(sink[0])
+        _on_side_stream([h, dHc], edge_weight_products)
         return None
     return ops.xty([h], dHc, x_rows=comp.pair_node, row_off=comp.type_row_off)                 # [T, D, D]
 

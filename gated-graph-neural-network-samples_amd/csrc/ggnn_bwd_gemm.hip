@@ -280,9 +280,12 @@ __global__ __launch_bounds__(kXtyWaves * 64) void xty_kernel(XtyArgs a) {
 #undef GGNN_XT
 }
 
-// C[b][i] = sum over the workgroup rows of batch b of part[row][i], in row order
+// C[b][i] = sum over the workgroup rows of batch b of part[row][i], in row order.  With a separate bias destination the K weight rows
+// go to C [nbatch][K][N] and the ones row to Cb [nbatch][N]; accumulate: the sums are ADDED to what the destinations hold (the
+// gradient buffers of the training step: one launch less per product, and no torch add on the side stream).
 struct XtyReduceArgs { int wg_off[kXtyMaxBatch + 1]; };
-__global__ void xty_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, int KN, int nbatch, XtyReduceArgs ra) {
+__global__ void xty_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, float* __restrict__ Cb, int KN, int KwN,
+                                  int nbatch, int accumulate, XtyReduceArgs ra) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)KN * nbatch) return;
     const int b = (int)(i / KN), j = (int)(i - (long long)b * KN);
@@ -296,7 +299,9 @@ __global__ void xty_reduce_kernel(const float* __restrict__ part, float* __restr
         for (int q = 0; q < 8; ++q) s[q] += src[(size_t)(p + q) * KN];
     }
     for (int q = 0; p < S; ++p, ++q) s[q] += src[(size_t)p * KN];
-    C[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    const float v = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    float* dst = (Cb && j >= KwN) ? Cb + (size_t)b * (KN - KwN) + (j - KwN) : C + (size_t)b * (Cb ? KwN : KN) + j;
+    *dst = accumulate ? *dst + v : v;
 }
 
 struct XtyPlan { int rows, kb_tiles, n_tiles, kblocks, px, py, wg_rows; size_t lds; int wg_off[kXtyMaxBatch + 1]; };
@@ -335,7 +340,7 @@ static XtyPlan xty_plan(const int* row_off, int nbatch, int Kout, int N) {
 }
 
 template <bool GATHER, int ROWS, int MTM, int NTM>
-static int launch_xty(const XtyArgs& a, const XtyPlan& p, float* C, hipStream_t st) {
+static int launch_xty(const XtyArgs& a, const XtyPlan& p, float* C, float* Cb, int accumulate, hipStream_t st) {
     static std::atomic<unsigned long long> lds_ok{0};
     if (p.wg_rows > 0) {
         if (p.lds > 64 * 1024) GGNN_CHECK_HIP((allow_dynamic_lds(&xty_kernel<GATHER, ROWS, MTM, NTM>, p.lds, lds_ok)));
@@ -345,8 +350,8 @@ static int launch_xty(const XtyArgs& a, const XtyPlan& p, float* C, hipStream_t 
     XtyReduceArgs ra;
     for (int b = 0; b <= kXtyMaxBatch; ++b) ra.wg_off[b] = a.wg_off[b <= a.nbatch ? b : a.nbatch];
     const long long total = (long long)a.Kout * a.N * a.nbatch;
-    hipLaunchKernelGGL(xty_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)a.part, C, a.Kout * a.N,
-                       a.nbatch, ra);
+    hipLaunchKernelGGL(xty_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)a.part, C, Cb, a.Kout * a.N,
+                       a.K * a.N, a.nbatch, accumulate, ra);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
@@ -401,7 +406,14 @@ extern "C" size_t ggnn_xty_workspace_bytes(int M_max, int K, int N, int nbatch) 
 extern "C" int ggnn_xty_f32(const float* const* x_segs, int nseg, int Dseg, const int32_t* ldx, const int32_t* x_rows,
                             const float* Y, int ldy, float* C, int K, int N, int ones_row, const int32_t* row_off, int nbatch,
                             void* ws, size_t ws_bytes, ggnn_stream_t stream) {
+    return ggnn_xty_acc_f32(x_segs, nseg, Dseg, ldx, x_rows, Y, ldy, C, nullptr, 0, K, N, ones_row, row_off, nbatch, ws, ws_bytes, stream);
+}
+
+extern "C" int ggnn_xty_acc_f32(const float* const* x_segs, int nseg, int Dseg, const int32_t* ldx, const int32_t* x_rows,
+                                const float* Y, int ldy, float* C, float* Cb, int accumulate, int K, int N, int ones_row,
+                                const int32_t* row_off, int nbatch, void* ws, size_t ws_bytes, ggnn_stream_t stream) {
     const int Kout = ones_row ? K + 1 : K;
+    GGNN_CHECK_ARG(!Cb || ones_row, "a bias destination needs the ones row");
     GGNN_CHECK_ARG(nseg >= 1 && nseg <= 4 && Dseg > 0 && Dseg % 4 == 0 && K == nseg * Dseg, "X is nseg <= 4 segments of Dseg columns (K = %d, nseg = %d, Dseg = %d)", K, nseg, Dseg);
     GGNN_CHECK_ARG(N > 0 && N % 4 == 0 && N <= 256, "N = %d must be a multiple of 4, <= 256", N);
     GGNN_CHECK_ARG(nbatch >= 1 && nbatch <= kXtyMaxBatch && row_off && C && ldx, "bad batch description");
@@ -413,8 +425,11 @@ extern "C" int ggnn_xty_f32(const float* const* x_segs, int nseg, int Dseg, cons
         a.row_off[b] = row_off[b];
         if (b) { GGNN_CHECK_ARG(row_off[b] >= row_off[b - 1], "row_off not monotone"); m_max = row_off[b] - row_off[b - 1] > m_max ? row_off[b] - row_off[b - 1] : m_max; }
     }
-    if (m_max == 0) {
-        GGNN_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)nbatch * Kout * N * sizeof(float), st));
+    if (m_max == 0) {                                   // empty sums
+        if (!accumulate) {
+            GGNN_CHECK_HIP(hipMemsetAsync(C, 0, (size_t)nbatch * (Cb ? K : Kout) * N * sizeof(float), st));
+            if (Cb) GGNN_CHECK_HIP(hipMemsetAsync(Cb, 0, (size_t)nbatch * N * sizeof(float), st));
+        }
         return GGNN_OK;
     }
     GGNN_CHECK_ARG(x_segs && Y && ws && aligned16(Y) && aligned16(ws), "null or misaligned pointer");
@@ -434,7 +449,7 @@ extern "C" int ggnn_xty_f32(const float* const* x_segs, int nseg, int Dseg, cons
         return fail(GGNN_E_UNSUPPORTED, "xty: slab too wide (K=%d N=%d)", K, N);
     const int mtm = (p.kb_tiles + 3) / 4, ntm = (p.n_tiles + 3) / 4;
     const bool g = x_rows != nullptr;
-#define GGNN_XTY_CASE(G, R, M, Nn) if (g == G && p.rows == R && mtm == M && ntm == Nn) return launch_xty<G, R, M, Nn>(a, p, C, st);
+#define GGNN_XTY_CASE(G, R, M, Nn) if (g == G && p.rows == R && mtm == M && ntm == Nn) return launch_xty<G, R, M, Nn>(a, p, C, Cb, accumulate, st);
 #define GGNN_XTY_ROW32(M) GGNN_XTY_CASE(false, 32, M, 1) GGNN_XTY_CASE(false, 32, M, 2) GGNN_XTY_CASE(false, 32, M, 3) GGNN_XTY_CASE(false, 32, M, 4)
     GGNN_XTY_ROW32(1) GGNN_XTY_ROW32(2) GGNN_XTY_ROW32(3) GGNN_XTY_ROW32(4)
     // 64-row slabs exist for the group shapes whose two slabs can fit the LDS (xty_plan picks them when they do)

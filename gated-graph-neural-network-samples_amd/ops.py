@@ -329,12 +329,15 @@ def gemm_tn(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
 
 
 def xty(x_segs: Sequence[torch.Tensor], dy: torch.Tensor, x_rows: Optional[torch.Tensor] = None,
-        row_off: Optional[Sequence[int]] = None, ones_row: bool = False) -> torch.Tensor:
+        row_off: Optional[Sequence[int]] = None, ones_row: bool = False, add_to: Optional[torch.Tensor] = None,
+        add_bias_to: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Weight-gradient product  concat(x_segs, dim=1)^T @ dy  on ggnn_xty_f32 (no concat materialised; deterministic).
     x_segs: [M', Dseg] float32 tensors with unit column stride (any row stride: column slices are fine); dy [M, N], N <= 208.
     x_rows (int32 [M]): row r of the X operand is x_segs[.][x_rows[r]] (edge-weight gradients on compact rows).
     row_off (host ints [B+1]): B independent products over the row ranges -> [B, K, N]; default one product -> [K, N].
-    ones_row: the result has K + 1 rows, the last one the column sums of dy (the bias gradient next to the weight gradient)."""
+    ones_row: the result has K + 1 rows, the last one the column sums of dy (the bias gradient next to the weight gradient).
+    add_to (contiguous float32, B*K*N elements) [, add_bias_to (N or B*N elements; needs ones_row)]: the product (and the column
+    sums) are ADDED into these buffers by the reduction kernel itself and nothing is returned (gradient accumulation)."""
     lib = _lib.load()
     nseg = len(x_segs)
     Dseg = x_segs[0].shape[1]
@@ -349,7 +352,15 @@ def xty(x_segs: Sequence[torch.Tensor], dy: torch.Tensor, x_rows: Optional[torch
     offs = [0, M] if row_off is None else [int(o) for o in row_off]
     B = len(offs) - 1
     Kout = K + 1 if ones_row else K
-    out = torch.empty((B, Kout, N), dtype=torch.float32, device=dy.device)
+    if add_to is not None:
+        if ones_row != (add_bias_to is not None):
+            raise ValueError("add_to with ones_row needs add_bias_to (and vice versa)")
+        for t, n in ((add_to, B * K * N), (add_bias_to, B * N)):
+            if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n):
+                raise TypeError("accumulation buffers must be contiguous float32 CUDA/HIP tensors of %d elements" % n)
+        out = None
+    else:
+        out = torch.empty((B, Kout, N), dtype=torch.float32, device=dy.device)
     m_max = max([offs[b + 1] - offs[b] for b in range(B)] + [0])
     ws_bytes = lib.ggnn_xty_workspace_bytes(m_max, K, N, B)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
@@ -359,6 +370,11 @@ def xty(x_segs: Sequence[torch.Tensor], dy: torch.Tensor, x_rows: Optional[torch
     ldy = dy.stride(0) if M > 1 else N
     if x_rows is not None:
         _req(x_rows, torch.int32, "x_rows")
+    if out is None:
+        _launch("xty[K=%d,N=%d%s]" % (K, N, ",x%d" % B if batched else ""), lambda: lib.ggnn_xty_acc_f32(
+            segs, nseg, Dseg, ldx, _ptr(x_rows), _ptr(dy), ldy, _ptr(add_to), _ptr(add_bias_to), 1, K, N, 1 if ones_row else 0, ro, B,
+            _ptr(ws), ws_bytes, _stream()))
+        return None
     _launch("xty[K=%d,N=%d%s]" % (K, N, ",x%d" % B if batched else ""), lambda: lib.ggnn_xty_f32(
         segs, nseg, Dseg, ldx, _ptr(x_rows), _ptr(dy), ldy, _ptr(out), K, N, 1 if ones_row else 0, ro, B, _ptr(ws), ws_bytes, _stream()))
     return out if batched else out[0]

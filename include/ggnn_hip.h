@@ -351,6 +351,12 @@ size_t ggnn_xty_workspace_bytes(int M_max, int K, int N, int nbatch);
 int ggnn_xty_f32(const float* const* x_segs, int nseg, int Dseg, const int32_t* ldx, const int32_t* x_rows, const float* Y,
                  int ldy, float* C, int K, int N, int ones_row, const int32_t* row_off, int nbatch, void* ws, size_t ws_bytes,
                  ggnn_stream_t stream);
+/* The same product written the way a training step consumes it (what TF's gradient accumulation over the timesteps of a layer
+ * does, chem_tensorflow.py:184):  Cb != NULL (needs ones_row): the K weight rows go to C [nbatch][K][N] and the column sums to
+ * Cb [nbatch][N];  accumulate != 0: the results are ADDED to the destinations' contents. */
+int ggnn_xty_acc_f32(const float* const* x_segs, int nseg, int Dseg, const int32_t* ldx, const int32_t* x_rows, const float* Y,
+                     int ldy, float* C, float* Cb, int accumulate, int K, int N, int ones_row, const int32_t* row_off, int nbatch,
+                     void* ws, size_t ws_bytes, ggnn_stream_t stream);
 size_t ggnn_colsum_workspace_bytes(int N);
 int ggnn_colsum_f32(const float* Y, int ldy, int M, int N, float* out, void* ws, size_t ws_bytes, ggnn_stream_t stream);
 int ggnn_gru_bwd_dx_cand_f32(const float* dpc, const float* WcT, const float* h, const float* r, float* dx, float* dh,

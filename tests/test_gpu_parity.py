@@ -612,6 +612,32 @@ def test_xty_weight_gradient_product(pkg, cuda, M, nseg, Dseg, N):
     np.testing.assert_allclose(both[-1].cpu().numpy(), wide[:, 4:4 + N].astype(np.float64).sum(0), atol=1e-3 + 4e-7 * M, rtol=1e-5)
 
 
+def test_xty_accumulates_into_gradient_buffers(pkg, cuda):
+    """add_to / add_bias_to: the reduction kernel adds the product (and the ones row) into existing buffers -- the same
+    floating-point operation as `buffer += xty(...)`, so the results are bit-identical."""
+    rng = np.random.default_rng(11)
+    M, D = 20011, 100
+    xs = [dev(rng.uniform(-1, 1, (M, D)).astype(np.float32), cuda) for _ in range(2)]
+    dy = dev(rng.uniform(-1, 1, (M, 2 * D)).astype(np.float32), cuda)
+    w0 = dev(rng.uniform(-1, 1, (2 * D, 2 * D)).astype(np.float32), cuda); b0 = dev(rng.uniform(-1, 1, 2 * D).astype(np.float32), cuda)
+    both = pkg.ops.xty(xs, dy, ones_row=True)
+    w, b = w0.clone(), b0.clone()
+    assert pkg.ops.xty(xs, dy, ones_row=True, add_to=w, add_bias_to=b) is None
+    assert torch.equal(w, w0 + both[:-1]) and torch.equal(b, b0 + both[-1])
+    # batched, row-gathered (edge weights): [T, D, D] buffer
+    V, R = 5000, 9000
+    h = dev(rng.uniform(-1, 1, (V, D)).astype(np.float32), cuda)
+    rows = dev(rng.integers(0, V, R).astype(np.int32), cuda)
+    dHc = dev(rng.uniform(-1, 1, (R, D)).astype(np.float32), cuda)
+    off = [0, 4000, 4000, 4100, R]
+    e0 = dev(rng.uniform(-1, 1, (4, D, D)).astype(np.float32), cuda)
+    e = e0.clone()
+    pkg.ops.xty([h], dHc, x_rows=rows, row_off=off, add_to=e)
+    assert torch.equal(e, e0 + pkg.ops.xty([h], dHc, x_rows=rows, row_off=off))
+    with pytest.raises(ValueError):
+        pkg.ops.xty(xs, dy, ones_row=True, add_to=w)
+
+
 def test_xty_row_gathered_batches_and_colsum(pkg, cuda):
     """The edge-weight gradient form: X rows gathered through an index, one [K,N] product per row range (edge type)."""
     rng = np.random.default_rng(5)
