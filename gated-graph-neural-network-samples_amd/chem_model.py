@@ -13,7 +13,7 @@ Differences that are deliberate:
     '--data_dir', '--log_dir', '--restore', '--freeze-graph-model', '--evaluate'); extra keys:
     'train_data' / 'valid_data' (in-memory MoleculeSet or raw JSON list instead of files),
     '--device' (default 'cuda:0'), '--quiet' (no log files), 'dist' (a DataParallelContext).
-  * no TensorBoard summaries (chem_tensorflow.py:195-200), no ThreadedIterator (utils.py:16-36).
+  * no TensorBoard summaries (chem_tensorflow.py:195-200).
 """
 from __future__ import annotations
 
@@ -270,7 +270,14 @@ class ChemModel(object):
         steps = 0
         sharded = self.dist is not None and self.dist.active
         shard_stats, shard_graphs = [], []
-        for step, batch_data in enumerate(self.make_minibatch_iterator(data, is_training)):
+        pending = None
+        batch_iterator = self.make_minibatch_iterator(data, is_training)
+        if is_training and self.params.get('threaded_batches', True):
+            # chem_tensorflow.py:219 ThreadedIterator(..., max_queue_size=5): the next batches are packed while this one trains
+            # (validation batches are packed once and stay resident: nothing to prefetch).  Two ahead is enough here.
+            from .utils import ThreadedIterator
+            batch_iterator = ThreadedIterator(batch_iterator, max_queue_size=2, device=getattr(self, "device", None))
+        for step, batch_data in enumerate(batch_iterator):
             num_graphs = batch_data['num_graphs']
             processed_graphs += num_graphs
             if is_training:
@@ -293,14 +300,17 @@ class ChemModel(object):
                 shard_graphs.append(float(num_graphs))
                 steps += 1
                 continue
-            batch_accuracies = [float(self.ops['accuracy_task%i' % t].detach()) for t in self.params['task_ids']]
-            batch_loss = float(batch_loss.detach())
-            loss += batch_loss * num_graphs
-            accuracies.append(np.array(batch_accuracies) * num_graphs)
-            if not self.quiet:
-                print("Running %s, batch %i (has %i graphs). Loss so far: %.4f" % (epoch_name, step, num_graphs,
-                                                                                   loss / processed_graphs), end='\r')
+            # The step's loss and per-task MAE stay on the device until the NEXT step has been queued: reading them now would
+            # stall the launching thread until the GPU has finished this step, and the GPU would then idle while the next
+            # step's ~250 launches are issued ("Loss so far" therefore trails by one batch; the epoch result does not).
+            stats = torch.stack([batch_loss.detach().reshape(()).to(torch.float64)] +
+                                [self.ops['accuracy_task%i' % t].detach().reshape(()).to(torch.float64) for t in self.params['task_ids']])
+            if pending is not None:
+                loss, processed_seen = self._absorb_step_stats(pending, loss, accuracies, epoch_name, step - 1)
+            pending = (stats, num_graphs, processed_graphs)
             steps += 1
+        if pending is not None:
+            loss, _ = self._absorb_step_stats(pending, loss, accuracies, epoch_name, steps - 1)
         if sharded:
             loss, accuracies, processed_graphs = self._reduce_epoch_stats(shard_stats, shard_graphs)
         else:
@@ -309,6 +319,16 @@ class ChemModel(object):
         error_ratios = accuracies / chemical_accuracies[self.params["task_ids"]]
         instance_per_sec = processed_graphs / (time.time() - start_time)
         return loss, accuracies, error_ratios, instance_per_sec, steps
+
+    def _absorb_step_stats(self, pending, loss, accuracies, epoch_name, step):
+        """chem_tensorflow.py:237-246: loss += batch_loss * num_graphs, accuracies likewise, progress line."""
+        stats, num_graphs, processed = pending
+        vals = stats.cpu().numpy()
+        loss += float(vals[0]) * num_graphs
+        accuracies.append(vals[1:] * num_graphs)
+        if not self.quiet:
+            print("Running %s, batch %i (has %i graphs). Loss so far: %.4f" % (epoch_name, step, num_graphs, loss / processed), end='\r')
+        return loss, processed
 
     def _reduce_epoch_stats(self, shard_stats, shard_graphs):
         """Epoch loss / per-task MAE under data parallelism: per step the global batch's loss is

@@ -60,7 +60,8 @@ def _ranges(starts: torch.Tensor, lengths: torch.Tensor, total: int) -> torch.Te
 
 
 def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_types: int, hidden_size: int,
-                      tie_fwd_bkwd: bool = True, task_ids: Sequence[int] = (0,), compact: bool = True) -> Dict[str, Any]:
+                      tie_fwd_bkwd: bool = True, task_ids: Sequence[int] = (0,), compact: bool = True,
+                      training: bool = False) -> Dict[str, Any]:
     """One batch from graphs `graph_ids` (in this order), assembled on the GPU: the feed dict of
     SparseGGNNChemModel.to_device_batch (chem_tensorflow_sparse.py:254-276, 298-348), message index included."""
     dev = dms.device
@@ -121,13 +122,13 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
         'target_mask': tm,
         'num_graphs': G,
         # (ids are offsets we just built from bond endpoints DeviceMoleculeSet checked: no per-batch validation)
-        'message_index': ops.prepare_message_index(ops.build_message_index(adjacency, V, validate=False), hidden_size, compact),
+        'message_index': ops.prepare_message_index(ops.build_message_index(adjacency, V, validate=False), hidden_size, compact, training),
         'graph_nodes_sorted': True,
     }
 
 
 def pack_batches_device(dms: DeviceMoleculeSet, params: dict, num_edge_types: int, order: Optional[np.ndarray] = None,
-                        rank: int = 0, world_size: int = 1, compact: bool = True):
+                        rank: int = 0, world_size: int = 1, compact: bool = True, training: bool = False):
     """Generator over one epoch's batches for graph order `order` -- data.pack_batches on the device (same batch
     boundaries, same rank assignment, same empty padding batches)."""
     ms = dms.host
@@ -140,4 +141,4 @@ def pack_batches_device(dms: DeviceMoleculeSet, params: dict, num_edge_types: in
         i = s * world_size + rank
         ids = order[bounds[i]:bounds[i + 1]] if i < nb else np.zeros(0, np.int64)
         yield pack_batch_device(dms, ids, num_edge_types, params["hidden_size"], params.get("tie_fwd_bkwd", True),
-                                params.get("task_ids", [0]), compact)
+                                params.get("task_ids", [0]), compact, training)

@@ -610,14 +610,22 @@ def build_compact_sources(index: MessageIndex) -> CompactSources:
     return CompactSources(pair_node[:max(type_row_off[-1], 1)], type_row_off, gather_c)
 
 
-def prepare_message_index(index: MessageIndex, hidden_size: int, compact: bool = True) -> MessageIndex:
+def prepare_message_index(index: MessageIndex, hidden_size: int, compact: bool = True, training: bool = False) -> MessageIndex:
     """Everything the propagation derives from a batch's message index, built EAGERLY when the batch is packed (it
     used to be built lazily on the first forward of each batch, which put a cold pass -- three small launches and a
     device->host sync -- inside whatever region timed that forward): the active (source node, edge type) pairs of the
-    compacted message transform for the hidden sizes that have one."""
+    compacted message transform for the hidden sizes that have one; training: also the transpose structures of the backward
+    pass (CompactBackward and the slot heads of its segment sums) -- ~25 small launches that would otherwise run inside the
+    first backward pass of every fresh batch, on the training stream, instead of on the packer's."""
     if compact and index.num_messages and compact_supported(hidden_size) and getattr(index, "_compact", None) is None:
         index._compact = build_compact_sources(index)
         slot_heads(index._compact, index.row_ptr, index._compact.gather_row, index.num_nodes)
+    comp = getattr(index, "_compact", None)
+    if training and comp is not None and comp.num_rows:
+        bwd = compact_backward(index, comp)
+        slot_heads(index, index.row_ptr, index.gather_row, index.num_nodes)
+        for si in (bwd.rows_index, bwd.node_index, bwd.source_node_index):
+            slot_heads(si, si.row_ptr, si.gather_row, si.num_nodes)
     return index
 
 
@@ -739,21 +747,34 @@ class PackedWeights:
         entry = table.get(key)
         if entry is None:
             return None
-        refs, versions, packed = entry
+        refs, versions, packed, ready, stream_id = entry
         for r, v, t in zip(refs, versions, tensors):
             if r() is not cls._base(t) or v != t._version:
                 return None
+        # the image was written on another stream: order this stream after the pack launch (an event wait on the device --
+        # a host synchronisation here used to drain the GPU queue once per layer and training step)
+        if ready is not None:
+            cur = torch.cuda.current_stream()
+            if cur.cuda_stream != stream_id:
+                if not ready.query():
+                    cur.wait_event(ready)
+                packed.record_stream(cur)                    # (its memory belongs to the packing stream's pool)
         return packed
 
     @classmethod
     def _store(cls, table, key, tensors, packed):
         import weakref
         if len(table) >= 64:     # drop the images of weights that no longer exist; never evict a live model's
-            for k in [k for k, (refs, _, _) in table.items() if any(r() is None for r in refs)]:
+            for k in [k for k, e in table.items() if any(r() is None for r in e[0])]:
                 del table[k]
             if len(table) >= 1024:
                 table.clear()
-        table[key] = ([weakref.ref(cls._base(t)) for t in tensors], [t._version for t in tensors], packed)
+        ready, stream_id = None, 0
+        if packed.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record()                                   # after the pack launch, on the stream that ran it
+            stream_id = torch.cuda.current_stream().cuda_stream
+        table[key] = ([weakref.ref(cls._base(t)) for t in tensors], [t._version for t in tensors], packed, ready, stream_id)
         return packed
 
     def gru(self, Wg: torch.Tensor, Wc: torch.Tensor, nx: int, D: int) -> torch.Tensor:
@@ -764,7 +785,6 @@ class PackedWeights:
             _req(Wg, torch.float32, "Wg"); _req(Wc, torch.float32, "Wc")
             packed = torch.empty(lib.ggnn_gru_packed_bytes(D, nx) // 4, dtype=torch.float32, device=Wg.device)
             check(lib.ggnn_gru_pack_weights_f32(_ptr(Wg), _ptr(Wc), nx, D, _ptr(packed), _stream()))
-            torch.cuda.current_stream().synchronize()    # rare (once per weight version); other streams may read it next
             hit = self._store(self._gru, key, (Wg, Wc), packed)
         return hit
 
@@ -792,7 +812,6 @@ class PackedWeights:
             T, D = W.shape[0], W.shape[1]
             packed = torch.empty(lib.ggnn_msg_transform_compact_workspace_bytes(D, T) // 4, dtype=torch.float32, device=W.device)
             check(lib.ggnn_edge_weights_pack_f32(_ptr(W), T, D, _ptr(packed), _stream()))
-            torch.cuda.current_stream().synchronize()
             hit = self._store(self._edge, key, (W,), packed)
         return hit
 

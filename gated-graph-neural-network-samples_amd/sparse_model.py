@@ -393,7 +393,8 @@ class SparseGGNNChemModel(ChemModel):
 
         def epoch_batches(order):
             if on_device:
-                return pack_batches_device(data["molecules_dev"], self.params, self.num_edge_types, order, rank, world, compact)
+                return pack_batches_device(data["molecules_dev"], self.params, self.num_edge_types, order, rank, world, compact,
+                                           training=is_training and compact)
             return (self.to_device_batch(b, compact) for b in
                     pack_batches(ms, self.params, self.num_edge_types, order, data["label_mask"], rank, world))
 

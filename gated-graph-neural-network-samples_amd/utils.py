@@ -1,13 +1,98 @@
 """Host-side mirror of the reference's utils.py pieces the hot path touches:
-SMALL_NUMBER (utils.py:8), glorot_init (:11-13) and MLP (:39-70).  ThreadedIterator (:16-36) is not
-mirrored: batches are packed once and kept resident in HBM instead of being prefetched by a thread.
+SMALL_NUMBER (utils.py:8), glorot_init (:11-13), ThreadedIterator (:16-36) and MLP (:39-70).
 """
 from __future__ import annotations
+
+import collections
+import queue
+import threading
 
 import numpy as np
 import torch
 
 SMALL_NUMBER = 1e-7
+
+
+class ThreadedIterator:
+    """utils.py:16-36: a producer thread runs the wrapped iterator `max_queue_size` elements ahead of the consumer.
+
+    The reference uses it to pack the next minibatch on the host while `sess.run` works on the current one
+    (chem_tensorflow.py:219).  Here the elements are batches assembled ON THE GPU (data_device.pack_batch_device: ~80 small
+    launches and two device->host reads per batch, 1 ms of mostly host time), so the producer works on its own HIP stream:
+    its launches and its host reads no longer sit in front of the training step's kernels in the consumer's stream.  An
+    element is handed over with an event (the consumer's stream waits for it, not the host), and the consumer's reference
+    to an element is kept until the work the consumer queued on it has completed -- its memory belongs to the producer
+    stream's allocator pool and must not be recycled under kernels that still read it.
+
+    device: a torch.device of type "cuda" to get the side stream; None / CPU: a plain prefetch thread."""
+
+    def __init__(self, original_iterator, max_queue_size: int = 2, device=None):
+        self.__queue = queue.Queue(maxsize=max_queue_size)
+        self.__cuda = device is not None and torch.device(device).type == "cuda" and torch.cuda.is_available()
+        self.__device = torch.device(device) if self.__cuda else None
+        self.__stream = torch.cuda.Stream(self.__device) if self.__cuda else None
+        self.__stop = threading.Event()
+        self.__retired = collections.deque()
+        self.__thread = threading.Thread(target=self.__worker, args=(original_iterator,), daemon=True)
+        self.__thread.start()
+
+    def __put(self, item) -> bool:
+        while not self.__stop.is_set():
+            try:
+                self.__queue.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def __worker(self, original_iterator):
+        try:
+            if self.__cuda:
+                torch.cuda.set_device(self.__device)
+                with torch.cuda.stream(self.__stream):
+                    for element in original_iterator:
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        if not self.__put((element, ev, None)):
+                            return
+            else:
+                for element in original_iterator:
+                    if not self.__put((element, None, None)):
+                        return
+            self.__put((None, None, None))
+        except BaseException as exc:                                  # surfaces in the consumer, like the reference's would
+            self.__put((None, None, exc))
+
+    def __retire(self, element):
+        if self.__cuda and element is not None:
+            ev = torch.cuda.Event()
+            ev.record()                                               # after everything the consumer queued on `element`
+            self.__retired.append((ev, element))
+        while self.__retired and self.__retired[0][0].query():
+            self.__retired.popleft()
+
+    def __iter__(self):
+        prev = None
+        try:
+            while True:
+                element, ev, exc = self.__queue.get()
+                self.__retire(prev)
+                prev = None
+                if exc is not None:
+                    raise exc
+                if element is None:
+                    break
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)
+                prev = element
+                yield element
+        finally:
+            self.__stop.set()                                         # consumer left early: let the producer go
+            self.__retire(prev)
+            for ev, _ in self.__retired:
+                ev.synchronize()
+            self.__retired.clear()
+            self.__thread.join(timeout=5.0)
 
 
 def glorot_init(shape):

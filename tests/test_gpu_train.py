@@ -121,6 +121,24 @@ def test_side_stream_weight_gradients_are_bit_identical(pkg, oracle, cuda, confi
         assert torch.equal(results[0][k], results[1][k]), k
 
 
+def test_threaded_batches_give_identical_epochs(pkg, oracle, cuda):
+    """run_epoch packs the training batches on a producer thread and a side stream (utils.ThreadedIterator, the reference's
+    chem_tensorflow.py:219): losses and weights after three epochs are bit-identical to packing them inline."""
+    ms = pkg.synthetic_qm9(500, mean_nodes=9, seed=5)
+    out = []
+    for threaded in (True, False):
+        np.random.seed(3); torch.manual_seed(3); torch.cuda.manual_seed(3)
+        model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms,
+                                         "--config": {"batch_size": 900, "layer_timesteps": [2, 1], "residual_connections": {"1": [0]},
+                                                      "threaded_batches": threaded, "random_seed": 7}})
+        losses = [model.run_epoch("train", model.train_data, True)[0] for _ in range(3)]
+        torch.cuda.synchronize()
+        out.append((losses, {k: v.detach().clone() for k, v in model.trainable_variables.items()}))
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+
+
 def test_training_reduces_loss(pkg, oracle, cuda):
     ms = pkg.synthetic_qm9(400, mean_nodes=9, seed=3)
     model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms,

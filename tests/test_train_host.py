@@ -233,3 +233,37 @@ def test_epoch_statistics_are_identical_on_every_rank_gloo(pkg):
     mp.spawn(_epoch_stats_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret[0][0] < 1e-12 and ret[0][1] < 1e-12 and ret[0][2] and ret[1][2]
     assert ret[0][3] == ret[1][3]                                  # bit-identical on the two ranks
+
+
+def test_threaded_iterator_mirrors_reference_prefetcher(pkg):
+    """utils.ThreadedIterator (reference utils.py:16-36): same elements in the same order, producer at most max_queue_size
+    ahead, a producer exception surfaces in the consumer, and a consumer that stops early does not leave the producer stuck."""
+    import threading, time
+    TI = pkg.utils.ThreadedIterator
+    assert list(TI(iter(range(100)), max_queue_size=3)) == list(range(100))
+    assert list(TI(iter(()), max_queue_size=1)) == []
+    produced = []
+
+    def gen(n):
+        for i in range(n):
+            produced.append(i)
+            yield i
+
+    it = iter(TI(gen(50), max_queue_size=2))
+    assert next(it) == 0
+    time.sleep(0.2)
+    assert len(produced) <= 1 + 2 + 1                    # consumed + queue + the one the producer holds while the queue is full
+    before = threading.active_count()
+    it.close()                                           # early exit: the producer must be released
+    time.sleep(0.3)
+    assert threading.active_count() <= before - 1 and len(produced) < 50
+
+    def bad():
+        yield 1
+        raise KeyError("boom")
+
+    got = []
+    with pytest.raises(KeyError):
+        for x in TI(bad(), max_queue_size=2):
+            got.append(x)
+    assert got == [1]

@@ -6,6 +6,7 @@ this entry point exists so that rocprofv3 can be pointed at ONE of them -- tools
     python tools/bench_extra.py large   # configs[4]: one graph, 100k nodes / 1M edges / 4 types, h = 256, 8 steps
     python tools/bench_extra.py train   # configs[1] shapes, full training step (fwd + bwd + clip + Adam)
     python tools/bench_extra.py pack    # the step before the path: batch packing + message-index build
+    python tools/bench_extra.py epoch   # training epochs as run_epoch runs them: every batch packed fresh after the shuffle
 
 Each prints one JSON line with wall-clock throughput and per-kernel HIP-event timings.
 """
@@ -76,5 +77,32 @@ def pack():
                       "speedup": th / td}))
 
 
+def epoch():
+    """Training epochs exactly as ChemModel.run_epoch runs them (chem_tensorflow.py:214-253): shuffle, pack every ~100k-node
+    batch fresh on the GPU, train on it -- with the batches packed inline, and by the producer thread on its side stream
+    (utils.ThreadedIterator, the reference's chem_tensorflow.py:219)."""
+    import time
+    NB = 32
+    ms = pkg.synthetic_qm9(5700 * NB, mean_nodes=18, seed=0)
+    res = {}
+    for threaded in (False, True):
+        np.random.seed(0); torch.manual_seed(0)
+        model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": str(DEV), "train_data": ms, "valid_data": ms,
+                                         "--config": {"threaded_batches": threaded}})
+        model.run_epoch("warm", model.train_data, True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        steps = 0
+        for _ in range(2):
+            steps += model.run_epoch("train", model.train_data, True)[4]
+        torch.cuda.synchronize()
+        res["threaded" if threaded else "inline"] = (time.perf_counter() - t0) / steps * 1e3
+        del model
+        torch.cuda.empty_cache()
+    V = int(np.diff(ms.node_ptr).sum() / NB)
+    print(json.dumps({"workload": "training epochs with fresh batches (shuffle, pack on the GPU, train), ~%d nodes per batch, h=100" % V,
+                      "ms_per_step_inline_packing": res["inline"], "ms_per_step_threaded_packing": res["threaded"],
+                      "node_state_updates_per_sec_threaded": V * 8 / (res["threaded"] * 1e-3)}))
+
+
 if __name__ == "__main__":
-    {"dense": dense, "large": large, "train": train, "pack": pack}[sys.argv[1]]()
+    {"dense": dense, "large": large, "train": train, "pack": pack, "epoch": epoch}[sys.argv[1]]()
