@@ -6,8 +6,9 @@ batch the packer -- the step immediately before the path -- would cap end-to-end
 dataset is uploaded ONCE in structure-of-arrays form and a batch is assembled on the GPU from the graph ids alone:
 index arithmetic, one key sort, two bincounts.  Same outputs as data.pack_batch, bit for bit (tests/test_gpu_parity.py).
 
-Only the batch boundaries (a greedy scan over at most G node counts, data.batch_boundaries) and the per-type message
-counts (T integers, needed as host sizes by the index builder) touch the host.
+Only the batch boundaries (a greedy scan over at most G node counts, data.batch_boundaries) and the per-type message and
+source-pair counts (sums over per-molecule tables, DeviceMoleculeSet.type_counts) are computed on the host; nothing is read
+back from the device, so packing a batch never waits for the GPU.
 """
 from __future__ import annotations
 
@@ -37,6 +38,7 @@ class DeviceMoleculeSet:
         self.bonds_per_graph = np.diff(ms.bond_ptr)
         self.max_bond_type = int(ms.bonds[:, 1].max()) if len(ms.bonds) else 0
         self.min_bond_type = int(ms.bonds[:, 1].min()) if len(ms.bonds) else 1
+        self._type_counts = {}                                 # (T, tie) -> per-graph message / source-pair counts per type
         # Bond endpoints come from the data file: check them ONCE against their graph's node count, so that the per-batch
         # index build can skip validation (pack_batch_device offsets them into the batch; a bad id would otherwise
         # become an out-of-bounds gather on the GPU).
@@ -48,6 +50,40 @@ class DeviceMoleculeSet:
                 g = int(np.searchsorted(ms.bond_ptr, bad, side='right') - 1)
                 raise IndexError("bond %d of graph %d mentions node %s outside [0, %d)" % (
                     bad - int(ms.bond_ptr[g]), g, ends[bad].tolist(), int(self.nodes_per_graph[g])))
+
+
+    def type_counts(self, num_edge_types: int, tie_fwd_bkwd: bool):
+        """Host tables [G, T]: directed messages of type t in graph g (chem_tensorflow_sparse.py:259-263: every bond gives the
+        forward edge of type t and the backward edge of type t, or t + T/2 when the directions are untied), and distinct
+        (source node, type) pairs among them.  Both are properties of a molecule, so the per-type sizes of a BATCH -- the
+        adjacency-list lengths and the row ranges of the compacted message transform, which the host needs as launch
+        arguments -- are sums over its graph ids: no device->host read per batch."""
+        key = (int(num_edge_types), bool(tie_fwd_bkwd))
+        hit = self._type_counts.get(key)
+        if hit is None:
+            ms = self.host
+            T = key[0]
+            F = T if key[1] else T // 2
+            G = ms.num_graphs
+            B = len(ms.bonds)
+            g_of_bond = np.repeat(np.arange(G, dtype=np.int64), self.bonds_per_graph)
+            typ = ms.bonds[:, 1].astype(np.int64) - 1
+            valid = (typ >= 0) & (typ < F)
+            msgs = np.zeros((G, T), dtype=np.int64)
+            pairs = np.zeros((G, T), dtype=np.int64)
+            if B:
+                node0 = np.asarray(ms.node_ptr, dtype=np.int64)[g_of_bond]
+                src_f = node0 + ms.bonds[:, 0]; src_b = node0 + ms.bonds[:, 2]           # global node ids
+                t_f = typ; t_b = typ if key[1] else typ + F
+                for srcs, ts in ((src_f, t_f), (src_b, t_b)):
+                    np.add.at(msgs, (g_of_bond[valid], ts[valid]), 1)
+                NN = int(ms.node_ptr[-1]) + 1
+                keys = np.unique(np.concatenate([(src_f * T + t_f)[valid], (src_b * T + t_b)[valid]]))      # (node, type) pairs
+                pn, pt = keys // T, keys % T
+                pg = np.searchsorted(np.asarray(ms.node_ptr, dtype=np.int64), pn, side='right') - 1
+                np.add.at(pairs, (pg, pt), 1)
+            hit = self._type_counts[key] = (msgs, pairs)
+        return hit
 
 
 def _ranges(starts: torch.Tensor, lengths: torch.Tensor, total: int) -> torch.Tensor:
@@ -100,10 +136,16 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
     ts = key // Vk
     s_sorted = ts % Vk
     t_sorted = ts // Vk
-    cnt = torch.bincount(t_sorted, minlength=T)
-    nin = torch.bincount(d_sorted * T + t_sorted, minlength=V * T).view(V, T).to(torch.float32)   # :310-313
+    # :310-313 incoming-edge counts per (node, type).  (scatter_add, not bincount: bincount reads max(input) back to the host)
+    nin = torch.zeros(V * T, dtype=torch.float32, device=dev).scatter_add_(
+        0, d_sorted * T + t_sorted, torch.ones(1, dtype=torch.float32, device=dev).expand(d_sorted.shape[0])).view(V, T)
     adj = torch.stack([s_sorted, d_sorted], dim=1).to(torch.int32)
-    counts: List[int] = [int(c) for c in cnt.tolist()]                              # the one host sync: T integers
+    msgs_gt, pairs_gt = dms.type_counts(T, tie_fwd_bkwd)
+    counts: List[int] = [int(c) for c in msgs_gt[gids_h].sum(axis=0)] if G else [0] * T      # per-type sizes from host tables
+    pair_counts = [int(c) for c in pairs_gt[gids_h].sum(axis=0)] if G else [0] * T
+    type_row_off = [0]
+    for c in pair_counts:
+        type_row_off.append(type_row_off[-1] + c)
     adjacency, o = [], 0
     for t in range(T):
         adjacency.append(adj[o:o + counts[t]])                                      # :343-348 (empty types: [0,2])
@@ -122,7 +164,8 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
         'target_mask': tm,
         'num_graphs': G,
         # (ids are offsets we just built from bond endpoints DeviceMoleculeSet checked: no per-batch validation)
-        'message_index': ops.prepare_message_index(ops.build_message_index(adjacency, V, validate=False), hidden_size, compact, training),
+        'message_index': ops.prepare_message_index(ops.build_message_index(adjacency, V, validate=False), hidden_size, compact, training,
+                                                   type_row_off=type_row_off),
         'graph_nodes_sorted': True,
     }
 

@@ -588,9 +588,11 @@ def gru_gather_fused(D: int) -> bool:
     return _lib.load().ggnn_gru_is_fused(D) == 1
 
 
-def build_compact_sources(index: MessageIndex) -> CompactSources:
+def build_compact_sources(index: MessageIndex, type_row_off: Optional[Sequence[int]] = None) -> CompactSources:
     """Enumerate the (node, type) pairs that emit at least one message and re-target the segment-sum's
-    gather rows at them.  index: the by-target MessageIndex of the batch (build_message_index)."""
+    gather rows at them.  index: the by-target MessageIndex of the batch (build_message_index).
+    type_row_off (host ints [T+1]): the per-type row ranges, when the caller knows them (data_device sums per-molecule
+    tables); otherwise they are read back from the device (one device->host sync)."""
     lib = _lib.load()
     T, V, M = index.num_edge_types, index.num_nodes, index.num_messages
     dev = index.adj.device
@@ -606,11 +608,19 @@ def build_compact_sources(index: MessageIndex) -> CompactSources:
                                          ws_bytes, _stream()))
     gather_c = torch.empty(M, dtype=torch.int32, device=dev)
     check(lib.ggnn_remap_gather_rows(_ptr(index.gather_row), _ptr(pair_id), _ptr(gather_c), M, _stream()))
-    type_row_off = [int(x) for x in off.cpu().tolist()]   # one device->host sync, once per batch
+    if type_row_off is None:
+        type_row_off = [int(x) for x in off.cpu().tolist()]   # one device->host sync, once per batch
+    else:
+        type_row_off = [int(x) for x in type_row_off]
+        if len(type_row_off) != T + 1:
+            raise ValueError("type_row_off needs T + 1 entries")
+        if os.environ.get("GGNN_CHECK_HOST_COUNTS", "0") != "0" and type_row_off != [int(x) for x in off.cpu().tolist()]:
+            raise AssertionError("host-side pair counts %s differ from the device's %s" % (type_row_off, off.cpu().tolist()))
     return CompactSources(pair_node[:max(type_row_off[-1], 1)], type_row_off, gather_c)
 
 
-def prepare_message_index(index: MessageIndex, hidden_size: int, compact: bool = True, training: bool = False) -> MessageIndex:
+def prepare_message_index(index: MessageIndex, hidden_size: int, compact: bool = True, training: bool = False,
+                          type_row_off: Optional[Sequence[int]] = None) -> MessageIndex:
     """Everything the propagation derives from a batch's message index, built EAGERLY when the batch is packed (it
     used to be built lazily on the first forward of each batch, which put a cold pass -- three small launches and a
     device->host sync -- inside whatever region timed that forward): the active (source node, edge type) pairs of the
@@ -618,7 +628,7 @@ def prepare_message_index(index: MessageIndex, hidden_size: int, compact: bool =
     pass (CompactBackward and the slot heads of its segment sums) -- ~25 small launches that would otherwise run inside the
     first backward pass of every fresh batch, on the training stream, instead of on the packer's."""
     if compact and index.num_messages and compact_supported(hidden_size) and getattr(index, "_compact", None) is None:
-        index._compact = build_compact_sources(index)
+        index._compact = build_compact_sources(index, type_row_off)
         slot_heads(index._compact, index.row_ptr, index._compact.gather_row, index.num_nodes)
     comp = getattr(index, "_compact", None)
     if training and comp is not None and comp.num_rows:
@@ -670,7 +680,8 @@ class CompactBackward:
         self.source_node_index = SegmentIndex(src.row_ptr[::T].contiguous(), src.gather_row, V, src.msg_perm)
         order = torch.sort(pn, stable=True)[1]                          # rows by node, type ascending inside a node
         rp_n = torch.zeros(V + 1, dtype=torch.int32, device=dev)
-        rp_n[1:] = torch.cumsum(torch.bincount(pn, minlength=V), 0).to(torch.int32)
+        per_node = torch.zeros(V, dtype=torch.int64, device=dev).scatter_add_(0, pn, torch.ones(1, dtype=torch.int64, device=dev).expand(R))
+        rp_n[1:] = torch.cumsum(per_node, 0).to(torch.int32)                # (scatter_add, not bincount: no host read-back)
         self.node_index = SegmentIndex(rp_n, order.to(torch.int32).contiguous(), V)
         self.identity = CompactSources(torch.arange(max(R, 1), dtype=torch.int32, device=dev), comp.type_row_off, comp.gather_row)
 
