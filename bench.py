@@ -181,7 +181,10 @@ def pmc_key(pmc, name, D):
         return next((k for k in pmc if k.startswith(name)), None) or \
             (next((k for k in pmc if k.startswith("msg_transform_panel")), None) if name == "msg_transform_compact" else None)
     if name == "msg_transform" or name.startswith("gru_gates") or name.startswith("gru_candidate"):
-        return None                                      # (all three are instances of ggnn_gemm_kernel: not separable by name)
+        # all three are instances of ggnn_gemm_kernel: separable by name only when the workload launched a single one
+        # (the dense configs[2]: the message transform is its only GEMM-kernel launch)
+        gemms = [k for k in pmc if k.startswith("gemm<")]
+        return gemms[0] if name == "msg_transform" and len(gemms) == 1 else None
     if name == "gather_segment_sum":
         return next((k for k in pmc if k.startswith("gather_segment_sum") and "attn" not in k), None)
     if name.startswith("gru_fused"):                     # template args <D, NX, NW, SAVE, GATHER>
