@@ -577,6 +577,11 @@ static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t
     // a pass with one or two busy waves takes less than half the time of a full one
     int nb = num_cus();
     if (nb > wt_total) nb = wt_total;
+    // Few tiles (the dense model's b = 256 x v = 29: 464): one tile per workgroup, worked cooperatively by its 8 waves (25 MFMAs
+    // per stage and wave, weights straight from L2), the workgroups beyond the CU count following as the first ones retire --
+    // instead of two-tile tickets on which two waves of a workgroup run the full 175-MFMA stages while six idle.
+    static const int coop_small = [] { const char* e = getenv("GGNN_GRU_COOP_SMALL"); return e ? atoi(e) : 1; }();
+    if (coop_small && wt_total > nb && wt_total <= 2 * nb && StageCfg<D>::NT <= NW) nb = wt_total;
     static std::atomic<unsigned long long> lds_ok{0};        // (one per template instantiation)
     if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER>, lds, lds_ok));
     hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
