@@ -12,13 +12,19 @@ back from the device, so packing a batch never waits for the GPU.
 """
 from __future__ import annotations
 
+import ctypes
+import os
 from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .data import MoleculeSet, batch_boundaries
+
+# Batches gathered from dataset-level tables (ggnn_assemble_batch) instead of being sorted and scanned one by one;
+# GGNN_PACK_STATIC=0 keeps the general per-batch builders (same outputs, bit for bit: tests/test_gpu_parity.py).
+USE_STATIC_TABLES = os.environ.get("GGNN_PACK_STATIC", "1") != "0"
 
 
 class DeviceMoleculeSet:
@@ -39,6 +45,7 @@ class DeviceMoleculeSet:
         self.max_bond_type = int(ms.bonds[:, 1].max()) if len(ms.bonds) else 0
         self.min_bond_type = int(ms.bonds[:, 1].min()) if len(ms.bonds) else 1
         self._type_counts = {}                                 # (T, tie) -> per-graph message / source-pair counts per type
+        self._static = {}                                      # (T, tie, compact) -> dataset-level tables of ggnn_assemble_batch
         # Bond endpoints come from the data file: check them ONCE against their graph's node count, so that the per-batch
         # index build can skip validation (pack_batch_device offsets them into the batch; a bad id would otherwise
         # become an out-of-bounds gather on the GPU).
@@ -86,6 +93,88 @@ class DeviceMoleculeSet:
         return hit
 
 
+    def static_tables(self, num_edge_types: int, tie_fwd_bkwd: bool, compact: bool):
+        """Dataset-level tables of ggnn_assemble_batch: the general builders run ONCE over all graphs taken as one batch (in
+        dataset order); every later batch is gathered from their outputs.  None when the whole dataset does not fit the
+        builders' 32-bit indices (then every batch is built on its own, as before)."""
+        key = (int(num_edge_types), bool(tie_fwd_bkwd), bool(compact))
+        if key in self._static:
+            return self._static[key]
+        T = key[0]
+        ms = self.host
+        Nd = int(ms.node_ptr[-1])
+        msgs_gt, pairs_gt = self.type_counts(T, key[1])
+        Md = int(msgs_gt.sum())
+        tab = None
+        if ms.num_graphs and Md and Nd * T < 2 ** 31 - 1 and Md < 2 ** 31 - 1 and T <= 16:
+            A = self.node_feat.shape[1]
+            full = pack_batch_device(self, np.arange(ms.num_graphs, dtype=np.int64), T, max(A, 4 * ((A + 3) // 4)), key[1], (0,),
+                                     compact=False, training=False, static=False)
+            idx = full['message_index']
+            dev = self.device
+            i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(dev)
+            excl = lambda c: np.cumsum(c, axis=0) - c
+            tab = {"A": A, "T": T, "node_ptr": i32(ms.node_ptr), "feat": self.node_feat.contiguous(),
+                   "nin": full['num_incoming_edges_per_type'].contiguous(), "row_ptr": idx.row_ptr, "adj": idx.adj,
+                   "slot_gather": idx.gather_row, "slot_msg": idx.msg_perm, "slot_crow": None, "pair_node": None,
+                   "e_off": i32(excl(msgs_gt)), "p_off": None, "type_off": [int(x) for x in idx.type_off], "type_row_off": [0] * (T + 1),
+                   "msgs_gt": msgs_gt, "pairs_gt": pairs_gt}
+            if compact:
+                comp = ops.build_compact_sources(idx)
+                tab.update(slot_crow=comp.gather_row, pair_node=comp.pair_node, p_off=i32(excl(pairs_gt)),
+                           type_row_off=[int(x) for x in comp.type_row_off])
+                want = [0] + [int(x) for x in np.cumsum(pairs_gt.sum(axis=0))]
+                if tab["type_row_off"] != want:
+                    raise AssertionError("per-molecule pair counts %s disagree with the device's compaction %s" % (want, tab["type_row_off"]))
+            if tab["type_off"] != [0] + [int(x) for x in np.cumsum(msgs_gt.sum(axis=0))]:
+                raise AssertionError("per-molecule message counts disagree with the packed dataset")
+            ptrs = [tab[k] for k in ("node_ptr", "feat", "nin", "row_ptr", "adj", "slot_gather", "slot_msg", "slot_crow", "pair_node", "e_off", "p_off")]
+            tab["ptrs"] = (ctypes.c_void_p * 11)(*[None if t is None else t.data_ptr() for t in ptrs])
+            tab["c_type_off"] = (ctypes.c_int64 * (T + 1))(*tab["type_off"])
+            tab["c_type_row_off"] = (ctypes.c_int64 * (T + 1))(*tab["type_row_off"])
+        self._static[key] = tab
+        return tab
+
+
+def _assemble_from_tables(dms: DeviceMoleculeSet, tab: dict, gids_h: np.ndarray, hidden_size: int):
+    """h0, graph_nodes_list, graph_ptr, nin and the batch's MessageIndex (+ compacted sources, slot heads) gathered from the
+    dataset-level tables: the (graph, type) prefix sums come from per-molecule count tables on the host, go up in one small copy,
+    and ggnn_assemble_batch does the rest in five launches."""
+    lib = _lib.load()
+    dev = dms.device
+    T, A = tab["T"], tab["A"]
+    compact = tab["slot_crow"] is not None
+    G = len(gids_h)
+    n = dms.nodes_per_graph[gids_h].astype(np.int64)
+    mg = tab["msgs_gt"][gids_h].reshape(G, T)
+    pg = tab["pairs_gt"][gids_h].reshape(G, T) if compact else np.zeros((G, T), np.int64)
+    incl = lambda c: np.concatenate([np.zeros((1,) + c.shape[1:], np.int64), np.cumsum(c, axis=0)])
+    node_off, slot_off, msg_off, pair_off = incl(n), incl(mg.sum(axis=1)), incl(mg), incl(pg)
+    V, M, R = int(node_off[-1]), int(slot_off[-1]), int(pair_off[-1].sum())
+    type_off = [0] + [int(x) for x in np.cumsum(msg_off[-1])]
+    type_row_off = [0] + [int(x) for x in np.cumsum(pair_off[-1])]
+    if V * T >= 2 ** 31 - 1 or V * hidden_size >= 2 ** 31 - 1:
+        raise ValueError("batch too large for 32-bit indices")
+    batch_tab = np.concatenate([gids_h, node_off, slot_off, msg_off.T.ravel(), pair_off.T.ravel()]).astype(np.int32)
+    bt = torch.from_numpy(batch_tab).to(dev)
+    i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
+    h0 = torch.empty((V, hidden_size), dtype=torch.float32, device=dev)
+    gnl, graph_ptr, nin = i32(V), i32(G + 1), torch.empty((V, T), dtype=torch.float32, device=dev)
+    adj, row_ptr, gather_row, msg_perm = i32(M, 2), i32(V + 1), i32(M), i32(M)
+    pair_node, gather_c = (i32(max(R, 1)), i32(M)) if compact else (None, None)
+    outs = [h0, gnl, graph_ptr, nin, adj, row_ptr, gather_row, msg_perm, pair_node, gather_c]
+    c_out = (ctypes.c_void_p * 10)(*[None if t is None or t.numel() == 0 else t.data_ptr() for t in outs])
+    c_to = (ctypes.c_int64 * (T + 1))(*type_off)
+    c_tro = (ctypes.c_int64 * (T + 1))(*type_row_off)
+    _lib.check(lib.ggnn_assemble_batch(tab["ptrs"], A, T, tab["c_type_off"], tab["c_type_row_off"], bt.data_ptr(), G, V, M, R,
+                                       hidden_size, c_to, c_tro, c_out, torch.cuda.current_stream().cuda_stream))
+    index = ops.MessageIndex(adj, type_off, row_ptr, gather_row, msg_perm, V, T)
+    if compact and M:
+        index._compact = ops.CompactSources(pair_node[:max(R, 1)], type_row_off, gather_c)
+        ops.slot_heads(index._compact, row_ptr, gather_c, V)
+    return h0, gnl, graph_ptr, nin, index, type_off
+
+
 def _ranges(starts: torch.Tensor, lengths: torch.Tensor, total: int) -> torch.Tensor:
     """cat_i arange(starts[i], starts[i] + lengths[i]) on the device; `total` = sum(lengths), known on the host."""
     if total == 0:
@@ -97,7 +186,7 @@ def _ranges(starts: torch.Tensor, lengths: torch.Tensor, total: int) -> torch.Te
 
 def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_types: int, hidden_size: int,
                       tie_fwd_bkwd: bool = True, task_ids: Sequence[int] = (0,), compact: bool = True,
-                      training: bool = False) -> Dict[str, Any]:
+                      training: bool = False, static: Optional[bool] = None) -> Dict[str, Any]:
     """One batch from graphs `graph_ids` (in this order), assembled on the GPU: the feed dict of
     SparseGGNNChemModel.to_device_batch (chem_tensorflow_sparse.py:254-276, 298-348), message index included."""
     dev = dms.device
@@ -113,6 +202,21 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
     if B and (dms.min_bond_type < 1 or dms.max_bond_type > F):
         raise IndexError("edge type outside [0, num_edge_types)")
     gids = torch.from_numpy(gids_h).to(dev)
+    tids = torch.as_tensor(list(task_ids), dtype=torch.int64, device=dev)
+    tv = dms.targets[gids][:, tids].t().contiguous()                                # :335
+    tm = torch.ones_like(tv) if dms.label_mask is None else dms.label_mask[gids][:, tids].t().contiguous()
+    tv = tv * tm                                                                    # masked labels feed 0. (:319-321)
+    want_compact = bool(compact and ops.compact_supported(hidden_size))
+    tab = dms.static_tables(T, tie_fwd_bkwd, want_compact) if (USE_STATIC_TABLES if static is None else static) else None
+    if tab is not None:
+        # gathered from the dataset-level tables: no sort, no scan, five launches (ggnn_assemble_batch)
+        h0, gnl, graph_ptr, nin, index, type_off = _assemble_from_tables(dms, tab, gids_h, hidden_size)
+        adjacency = [index.adj[type_off[t]:type_off[t + 1]] for t in range(T)]
+        return {
+            'initial_node_representation': h0, 'adjacency_lists': adjacency, 'num_incoming_edges_per_type': nin,
+            'graph_nodes_list': gnl, 'graph_ptr': graph_ptr, 'target_values': tv, 'target_mask': tm, 'num_graphs': G,
+            'message_index': ops.prepare_message_index(index, hidden_size, compact, training), 'graph_nodes_sorted': True,
+        }
     n = dms.node_ptr[gids + 1] - dms.node_ptr[gids]
     offs = torch.cumsum(n, 0) - n                                                   # node offset of each graph (:297)
     nsel = _ranges(dms.node_ptr[gids], n, V)
@@ -150,10 +254,6 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
     for t in range(T):
         adjacency.append(adj[o:o + counts[t]])                                      # :343-348 (empty types: [0,2])
         o += counts[t]
-    tids = torch.as_tensor(list(task_ids), dtype=torch.int64, device=dev)
-    tv = dms.targets[gids][:, tids].t().contiguous()                                # :335
-    tm = torch.ones_like(tv) if dms.label_mask is None else dms.label_mask[gids][:, tids].t().contiguous()
-    tv = tv * tm                                                                    # masked labels feed 0. (:319-321)
     return {
         'initial_node_representation': h0,
         'adjacency_lists': adjacency,

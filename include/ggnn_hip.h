@@ -410,6 +410,24 @@ int ggnn_clip_adam_f32(float* const* param_ptrs, const int32_t* var_numel, const
                        const int32_t* block_var, const int32_t* var_first, const int32_t* var_active, int nblocks, float clip_norm,
                        float lr_t, float beta1, float beta2, float epsilon, ggnn_stream_t stream);
 
+/* ---- batch assembly from dataset-level tables (the step BEFORE the path: chem_tensorflow_sparse.py:278-350 packs a minibatch as
+ * one disconnected super-graph, :120-129 derives the message index) --------------------------------------------------------------
+ * Every per-batch index structure is a concatenation of per-molecule pieces plus offsets, so the general builders (sorts, scans)
+ * run ONCE over the whole dataset taken as one batch and a batch is gathered from their outputs.
+ *   ds_tables [11] device pointers for the whole dataset (Gd graphs, Nd nodes, Md messages, Rd compact rows):
+ *     0 node_ptr i32[Gd+1]   1 annotations f32[Nd,A]   2 nin f32[Nd,T]   3 row_ptr i32[Nd+1]   4 adj i32[Md,2] (type-major)
+ *     5 slot -> src*T+type i32[Md]   6 slot -> message id i32[Md]   7 slot -> compact row i32[Md] (NULL: no compaction)
+ *     8 compact row -> node i32[Rd]   9 first message of graph g in the type-t list i32[Gd,T]   10 first compact row, i32[Gd,T]
+ *   ds_type_off / ds_type_row_off: host [T+1], type ranges of tables 4 and 8.
+ *   batch_tab (device i32): gid[G] | node_off[G+1] | slot_off[G+1] | msg_off[T][G+1] | pair_off[T][G+1]   (exclusive prefix sums over
+ *     the batch's graphs, in batch order);  type_off / type_row_off: host [T+1] of the batch.
+ *   out [10]: 0 h0 f32[V,D] (annotation, zero-padded: :300-302)  1 graph_nodes_list i32[V]  2 graph_ptr i32[G+1]  3 nin f32[V,T]
+ *     4 adj i32[M,2]  5 row_ptr i32[V+1]  6 gather_row i32[M]  7 msg_perm i32[M]  8 pair_node i32[R]  9 compact gather rows i32[M]
+ *   -- exactly what ggnn_build_target_csr + ggnn_build_compact_sources + ggnn_remap_gather_rows produce for the batch. */
+int ggnn_assemble_batch(const void* const* ds_tables, int A, int T, const int64_t* ds_type_off, const int64_t* ds_type_row_off,
+                        const int32_t* batch_tab, int G, int V, int M, int R, int D, const int64_t* type_off,
+                        const int64_t* type_row_off, void* const* out, ggnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

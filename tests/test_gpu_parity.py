@@ -674,3 +674,34 @@ def test_slot_heads_segment_sum_is_bit_identical(pkg, cuda, V, M, D, T, monkeypa
     monkeypatch.setattr(pkg.ops, "USE_SLOT_HEADS", False)
     b = pkg.ops.gather_segment_sum(H, index, nd, bias, True)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("tie", [True, False])
+def test_batches_gathered_from_dataset_tables_equal_per_batch_builds(pkg, cuda, tie):
+    """data_device: a batch gathered from the dataset-level tables (ggnn_assemble_batch: no sort, no scan) is bit-identical, field
+    by field, to the batch the general per-batch builders produce -- shuffled graph orders, an empty batch, a one-graph batch."""
+    ms = pkg.synthetic_qm9(400, mean_nodes=9, seed=11)
+    dms = pkg.data_device.DeviceMoleculeSet(ms, cuda, None)
+    T = 4 if tie else 8
+    rng = np.random.default_rng(3)
+    cases = [rng.permutation(400)[:n] for n in (400, 137, 1)] + [np.zeros(0, np.int64), np.array([5, 5, 7])]
+    for training in (False, True):
+        for gids in cases:
+            a = pkg.data_device.pack_batch_device(dms, gids, T, 100, tie, (0,), True, training, static=True)
+            b = pkg.data_device.pack_batch_device(dms, gids, T, 100, tie, (0,), True, training, static=False)
+            for k in ('initial_node_representation', 'num_incoming_edges_per_type', 'graph_nodes_list', 'graph_ptr', 'target_values', 'target_mask'):
+                assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), k
+            assert a['num_graphs'] == b['num_graphs'] and len(a['adjacency_lists']) == T
+            for x, y in zip(a['adjacency_lists'], b['adjacency_lists']):
+                assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y)
+            ia, ib = a['message_index'], b['message_index']
+            assert ia.type_off == ib.type_off and ia.num_nodes == ib.num_nodes and ia.num_edge_types == ib.num_edge_types
+            for f in ('adj', 'row_ptr', 'gather_row', 'msg_perm'):
+                assert torch.equal(getattr(ia, f), getattr(ib, f)), f
+            ca, cb = getattr(ia, '_compact', None), getattr(ib, '_compact', None)
+            assert (ca is None) == (cb is None)
+            if ca is not None:
+                R = cb.num_rows
+                assert ca.type_row_off == cb.type_row_off and torch.equal(ca.pair_node[:R], cb.pair_node[:R]) and torch.equal(ca.gather_row, cb.gather_row)
+                assert torch.equal(ca._slot_heads[1], cb._slot_heads[1])
+    assert dms.static_tables(T, tie, True) is not None
