@@ -93,6 +93,22 @@ class DeviceMoleculeSet:
         return hit
 
 
+    def static_backward_tables(self, num_edge_types: int, tie_fwd_bkwd: bool):
+        """The same for the backward pass's transpose structures (by-source CSR, ops.CompactBackward), built lazily on the first
+        training batch."""
+        tab = self.static_tables(num_edge_types, tie_fwd_bkwd, True)
+        if tab is None or tab["slot_crow"] is None:
+            return None
+        if "bwd_ptrs" not in tab:
+            idx, comp = tab["_index"], tab["_comp"]
+            bwd = ops.compact_backward(idx, comp)
+            src = idx._source_index
+            keep = [src.row_ptr, src.gather_row, src.msg_perm, bwd.rows_index.row_ptr, bwd.rows_index.gather_row, bwd.rows_index.msg,
+                    bwd.node_index.row_ptr, bwd.node_index.gather_row]
+            tab["bwd_keep"] = keep
+            tab["bwd_ptrs"] = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in keep])
+        return tab
+
     def static_tables(self, num_edge_types: int, tie_fwd_bkwd: bool, compact: bool):
         """Dataset-level tables of ggnn_assemble_batch: the general builders run ONCE over all graphs taken as one batch (in
         dataset order); every later batch is gathered from their outputs.  None when the whole dataset does not fit the
@@ -118,11 +134,11 @@ class DeviceMoleculeSet:
                    "nin": full['num_incoming_edges_per_type'].contiguous(), "row_ptr": idx.row_ptr, "adj": idx.adj,
                    "slot_gather": idx.gather_row, "slot_msg": idx.msg_perm, "slot_crow": None, "pair_node": None,
                    "e_off": i32(excl(msgs_gt)), "p_off": None, "type_off": [int(x) for x in idx.type_off], "type_row_off": [0] * (T + 1),
-                   "msgs_gt": msgs_gt, "pairs_gt": pairs_gt}
+                   "msgs_gt": msgs_gt, "pairs_gt": pairs_gt, "tie": key[1]}
             if compact:
                 comp = ops.build_compact_sources(idx)
                 tab.update(slot_crow=comp.gather_row, pair_node=comp.pair_node, p_off=i32(excl(pairs_gt)),
-                           type_row_off=[int(x) for x in comp.type_row_off])
+                           type_row_off=[int(x) for x in comp.type_row_off], _index=idx, _comp=comp)
                 want = [0] + [int(x) for x in np.cumsum(pairs_gt.sum(axis=0))]
                 if tab["type_row_off"] != want:
                     raise AssertionError("per-molecule pair counts %s disagree with the device's compaction %s" % (want, tab["type_row_off"]))
@@ -136,7 +152,7 @@ class DeviceMoleculeSet:
         return tab
 
 
-def _assemble_from_tables(dms: DeviceMoleculeSet, tab: dict, gids_h: np.ndarray, hidden_size: int):
+def _assemble_from_tables(dms: DeviceMoleculeSet, tab: dict, gids_h: np.ndarray, hidden_size: int, training: bool = False):
     """h0, graph_nodes_list, graph_ptr, nin and the batch's MessageIndex (+ compacted sources, slot heads) gathered from the
     dataset-level tables: the (graph, type) prefix sums come from per-molecule count tables on the host, go up in one small copy,
     and ggnn_assemble_batch does the rest in five launches."""
@@ -155,7 +171,7 @@ def _assemble_from_tables(dms: DeviceMoleculeSet, tab: dict, gids_h: np.ndarray,
     type_row_off = [0] + [int(x) for x in np.cumsum(pair_off[-1])]
     if V * T >= 2 ** 31 - 1 or V * hidden_size >= 2 ** 31 - 1:
         raise ValueError("batch too large for 32-bit indices")
-    batch_tab = np.concatenate([gids_h, node_off, slot_off, msg_off.T.ravel(), pair_off.T.ravel()]).astype(np.int32)
+    batch_tab = np.concatenate([gids_h, node_off, slot_off, msg_off.T.ravel(), pair_off.T.ravel(), pair_off.sum(axis=1)]).astype(np.int32)
     bt = torch.from_numpy(batch_tab).to(dev)
     i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
     h0 = torch.empty((V, hidden_size), dtype=torch.float32, device=dev)
@@ -170,8 +186,24 @@ def _assemble_from_tables(dms: DeviceMoleculeSet, tab: dict, gids_h: np.ndarray,
                                        hidden_size, c_to, c_tro, c_out, torch.cuda.current_stream().cuda_stream))
     index = ops.MessageIndex(adj, type_off, row_ptr, gather_row, msg_perm, V, T)
     if compact and M:
-        index._compact = ops.CompactSources(pair_node[:max(R, 1)], type_row_off, gather_c)
-        ops.slot_heads(index._compact, row_ptr, gather_c, V)
+        comp = index._compact = ops.CompactSources(pair_node[:max(R, 1)], type_row_off, gather_c)
+        ops.slot_heads(comp, row_ptr, gather_c, V)
+        btab = dms.static_backward_tables(T, tab["tie"]) if training and R else None
+        if btab is not None:
+            # the backward's transpose structures, gathered as well (ggnn_assemble_batch_backward: five more launches)
+            src_rp, src_g, src_m = i32(V * T + 1), i32(M), i32(M)
+            rows_rp, rows_g, rows_m, node_rp, node_order = i32(R + 1), i32(M), i32(M), i32(V + 1), i32(R)
+            c_bout = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in (src_rp, src_g, src_m, rows_rp, rows_g, rows_m, node_rp, node_order)])
+            _lib.check(lib.ggnn_assemble_batch_backward(tab["ptrs"], btab["bwd_ptrs"], A, T, tab["c_type_off"], tab["c_type_row_off"],
+                                                        bt.data_ptr(), gnl.data_ptr(), G, V, M, R, hidden_size, c_to, c_tro, c_bout,
+                                                        torch.cuda.current_stream().cuda_stream))
+            index._source_index = ops.MessageIndex(adj, type_off, src_rp, src_g, src_m, V * T, T)
+            bwd = object.__new__(ops.CompactBackward)
+            bwd.rows_index = ops.SegmentIndex(rows_rp, rows_g, R, rows_m)
+            bwd.source_node_index = ops.SegmentIndex(src_rp[::T].contiguous(), src_g, V, src_m)
+            bwd.node_index = ops.SegmentIndex(node_rp, node_order, V)
+            bwd.identity = ops.CompactSources(torch.arange(max(R, 1), dtype=torch.int32, device=dev), type_row_off, gather_c)
+            comp._bwd = bwd
     return h0, gnl, graph_ptr, nin, index, type_off
 
 
@@ -210,7 +242,7 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
     tab = dms.static_tables(T, tie_fwd_bkwd, want_compact) if (USE_STATIC_TABLES if static is None else static) else None
     if tab is not None:
         # gathered from the dataset-level tables: no sort, no scan, five launches (ggnn_assemble_batch)
-        h0, gnl, graph_ptr, nin, index, type_off = _assemble_from_tables(dms, tab, gids_h, hidden_size)
+        h0, gnl, graph_ptr, nin, index, type_off = _assemble_from_tables(dms, tab, gids_h, hidden_size, training)
         adjacency = [index.adj[type_off[t]:type_off[t + 1]] for t in range(T)]
         return {
             'initial_node_representation': h0, 'adjacency_lists': adjacency, 'num_incoming_edges_per_type': nin,

@@ -424,6 +424,15 @@ int ggnn_clip_adam_f32(float* const* param_ptrs, const int32_t* var_numel, const
  *   out [10]: 0 h0 f32[V,D] (annotation, zero-padded: :300-302)  1 graph_nodes_list i32[V]  2 graph_ptr i32[G+1]  3 nin f32[V,T]
  *     4 adj i32[M,2]  5 row_ptr i32[V+1]  6 gather_row i32[M]  7 msg_perm i32[M]  8 pair_node i32[R]  9 compact gather rows i32[M]
  *   -- exactly what ggnn_build_target_csr + ggnn_build_compact_sources + ggnn_remap_gather_rows produce for the batch. */
+/* ... and the transpose structures of the backward pass for the same batch (graph_nodes_list = out[1] of ggnn_assemble_batch; batch_tab
+ * carries one more array at its end: ptot[G+1], compact rows of the graphs before k over all types).
+ *   bwd_tables [8]: 0 by-(src*T+type) row_ptr i32[Nd*T+1]  1 slot -> dst  2 slot -> message id  3 compact row -> first message slot
+ *     i32[Rd+1]  4 slot -> dst  5 slot -> message id (type-major slots)  6 node -> first of its compact rows i32[Nd+1]  7 those rows i32[Rd]
+ *   out [8]: the same eight arrays for the batch (V*T+1, M, M, R+1, M, M, V+1, R elements). */
+int ggnn_assemble_batch_backward(const void* const* ds_tables, const void* const* bwd_tables, int A, int T, const int64_t* ds_type_off,
+                                 const int64_t* ds_type_row_off, const int32_t* batch_tab, const int32_t* graph_nodes_list, int G, int V,
+                                 int M, int R, int D, const int64_t* type_off, const int64_t* type_row_off, void* const* out,
+                                 ggnn_stream_t stream);
 int ggnn_assemble_batch(const void* const* ds_tables, int A, int T, const int64_t* ds_type_off, const int64_t* ds_type_row_off,
                         const int32_t* batch_tab, int G, int V, int M, int R, int D, const int64_t* type_off,
                         const int64_t* type_row_off, void* const* out, ggnn_stream_t stream);

@@ -704,4 +704,16 @@ def test_batches_gathered_from_dataset_tables_equal_per_batch_builds(pkg, cuda, 
                 R = cb.num_rows
                 assert ca.type_row_off == cb.type_row_off and torch.equal(ca.pair_node[:R], cb.pair_node[:R]) and torch.equal(ca.gather_row, cb.gather_row)
                 assert torch.equal(ca._slot_heads[1], cb._slot_heads[1])
+            if training and ca is not None and cb.num_rows:
+                sa, sb = ia._source_index, ib._source_index
+                for f in ('row_ptr', 'gather_row', 'msg_perm'):
+                    assert torch.equal(getattr(sa, f), getattr(sb, f)), f
+                assert sa.num_nodes == sb.num_nodes
+                for name in ('rows_index', 'source_node_index', 'node_index'):
+                    xa, xb = getattr(ca._bwd, name), getattr(cb._bwd, name)
+                    assert xa.num_nodes == xb.num_nodes
+                    for f in ('row_ptr', 'gather_row', 'msg'):
+                        ta, tb = getattr(xa, f), getattr(xb, f)
+                        assert (ta is None) == (tb is None) and (ta is None or (ta.dtype == tb.dtype and torch.equal(ta, tb))), (name, f)
+                assert torch.equal(ca._bwd.identity.pair_node, cb._bwd.identity.pair_node)
     assert dms.static_tables(T, tie, True) is not None
