@@ -93,6 +93,12 @@ class DeviceMoleculeSet:
         return hit
 
 
+    def task_ids_dev(self, task_ids) -> torch.Tensor:
+        key = tuple(int(t) for t in task_ids)
+        if getattr(self, "_tids", (None, None))[0] != key:
+            self._tids = (key, torch.as_tensor(list(key), dtype=torch.int64, device=self.device))
+        return self._tids[1]
+
     def static_backward_tables(self, num_edge_types: int, tie_fwd_bkwd: bool):
         """The same for the backward pass's transpose structures (by-source CSR, ops.CompactBackward), built lazily on the first
         training batch."""
@@ -134,7 +140,11 @@ class DeviceMoleculeSet:
                    "nin": full['num_incoming_edges_per_type'].contiguous(), "row_ptr": idx.row_ptr, "adj": idx.adj,
                    "slot_gather": idx.gather_row, "slot_msg": idx.msg_perm, "slot_crow": None, "pair_node": None,
                    "e_off": i32(excl(msgs_gt)), "p_off": None, "type_off": [int(x) for x in idx.type_off], "type_row_off": [0] * (T + 1),
-                   "msgs_gt": msgs_gt, "pairs_gt": pairs_gt, "tie": key[1]}
+                   "msgs_gt": msgs_gt, "pairs_gt": pairs_gt, "tie": key[1],
+                   # [Gd, 2 + 2T + 1] per graph: nodes, message slots, messages per type, compact rows per type, compact rows
+                   "counts_dev_t": i32(np.concatenate([self.nodes_per_graph[:, None], msgs_gt.sum(axis=1, keepdims=True), msgs_gt,
+                                                       pairs_gt if compact else np.zeros_like(pairs_gt),
+                                                       (pairs_gt if compact else np.zeros_like(pairs_gt)).sum(axis=1, keepdims=True)], axis=1).T)}
             if compact:
                 comp = ops.build_compact_sources(idx)
                 tab.update(slot_crow=comp.gather_row, pair_node=comp.pair_node, p_off=i32(excl(pairs_gt)),
@@ -152,7 +162,8 @@ class DeviceMoleculeSet:
         return tab
 
 
-def _assemble_from_tables(dms: DeviceMoleculeSet, tab: dict, gids_h: np.ndarray, hidden_size: int, training: bool = False):
+def _assemble_from_tables(dms: DeviceMoleculeSet, tab: dict, gids_h: np.ndarray, hidden_size: int, training: bool = False,
+                          gids_dev: Optional[torch.Tensor] = None):
     """h0, graph_nodes_list, graph_ptr, nin and the batch's MessageIndex (+ compacted sources, slot heads) gathered from the
     dataset-level tables: the (graph, type) prefix sums come from per-molecule count tables on the host, go up in one small copy,
     and ggnn_assemble_batch does the rest in five launches."""
@@ -171,8 +182,18 @@ def _assemble_from_tables(dms: DeviceMoleculeSet, tab: dict, gids_h: np.ndarray,
     type_row_off = [0] + [int(x) for x in np.cumsum(pair_off[-1])]
     if V * T >= 2 ** 31 - 1 or V * hidden_size >= 2 ** 31 - 1:
         raise ValueError("batch too large for 32-bit indices")
-    batch_tab = np.concatenate([gids_h, node_off, slot_off, msg_off.T.ravel(), pair_off.T.ravel(), pair_off.sum(axis=1)]).astype(np.int32)
-    bt = torch.from_numpy(batch_tab).to(dev)
+    if gids_dev is not None:
+        # the graph ids are on the device already (pack_batches_device uploads an epoch's order once): the prefix sums are formed
+        # there too -- a host->device copy per batch would make the host wait for everything queued on the stream, i.e. for
+        # the previous batch's whole forward pass (tools/h2d_probe.py)
+        ct = tab["counts_dev_t"]                                                # [2 + 2T + 1, Gd]
+        pre = torch.zeros((ct.shape[0], G + 1), dtype=torch.int32, device=dev)
+        if G:
+            torch.cumsum(torch.index_select(ct, 1, gids_dev), 1, dtype=torch.int32, out=pre[:, 1:])     # (scans along contiguous rows)
+        bt = torch.cat([gids_dev.to(torch.int32), pre.reshape(-1)])
+    else:
+        batch_tab = np.concatenate([gids_h, node_off, slot_off, msg_off.T.ravel(), pair_off.T.ravel(), pair_off.sum(axis=1)]).astype(np.int32)
+        bt = torch.from_numpy(batch_tab).to(dev)
     i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)
     h0 = torch.empty((V, hidden_size), dtype=torch.float32, device=dev)
     gnl, graph_ptr, nin = i32(V), i32(G + 1), torch.empty((V, T), dtype=torch.float32, device=dev)
@@ -218,7 +239,8 @@ def _ranges(starts: torch.Tensor, lengths: torch.Tensor, total: int) -> torch.Te
 
 def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_types: int, hidden_size: int,
                       tie_fwd_bkwd: bool = True, task_ids: Sequence[int] = (0,), compact: bool = True,
-                      training: bool = False, static: Optional[bool] = None) -> Dict[str, Any]:
+                      training: bool = False, static: Optional[bool] = None,
+                      graph_ids_dev: Optional[torch.Tensor] = None) -> Dict[str, Any]:
     """One batch from graphs `graph_ids` (in this order), assembled on the GPU: the feed dict of
     SparseGGNNChemModel.to_device_batch (chem_tensorflow_sparse.py:254-276, 298-348), message index included."""
     dev = dms.device
@@ -233,8 +255,8 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
     F = T if tie_fwd_bkwd else T // 2
     if B and (dms.min_bond_type < 1 or dms.max_bond_type > F):
         raise IndexError("edge type outside [0, num_edge_types)")
-    gids = torch.from_numpy(gids_h).to(dev)
-    tids = torch.as_tensor(list(task_ids), dtype=torch.int64, device=dev)
+    gids = torch.from_numpy(gids_h).to(dev) if graph_ids_dev is None else graph_ids_dev      # (int64, the batch's graphs on the device)
+    tids = dms.task_ids_dev(task_ids)
     tv = dms.targets[gids][:, tids].t().contiguous()                                # :335
     tm = torch.ones_like(tv) if dms.label_mask is None else dms.label_mask[gids][:, tids].t().contiguous()
     tv = tv * tm                                                                    # masked labels feed 0. (:319-321)
@@ -242,7 +264,7 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
     tab = dms.static_tables(T, tie_fwd_bkwd, want_compact) if (USE_STATIC_TABLES if static is None else static) else None
     if tab is not None:
         # gathered from the dataset-level tables: no sort, no scan, five launches (ggnn_assemble_batch)
-        h0, gnl, graph_ptr, nin, index, type_off = _assemble_from_tables(dms, tab, gids_h, hidden_size, training)
+        h0, gnl, graph_ptr, nin, index, type_off = _assemble_from_tables(dms, tab, gids_h, hidden_size, training, graph_ids_dev)
         adjacency = [index.adj[type_off[t]:type_off[t + 1]] for t in range(T)]
         return {
             'initial_node_representation': h0, 'adjacency_lists': adjacency, 'num_incoming_edges_per_type': nin,
@@ -312,8 +334,10 @@ def pack_batches_device(dms: DeviceMoleculeSet, params: dict, num_edge_types: in
     bounds = batch_boundaries(dms.nodes_per_graph[order], params["batch_size"])
     nb = len(bounds) - 1
     steps = (nb + world_size - 1) // world_size
+    order_dev = torch.from_numpy(order).to(dms.device)          # ONE upload per epoch: the batches slice it on the device
     for s in range(steps):
         i = s * world_size + rank
         ids = order[bounds[i]:bounds[i + 1]] if i < nb else np.zeros(0, np.int64)
+        ids_dev = order_dev[bounds[i]:bounds[i + 1]] if i < nb else order_dev[:0]
         yield pack_batch_device(dms, ids, num_edge_types, params["hidden_size"], params.get("tie_fwd_bkwd", True),
-                                params.get("task_ids", [0]), compact, training)
+                                params.get("task_ids", [0]), compact, training, graph_ids_dev=ids_dev)

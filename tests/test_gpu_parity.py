@@ -717,3 +717,12 @@ def test_batches_gathered_from_dataset_tables_equal_per_batch_builds(pkg, cuda, 
                         assert (ta is None) == (tb is None) and (ta is None or (ta.dtype == tb.dtype and torch.equal(ta, tb))), (name, f)
                 assert torch.equal(ca._bwd.identity.pair_node, cb._bwd.identity.pair_node)
     assert dms.static_tables(T, tie, True) is not None
+    # graph ids given on the device (what pack_batches_device does for every batch of an epoch): the prefix sums are formed there
+    gids = rng.permutation(400)[:211]
+    a = pkg.data_device.pack_batch_device(dms, gids, T, 100, tie, (0,), True, True, static=True, graph_ids_dev=dev(gids.astype(np.int64), cuda))
+    b = pkg.data_device.pack_batch_device(dms, gids, T, 100, tie, (0,), True, True, static=False)
+    for f in ('adj', 'row_ptr', 'gather_row', 'msg_perm'):
+        assert torch.equal(getattr(a['message_index'], f), getattr(b['message_index'], f)), f
+    assert torch.equal(a['message_index']._compact.gather_row, b['message_index']._compact.gather_row)
+    assert torch.equal(a['message_index']._compact._bwd.node_index.gather_row, b['message_index']._compact._bwd.node_index.gather_row)
+    assert torch.equal(a['initial_node_representation'], b['initial_node_representation']) and torch.equal(a['target_values'], b['target_values'])
