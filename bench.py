@@ -86,6 +86,9 @@ def kernel_model(name, V, M, D, T, R=None):
         return "mfma", 2.0 * R * D * D
     if name in ("gather_segment_sum", "dense_aggregate"):
         return "hbm", kernel_bytes(name, V, M, D, T, R)
+    if name.startswith("dense_propagate"):                  # the whole dense forward: per timestep T transforms + the GRU (+ aggregation)
+        steps = int(name.split("steps=")[1].rstrip("]"))
+        return "mfma", steps * (2.0 * V * D * T * D + 12.0 * V * D * D)
     if name.startswith("gru_fused"):
         nx = int(name.split("nx=")[1].rstrip("]"))
         return "mfma", 6.0 * V * (nx + 1) * D * D
@@ -108,6 +111,9 @@ def kernel_bytes(name, V, M, D, T, R=None):
         return float(M * D * 4 + M * 8 + V * D * 4)
     if name == "dense_aggregate":                            # adjacency [b,T,v,v] (= M floats here) + transformed rows + output
         return float(M * 4 + V * T * D * 4 + V * D * 4)
+    if name.startswith("dense_propagate"):                   # states in and out once, the adjacency tensor once per timestep
+        steps = int(name.split("steps=")[1].rstrip("]"))
+        return float(2 * V * D * 4 + steps * M * 4)
     nx = int(name.split("nx=")[1].rstrip("]"))
     if name.startswith("gru_fused_gather"):                  # residual segments + h + h_out + gathered rows + slots
         return float((nx - 1 + 2) * V * D * 4 + M * D * 4 + M * 4 + V * 4 + V * T * 4)

@@ -21,6 +21,11 @@ from .data import DENSE_BUCKET_SIZES, MoleculeSet, pack_dense_batch
 from .sparse_model import GRUCellWeights
 from .utils import glorot_init, tf_dropout, tf_glorot_uniform
 
+import os
+
+# Inference with all timesteps in one graph-resident launch (GGNN_DENSE_GRAPH_KERNEL=0: three launches per timestep)
+USE_GRAPH_RESIDENT_KERNEL = os.environ.get("GGNN_DENSE_GRAPH_KERNEL", "1") != "0"
+
 
 class DenseGGNNChemModel(ChemModel):
     def __init__(self, args):
@@ -94,6 +99,13 @@ class DenseGGNNChemModel(ChemModel):
         cell = self.weights['node_gru']
         # the GRU's LDS weight images are packed once per weight version (the one cell is shared by all timesteps, :101-102)
         from .autograd import _PACKED
+        if USE_GRAPH_RESIDENT_KERNEL and keep_w >= 1.0 and keep_s >= 1.0 and h.is_cuda \
+                and ops.dense_propagate_supported(int(v), self.num_edge_types, h_dim):
+            # all timesteps in ONE launch: a graph's states stay on its CU (ggnn_dense_propagate_f32)
+            W = self.weights['edge_weights'].contiguous()
+            return ops.dense_propagate(h.reshape(b, int(v), h_dim), A.contiguous(), _PACKED.edge(W),
+                                       _PACKED.dense_gru(cell.gates_kernel, cell.candidate_kernel, h_dim), bias,
+                                       cell.gates_bias, cell.candidate_bias, self.params['num_timesteps'])
         packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, 1, h_dim) if ops.gru_is_fused(h_dim) else None
         for i in range(self.params['num_timesteps']):                  # :100
             # :104 a fresh weight-dropout mask per (timestep, edge type)

@@ -556,6 +556,35 @@ def dense_aggregate(adjacency: torch.Tensor, Hm: torch.Tensor, edge_biases: Opti
     return out
 
 
+def dense_propagate_supported(v: int, E: int, D: int) -> bool:
+    return bool(_lib.load().ggnn_dense_propagate_supported(int(v), int(E), int(D)))
+
+
+def dense_propagate(h0: torch.Tensor, adjacency: torch.Tensor, edge_packed: torch.Tensor, gru_packed: torch.Tensor,
+                    edge_biases: Optional[torch.Tensor], bg: torch.Tensor, bc: torch.Tensor, steps: int) -> torch.Tensor:
+    """The whole dense forward (chem_tensorflow_dense.py:93-117) in one launch, graph-resident (ggnn_dense_propagate_f32).
+    h0 [b,v,D], adjacency [b,e,v,v]; edge_packed = PackedWeights.edge(W [e,D,D]); gru_packed = PackedWeights.dense_gru(Wg, Wc)."""
+    lib = _lib.load()
+    _req(h0, torch.float32, "h0"); _req(adjacency, torch.float32, "adjacency")
+    b, v, D = h0.shape
+    E = adjacency.shape[1]
+    if adjacency.shape != (b, E, v, v):
+        raise ValueError("adjacency must be [b,e,v,v]")
+    for t, n, name in ((bg, 2 * D, "bg"), (bc, D, "bc")):
+        _req(t, torch.float32, name)
+        if t.numel() != n:
+            raise ValueError("%s must have %d elements" % (name, n))
+    if edge_biases is not None:
+        _req(edge_biases, torch.float32, "edge_biases")
+        if edge_biases.numel() != E * D:
+            raise ValueError("edge_biases must be [e,D]")
+    out = torch.empty_like(h0)
+    _launch("dense_propagate[steps=%d]" % steps, lambda: lib.ggnn_dense_propagate_f32(
+        _ptr(h0), _ptr(adjacency), _ptr(edge_packed), _ptr(gru_packed), _ptr(edge_biases), _ptr(bg), _ptr(bc), _ptr(out), b, v, E, D,
+        int(steps), _stream()))
+    return out
+
+
 # ---- source-compacted message transform -----------------------------------------------------------------
 @dataclass
 class CompactSources:
@@ -797,6 +826,20 @@ class PackedWeights:
             packed = torch.empty(lib.ggnn_gru_packed_bytes(D, nx) // 4, dtype=torch.float32, device=Wg.device)
             check(lib.ggnn_gru_pack_weights_f32(_ptr(Wg), _ptr(Wc), nx, D, _ptr(packed), _stream()))
             hit = self._store(self._gru, key, (Wg, Wc), packed)
+        return hit
+
+    def dense_gru(self, Wg: torch.Tensor, Wc: torch.Tensor, D: int) -> torch.Tensor:
+        """The six plain stage images of the graph-resident dense kernel (ggnn_dense_gru_pack_f32), once per weight version."""
+        lib = _lib.load()
+        if not hasattr(self, "_dense_gru"):
+            self._dense_gru = {}
+        key = self._key(Wg, Wc)
+        hit = self._lookup(self._dense_gru, key, (Wg, Wc))
+        if hit is None:
+            _req(Wg, torch.float32, "Wg"); _req(Wc, torch.float32, "Wc")
+            packed = torch.empty(lib.ggnn_dense_gru_packed_bytes(D) // 4, dtype=torch.float32, device=Wg.device)
+            check(lib.ggnn_dense_gru_pack_f32(_ptr(Wg), _ptr(Wc), D, _ptr(packed), _stream()))
+            hit = self._store(self._dense_gru, key, (Wg, Wc), packed)
         return hit
 
     def gru_bwd(self, Wg: torch.Tensor, Wc: torch.Tensor, nx: int, D: int) -> torch.Tensor:

@@ -26,6 +26,37 @@ def test_dense_aggregate(pkg, cuda, b, v, E, D, bias):
     np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("b,v,E,D,bias,steps", [(7, 29, 4, 100, True, 4), (3, 32, 4, 100, False, 2), (5, 17, 8, 64, True, 3),
+                                                 (4, 5, 2, 32, True, 4), (2, 16, 6, 100, True, 1), (256, 29, 4, 100, True, 4)])
+def test_graph_resident_dense_forward(pkg, oracle, cuda, b, v, E, D, bias, steps):
+    """ggnn_dense_propagate_f32 -- all timesteps of a graph in one workgroup -- against the fp64 oracle of
+    chem_tensorflow_dense.py:93-117 and against the three-launches-per-timestep path on the same inputs (both run fp32 MFMA
+    products in different summation orders: tolerance, not bit equality); repeatable bit for bit."""
+    rng = np.random.default_rng(b * v + E)
+    A = (rng.random((b, E, v, v)) < 2.0 / v).astype(np.float32)
+    h0 = rng.uniform(-1, 1, (b, v, D)).astype(np.float32)
+    W = oracle.glorot_init(rng, [E, D, D])
+    eb = rng.normal(0, 0.1, [E, 1, D]).astype(np.float32) if bias else None
+    gru = {"Wg": oracle.glorot_init(rng, [2 * D, 2 * D]), "bg": (1 + rng.normal(0, 0.1, 2 * D)).astype(np.float32),
+           "Wc": oracle.glorot_init(rng, [2 * D, D]), "bc": rng.normal(0, 0.1, D).astype(np.float32)}
+    assert pkg.ops.dense_propagate_supported(v, E, D)
+    P = pkg.ops.PackedWeights()
+    dW, dWg, dWc = dev(W, cuda), dev(gru["Wg"], cuda), dev(gru["Wc"], cuda)
+    dbias = None if eb is None else dev(eb.reshape(E, D), cuda)
+    run = lambda: pkg.ops.dense_propagate(dev(h0, cuda), dev(A, cuda), P.edge(dW), P.dense_gru(dWg, dWc, D), dbias,
+                                          dev(gru["bg"], cuda), dev(gru["bc"], cuda), steps)
+    got = run()
+    want = oracle.dense_propagate(h0, A, W, eb, gru, steps)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=1e-5, rtol=1e-4)
+    assert torch.equal(got, run())
+    h = dev(h0, cuda).reshape(b * v, D)
+    for _ in range(steps):
+        acts = pkg.ops.dense_aggregate(dev(A, cuda), pkg.ops.msg_transform(h, dW), dbias)
+        h = pkg.ops.gru([acts], h, dWg, dev(gru["bg"], cuda), dWc, dev(gru["bc"], cuda), "tanh")
+    np.testing.assert_allclose(got.cpu().numpy().reshape(b * v, D), h.cpu().numpy(), atol=5e-6, rtol=1e-5)
+    assert not pkg.ops.dense_propagate_supported(33, 4, 100) and not pkg.ops.dense_propagate_supported(29, 4, 128)
+
+
 def _dense_model(pkg, oracle, ms, config=None):
     cfg = {"batch_size": 16}
     cfg.update(config or {})
