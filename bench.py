@@ -193,6 +193,8 @@ def pmc_key(pmc, name, D):
         return gemms[0] if name == "msg_transform" and len(gemms) == 1 else None
     if name == "gather_segment_sum":
         return next((k for k in pmc if k.startswith("gather_segment_sum") and "attn" not in k), None)
+    if name.startswith("dense_propagate"):
+        return next((k for k in pmc if k.startswith("dense_graph")), None)
     if name.startswith("gru_fused"):                     # template args <D, NX, NW, SAVE, GATHER>
         nx = name.split("nx=")[1].rstrip("]")
         tail = "true>" if name.startswith("gru_fused_gather") else "false>"
