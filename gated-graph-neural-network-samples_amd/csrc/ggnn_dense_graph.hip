@@ -11,7 +11,7 @@
 //     lane -- comes straight from L2 into registers one stage ahead (tile_mma_regs): no LDS ring, no barrier per stage.
 //   * every wave holds the full activation fragments (the MFMA's B operand: state h, then acts / r*h) of both row tiles.  What a
 //     stage produces per column tile is exchanged through LDS: the transformed states M_e (all E of them: the aggregation reads
-//     rows of OTHER vertices), acts, r*h and the new state -- six workgroup barriers per timestep.
+//     rows of OTHER vertices), acts, r*h and the new state -- four workgroup barriers per timestep.
 //   * aggregation acts[i] = sum_e sum_j A_e[i,j] (M_e[j] + b_e) (:103-112; bias on every row before A_e, :107-108) runs on the matrix
 //     pipe too: the graph's 0/1 adjacency rows sit in LDS for the whole launch, the products A_e[i,j] M_e[j] are exact, and the bias
 //     term is nin_e[i] b_e (the row sums of A_e, formed once).
@@ -51,10 +51,12 @@ __global__ __launch_bounds__(NW * 64) void ggnn_dense_graph_kernel(DenseGraphArg
     constexpr int NS = E + 6;                                          // stages per timestep
     constexpr int AP = 33;                                             // pitch of an adjacency row in LDS (16 rows x one column: 16 banks)
     static_assert(NT <= NW && NS % 2 == 0, "one column tile per wave; the two weight slots alternate with a fixed phase per timestep");
-    extern __shared__ __attribute__((aligned(16))) float lds[];        // Mbuf [E][32][MP] | Xbuf [32][MP] | Abuf [E][32][32]
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // Mbuf [E][32][MP] | Xbuf, Rbuf, Hbuf [32][MP] | Abuf [E][32][AP] | ...
     float* Mbuf = lds;
-    float* Xbuf = lds + (size_t)E * 32 * MP;
-    float* Abuf = Xbuf + (size_t)32 * MP;                              // the graph's adjacency rows: read once, used by every timestep
+    float* Xbuf = lds + (size_t)E * 32 * MP;                           // exchange blocks: acts, r*h, the new state -- one each, so that a
+    float* Rbuf = Xbuf + (size_t)32 * MP;                              // block is rewritten a whole timestep after it was last read and
+    float* Hbuf = Rbuf + (size_t)32 * MP;                              // "everyone has read it" needs no barrier of its own
+    float* Abuf = Hbuf + (size_t)32 * MP;                              // the graph's adjacency rows: read once, used by every timestep
     float* Nbuf = Abuf + (size_t)E * 32 * AP;                          // [E][32] incoming edges per type (row sums of A_e)
     float* Bbuf = Nbuf + E * 32;                                       // [E][BN] edge biases, zero-padded
     const int tid = threadIdx.x, lane = tid & 63;
@@ -232,10 +234,9 @@ __global__ __launch_bounds__(NW * 64) void ggnn_dense_graph_kernel(DenseGraphArg
             ar[t] = r4 * hv;                                           // r * h tile
         }
         GGNN_DG_T(5)
-        __syncthreads();                                               // (3) everyone has read acts out of Xbuf
-        if (mm) { tile_to_lds(Xbuf, 0, ar[0]); tile_to_lds(Xbuf, 1, ar[1]); }
-        __syncthreads();                                               // (4) r*h complete
-        frag_from_lds(xf[0], Xbuf, 0); frag_from_lds(xf[1], Xbuf, 1);
+        if (mm) { tile_to_lds(Rbuf, 0, ar[0]); tile_to_lds(Rbuf, 1, ar[1]); }
+        __syncthreads();                                               // (3) r*h complete
+        frag_from_lds(xf[0], Rbuf, 0); frag_from_lds(xf[1], Rbuf, 1);
         GGNN_DG_T(6)
         GGNN_DG_STAGE(E + 5, ac, xf, false)                            // candidate, r*h part
         GGNN_DG_T(7)
@@ -257,10 +258,9 @@ __global__ __launch_bounds__(NW * 64) void ggnn_dense_graph_kernel(DenseGraphArg
                 }
             }
         } else {
-            __syncthreads();                                           // (5) everyone has read r*h out of Xbuf
-            if (mm) { tile_to_lds(Xbuf, 0, hn[0]); tile_to_lds(Xbuf, 1, hn[1]); }
-            __syncthreads();                                           // (6) new state complete
-            frag_from_lds(hf[0], Xbuf, 0); frag_from_lds(hf[1], Xbuf, 1);
+            if (mm) { tile_to_lds(Hbuf, 0, hn[0]); tile_to_lds(Hbuf, 1, hn[1]); }
+            __syncthreads();                                           // (4) new state complete
+            frag_from_lds(hf[0], Hbuf, 0); frag_from_lds(hf[1], Hbuf, 1);
         }
 #undef GGNN_DG_STAGE
     }
@@ -270,7 +270,7 @@ template <int D, int E>
 static int launch_dense_graph(const DenseGraphArgs& a, hipStream_t st) {
     using C = StageCfg<D>;
     constexpr int NW = 8;
-    const size_t ldsb = ((size_t)(E + 1) * 32 * (C::BN + 4) + (size_t)E * 32 * 33 + (size_t)E * 32 + (size_t)E * C::BN) * sizeof(float);
+    const size_t ldsb = ((size_t)(E + 3) * 32 * (C::BN + 4) + (size_t)E * 32 * 33 + (size_t)E * 32 + (size_t)E * C::BN) * sizeof(float);
     static std::atomic<unsigned long long> lds_ok{0};
     if (ldsb > 64 * 1024) GGNN_CHECK_HIP((allow_dynamic_lds(&ggnn_dense_graph_kernel<D, E, NW>, ldsb, lds_ok)));
     hipLaunchKernelGGL((ggnn_dense_graph_kernel<D, E, NW>), dim3(a.b), dim3(NW * 64), ldsb, st, a);
@@ -285,7 +285,7 @@ using namespace ggnn;
 extern "C" int ggnn_dense_propagate_supported(int v, int E, int D) {
     if (!(v >= 1 && v <= 32 && (E == 2 || E == 4 || E == 6 || E == 8) && (D == 100 || D == 64 || D == 32))) return 0;
     const int bn = (D + 15) / 16 * 16;
-    const size_t ldsb = ((size_t)(E + 1) * 32 * (bn + 4) + (size_t)E * 32 * 33 + (size_t)E * 32 + (size_t)E * bn) * sizeof(float);   // M_e, exchange block, adjacency rows, in-degrees, biases
+    const size_t ldsb = ((size_t)(E + 3) * 32 * (bn + 4) + (size_t)E * 32 * 33 + (size_t)E * 32 + (size_t)E * bn) * sizeof(float);   // M_e, exchange block, adjacency rows, in-degrees, biases
     return ldsb <= (size_t)160 * 1024;
 }
 
