@@ -29,17 +29,19 @@ __global__ __launch_bounds__(512) void k(float* __restrict__ p, int rows, float*
     if (!STORE && s.x + s.y + s.z + s.w == 12345.678f) sink[0] = s.x;
 }
 
+static int g_blocks = 256;
 template <int PAT, bool STORE>
 static void run(const char* name, float* d, int rows, float* sink) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<PAT, STORE>), dim3(256), dim3(512), 0, 0, d, rows, sink);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<PAT, STORE>), dim3(g_blocks), dim3(512), 0, 0, d, rows, sink);
     hipEventRecord(e0);
     const int reps = 20;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<PAT, STORE>), dim3(256), dim3(512), 0, 0, d, rows, sink);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<PAT, STORE>), dim3(g_blocks), dim3(512), 0, 0, d, rows, sink);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double bytes = (double)(rows / 16) * 6 * 1024;
-    printf("%-28s rows %7d: %7.1f us  %6.2f TB/s\n", name, rows, ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e12);
+    printf("%-28s rows %7d, %3d workgroups: %7.1f us  %6.2f TB/s = %5.1f B/clock per workgroup (2.4 GHz)\n", name, rows, g_blocks, ms / reps * 1e3,
+           bytes / (ms / reps * 1e-3) / 1e12, bytes / (ms / reps * 1e-3) / g_blocks / 2.4e9);
 }
 
 int main() {
@@ -47,7 +49,9 @@ int main() {
     const int maxrows = 1600000;
     hipMalloc(&d, (size_t)maxrows * 400); hipMalloc(&sink, 64);
     hipMemset(d, 0, (size_t)maxrows * 400);
-    for (int rows : {32768, 100000, 1600000}) {       // 13 MB (L2), 40 MB (Infinity Cache), 640 MB (HBM)
+    for (int nb : {16, 64, 256})
+    for (int rows : {100000, 1600000}) {              // 40 MB (Infinity Cache), 640 MB (HBM); 16 / 64 / 256 workgroups: per-CU or shared limit?
+        g_blocks = nb;
         run<0, false>("load  A linear", d, rows, sink);
         run<1, false>("load  B fragment (4 rows/quad)", d, rows, sink);
         run<2, false>("load  C row quads", d, rows, sink);
