@@ -2,8 +2,9 @@
 chem_tensorflow_sparse.py:153-216 via optimizer.compute_gradients, chem_tensorflow.py:184) -- every launch a
 hand-written HIP kernel of libggnn_hip.so; torch only allocates the buffers.
 
-Forward (training) = the inference kernels: compacted message transform on the active (node, type) pairs, stand-alone
-segment sum (its result is a saved operand of the weight gradients), fused GRU in its r/u/c-saving form.
+Forward (training) = the inference kernels: compacted message transform on the active (node, type) pairs, then the fused GRU
+with the segment sum gathered inside the launch, in its training form (r, u, c and the gathered segment written for the backward
+pass); layers with an edge bias keep the stand-alone segment sum (bias epilogue).
 
 Backward, per timestep (nx = residual inputs + 1, K = (nx+1) D):
   1. ggnn_gru_bwd_stage1_f32      g, h, r, u, c -> dpc, dpu (= dpg[:, D:]), dh = g*u, r*h           (one element-wise pass)
@@ -48,6 +49,8 @@ USE_TN_KERNEL = os.environ.get("GGNN_TN_KERNEL", "0") != "0"
 # spends a third of each pass waiting for HBM; the products are matrix-pipe bound).  The sums are the ones autograd would have
 # formed, in the same order (timesteps in backward order, one in-order stream), so the result is bit-identical.
 USE_WGRAD_STREAM = os.environ.get("GGNN_WGRAD_STREAM", "1") != "0"
+# Training forward with the segment sum gathered inside the GRU launch (ggnn_gru_packed_gather_train_f32); 0: separate launch
+TRAIN_GATHER_IN_GRU = os.environ.get("GGNN_TRAIN_GATHER_IN_GRU", "1") != "0"
 
 
 class _WeightGradSink:
@@ -160,8 +163,18 @@ class PropagationStepFn(torch.autograd.Function):
             ctx.comp = comp
             ew = edge_weights if edge_weights.is_contiguous() else edge_weights.contiguous()
             H = ops.msg_transform_compact_packed(h, _PACKED.edge(ew), ew.shape[0], comp)
-            incoming = ops.gather_segment_sum_compact(H, index, comp, nin, edge_biases, use_avg)
             edge_weights = ew
+            if TRAIN_GATHER_IN_GRU and edge_biases is None and ops.gru_gather_fused(D):
+                # the segment sum gathered inside the GRU launch, as on the inference path; the kernel also writes r, u, c and the
+                # gathered segment, which the backward pass needs (one launch and one pass over `incoming` less per timestep)
+                save = {}
+                h_new = ops.gru_packed_gather(list(residuals), h, _PACKED.gru(Wg, Wc, len(residuals) + 1, D), bg, bc, H, index,
+                                              comp.gather_row, nin if use_avg else None, activation, save=save)
+                del H
+                ctx.index, ctx.use_avg, ctx.activation, ctx.has_bias = index, use_avg, activation.lower(), False
+                ctx.save_for_backward(h, nin, edge_weights, Wg, Wc, save["incoming"], save["r"], save["u"], save["c"], *residuals)
+                return h_new
+            incoming = ops.gather_segment_sum_compact(H, index, comp, nin, edge_biases, use_avg)
         else:
             edge_weights = edge_weights.contiguous()
             H = ops.msg_transform(h, edge_weights)

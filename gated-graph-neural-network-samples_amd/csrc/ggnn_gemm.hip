@@ -305,7 +305,20 @@ extern "C" int ggnn_gru_packed_gather_f32(const float* const* x_segs, int nx, co
                                           const float* bg, const float* bc, float* h_out, const float* Hrows,
                                           const int32_t* row_ptr, const int32_t* gather_row, const float* nin, int T, int use_avg,
                                           int V, int D, int act, int32_t* tile_counter, ggnn_stream_t stream) {
+    return ggnn_gru_packed_gather_train_f32(x_segs, nx, h, packed, bg, bc, h_out, Hrows, row_ptr, gather_row, nin, T, use_avg,
+                                            nullptr, nullptr, nullptr, nullptr, V, D, act, tile_counter, stream);
+}
+
+// ... the training form: also writes r, u, c and the gathered segment `incoming` (all four or none) for the backward pass
+extern "C" int ggnn_gru_packed_gather_train_f32(const float* const* x_segs, int nx, const float* h, const float* packed,
+                                                const float* bg, const float* bc, float* h_out, const float* Hrows,
+                                                const int32_t* row_ptr, const int32_t* gather_row, const float* nin, int T,
+                                                int use_avg, float* save_r, float* save_u, float* save_c, float* save_incoming,
+                                                int V, int D, int act, int32_t* tile_counter, ggnn_stream_t stream) {
     if (int rc = check_common(V, D)) return rc;
+    const bool save = save_r || save_u || save_c || save_incoming;
+    GGNN_CHECK_ARG(!save || (save_r && save_u && save_c && save_incoming && aligned16(save_r) && aligned16(save_u) && aligned16(save_c) &&
+                             aligned16(save_incoming)), "save_r / save_u / save_c / save_incoming must be given together, 16-byte aligned");
     GGNN_CHECK_ARG(nx >= 1 && nx <= 3, "nx %d outside 1..3", nx);
     GGNN_CHECK_ARG(act == GGNN_ACT_TANH || act == GGNN_ACT_RELU, "unknown activation %d", act);
     if (!gru_fused_supported(D)) return fail(GGNN_E_UNSUPPORTED, "no fused GRU for hidden size %d", D);
@@ -321,6 +334,7 @@ extern "C" int ggnn_gru_packed_gather_f32(const float* const* x_segs, int nx, co
         a.x[s] = x_segs[s];
     }
     a.nx = nx; a.h = h; a.bg = bg; a.bc = bc; a.h_out = h_out; a.V = V; a.act = act;
+    a.save_r = save_r; a.save_u = save_u; a.save_c = save_c; a.save_x = save_incoming;
     a.g_H = Hrows; a.g_row_ptr = row_ptr; a.g_idx = gather_row; a.g_nin = nin; a.g_T = T; a.g_use_avg = use_avg;
     a.tickets = tile_counter;
     return gru_fused_dispatch(a, D, const_cast<float*>(packed), (hipStream_t)stream);

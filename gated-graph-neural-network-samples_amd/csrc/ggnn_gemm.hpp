@@ -209,6 +209,7 @@ struct GruFusedArgs {
     const float* h;
     const float* Wg; const float* bg; const float* Wc; const float* bc;
     float* h_out; float* save_r; float* save_u; float* save_c;
+    float* save_x;         // gather-fused variant with save_r/u/c: the gathered last segment (incoming), an operand of the weight gradients
     int V; int act;
     // gather-fused variant: the last x segment = segment sum of g_H rows (NULL: plain loads from x[nx-1])
     const float* g_H; const int* g_row_ptr; const int* g_idx; const float* g_nin; int g_T; int g_use_avg;

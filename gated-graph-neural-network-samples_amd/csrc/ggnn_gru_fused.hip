@@ -237,6 +237,14 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         }
     };
 
+    // (training) the gathered segment is an operand of the weight gradients: written once, when it is complete
+    auto store_x = [&](const Frag<D>& f, int row_) {
+        const unsigned ob = ((unsigned)row_ * (unsigned)D + 4u * (unsigned)kq) * 4u;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) st4_b(a.save_x, ob + 64u * c, f.v[c]);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.save_x) + ob - 16u * (unsigned)kq + (16u * NC + 4u * q + (unsigned)kq) * 4u) = f.r[q];
+    };
     // x fragments rotate through two register sets: segment s lives in xf[s & 1].
     Frag<D> hf, xf[2];
     {
@@ -248,6 +256,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             if constexpr (G_NEXT) {
                 g_ptrs(r0c, on);
                 if (on) { g_index(); g_rows0(xf[0]); g_rows(xf[0], 2); g_rows(xf[0], 3); g_finish(xf[0]); }
+                if constexpr (SAVE) { if (on && r0 < a.V) store_x(xf[0], r0); }
             } else {
                 if constexpr (G_U - 5 < 0) g_ptrs(r0c, on);
                 if constexpr (G_U - 4 < 0) g_index();         // (also for a wave without a tile: its slots -> row 0)
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         {                                                                                                \
             GGNN_T(POS, 0)                                                                               \
             if constexpr (GATHER && (POS) == G_U % NSTAGE) {                                             \
-                if (active && (!G_NEXT || p > 0)) g_finish(xf[GBUF]);                                    \
+                if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVE) { if (row < a.V) store_x(xf[GBUF], row); } } \
             }                                                                                            \
             if constexpr ((POS) + TWD < NSTAGE) {                                                        \
                 if (wave < NT) load_tile_weights<D>(tw[((POS) + TWD) % (TWD + 1)],                       \
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             float* ndst_ = ring + (cur ^ 1) * C::IMG;                                                    \
             GGNN_T(POS, 0)                                                                               \
             if constexpr (GATHER && (POS) == G_U % NSTAGE) {   /* the fragment this stage multiplies */  \
-                if (active && (!G_NEXT || p > 0)) g_finish(xf[GBUF]);                                    \
+                if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVE) { if (row < a.V) store_x(xf[GBUF], row); } } \
             }                                                                                            \
             /* Side work of the stage (prefetches, the DMA of the whole next image): the LATE waves do it  \
                before their MFMA burst, the EARLY waves after theirs, so its memory instructions issue      \
@@ -595,11 +604,11 @@ static int dispatch_nx(const GruFusedArgs& a, float* packed, hipStream_t st) {
     if (save && !(a.save_r && a.save_u && a.save_c))
         return fail(GGNN_E_INVALID, "save_r / save_u / save_c must be given together");
     if (a.g_H) {
-        if (save) return fail(GGNN_E_UNSUPPORTED, "the gather-fused GRU has no save_r/u/c variant");
+        if (save && !a.save_x) return fail(GGNN_E_INVALID, "the gather-fused GRU saves r/u/c together with the gathered segment (save_x)");
         switch (a.nx) {
-            case 1: return launch_gru_fused<D, 1, 8, false, true>(a, packed, st);
-            case 2: return launch_gru_fused<D, 2, 8, false, true>(a, packed, st);
-            case 3: return launch_gru_fused<D, 3, 8, false, true>(a, packed, st);
+            case 1: return save ? launch_gru_fused<D, 1, 8, true, true>(a, packed, st) : launch_gru_fused<D, 1, 8, false, true>(a, packed, st);
+            case 2: return save ? launch_gru_fused<D, 2, 8, true, true>(a, packed, st) : launch_gru_fused<D, 2, 8, false, true>(a, packed, st);
+            case 3: return save ? launch_gru_fused<D, 3, 8, true, true>(a, packed, st) : launch_gru_fused<D, 3, 8, false, true>(a, packed, st);
             default: return fail(GGNN_E_INVALID, "nx %d outside 1..3", a.nx);
         }
     }

@@ -957,9 +957,10 @@ def sparse_propagate(h0: torch.Tensor, index: MessageIndex, comp: Optional[Compa
 def gru_packed_gather(residual_segs: Sequence[torch.Tensor], h: torch.Tensor, packed: torch.Tensor, bg: torch.Tensor,
                       bc: torch.Tensor, H: torch.Tensor, index: MessageIndex, gather_row: Optional[torch.Tensor],
                       num_incoming_edges_per_type: Optional[torch.Tensor], activation: str = "tanh",
-                      tile_counter: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      tile_counter: Optional[torch.Tensor] = None, save: Optional[dict] = None) -> torch.Tensor:
     """chem_tensorflow_sparse.py:198-216 in one launch (ggnn_gru_packed_gather_f32): the GRU whose last input
-    segment -- the aggregated messages -- is summed from the transformed rows `H` inside the kernel."""
+    segment -- the aggregated messages -- is summed from the transformed rows `H` inside the kernel.
+    save (dict): filled with r, u, c and the gathered segment "incoming" (training: what the backward pass needs)."""
     lib = _lib.load()
     _req(h, torch.float32, "h"); _req(H, torch.float32, "H")
     V, D = h.shape
@@ -970,6 +971,14 @@ def gru_packed_gather(residual_segs: Sequence[torch.Tensor], h: torch.Tensor, pa
     out = torch.empty_like(h)
     nin = num_incoming_edges_per_type
     gather = index.gather_row if gather_row is None else gather_row
+    if save is not None:
+        for k in ("r", "u", "c", "incoming"):
+            save[k] = torch.empty_like(h)
+        _launch("gru_fused_gather_train[nx=%d]" % (len(residual_segs) + 1), lambda: lib.ggnn_gru_packed_gather_train_f32(
+            segs, len(residual_segs) + 1, _ptr(h), _ptr(packed), _ptr(bg), _ptr(bc), _ptr(out), _ptr(H), _ptr(index.row_ptr),
+            _ptr(gather), None if nin is None else _ptr(nin), index.num_edge_types, 0 if nin is None else 1, _ptr(save["r"]),
+            _ptr(save["u"]), _ptr(save["c"]), _ptr(save["incoming"]), V, D, act, _ptr(tile_counter), _stream()))
+        return out
     _launch("gru_fused_gather[nx=%d]" % (len(residual_segs) + 1), lambda: lib.ggnn_gru_packed_gather_f32(
         segs, len(residual_segs) + 1, _ptr(h), _ptr(packed), _ptr(bg), _ptr(bc), _ptr(out), _ptr(H), _ptr(index.row_ptr),
         _ptr(gather), None if nin is None else _ptr(nin), index.num_edge_types, 0 if nin is None else 1, V, D, act,

@@ -260,6 +260,13 @@ int ggnn_gru_packed_gather_f32(const float* const* x_segs, int nx, const float* 
                                const float* bc, float* h_out, const float* Hrows, const int32_t* row_ptr,
                                const int32_t* gather_row, const float* nin, int T, int use_avg, int V, int D, int act,
                                int32_t* tile_counter, ggnn_stream_t stream);
+/* The training form of the same launch: r, u, c [V,D] and the gathered segment `incoming` [V,D] (an operand of the weight gradients)
+ * are written for the backward pass -- all four pointers or none. */
+int ggnn_gru_packed_gather_train_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
+                                     const float* bc, float* h_out, const float* Hrows, const int32_t* row_ptr,
+                                     const int32_t* gather_row, const float* nin, int T, int use_avg, float* save_r, float* save_u,
+                                     float* save_c, float* save_incoming, int V, int D, int act, int32_t* tile_counter,
+                                     ggnn_stream_t stream);
 
 /* The two launches of the un-fused ggnn_gru_f32, separately addressable (profiling, large D):
  *   gates:     [r|u] = sigmoid([x|h] Wg + bg) -> rh = r*h [V,D], u [V,D] (save_r optional)
