@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void gated_readout_kernel(const float* __restr
 //             final kernel: the block partials summed in block order -> d_gate_W [2D], d_gate_b, d_transform_W [D], d_transform_b
 constexpr int kReadoutLanes = 16;               // lanes per node
 constexpr int kReadoutMaxSlots = 4;             // float4 column slots per lane: D <= 16 * 4 * 4 = 256
-constexpr int kReadoutBwdBlocks = 256;
+constexpr int kReadoutBwdBlocks = 1024;        // (four 4-wave blocks per CU: a block walks its nodes through a chain of dependent loads)
 
 __global__ __launch_bounds__(256) void readout_node_kernel(const float* __restrict__ hT, const float* __restrict__ h0,
                                                            const float* __restrict__ Wg, const float* __restrict__ bgp,
