@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Started as plain `python bench.py --gpus N` with N > 1 (no WORLD_SIZE in the environment) it launches its own N ranks through
+torch.distributed.run on 127.0.0.1 and exits with their status; `ranks_seen` on the JSON line is the size of the process
+group the ranks actually formed and `allreduce_us` the flat gradient all-reduce timed on its own (N > 1).
+
 Workload (BASELINE.json configs[1]): sparse GGNN, full-QM9-sized synthetic data (QM9-shaped molecules,
 mean 18 atoms incl. hydrogens, 4 edge types), packed as the reference does into super-graph batches of
 < 100,000 nodes (chem_tensorflow_sparse.py:44,297), hidden 100, layer_timesteps [2,2,1,2,1] = 8
@@ -38,6 +42,8 @@ from __future__ import annotations
 
 import argparse
 import gc
+import socket
+import subprocess
 import glob
 import hashlib
 import importlib
@@ -74,7 +80,25 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] / train legs")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--batch-size", type=int, default=0, help="override the reference's batch_size (100000 nodes); experiments only")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no kernels: rendezvous, per-rank data sharding, the flat gradient all-reduce and the timing bracket only "
+                         "(runs on CPU over gloo; exercises the N-rank launch path where there is no GPU)")
     return ap.parse_args()
+
+
+def respawn_as_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script through torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1) and leave with their exit status.  Under torchrun (WORLD_SIZE set) this is a no-op."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL's only working mode on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] no launcher detected: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 # ---- algorithmic work per launch (SURVEY 8d) -----------------------------------------------------------------------
@@ -309,13 +333,62 @@ def secondary_dense(pkg, dev):
     return out
 
 
+def ranks_seen(dist_ctx):
+    """Size of the process group the ranks actually formed (1 without one)."""
+    return torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+
+
+def dry_run(args, pkg, dist_ctx):
+    """--dry-run: everything around the kernels.  Each rank builds ITS shard of a small synthetic dataset with the host packer
+    (the rank/world assignment of data.pack_batches), the ranks all-reduce a gradient-sized flat fp32 buffer and run the timing
+    bracket (barrier | K no-op steps | barrier, MAX over ranks); rank 0 prints a JSON line with value null."""
+    rank, world = dist_ctx.rank, dist_ctx.world_size
+    ms = pkg.synthetic_qm9(400, mean_nodes=args.mean_nodes, seed=1000)
+    model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cpu", "train_data": None, "valid_data": ms, "dist": dist_ctx,
+                                     "--config": {"batch_size": args.batch_size or 1200}})
+    if world > 1:
+        dist_ctx.broadcast_(list(model.named_variables().values()))
+    batches = pkg.data.pack_batches(ms, model.params, model.num_edge_types, None, None, rank, world)
+    tot = torch.tensor([sum(b.num_nodes for b in batches), sum(b.num_graphs for b in batches), len(batches)], dtype=torch.float64)
+    dist_ctx.all_reduce_sum_(tot)
+    variables = list(model.trainable_variables.values())
+    grads = [torch.full_like(v, float(rank + 1)) for v in variables]
+    ar = []
+    for _ in range(5):
+        g = list(grads)
+        t0 = time.perf_counter(); dist_ctx.reduce_gradients(variables, g); ar.append((time.perf_counter() - t0) * 1e6)
+    want = float(sum(r + 1 for r in range(world)))
+    assert all(bool((x == want).all()) for x in g), "flat gradient all-reduce returned a wrong sum"
+    dist_ctx.barrier(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    dist_ctx.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64); dist_ctx.all_reduce_max_(el)
+    if rank == 0:
+        print(json.dumps({"metric": "node-state updates/sec on QM9-shaped graphs, h=100, 4 edge types", "value": None, "dry_run": True,
+                          "unit": "node-state updates/s", "n_gpus": world, "ranks_seen": ranks_seen(dist_ctx), "steps": args.steps,
+                          "warmup": args.warmup, "scaling": "weak", "data": "synthetic",
+                          "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                          "allreduce_us": float(np.min(ar)) if world > 1 else None,
+                          "allreduce_bytes": int(sum(v.numel() for v in variables) * 4),
+                          "sharded_nodes_total": float(tot[0]), "sharded_graphs_total": float(tot[1]), "dataset_graphs": ms.num_graphs,
+                          "batches_total_incl_padding": float(tot[2]), "bracket_seconds": float(el.item())}))
+    if world > 1:
+        dist_ctx.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    respawn_as_ranks(args)
     pkg = importlib.import_module(PKG)
     dist_ctx = pkg.parallel.DataParallelContext.from_env()
     rank, world = dist_ctx.rank, dist_ctx.world_size
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, pkg, dist_ctx)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU implementation)"
-    assert world == args.gpus, "launch with torchrun --nproc-per-node == --gpus"
     dev = dist_ctx.device
 
     # ---- data: enough QM9-shaped molecules for `batches` distinct ~100k-node batches per rank ------
@@ -432,7 +505,7 @@ def main():
         "metric": "node-state updates/sec on QM9-shaped graphs, h=100, 4 edge types" + (" (training step)" if headline_train else ""),
         "value": value, "unit": "node-state updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / steps_timed * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen(dist_ctx), "allreduce_us": None,
         "steps_timed": steps_timed, "timed_repeats": repeats, "timed_seconds": elapsed,
         "config": {"workload": what + ", full-QM9-sized synthetic batches (configs[%d])" % (3 if world > 1 else 1),
                    "mode": args.mode, "hidden_size": D, "num_edge_types": T, "propagation_steps": n_prop,
@@ -475,6 +548,7 @@ def main():
         rec = {"allreduce_us": float(np.mean(ar)), "allreduce_min_us": float(np.min(ar)),
                "allreduce_bytes": int(sum(v.numel() for v in variables) * 4), "backend": "nccl (RCCL)"}
         out.setdefault("train", {}).update(rec) if not headline_train else out.update({"collective": rec})
+        out["allreduce_us"] = rec["allreduce_us"]
 
     # ---- index prep / packing outside the timed region, and the rate with them inside (rank 0) ----------------------
     if rank == 0 and not headline_train:

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libggnn_hip.so")
@@ -113,6 +113,7 @@ SYMBOLS = {
     "ggnn_clip_adam_f32": (c_int, [c_void_p] * 9 + [c_int, c_float, c_float, c_float, c_float, c_float, c_void_p]),
     "ggnn_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ggnn_gemm_tn_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ggnn_dropout_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_uint64, c_float, c_int64, c_int, c_void_p]),
 }
 
 _lib = None

@@ -25,12 +25,15 @@ _PACKED = ops.PackedWeights()
 
 def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tensor, edge_weights: torch.Tensor,
                      edge_biases: Optional[torch.Tensor], use_avg: bool, residual_states: Sequence[torch.Tensor],
-                     cell, activation: str, need_grad: bool = False) -> torch.Tensor:
+                     cell, activation: str, need_grad: bool = False, ew_mask=None) -> torch.Tensor:
+    """ew_mask (training only): (keep_prob, seed) of the layer's edge-weight dropout (chem_tensorflow_sparse.py:91) -- `edge_weights`
+    is then the VARIABLE (viewed [T,D,D]); the step multiplies by the masked weights and routes the gradient back through the mask."""
     if need_grad:
         from .backward import PropagationStepFn
         return PropagationStepFn.apply(h, index, nin, edge_weights, edge_biases, use_avg, activation,
                                        cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias,
-                                       *residual_states)
+                                       ew_mask, *residual_states)
+    assert ew_mask is None
     D = h.shape[1]
     # same choice as the native driver (ggnn_propagate.hip): segment sum gathered inside the GRU kernel
     gather_in_gru = len(residual_states) + 1 <= int(ops.FUSE_GATHER) and ops.gru_gather_fused(D) and edge_biases is None

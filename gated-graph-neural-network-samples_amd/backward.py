@@ -58,14 +58,29 @@ class _WeightGradSink:
         self.targets = None          # {data_ptr of a variable: float32 buffer of its shape}
         self.stream = None
         self.used = set()            # data_ptrs that received a gradient while the sink was active
+        self.masks = {}              # data_ptr -> (keep_prob, seed): dropout mask to apply to the accumulated gradient at the end
 
     def target(self, ptr, shape):
+        """The buffer registered for the variable at `ptr`, if it holds as many elements as `shape` (the propagation step sees the
+        edge weights as a [T,D,D] view of the [T*D, D] variable: same memory, same element order)."""
         if self.targets is None or ptr is None:
             return None
         t = self.targets.get(ptr)
-        if t is None or tuple(t.shape) != tuple(shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if t is None or t.numel() != n:
             return None
         return t
+
+    def finish(self):
+        """After the side stream's products have been ordered before the current stream: gradients that were accumulated in
+        front of a weight-dropout mask (chem_tensorflow_sparse.py:91: d variable = mask/keep * d masked weights, one mask per layer
+        and step) are masked in place, once per variable instead of once per timestep."""
+        for ptr, (keep, seed) in self.masks.items():
+            t = self.targets[ptr]
+            ops.dropout(t, keep, seed, out=t)
+        self.masks = {}
 
     def add(self, ptr, target, value):
         target.add_(value.view_as(target))
@@ -88,10 +103,12 @@ def weight_gradient_sink(targets):
         return
     if _SINK.stream is None:
         _SINK.stream = torch.cuda.Stream()        # (a high-priority stream measured the same: 6.55-6.77 ms either way)
-    _SINK.targets, _SINK.used = dict(targets), set()
+    _SINK.targets, _SINK.used, _SINK.masks = dict(targets), set(), {}
     try:
         yield _SINK
     finally:
+        if _SINK.masks:
+            raise RuntimeError("weight_gradient_sink left without sink.finish(): masked gradients pending")
         _SINK.targets = None
 
 
@@ -145,15 +162,42 @@ class _TransposeCache:
 _TRANSPOSED = _TransposeCache()
 
 
+class _MaskedWeights:
+    """The dropped-out edge weights of a layer (chem_tensorflow_sparse.py:91), formed once per (variable version, mask) and shared
+    by the layer's timesteps."""
+
+    def __init__(self):
+        self._t = {}
+
+    def get(self, W: torch.Tensor, keep: float, seed: int) -> torch.Tensor:
+        base = W._base if W._base is not None else W
+        key = (id(base), W.data_ptr(), tuple(W.shape))
+        hit = self._t.get(key)
+        if hit is not None and hit[0]() is base and hit[1] == (base._version, keep, seed):
+            return hit[2]
+        if len(self._t) > 64:
+            self._t.clear()
+        Wm = ops.dropout(W.detach().contiguous(), keep, seed)
+        self._t[key] = (weakref.ref(base), (base._version, keep, seed), Wm)
+        return Wm
+
+
+_MASKED = _MaskedWeights()
+
+
 class PropagationStepFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, index, nin, edge_weights, edge_biases, use_avg, activation, Wg, bg, Wc, bc, *residuals):
+    def forward(ctx, h, index, nin, edge_weights, edge_biases, use_avg, activation, Wg, bg, Wc, bc, ew_mask, *residuals):
         h = h.contiguous()
         D = h.shape[1]
         ctx.comp = None
+        ctx.ew_mask = ew_mask
         # (addresses of the variables as they were passed in: keys of the weight-gradient sink)
         ctx.var_ptrs = tuple(None if t is None else t.data_ptr() for t in (edge_weights, edge_biases, Wg, bg, Wc, bc))
         ctx.var_shapes = tuple(None if t is None else tuple(t.shape) for t in (edge_weights, edge_biases, Wg, bg, Wc, bc))
+        if ew_mask is not None:
+            # `edge_weights` is the variable: multiply by its masked copy; backward() sends the gradient back through the mask
+            edge_weights = _MASKED.get(edge_weights, float(ew_mask[0]), int(ew_mask[1]))
         if USE_COMPACT_TRANSFORM and ops.compact_supported(D) and D <= 104:
             # transform only the (node, type) pairs that emit a message (~1.2 V rows instead of T V)
             from .autograd import _PACKED
@@ -235,7 +279,12 @@ class PropagationStepFn(torch.autograd.Function):
         # ---- 6.-8. segment sum and compacted transform  Hc[r] = h[node(r)] W_type(r)  on the same R rows
         tW = _SINK.target(ctx.var_ptrs[0], ctx.var_shapes[0])
         dW = transform_backward(ctx.index, ctx.comp, h, W, dinc, dh, sink=None if tW is None else (ctx.var_ptrs[0], tW))
-        return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, *d_res)
+        if ctx.ew_mask is not None:
+            if tW is not None:
+                _SINK.masks[ctx.var_ptrs[0]] = (float(ctx.ew_mask[0]), int(ctx.ew_mask[1]))      # masked once, in sink.finish()
+            else:
+                dW = ops.dropout(dW.contiguous(), float(ctx.ew_mask[0]), int(ctx.ew_mask[1]))
+        return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, None, *d_res)
 
 
 def transform_backward(index, comp, h, W, dinc, dh, message_weights=None, sink=None):
@@ -251,7 +300,10 @@ def transform_backward(index, comp, h, W, dinc, dh, message_weights=None, sink=N
     bwd = ops.compact_backward(index, comp)
     R = comp.num_rows
     if not R:
-        return None if sink is not None else torch.zeros_like(W)
+        if sink is not None:
+            _SINK.mark(sink[0])                      # a zero gradient is still a gradient: Adam's m / v decay (TF semantics)
+            return None
+        return torch.zeros_like(W)
     if message_weights is None:
         dHc = ops.segment_sum_rows_by_index(dinc, bwd.rows_index)                              # [R,D], transpose gather
     else:
@@ -342,4 +394,6 @@ def _backward_dense_form(ctx, g):
         t1 = min(t0 + 4, T)
         dh += ops.gemm([dH[:, t * D:(t + 1) * D] for t in range(t0, t1)], WT[t0 * D:t1 * D])
     dW = _tn(h, dH).view(D, T, D).transpose(0, 1)
-    return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, *d_res)
+    if ctx.ew_mask is not None:
+        dW = ops.dropout(dW.contiguous(), float(ctx.ew_mask[0]), int(ctx.ew_mask[1]))
+    return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, None, *d_res)

@@ -103,6 +103,7 @@ class ChemModel(object):
         self.weights: Dict[str, Any] = {}
         self.ops: Dict[str, Any] = {}
         self.training = False
+        self.dropout_step = 0                    # optimisation steps taken: part of every dropout mask's key (dropout_seed)
         self.make_model()
         self.make_train_step()
 
@@ -158,6 +159,16 @@ class ChemModel(object):
                                                                    device=self.device)
             self.weights['regression_transform_task%i' % task_id] = MLP(self.params['hidden_size'], 1, [], keep,
                                                                         device=self.device)
+            for kind in ('regression_gate', 'regression_transform'):
+                self.weights['%s_task%i' % (kind, task_id)].dropout_seed = \
+                    lambda layer, kind=kind, task_id=task_id: self.dropout_seed(kind, task_id, layer)
+
+    def dropout_seed(self, *site) -> int:
+        """Key of the dropout mask drawn at `site` in the current optimisation step: a hash of (random_seed, step, site), hence
+        identical on every rank of a data-parallel job whatever else a rank draws (the reference's masks come from TF's
+        graph-seeded stream, chem_tensorflow.py:85; under DP every rank must hold the same weight mask)."""
+        from .utils import dropout_seed
+        return dropout_seed(self.params['random_seed'], self.dropout_step, *site)
 
     def named_variables(self) -> Dict[str, torch.Tensor]:
         """All trainable tensors under TF-style variable names (chem_tensorflow.py:311-313 naming)."""
@@ -224,7 +235,7 @@ class ChemModel(object):
         self.placeholders.update(batch_data)
 
     DERIVED_PLACEHOLDERS = {'adjacency_lists': ('message_index',), 'adjacency_matrix': ('_sparse_form',),
-                            'graph_nodes_list': ('graph_ptr', 'graph_nodes_sorted')}
+                            'graph_nodes_list': ('graph_ptr', 'graph_nodes_sorted', 'graph_ids', 'node_uid')}
 
     def make_train_step(self):
         """chem_tensorflow.py:172-193: Adam(lr) on all trainable variables (minus graph_model/* when
@@ -256,7 +267,10 @@ class ChemModel(object):
     def train_batch(self, batch_data: Dict[str, Any]):
         """One optimisation step (the fetch of ops['train_step'], chem_tensorflow.py:231,183-191)."""
         from .train import train_step
-        return train_step(self, batch_data)
+        try:
+            return train_step(self, batch_data)
+        finally:
+            self.dropout_step += 1
 
     def run_epoch(self, epoch_name: str, data, is_training: bool, start_step: int = 0):
         """chem_tensorflow.py:214-253."""
@@ -276,7 +290,13 @@ class ChemModel(object):
             # chem_tensorflow.py:219 ThreadedIterator(..., max_queue_size=5): the next batches are packed while this one trains
             # (validation batches are packed once and stay resident: nothing to prefetch).  Two ahead is enough here.
             from .utils import ThreadedIterator
-            batch_iterator = ThreadedIterator(batch_iterator, max_queue_size=2, device=getattr(self, "device", None))
+            prepare = getattr(self, 'prepare_resident_data', None)
+            if prepare is not None:
+                prepare(data, is_training)               # resident dataset + tables on THIS stream, before the producer starts
+            dev = getattr(self, "device", None)
+            if dev is not None and torch.device(dev).type == "cuda" and torch.cuda.is_available() and getattr(self, '_packer_stream', None) is None:
+                self._packer_stream = torch.cuda.Stream(dev)   # one packer stream for all epochs of this model
+            batch_iterator = ThreadedIterator(batch_iterator, max_queue_size=2, device=dev, stream=getattr(self, '_packer_stream', None))
         for step, batch_data in enumerate(batch_iterator):
             num_graphs = batch_data['num_graphs']
             processed_graphs += num_graphs

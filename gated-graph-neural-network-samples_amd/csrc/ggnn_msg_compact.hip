@@ -10,7 +10,8 @@
 // Same arithmetic per message as the dense form (identical fmaf chains), ~3.3x fewer flops, and the
 // transformed-state buffer shrinks from V*T*D to R*D floats (fits the 256 MiB Infinity Cache).
 #include "ggnn_stage.hpp"
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
 
 namespace ggnn {
 
@@ -49,7 +50,7 @@ __global__ void remap_rows_kernel(const int* __restrict__ gather_row, const int*
 
 static size_t scan_temp_bytes(long long n) {
     size_t bytes = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (int)n, (hipStream_t)0);
+    (void)rocprim::exclusive_scan(nullptr, bytes, (const int*)nullptr, (int*)nullptr, 0, (size_t)n, rocprim::plus<int>(), (hipStream_t)0);
     return bytes;
 }
 
@@ -217,7 +218,7 @@ extern "C" int ggnn_build_compact_sources(const int32_t* src_row_ptr, int V, int
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(compact_flags_kernel, dim3(blocks), dim3(256), 0, st, src_row_ptr, V, T, flags);
     GGNN_CHECK_HIP(hipGetLastError());
-    GGNN_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, (const int*)flags, scan, (int)n, st));
+    GGNN_CHECK_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, (const int*)flags, scan, 0, (size_t)n, rocprim::plus<int>(), st));
     hipLaunchKernelGGL(compact_fill_kernel, dim3(blocks), dim3(256), 0, st, (const int*)flags, (const int*)scan, V, T, pair_node,
                        pair_id, type_row_off);
     GGNN_CHECK_HIP(hipGetLastError());

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void readout_bwd_node_kernel(
         const float* __restrict__ d_stats, float* __restrict__ d_hT, int accumulate, float* __restrict__ partials,
         int V, int D, int G) {
     constexpr int LPN = kReadoutLanes, NPB = 256 / LPN, S = kReadoutMaxSlots;
-    extern __shared__ float red_s[];                                // [NPB][3*D + 2]
+    extern __shared__ float red_s[];                                // [NPB][3*D + 4]: group stride a multiple of 4 floats (f32x4 stores)
     const int l = threadIdx.x % LPN, grp = threadIdx.x / LPN;
     const int D4 = D >> 2;
     const float d_num = d_stats ? d_stats[0] : 0.f, d_abs = d_stats ? d_stats[1] : 0.f;
@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256) void readout_bwd_node_kernel(
         ppre += dpre; pval += dval;
     }
     // block reduction over the NPB node groups, in group order
-    const int W = 3 * D + 2;
-    float* mine = red_s + grp * W;
+    const int W = 3 * D + 2, WL = 3 * D + 4;
+    float* mine = red_s + grp * WL;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int c4 = l + s * LPN;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void readout_bwd_node_kernel(
     __syncthreads();
     for (int i = threadIdx.x; i < W; i += 256) {
         float s = 0.f;
-        for (int q = 0; q < NPB; ++q) s += red_s[q * W + i];
+        for (int q = 0; q < NPB; ++q) s += red_s[q * WL + i];
         partials[(size_t)blockIdx.x * W + i] = s;
     }
 }
@@ -318,7 +318,7 @@ extern "C" int ggnn_readout_loss_bwd_f32(const float* hT, const float* h0, const
         GGNN_CHECK_ARG(aligned16(hT) && aligned16(h0) && aligned16(gate_W) && aligned16(transform_W) && aligned16(d_hT), "pointers must be 16-byte aligned");
         nb = (V + 15) / 16;
         if (nb > kReadoutBwdBlocks) nb = kReadoutBwdBlocks;
-        const size_t lds = (size_t)16 * W * sizeof(float);
+        const size_t lds = (size_t)16 * (W + 2) * sizeof(float);         // 16 node groups x (3 D + 4) floats
         static std::atomic<unsigned long long> lds_ok{0};
         if (lds > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&readout_bwd_node_kernel, lds, lds_ok));
         hipLaunchKernelGGL(readout_bwd_node_kernel, dim3(nb), dim3(256), lds, st, hT, h0, graph_nodes_list, node_mask, gate_W, transform_W,

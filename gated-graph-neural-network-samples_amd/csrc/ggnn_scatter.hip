@@ -2,9 +2,9 @@
 // chem_tensorflow_sparse.py:160-162,168,198-209) and its index prep (:120-129).
 //
 // HBM-bound.  Design (DESIGN.md "K2"):
-//   * the M messages are bucketed by TARGET once per batch with a stable radix sort (rocPRIM via
-//     hipcub): inside a node the slots keep the reference's accumulation order (type ascending,
-//     then list order), the sum needs no atomics and is bit-reproducible.
+//   * the M messages are bucketed by TARGET once per batch with a stable radix sort (rocPRIM,
+//     called directly): inside a node the slots keep the reference's accumulation order (type
+//     ascending, then list order), the sum needs no atomics and is bit-reproducible.
 //   * one sub-wave (16/32/64 lanes, 16 B per lane) owns one target node: it loads up to LPR slot
 //     indices with ONE coalesced read, broadcasts them with __shfl, and streams the gathered
 //     D-float source rows (each a contiguous, 16-byte aligned 4*D-byte read) with 4 rows in flight
@@ -13,7 +13,8 @@
 //     epilogue; [M,D] messages are never materialised (the reference materialises them twice,
 //     :161-168).
 #include "ggnn_common.h"
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace ggnn {
 
@@ -68,8 +69,8 @@ __global__ void csr_rowptr_kernel(const int* __restrict__ keys_sorted, long long
 
 static size_t cub_temp_bytes(long long M, int end_bit) {
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (const int*)nullptr,
-                                       (int*)nullptr, (int)M, 0, end_bit, (hipStream_t)0);
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr,
+                                    (unsigned int)M, 0u, (unsigned int)end_bit, (hipStream_t)0);
     return bytes;
 }
 
@@ -445,8 +446,8 @@ static int build_csr(const int32_t* adj, const int64_t* type_off, int T, int V, 
     hipLaunchKernelGGL(csr_prep_kernel, dim3(blocks_m), dim3(threads), 0, st, adj, to, (long long)M, V, by_source,
                        keys_in, vals_in, err_flag);
     GGNN_CHECK_HIP(hipGetLastError());
-    GGNN_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(cub_ws, cub_bytes, (const int*)keys_in, keys_out,
-                                                      (const int*)vals_in, vals_out, (int)M, 0, bits, st));
+    GGNN_CHECK_HIP(rocprim::radix_sort_pairs(cub_ws, cub_bytes, (const int*)keys_in, keys_out, (const int*)vals_in, vals_out,
+                                             (unsigned int)M, 0u, (unsigned int)bits, st));
     hipLaunchKernelGGL(csr_finalize_kernel, dim3(blocks_m), dim3(threads), 0, st, adj, (const int*)vals_out, to,
                        (long long)M, V, by_source, gather_row, msg_perm);
     GGNN_CHECK_HIP(hipGetLastError());

@@ -312,7 +312,7 @@ def pack_batch(ms: MoleculeSet, graph_ids: np.ndarray, num_edge_types: int, hidd
     tv = ms.targets[graph_ids][:, task_ids].T.astype(np.float32).copy()          # :335
     tm = np.ones_like(tv) if label_mask is None else label_mask[graph_ids][:, task_ids].T.astype(np.float32)
     tv = tv * tm                                                                 # masked labels feed 0. (:319-321)
-    return SparseBatch(feats, hidden_size, adjacency, nin, gnl, tv, tm, G)
+    return SparseBatch(feats, hidden_size, adjacency, nin, gnl, tv, tm, G, extras={"graph_ids": graph_ids})
 
 
 def pack_batches(ms: MoleculeSet, params: dict, num_edge_types: int, order: Optional[np.ndarray] = None,

@@ -270,6 +270,7 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
             'initial_node_representation': h0, 'adjacency_lists': adjacency, 'num_incoming_edges_per_type': nin,
             'graph_nodes_list': gnl, 'graph_ptr': graph_ptr, 'target_values': tv, 'target_mask': tm, 'num_graphs': G,
             'message_index': ops.prepare_message_index(index, hidden_size, compact, training), 'graph_nodes_sorted': True,
+            'graph_ids': gids,
         }
     n = dms.node_ptr[gids + 1] - dms.node_ptr[gids]
     offs = torch.cumsum(n, 0) - n                                                   # node offset of each graph (:297)
@@ -321,6 +322,7 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
         'message_index': ops.prepare_message_index(ops.build_message_index(adjacency, V, validate=False), hidden_size, compact, training,
                                                    type_row_off=type_row_off),
         'graph_nodes_sorted': True,
+        'graph_ids': gids,
     }
 
 

@@ -109,7 +109,7 @@ class DenseGGNNChemModel(ChemModel):
         packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, 1, h_dim) if ops.gru_is_fused(h_dim) else None
         for i in range(self.params['num_timesteps']):                  # :100
             # :104 a fresh weight-dropout mask per (timestep, edge type)
-            W = tf_dropout(self.weights['edge_weights'], keep_w).contiguous()
+            W = tf_dropout(self.weights['edge_weights'], keep_w, self.dropout_seed('edge_weights', i)).contiguous()
             Hm = ops.msg_transform(h, W)                               # :104-106 for all edge types
             acts = ops.dense_aggregate(A, Hm, bias)                    # :107-112
             if packed is not None:
@@ -117,7 +117,7 @@ class DenseGGNNChemModel(ChemModel):
             else:
                 h = ops.gru([acts], h, cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias,
                             "tanh")                                    # :115
-            h = tf_dropout(h, keep_s)
+            h = tf_dropout(h, keep_s, self.dropout_seed('state', i))
         return h.reshape(b, v, h_dim)                                  # :116
 
     def _compute_for_training(self) -> torch.Tensor:
@@ -151,9 +151,11 @@ class DenseGGNNChemModel(ChemModel):
         cell = self.weights['node_gru']
         h = h0.reshape(-1, h_dim).contiguous()
         for i in range(self.params['num_timesteps']):
-            W = tf_dropout(self.weights['edge_weights'], keep_w)        # :104 fresh mask per (timestep, edge type)
-            h = propagation_step(h, index, nin, W, bias, False, [], cell, "tanh", need_grad=True)
-            h = tf_dropout(h, keep_s)
+            # :104 a fresh mask per (timestep, edge type): the [e, h, h] tensor's rows are keyed (e, row), one seed per timestep
+            ew_mask = (keep_w, self.dropout_seed('edge_weights', i)) if keep_w < 1.0 else None
+            h = propagation_step(h, index, nin, self.weights['edge_weights'], bias, False, [], cell, "tanh", need_grad=True,
+                                 ew_mask=ew_mask)
+            h = tf_dropout(h, keep_s, self.dropout_seed('state', i))
         return h.reshape(b, v, h_dim)
 
     def gated_regression_with_loss(self, last_h, regression_gate, regression_transform, target_values, target_mask):
@@ -175,7 +177,7 @@ class DenseGGNNChemModel(ChemModel):
         keep = float(ph.get('out_layer_dropout_keep_prob', 1.0))
         out, num, ab, ms = readout_loss(last_h.reshape(-1, h_dim), ph['initial_node_representation'].reshape(-1, h_dim).contiguous(),
                                         cached[1], cached[2], ph['node_mask'].reshape(-1).contiguous(), b,
-                                        tf_dropout(g["weights"][0], keep), g["biases"][0], tf_dropout(t["weights"][0], keep),
+                                        regression_gate.dropped_weight(0), g["biases"][0], regression_transform.dropped_weight(0),
                                         t["biases"][0], target_values.contiguous(), target_mask.contiguous())
         self.output = out
         return out, num, ab, ms
@@ -218,18 +220,19 @@ class DenseGGNNChemModel(ChemModel):
         for g, bi in enumerate(chosen):
             bucketed[int(bi)].append(g)
         # :153-158 per bucket: shuffle, then labels of the examples beyond task_sample_ratios are masked.  The mask
-        # belongs to the graph (it follows it through the later per-epoch shuffles); like the reference's
-        # `labels[task_id] = None` it addresses the label by TASK ID in the per-task label list.
+        # belongs to the graph (it follows it through the later per-epoch shuffles).  The reference's `labels[task_id] = None`
+        # indexes the per-task label list (len(task_ids) entries) by TASK ID: the right label only for task_ids == [0..k), an
+        # IndexError or a neighbour's label otherwise.  Like the sparse model here, the label of THAT task is masked.
         label_mask = np.ones((ms.num_graphs, len(self.params['task_ids'])), dtype=np.float32)
         if is_training_data:
             for bucket_list in bucketed.values():
                 np.random.shuffle(bucket_list)
-                for task_id in self.params['task_ids']:
+                for internal_id, task_id in enumerate(self.params['task_ids']):
                     task_sample_ratio = self.params['task_sample_ratios'].get(str(task_id))
                     if task_sample_ratio is not None:
                         ex_to_sample = int(len(bucket_list) * task_sample_ratio)
                         if bucket_list[ex_to_sample:]:
-                            label_mask[np.asarray(bucket_list[ex_to_sample:]), task_id] = 0.0
+                            label_mask[np.asarray(bucket_list[ex_to_sample:]), internal_id] = 0.0
         # :160-162 one entry per full batch of a bucket (remainder graphs are dropped)
         bucket_at_step = [[bucket_idx for _ in range(len(bucket_data) // self.params['batch_size'])]
                           for bucket_idx, bucket_data in bucketed.items()]

@@ -510,6 +510,27 @@ def cudnn_gru_bwd_stage(g, h, r, u, c, hc):
     return dpc, dpg, dh, dhc
 
 
+def dropout(x: torch.Tensor, keep_prob: float, seed: int, row_key: Optional[torch.Tensor] = None, row_key_base: int = 0,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """tf.nn.dropout with the counter-based mask of ggnn_dropout_f32: x / keep * floor(keep + U(seed, row key, column)).
+    x [rows, cols] (or [cols]: one row) contiguous float32; row_key: optional int64 [rows] (default row_key_base + row)."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    if x.dim() < 1:
+        raise ValueError("x must have at least one dimension")
+    cols = x.shape[-1]
+    rows = x.numel() // cols if cols else 0
+    if row_key is not None:
+        _req(row_key, torch.int64, "row_key")
+        if row_key.numel() != rows:
+            raise ValueError("row_key must have one entry per row")
+    if out is None:
+        out = torch.empty_like(x)
+    _launch("dropout", lambda: lib.ggnn_dropout_f32(_ptr(x), _ptr(out), _ptr(row_key), int(row_key_base),
+                                                    int(seed) & 0xFFFFFFFFFFFFFFFF, float(keep_prob), rows, cols, _stream()))
+    return out
+
+
 def unsorted_segment_sum(data: torch.Tensor, segment_ids: torch.Tensor, num_segments: int) -> torch.Tensor:
     """tf.unsorted_segment_sum (fp32 atomics; any id order).  data [M,D] or [M], ids [M] int32."""
     lib = _lib.load()

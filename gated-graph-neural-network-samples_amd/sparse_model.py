@@ -209,7 +209,17 @@ class SparseGGNNChemModel(ChemModel):
             # :91 one weight-dropout mask per layer per run, shared by the layer's timesteps
             # (a fresh view of the [T*D, D] variable, :90, so autograd sees the variable when training)
             h_dim = self.params['hidden_size']
-            edge_weights = tf_dropout(self._edge_weight_vars[layer_idx].view(self.num_edge_types, h_dim, h_dim), ew_keep)
+            ew_var = self._edge_weight_vars[layer_idx].view(self.num_edge_types, h_dim, h_dim)
+            ew_mask = None
+            if ew_keep < 1.0:
+                ew_mask = (ew_keep, self.dropout_seed('edge_weights', layer_idx))
+            plain_step = not variant
+            if ew_mask is None or (plain_step and need_grad):
+                # (training on the default cell: the propagation step gets the variable AND the mask, so that its weight
+                # gradient can be accumulated unmasked and masked once per layer -- backward.PropagationStepFn)
+                edge_weights = ew_var
+            else:
+                edge_weights = tf_dropout(ew_var, ew_mask[0], ew_mask[1])
             edge_biases = self.gnn_weights.edge_biases[layer_idx] if self.params['use_edge_bias'] else None
             cell = self.gnn_weights.rnn_cells[layer_idx]
             cur = node_states_per_layer[-1]                                        # :152
@@ -226,10 +236,25 @@ class SparseGGNNChemModel(ChemModel):
                                              layer_residual_states, layer_idx, act)
                 else:
                     cur = propagation_step(cur, index, nin, edge_weights, edge_biases, use_avg,
-                                           layer_residual_states, cell, act, need_grad)
-                cur = tf_dropout(cur, st_keep)                                     # :113-114 DropoutWrapper(state)
+                                           layer_residual_states, cell, act, need_grad, ew_mask if need_grad else None)
+                if st_keep < 1.0:                                                  # :113-114 DropoutWrapper(state)
+                    cur = tf_dropout(cur, st_keep, self.dropout_seed('state', layer_idx, step), self._node_uid())
             node_states_per_layer.append(cur)
         return node_states_per_layer[-1]                                           # :218
+
+    def _node_uid(self) -> Optional[torch.Tensor]:
+        """int64 [V]: (dataset graph id << 20) + node index within its graph -- the row keys of the state-dropout mask, so
+        that a node's mask does not depend on the batch (or the data-parallel shard) the node was packed into.  Needs the
+        packers' 'graph_ids'; a foreign feed without them gets row-index keys (None)."""
+        ph = self.placeholders
+        uid = ph.get('node_uid')
+        if uid is None and ph.get('graph_ids') is not None and ph.get('graph_ptr') is not None:
+            gnl = ph['graph_nodes_list'].long()
+            V = gnl.shape[0]
+            first = ph['graph_ptr'].long()[gnl]
+            uid = (ph['graph_ids'].long()[gnl] << 20) + (torch.arange(V, device=gnl.device) - first)
+            ph['node_uid'] = uid = uid.contiguous()
+        return uid
 
     def _variant_step(self, h, index, nin, edge_weights, edge_biases, use_avg, residual_states, layer_idx, act):
         """One timestep with the non-default switches of chem_tensorflow_sparse.py: propagation attention
@@ -299,8 +324,8 @@ class SparseGGNNChemModel(ChemModel):
             return None
         ph = self.placeholders
         out, num, ab, ms = readout_loss(last_h, ph['initial_node_representation'], ph['graph_nodes_list'], ph.get('graph_ptr'), None,
-                                        ph['num_graphs'], tf_dropout(g["weights"][0], keep), g["biases"][0],
-                                        tf_dropout(t["weights"][0], keep), t["biases"][0],          # utils.py:68 dropout on W
+                                        ph['num_graphs'], regression_gate.dropped_weight(0), g["biases"][0],
+                                        regression_transform.dropped_weight(0), t["biases"][0],    # utils.py:68 dropout on W
                                         target_values.contiguous(), target_mask.contiguous())
         self.output = out
         return out, num, ab, ms
@@ -370,7 +395,23 @@ class SparseGGNNChemModel(ChemModel):
             'num_graphs': b.num_graphs,
             'message_index': ops.prepare_message_index(ops.build_message_index(adjacency, V), b.hidden_size, compact),
             'graph_nodes_sorted': True,
+            'graph_ids': None if b.extras.get("graph_ids") is None else t(np.asarray(b.extras["graph_ids"], dtype=np.int64)),
         }
+
+    def prepare_resident_data(self, data: Any, is_training: bool) -> None:
+        """Upload the dataset and build the dataset-level tables of the device packer on the CURRENT stream (run_epoch calls this
+        before it hands the epoch to the producer thread, whose stream is ordered behind it)."""
+        if not bool(self.params.get('pack_on_device', True)) or data is None:
+            return
+        if data.get("molecules_dev") is None:
+            data["molecules_dev"] = DeviceMoleculeSet(data["molecules"], self.device, data["label_mask"])
+        from . import backward, data_device
+        if data_device.USE_STATIC_TABLES:
+            compact = ((not is_training) or backward.USE_COMPACT_TRANSFORM) and ops.compact_supported(self.params['hidden_size'])
+            tie = self.params.get("tie_fwd_bkwd", True)
+            data["molecules_dev"].static_tables(self.num_edge_types, tie, compact)
+            if is_training and compact:
+                data["molecules_dev"].static_backward_tables(self.num_edge_types, tie)
 
     def make_minibatch_iterator(self, data: Any, is_training: bool):
         """chem_tensorflow_sparse.py:278-350: minibatches as one disconnected super-graph each.

@@ -235,9 +235,10 @@ def train_step(model, batch_data) -> torch.Tensor:
             opt.zero_gradient_views()
             with weight_gradient_sink(opt.sink_targets()) as sink:
                 loss_for_grad.backward()
-            if sink is not None:
-                torch.cuda.current_stream().wait_stream(sink.stream)
-                in_place = frozenset(sink.used)
+                if sink is not None:
+                    torch.cuda.current_stream().wait_stream(sink.stream)
+                    sink.finish()                              # pending weight-dropout masks on the accumulated gradients
+                    in_place = frozenset(sink.used)
         else:
             loss_for_grad.backward()
     finally:

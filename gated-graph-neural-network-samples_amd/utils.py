@@ -24,13 +24,21 @@ class ThreadedIterator:
     to an element is kept until the work the consumer queued on it has completed -- its memory belongs to the producer
     stream's allocator pool and must not be recycled under kernels that still read it.
 
-    device: a torch.device of type "cuda" to get the side stream; None / CPU: a plain prefetch thread."""
+    device: a torch.device of type "cuda" to get the side stream; None / CPU: a plain prefetch thread.
+    stream: the side stream to use (a model keeps ONE packer stream for all its epochs: a fresh stream per epoch leaves every
+    epoch's batch memory cached in its own allocator pool); default: a new stream.  Whatever the constructing thread has queued on
+    ITS current stream so far (the resident dataset and its tables) is ordered before the producer's first launch."""
 
-    def __init__(self, original_iterator, max_queue_size: int = 2, device=None):
+    def __init__(self, original_iterator, max_queue_size: int = 2, device=None, stream=None):
         self.__queue = queue.Queue(maxsize=max_queue_size)
         self.__cuda = device is not None and torch.device(device).type == "cuda" and torch.cuda.is_available()
         self.__device = torch.device(device) if self.__cuda else None
-        self.__stream = torch.cuda.Stream(self.__device) if self.__cuda else None
+        self.__stream = (stream if stream is not None else torch.cuda.Stream(self.__device)) if self.__cuda else None
+        self.__start_after = None
+        if self.__cuda:
+            with torch.cuda.device(self.__device):
+                self.__start_after = torch.cuda.Event()
+                self.__start_after.record()
         self.__stop = threading.Event()
         self.__retired = collections.deque()
         self.__thread = threading.Thread(target=self.__worker, args=(original_iterator,), daemon=True)
@@ -50,6 +58,7 @@ class ThreadedIterator:
             if self.__cuda:
                 torch.cuda.set_device(self.__device)
                 with torch.cuda.stream(self.__stream):
+                    self.__stream.wait_event(self.__start_after)
                     for element in original_iterator:
                         ev = torch.cuda.Event()
                         ev.record()
@@ -112,12 +121,38 @@ def tf_glorot_uniform(shape, generator: torch.Generator) -> torch.Tensor:
     return (torch.rand(tuple(shape), generator=generator, dtype=torch.float32) * 2 - 1) * limit
 
 
-def tf_dropout(x: torch.Tensor, keep_prob: float, generator=None) -> torch.Tensor:
-    """tf.nn.dropout: x / keep * floor(keep + U[0,1)); identity at keep_prob == 1."""
+def dropout_seed(random_seed: int, step: int, *site) -> int:
+    """64-bit Philox key of one dropout site: a hash of (random_seed, optimisation step, site) -- the same on every rank of a
+    data-parallel job and on every platform (no generator state anywhere)."""
+    import hashlib
+    text = repr((int(random_seed), int(step)) + tuple(site)).encode()
+    return int.from_bytes(hashlib.blake2b(text, digest_size=8).digest(), "little")
+
+
+class _CounterDropout(torch.autograd.Function):
+    """x / keep * floor(keep + U) with the mask re-derived from (seed, row key, column) in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, keep_prob, seed, row_key):
+        from . import ops
+        ctx.args = (float(keep_prob), int(seed), row_key)
+        return ops.dropout(x.contiguous(), keep_prob, seed, row_key)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        keep_prob, seed, row_key = ctx.args
+        return ops.dropout(dy.contiguous(), keep_prob, seed, row_key), None, None, None
+
+
+def tf_dropout(x: torch.Tensor, keep_prob: float, seed=None, row_key=None) -> torch.Tensor:
+    """tf.nn.dropout: x / keep * floor(keep + U[0,1)); identity at keep_prob == 1.  U is counter-based (ggnn_dropout_f32): a
+    function of (seed, row key, column) -- see dropout_seed.  Like every op of the path it runs on the GPU only."""
     if keep_prob >= 1.0:
         return x
-    u = torch.rand(x.shape, device=x.device, dtype=x.dtype, generator=generator)
-    return x / keep_prob * torch.floor(keep_prob + u)
+    if seed is None:
+        raise ValueError("dropout with keep_prob < 1 needs a seed (utils.dropout_seed)")
+    return _CounterDropout.apply(x, float(keep_prob), int(seed), row_key)
 
 
 def tn_matmul(x: torch.Tensor, dy: torch.Tensor, chunk: int = 2048) -> torch.Tensor:
@@ -169,6 +204,7 @@ class MLP(object):
         self.hid_sizes = list(hid_sizes)
         self.dropout_keep_prob = dropout_keep_prob
         self.device = device
+        self.dropout_seed = None      # callable(layer) -> 64-bit seed of this layer's weight mask (set by the model)
         self.params = self.make_network_params()
 
     def make_network_params(self):
@@ -183,11 +219,18 @@ class MLP(object):
         # promote to float64 through the np.float64 scalar, so cast explicitly
         return (np.sqrt(6.0 / (shape[-2] + shape[-1])) * (2 * np.random.rand(*shape).astype(np.float32) - 1)).astype(np.float32)
 
+    def dropped_weight(self, layer: int) -> torch.Tensor:
+        """utils.py:68: tf.nn.dropout on the layer's weight matrix (identity at keep_prob 1)."""
+        keep = self.dropout_keep_prob() if callable(self.dropout_keep_prob) else self.dropout_keep_prob
+        W = self.params["weights"][layer]
+        if keep >= 1.0:
+            return W
+        return tf_dropout(W, keep, self.dropout_seed(layer) if self.dropout_seed is not None else None)
+
     def __call__(self, inputs):
         acts = inputs
-        keep = self.dropout_keep_prob() if callable(self.dropout_keep_prob) else self.dropout_keep_prob
         hid = acts
-        for W, b in zip(self.params["weights"], self.params["biases"]):
-            hid = _TallLinear.apply(acts, tf_dropout(W, keep), b)
+        for i, b in enumerate(self.params["biases"]):
+            hid = _TallLinear.apply(acts, self.dropped_weight(i), b)
             acts = torch.relu(hid)
         return hid

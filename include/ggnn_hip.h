@@ -454,6 +454,16 @@ int ggnn_assemble_batch(const void* const* ds_tables, int A, int T, const int64_
                         const int32_t* batch_tab, int G, int V, int M, int R, int D, const int64_t* type_off,
                         const int64_t* type_row_off, void* const* out, ggnn_stream_t stream);
 
+/* ---- tf.nn.dropout with a counter-based mask (chem_tensorflow_sparse.py:91 edge-weight dropout, :113-114 DropoutWrapper on the
+ * new node state; chem_tensorflow_dense.py:104; utils.py:68 readout weights) ------------------------------------------------------
+ *   out[r,c] = x[r,c] / keep_prob * floor(keep_prob + U),   U = (Philox4x32-10(counter, key)[c % 4] >> 8) * 2^-24
+ *   key = (seed lo, seed hi), counter = (rowkey lo, rowkey hi, c / 4, 0), rowkey = row_key[r] (row_key != NULL) or row_key_base + r.
+ * The mask is a pure function of (seed, row key, column): ranks of a data-parallel job derive identical weight masks from the
+ * same seed, a node's state mask does not depend on the batch it sits in, and the backward pass is the same call on dL/dout.
+ * x, out [rows, cols] contiguous fp32 (in place allowed); any cols (16-byte accesses when cols % 4 == 0). */
+int ggnn_dropout_f32(const float* x, float* out, const int64_t* row_key, int64_t row_key_base, uint64_t seed, float keep_prob,
+                     int64_t rows, int cols, ggnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,44 @@ def basic_rnn_cell(x, h, W, b, act=np.tanh):
 # ----------------------------------------------------------------------------------------------
 # One sparse propagation step and the layer/timestep driver
 # ----------------------------------------------------------------------------------------------
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123) on uint32 arrays:
+    counter [..., 4], key [..., 2] -> [..., 4].  Pinned by Random123's published known-answer vectors (tests/test_oracle.py)."""
+    c = [np.asarray(counter[..., i], dtype=np.uint64) for i in range(4)]
+    k0 = np.asarray(key[..., 0], dtype=np.uint64)
+    k1 = np.asarray(key[..., 1], dtype=np.uint64)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & mask, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & mask]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def counter_dropout(x, keep_prob, seed, row_key=None, row_key_base=0):
+    """tf.nn.dropout's arithmetic, x / keep * floor(keep + U) (nn_ops.py @ TF r1.3; reference call sites
+    chem_tensorflow_sparse.py:91,113-114, chem_tensorflow_dense.py:104, utils.py:68), with the package's counter-based
+    uniform: U[r, c] = (philox(counter=(key_r lo, key_r hi, c // 4, 0), key=(seed lo, seed hi))[c % 4] >> 8) * 2^-24,
+    key_r = row_key[r] or row_key_base + r.  x [rows, cols] float32 -> float32 (bit-exact twin of ggnn_dropout_f32)."""
+    x = np.asarray(x, dtype=np.float32)
+    rows, cols = x.shape
+    quads = (cols + 3) // 4
+    keys = (np.asarray(row_key, dtype=np.int64) if row_key is not None else np.int64(row_key_base) + np.arange(rows, dtype=np.int64))
+    keys = keys.astype(np.uint64)
+    ctr = np.zeros((rows, quads, 4), dtype=np.uint64)
+    ctr[..., 0] = (keys & np.uint64(0xFFFFFFFF))[:, None]
+    ctr[..., 1] = (keys >> np.uint64(32))[:, None]
+    ctr[..., 2] = np.arange(quads, dtype=np.uint64)[None, :]
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, seed >> 32], dtype=np.uint64), (rows, quads, 2))
+    u = philox4x32_10(ctr, key).reshape(rows, quads * 4)[:, :cols]
+    U = (u >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    keep = np.float32(keep_prob)
+    return (x / keep * np.floor(keep + U)).astype(np.float32)
+
+
 def unsorted_segment_max(data, segment_ids, num_segments):
     """tf.unsorted_segment_max (chem_tensorflow_sparse.py:180-182): segments without entries hold the lowest
     representable value of the dtype."""

@@ -20,6 +20,10 @@ pytestmark = pytest.mark.gpu
 PKG = "gated-graph-neural-network-samples_amd"
 CFG = {"batch_size": 700, "edge_weight_dropout_keep_prob": 1.0, "graph_state_dropout_keep_prob": 1.0,
        "task_sample_ratios": {}}
+# the reference's training recipe (chem_tensorflow_sparse.py:59,91,113-114,285): weight dropout 0.8, plus state and readout
+# dropout -- every mask is counter-based (ggnn_dropout_f32), so the ranks' weight masks agree by construction and a node keeps
+# its state mask whichever shard it lands in
+CFG_DROPOUT = dict(CFG, edge_weight_dropout_keep_prob=0.8, graph_state_dropout_keep_prob=0.9, out_layer_dropout_keep_prob=0.9)
 
 
 def _free_port():
@@ -30,15 +34,18 @@ def _dataset(pkg):
     return pkg.synthetic_qm9(110, mean_nodes=14, seed=21)
 
 
-def _rank_worker(rank, world, port, backend, ret):
+def _rank_worker(rank, world, port, backend, ret, cfg=None):
+    cfg = CFG if cfg is None else cfg
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), GGNN_LOCAL_DEVICE="0", GGNN_DIST_BACKEND=backend)
     pkg = importlib.import_module(PKG)
     ctx = pkg.parallel.DataParallelContext.from_env()
     ms = _dataset(pkg)
     model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms,
-                                     "--config": dict(CFG), "dist": ctx})
+                                     "--config": dict(cfg), "dist": ctx})
     ctx.broadcast_(list(model.named_variables().values()))
+    if rank == 1 and cfg is not CFG:
+        torch.rand(977, device="cuda:0"); np.random.rand(3)    # a rank that drew something else: the masks must not care
     np.random.seed(123)                                        # the epoch shuffle: same order on every rank
     loss, accs, errs, speed, steps = model.run_epoch("epoch 1 (training)", model.train_data, True)
     ret[rank] = {"weights": {k: v.detach().cpu().numpy() for k, v in model.named_variables().items()},
@@ -46,11 +53,11 @@ def _rank_worker(rank, world, port, backend, ret):
     torch.distributed.destroy_process_group()
 
 
-def _single_process_reference(pkg, world):
+def _single_process_reference(pkg, world, cfg=CFG):
     """The same epoch in ONE process: step s trains on the union of the batches the ranks hold at step s."""
     ms = _dataset(pkg)
     model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms,
-                                     "--config": dict(CFG)})
+                                     "--config": dict(cfg)})
     np.random.seed(123)
     data = model.train_data
     msd = data["molecules"]
@@ -64,7 +71,9 @@ def _single_process_reference(pkg, world):
         ids = perm[lo:hi]
         sb = pkg.data.pack_batch(msd, ids, model.num_edge_types, model.params["hidden_size"], label_mask=data["label_mask"])
         feed = model.to_device_batch(sb)
-        feed["graph_state_keep_prob"] = 1.0; feed["edge_weight_dropout_keep_prob"] = 1.0; feed["out_layer_dropout_keep_prob"] = 1.0
+        feed["graph_state_keep_prob"] = cfg["graph_state_dropout_keep_prob"]
+        feed["edge_weight_dropout_keep_prob"] = cfg["edge_weight_dropout_keep_prob"]
+        feed["out_layer_dropout_keep_prob"] = cfg.get("out_layer_dropout_keep_prob", 1.0)
         l = model.train_batch(feed)
         losses.append(float(l)); graphs.append(len(ids)); accs.append(float(model.ops["accuracy_task0"]))
     g = np.asarray(graphs, float)
@@ -72,11 +81,12 @@ def _single_process_reference(pkg, world):
             float((np.asarray(losses) * g).sum() / g.sum()), float((np.asarray(accs) * g).sum() / g.sum()), len(losses))
 
 
-def test_two_ranks_on_one_gpu_equal_single_process_union_batches(pkg, cuda):
+@pytest.mark.parametrize("cfg", [CFG, CFG_DROPOUT], ids=["keep1", "reference-dropout"])
+def test_two_ranks_on_one_gpu_equal_single_process_union_batches(pkg, cuda, cfg):
     world = 2
     mgr = mp.Manager(); ret = mgr.dict()
-    mp.spawn(_rank_worker, args=(world, _free_port(), "gloo", ret), nprocs=world, join=True)
-    want_w, want_loss, want_acc, steps = _single_process_reference(pkg, world)
+    mp.spawn(_rank_worker, args=(world, _free_port(), "gloo", ret, cfg), nprocs=world, join=True)
+    want_w, want_loss, want_acc, steps = _single_process_reference(pkg, world, cfg)
     assert ret[0]["steps"] == ret[1]["steps"] == steps
     for r in range(world):
         assert abs(ret[r]["loss"] - want_loss) < 1e-5 * max(1.0, abs(want_loss)), (ret[r]["loss"], want_loss)
@@ -114,3 +124,18 @@ def test_one_rank_rccl_process_group_runs_the_training_collectives(pkg, cuda):
     mp.spawn(_nccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
     l1, l0 = ret["loss"]
     assert abs(l1 - l0) <= 1e-6 * max(1.0, abs(l0)) and ret["worst"] <= 1e-6
+
+
+def test_bench_two_ranks_on_one_gpu(cuda):
+    """`python bench.py --gpus 2` as the driver starts it (no launcher): two ranks, here sharing cuda:0 and talking over gloo
+    (GGNN_LOCAL_DEVICE / GGNN_DIST_BACKEND), run the forward headline and the training step with its flat gradient all-reduce."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GGNN_LOCAL_DEVICE="0", GGNN_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batches", "2",
+                        "--min-time", "0.05", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["value"] > 0
+    assert line["train"]["n_gpus"] == 2 and line["train"]["ms_per_step"] > 0 and line["allreduce_us"] > 0

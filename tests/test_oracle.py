@@ -196,3 +196,26 @@ def test_golden_fixture(oracle):
     states = oracle.sparse_propagate(g["h0"], adj, g["nin"], layers, p, return_all_layers=True)
     for i, s in enumerate(states):
         assert np.abs(s - g["state_%d" % i]).max() < 1e-12
+
+
+def test_philox_known_answers_and_counter_dropout(oracle):
+    """The counter-based dropout mask (ggnn_dropout_f32) is Philox4x32-10: Random123's published known-answer vectors
+    (kat_vectors: zero, all-ones, pi digits) pin the restatement; the mask keeps a fraction keep_prob, scales by 1/keep_prob, and
+    depends on (seed, row key, column) only."""
+    kat = lambda c, k: [int(v) for v in oracle.philox4x32_10(np.array(c, dtype=np.uint32), np.array(k, dtype=np.uint32))]
+    assert kat([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert kat([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert kat([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    x = np.random.default_rng(0).uniform(-1, 1, (3000, 100)).astype(np.float32)
+    y = oracle.counter_dropout(x, 0.8, 99)
+    kept = y != 0
+    assert abs(kept.mean() - 0.8) < 0.01
+    assert np.array_equal(y[kept], (x / np.float32(0.8))[kept])
+    # row keys, not row positions, select the mask: a permuted batch carries its masks along
+    keys = np.arange(3000, dtype=np.int64) * 7 + 5
+    perm = np.random.default_rng(1).permutation(3000)
+    a = oracle.counter_dropout(x, 0.8, 99, row_key=keys)
+    b = oracle.counter_dropout(x[perm], 0.8, 99, row_key=keys[perm])
+    assert np.array_equal(a[perm], b)
+    assert not np.array_equal(oracle.counter_dropout(x, 0.8, 100), y)
+    assert np.array_equal(oracle.counter_dropout(x, 0.8, 99, row_key_base=0), y)

@@ -267,3 +267,33 @@ def test_threaded_iterator_mirrors_reference_prefetcher(pkg):
         for x in TI(bad(), max_queue_size=2):
             got.append(x)
     assert got == [1]
+
+
+def test_bench_spawns_its_own_ranks_dry_run():
+    """Round-2 review item 1: `python bench.py --gpus 2` started WITHOUT a launcher must bring up its own two ranks (it used
+    to die on an assert).  --dry-run keeps everything around the kernels: rendezvous on 127.0.0.1, the rank/world sharding
+    of the host packer, the flat gradient all-reduce (gloo here, RCCL on GPUs), the barrier-bracketed timing."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["dry_run"] is True
+    assert line["sharded_graphs_total"] == line["dataset_graphs"]            # the two shards partition the dataset
+    assert line["allreduce_us"] > 0 and line["allreduce_bytes"] == 591802 * 4  # SURVEY 8e: 591,802 parameters
+    # a wrong --gpus / WORLD_SIZE pairing is an error message, not an assert
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode != 0 and "--gpus 2" in r.stderr
+
+
+def test_dropout_seed_is_a_pure_function_of_seed_step_site(pkg):
+    ds = pkg.utils.dropout_seed
+    a = ds(0, 3, "edge_weights", 2)
+    assert a == ds(0, 3, "edge_weights", 2) and 0 <= a < 2 ** 64
+    assert len({ds(0, 3, "edge_weights", 2), ds(1, 3, "edge_weights", 2), ds(0, 4, "edge_weights", 2), ds(0, 3, "edge_weights", 1),
+                ds(0, 3, "state", 2, 0)}) == 5
+    assert a == 0xeb003e833a661aac                                                         # platform-independent (blake2b of the repr)
