@@ -104,6 +104,60 @@ class ThreadedIterator:
             self.__thread.join(timeout=5.0)
 
 
+class StreamPrefetcher:
+    """Software pipeline over HIP streams, on ONE host thread: element i+1 of the wrapped iterator (a batch assembled on the GPU,
+    data_device.pack_batches_device) is produced on a side stream right after element i has been handed out, i.e. while the
+    consumer's kernels for element i run; the consumer's work goes round-robin onto `consumer_streams` (independent batches: the
+    tail of one batch's kernels is back-filled by the next batch's).  Yields (element, stream): the stream already waits for the
+    element's packing; the caller queues its work on it (`with torch.cuda.stream(stream)`).  An element is kept alive until the
+    work queued on its stream up to the next hand-out has completed (its memory belongs to the packing stream's pool).
+
+    The reference overlaps host-side packing with sess.run through a producer thread (utils.py:16-36, ThreadedIterator above);
+    with packing on the device a thread is not needed to overlap it -- only a second stream -- and the launching thread keeps
+    the interpreter lock to itself."""
+
+    def __init__(self, original_iterator, device, consumer_streams=None, pack_stream=None):
+        self._it = original_iterator
+        self._device = torch.device(device)
+        self._pack = pack_stream if pack_stream is not None else torch.cuda.Stream(self._device)
+        self._streams = list(consumer_streams) if consumer_streams else [None]
+        self._retired = collections.deque()
+
+    def _retire(self, element, stream):
+        if element is not None:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self._retired.append((ev, element))
+        while self._retired and self._retired[0][0].query():
+            self._retired.popleft()
+
+    def __iter__(self):
+        it = iter(self._it)
+        prev, prev_stream, k = None, None, 0
+        start = torch.cuda.Event()
+        start.record()                                   # whatever built the resident dataset is ordered before the first pack
+        self._pack.wait_event(start)
+        try:
+            while True:
+                with torch.cuda.stream(self._pack):
+                    try:
+                        element = next(it)
+                    except StopIteration:
+                        break
+                    ready = torch.cuda.Event()
+                    ready.record()
+                self._retire(prev, prev_stream)
+                stream = self._streams[k % len(self._streams)] or torch.cuda.current_stream(self._device)
+                stream.wait_event(ready)
+                prev, prev_stream, k = element, stream, k + 1
+                yield element, stream
+        finally:
+            self._retire(prev, prev_stream)
+            for ev, _ in self._retired:
+                ev.synchronize()
+            self._retired.clear()
+
+
 def glorot_init(shape):
     """utils.py:11-13 -- uniform(+-sqrt(6/(shape[-2]+shape[-1]))) from the global NumPy RNG."""
     initialization_range = np.sqrt(6.0 / (shape[-2] + shape[-1]))

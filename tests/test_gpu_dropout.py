@@ -84,17 +84,20 @@ def test_edge_weight_dropout_gradients_match_oracle(pkg, oracle, oracle_torch, c
         v.requires_grad_(False); v.grad = None
 
 
+@pytest.mark.parametrize("keep", [1.0, 0.8])
 @pytest.mark.parametrize("cfg", [{}, {"use_edge_bias": True, "layer_timesteps": [2, 1, 2], "residual_connections": {"1": [0], "2": [0, 1]}}])
-def test_edge_weight_gradients_go_through_the_sink_and_are_masked_once(pkg, oracle, cuda, cfg, monkeypatch):
+def test_edge_weight_gradients_go_through_the_sink_and_are_masked_once(pkg, oracle, cuda, cfg, keep, monkeypatch):
     """Advisor finding (round 2): the edge-weight products never reached the side-stream sink (the step saw a [T,D,D] view, the sink
-    a [T*D,D] variable).  They do now, also under weight dropout (raw products accumulate, the mask is applied once per layer in
-    sink.finish()); three steps with and without the sink end in the same weights, bit for bit."""
+    a [T*D,D] variable).  They do now.  Without weight dropout three steps with and without the sink end in the same weights, bit
+    for bit.  Under weight dropout the sink accumulates the RAW products of a layer's timesteps and masks the sum once
+    (mask * (dW_1 + dW_2) / keep), autograd sums the masked products (dW_1 / keep + dW_2 / keep on the kept entries): the same
+    gradient up to one rounding per addend, and exactly zero on the dropped entries either way."""
     results = []
     for side in (True, False):
         monkeypatch.setattr(pkg.backward, "USE_WGRAD_STREAM", side)
         model, layers, feed = _model(pkg, oracle, cfg, n=300, seed=4)
         feed["out_layer_dropout_keep_prob"] = 1.0
-        feed["edge_weight_dropout_keep_prob"] = 0.8
+        feed["edge_weight_dropout_keep_prob"] = keep
         for _ in range(3):
             model.train_batch(feed)
         torch.cuda.synchronize()
@@ -105,7 +108,11 @@ def test_edge_weight_gradients_go_through_the_sink_and_are_masked_once(pkg, orac
                 assert model._edge_weight_vars[l].data_ptr() in used, "edge weights of layer %d bypassed the sink" % l
             assert not pkg.backward._SINK.masks
     for k in results[0]:
-        assert torch.equal(results[0][k], results[1][k]), k
+        if keep >= 1.0:
+            assert torch.equal(results[0][k], results[1][k]), k
+        else:
+            # three Adam steps of size ~lr = 1e-3 each: 1 % of one step
+            assert float((results[0][k] - results[1][k]).abs().max()) < 1e-5, k
 
 
 def test_masks_follow_step_and_node_identity(pkg, oracle, cuda):

@@ -184,3 +184,34 @@ def test_variant_hip_backward_equals_autograd_of_torch_restatement(pkg, oracle, 
         scale = float(want.abs().max()) + 1e-12
         err = float((got - want).abs().max())
         assert err <= 3e-4 * scale + 1e-7, (name, err, scale)
+
+
+def test_stream_prefetcher_matches_sequential_packing(pkg, oracle, cuda):
+    """utils.StreamPrefetcher: batch i+1 assembled on a side stream under batch i's forward, forwards alternating over two compute
+    streams -- every batch's final states are bit-identical to packing and running the batches one after the other on one
+    stream (three passes, so that the packing stream's allocator pool is recycled under load)."""
+    ms = pkg.synthetic_qm9(700, mean_nodes=11, seed=12)
+    model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": None, "valid_data": ms,
+                                     "--config": {"batch_size": 1100}})
+    model.set_graph_weights(oracle.make_sparse_layers(np.random.default_rng(3), model.params, model.num_edge_types, random_bias=True))
+    dd = pkg.data_device
+    model.prepare_resident_data(model.valid_data, False)
+    dms = model.valid_data["molecules_dev"]
+    want = []
+    with torch.no_grad():
+        for fb in dd.pack_batches_device(dms, model.params, model.num_edge_types, None):
+            model.feed(fb)
+            want.append(model.compute_final_node_representations().cpu())
+        assert len(want) >= 6
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for _ in range(3):
+            got = []
+            gen = dd.pack_batches_device(dms, model.params, model.num_edge_types, None)
+            for fb, st in pkg.utils.StreamPrefetcher(gen, cuda, consumer_streams=streams):
+                with torch.cuda.stream(st):
+                    model.feed(fb)
+                    got.append(model.compute_final_node_representations())
+            torch.cuda.synchronize()
+            assert len(got) == len(want)
+            for a, b in zip(got, want):
+                assert torch.equal(a.cpu(), b)
