@@ -571,6 +571,12 @@ def main():
         del packed
         pool = torch.rand((max(params["batch_size"], max(nodes)), D), device=dev) * 2 - 1     # dense random states, as above
         e2e_streams = streams if streams is not None else [torch.cuda.current_stream()]
+        # the end-to-end leg runs whole epochs over a FULL-QM9-sized dataset (133,885 molecules, ~25 batches: configs[1]), so that
+        # the pipeline's fill and drain weigh what they weigh in an epoch of the real dataset (6-batch epochs overstate them 4x)
+        ms_full = pkg.synthetic_qm9(133885, mean_nodes=args.mean_nodes, seed=2000 + rank)
+        dms_e2e = dd.DeviceMoleculeSet(ms_full, dev, None)
+        dms_e2e.static_tables(T, params.get("tie_fwd_bkwd", True), pkg.ops.compact_supported(D))
+        e2e_batches = len(pkg.data.batch_boundaries(dms_e2e.nodes_per_graph, params["batch_size"])) - 1
 
         def fresh_epochs(reps, pipelined):
             """`reps` passes over the dataset, every batch packed fresh.  pipelined: batch i+1 is assembled on a side stream while
@@ -579,7 +585,7 @@ def main():
             with torch.no_grad():
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 for rep in range(reps):
-                    gen = dd.pack_batches_device(dms, params, T, None)
+                    gen = dd.pack_batches_device(dms_e2e, params, T, None)
                     if pipelined:
                         for fb, st in pkg.utils.StreamPrefetcher(gen, dev, consumer_streams=e2e_streams):
                             Vf = fb["initial_node_representation"].shape[0]
@@ -600,17 +606,18 @@ def main():
 
         gc.collect(); gc.freeze(); gc.disable()
         fresh_epochs(1, True)                                                       # warm (the side stream's allocator pool)
-        nn1, e2e1 = fresh_epochs(2, False)
-        reps = max(2, int(np.ceil(0.25 / max(e2e1 / 2, 1e-3))))
+        nn1, e2e1 = fresh_epochs(1, False)
+        reps = max(2, int(np.ceil(0.25 / max(e2e1, 1e-3))))
         nn, e2e = fresh_epochs(reps, True)
         gc.enable()
-        del pool
+        del pool, dms_e2e
         out["index_build_ms_per_batch"] = idx_ms
         out["pack_ms_per_batch"] = pack_ms
         out["end_to_end_fresh_batch"] = {
             "value": nn * n_prop / e2e, "unit": "node-state updates/s", "hip_streams": "%d compute + 1 packing" % len(e2e_streams),
-            "batches_timed": reps * len(feeds), "seconds": e2e, "one_stream_value": nn1 * n_prop / e2e1,
-            "what": "every step assembles a fresh ~100k-node batch on the GPU from graph ids (chem_tensorflow_sparse.py:278-350: h0, "
+            "epochs_timed": reps, "batches_per_epoch": e2e_batches, "molecules": ms_full.num_graphs, "seconds": e2e,
+            "one_stream_value": nn1 * n_prop / e2e1,
+            "what": "whole epochs over a full-QM9-sized synthetic dataset; every step assembles a fresh ~100k-node batch on the GPU from graph ids (chem_tensorflow_sparse.py:278-350: h0, "
                     "adjacency lists, in-degree table, graph_nodes_list, plus the message index of :120-129 and the source-pair "
                     "compaction) and runs the 8-step forward on it; batch i+1 is assembled on a side stream under batch i's forward, "
                     "forwards alternate over the compute streams (utils.StreamPrefetcher); one_stream_value: packing and forward "

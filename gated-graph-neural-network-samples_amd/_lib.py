@@ -113,6 +113,8 @@ SYMBOLS = {
     "ggnn_clip_adam_f32": (c_int, [c_void_p] * 9 + [c_int, c_float, c_float, c_float, c_float, c_float, c_void_p]),
     "ggnn_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ggnn_gemm_tn_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ggnn_pack_batch_tables": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
     "ggnn_dropout_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_uint64, c_float, c_int64, c_int, c_void_p]),
 }
 

@@ -50,9 +50,23 @@ __device__ __forceinline__ int seg_of(const int* __restrict__ tab, int n, int x)
     return lo;
 }
 
-__global__ void pack_nodes_kernel(PackTables ds, PackBatch b, int* __restrict__ gnl, int* __restrict__ graph_ptr,
-                                  float* __restrict__ nin, int* __restrict__ row_ptr) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+// The five gathers of a batch are independent of each other (every one derives the graph of its element from the prefix-sum tables),
+// so they run as ONE launch: consecutive block ranges work on nodes / state rows / messages / slots / compact rows (PackPlan).  A
+// batch is assembled next to a forward pass whose persistent workgroups own every CU for the length of a launch: each dependent
+// launch of the packer then waits for a launch boundary of the forward stream, and five of them (plus the slot heads) were most of
+// the time a batch spent coming together.
+struct PackPlan { int e_nodes, e_states, e_msgs, e_slots, e_pairs; };      // first block AFTER each task's range
+
+// compact row (slot_crow given) or transformed-state row of the message in dataset slot q of graph k (= dataset graph g)
+__device__ __forceinline__ void slot_rows(const PackTables& ds, const PackBatch& b, int q, int k, int g, int& row, int& crow) {
+    const int val = ds.slot_gather[q];
+    const int src = val / ds.T, t = val - src * ds.T;
+    row = (src - ds.node_ptr[g] + b.node_off[k]) * ds.T + t;
+    crow = ds.slot_crow ? b.type_row_off[t] + b.pair_off[(size_t)t * (b.G + 1) + k] + (ds.slot_crow[q] - ds.type_row_off[t] - ds.p_off[g * ds.T + t]) : -1;
+}
+
+__device__ __forceinline__ void pack_nodes(const PackTables& ds, const PackBatch& b, int v, int* __restrict__ gnl, int* __restrict__ graph_ptr,
+                                           float* __restrict__ nin, int* __restrict__ row_ptr, int4* __restrict__ heads) {
     if (v <= b.G) graph_ptr[v] = b.node_off[v];
     if (v == b.V) row_ptr[v] = b.M;
     if (v >= b.V) return;
@@ -62,16 +76,31 @@ __global__ void pack_nodes_kernel(PackTables ds, PackBatch b, int* __restrict__ 
     const int s = ds.node_ptr[g] + (v - b.node_off[k]);
     gnl[v] = k;
     for (int t = 0; t < ds.T; ++t) nin[(size_t)v * ds.T + t] = ds.nin[(size_t)s * ds.T + t];
-    row_ptr[v] = b.slot_off[k] + (ds.row_ptr[s] - ds.row_ptr[ds.node_ptr[g]]);
+    const int q0 = ds.row_ptr[s];
+    row_ptr[v] = b.slot_off[k] + (q0 - ds.row_ptr[ds.node_ptr[g]]);
+    if (heads) {
+        // the node's first four gather rows (ggnn_build_slot_heads) -- of the compacted rows when the batch has them
+        const int n = ds.row_ptr[s + 1] - q0;
+        int h[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = -1;
+            if (j < n) {
+                int row, crow;
+                slot_rows(ds, b, q0 + j, k, g, row, crow);
+                h[j] = ds.slot_crow ? crow : row;
+            }
+        }
+        heads[v] = make_int4(h[0], h[1], h[2], h[3]);
+    }
 }
 
 // h0[v, :] = [annotation | 0 ...]   (:300-302), one lane per (node, float4 column)
-__global__ void pack_states_kernel(PackTables ds, PackBatch b, const int* __restrict__ gnl, float* __restrict__ h0) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_states(const PackTables& ds, const PackBatch& b, long long i, float* __restrict__ h0) {
     const int D4 = b.D >> 2;
     if (i >= (long long)b.V * D4) return;
     const int v = (int)(i / D4), c4 = (int)(i - (long long)v * D4);
-    const int k = gnl[v];
+    const int k = seg_of(b.node_off, b.G + 1, v);          // (the D/4 lanes of a row search the same path: broadcast loads)
     const int s = ds.node_ptr[b.gid[k]] + (v - b.node_off[k]);
     float o[4];
 #pragma unroll
@@ -82,8 +111,7 @@ __global__ void pack_states_kernel(PackTables ds, PackBatch b, const int* __rest
     *reinterpret_cast<float4*>(h0 + (size_t)v * b.D + 4 * c4) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-__global__ void pack_messages_kernel(PackTables ds, PackBatch b, int2* __restrict__ adj) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_messages(const PackTables& ds, const PackBatch& b, int p, int2* __restrict__ adj) {
     if (p >= b.M) return;
     int t = 0;
     while (t + 1 < ds.T && p >= b.type_off[t + 1]) ++t;
@@ -97,23 +125,21 @@ __global__ void pack_messages_kernel(PackTables ds, PackBatch b, int2* __restric
     adj[p] = make_int2(e.x + shift, e.y + shift);
 }
 
-__global__ void pack_slots_kernel(PackTables ds, PackBatch b, int* __restrict__ gather_row, int* __restrict__ msg_perm,
-                                  int* __restrict__ gather_c) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_slots(const PackTables& ds, const PackBatch& b, int s, int* __restrict__ gather_row,
+                                           int* __restrict__ msg_perm, int* __restrict__ gather_c) {
     if (s >= b.M) return;
     const int k = seg_of(b.slot_off, b.G + 1, s);
     const int g = b.gid[k];
     const int q = ds.row_ptr[ds.node_ptr[g]] + (s - b.slot_off[k]);
-    const int val = ds.slot_gather[q];
-    const int src = val / ds.T, t = val - src * ds.T;
-    gather_row[s] = (src - ds.node_ptr[g] + b.node_off[k]) * ds.T + t;
-    const int gt = g * ds.T + t;
-    msg_perm[s] = b.type_off[t] + b.msg_off[(size_t)t * (b.G + 1) + k] + (ds.slot_msg[q] - ds.type_off[t] - ds.e_off[gt]);
-    if (gather_c) gather_c[s] = b.type_row_off[t] + b.pair_off[(size_t)t * (b.G + 1) + k] + (ds.slot_crow[q] - ds.type_row_off[t] - ds.p_off[gt]);
+    int row, crow;
+    slot_rows(ds, b, q, k, g, row, crow);
+    gather_row[s] = row;
+    const int t = row % ds.T;
+    msg_perm[s] = b.type_off[t] + b.msg_off[(size_t)t * (b.G + 1) + k] + (ds.slot_msg[q] - ds.type_off[t] - ds.e_off[g * ds.T + t]);
+    if (gather_c) gather_c[s] = crow;
 }
 
-__global__ void pack_pairs_kernel(PackTables ds, PackBatch b, int* __restrict__ pair_node) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_pairs(const PackTables& ds, const PackBatch& b, int r, int* __restrict__ pair_node) {
     if (r >= b.R) return;
     int t = 0;
     while (t + 1 < ds.T && r >= b.type_row_off[t + 1]) ++t;
@@ -123,6 +149,64 @@ __global__ void pack_pairs_kernel(PackTables ds, PackBatch b, int* __restrict__ 
     const int g = b.gid[k];
     const int q = ds.type_row_off[t] + ds.p_off[(size_t)g * ds.T + t] + (w - po[k]);
     pair_node[r] = ds.pair_node[q] - ds.node_ptr[g] + b.node_off[k];
+}
+
+__global__ __launch_bounds__(256) void pack_batch_kernel(PackTables ds, PackBatch b, PackPlan plan, float* __restrict__ h0, int* __restrict__ gnl,
+                                                         int* __restrict__ graph_ptr, float* __restrict__ nin, int2* __restrict__ adj,
+                                                         int* __restrict__ row_ptr, int* __restrict__ gather_row, int* __restrict__ msg_perm,
+                                                         int* __restrict__ pair_node, int* __restrict__ gather_c, int4* __restrict__ heads) {
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    if (blk < plan.e_nodes) pack_nodes(ds, b, blk * 256 + tid, gnl, graph_ptr, nin, row_ptr, heads);
+    else if (blk < plan.e_states) pack_states(ds, b, (long long)(blk - plan.e_nodes) * 256 + tid, h0);
+    else if (blk < plan.e_msgs) pack_messages(ds, b, (blk - plan.e_states) * 256 + tid, adj);
+    else if (blk < plan.e_slots) pack_slots(ds, b, (blk - plan.e_msgs) * 256 + tid, gather_row, msg_perm, gather_c);
+    else pack_pairs(ds, b, (blk - plan.e_slots) * 256 + tid, pair_node);
+}
+
+// ---- the (graph, type) prefix sums of a batch and its labels, on the device -----------------------------------------------------------
+// batch_tab = gid[G] | pre[rows][G+1] with pre[r][k] = sum of counts_t[r][gid[j]] over j < k  (rows: nodes, message slots, messages per
+// type, compact rows per type, compact rows -- the order ggnn_assemble_batch[_backward] read them in); one 1024-thread block per row.
+// Further blocks gather the batch's labels: target_values[i][j] = targets[gid[j]][task_ids[i]] * mask, target_mask[i][j] = mask
+// (chem_tensorflow_sparse.py:319-321, 335: masked labels feed 0).  Replaces ~10 small torch launches per batch by one.
+__global__ __launch_bounds__(1024) void pack_tables_kernel(const int* __restrict__ counts_t, int Gd, int rows, const long long* __restrict__ gids,
+                                                           int G, int* __restrict__ batch_tab, const float* __restrict__ targets,
+                                                           const float* __restrict__ label_mask, int num_targets,
+                                                           const long long* __restrict__ task_ids, int K, float* __restrict__ tv,
+                                                           float* __restrict__ tm) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < rows) {
+        const int row = blockIdx.x;
+        const int* c = counts_t + (size_t)row * Gd;
+        int* pre = batch_tab + G + (size_t)row * (G + 1);
+        const int chunk = (G + 1023) / 1024;
+        const int beg = min(tid * chunk, G), end = min(beg + chunk, G);
+        int sum = 0;
+        for (int j = beg; j < end; ++j) sum += c[gids[j]];
+        part[tid] = sum;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {                  // inclusive scan of the 1024 chunk sums
+            const int add = tid >= off ? part[tid - off] : 0;
+            __syncthreads();
+            part[tid] += add;
+            __syncthreads();
+        }
+        int run = part[tid] - sum;
+        if (tid == 0) pre[0] = 0;
+        for (int j = beg; j < end; ++j) {
+            run += c[gids[j]];
+            pre[j + 1] = run;
+            if (row == 0) batch_tab[j] = (int)gids[j];
+        }
+    } else {
+        const long long i = (long long)(blockIdx.x - rows) * 1024 + tid;
+        if (i >= (long long)K * G) return;
+        const int ti = (int)(i / G), j = (int)(i - (long long)ti * G);
+        const size_t src = (size_t)gids[j] * num_targets + task_ids[ti];
+        const float m = label_mask ? label_mask[src] : 1.0f;
+        tv[i] = targets[src] * m;
+        tm[i] = m;
+    }
 }
 
 // ---- the backward pass's transpose structures (ops.CompactBackward, the by-source CSR), gathered the same way -----------------------
@@ -149,8 +233,8 @@ __device__ __forceinline__ int remap_msg(const PackTables& ds, const PackBatch& 
     return b.type_off[t] + b.msg_off[(size_t)t * (b.G + 1) + k] + (m_ds - ds.type_off[t] - ds.e_off[(size_t)g * ds.T + t]);
 }
 
-__global__ void pack_src_rowptr_kernel(PackTables ds, PackBwdTables bw, PackBatch b, const int* __restrict__ gnl, int* __restrict__ src_row_ptr) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_src_rowptr(const PackTables& ds, const PackBwdTables& bw, const PackBatch& b, long long i,
+                                                const int* __restrict__ gnl, int* __restrict__ src_row_ptr) {
     const long long n = (long long)b.V * ds.T;
     if (i == n) src_row_ptr[i] = b.M;
     if (i >= n) return;
@@ -161,8 +245,8 @@ __global__ void pack_src_rowptr_kernel(PackTables ds, PackBwdTables bw, PackBatc
     src_row_ptr[i] = b.slot_off[k] + (bw.src_row_ptr[(size_t)s * ds.T + t] - bw.src_row_ptr[(size_t)n0 * ds.T]);
 }
 
-__global__ void pack_src_slots_kernel(PackTables ds, PackBwdTables bw, PackBatch b, int* __restrict__ src_gather, int* __restrict__ src_msg) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_src_slots(const PackTables& ds, const PackBwdTables& bw, const PackBatch& b, int s,
+                                               int* __restrict__ src_gather, int* __restrict__ src_msg) {
     if (s >= b.M) return;
     const int k = seg_of(b.slot_off, b.G + 1, s);
     const int g = b.gid[k];
@@ -172,8 +256,8 @@ __global__ void pack_src_slots_kernel(PackTables ds, PackBwdTables bw, PackBatch
 }
 
 // slots of the compact rows: type-major like the message lists, so the (type, graph) lookup of pack_messages_kernel applies
-__global__ void pack_rows_slots_kernel(PackTables ds, PackBwdTables bw, PackBatch b, int* __restrict__ rows_gather, int* __restrict__ rows_msg) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_rows_slots(const PackTables& ds, const PackBwdTables& bw, const PackBatch& b, int p,
+                                                int* __restrict__ rows_gather, int* __restrict__ rows_msg) {
     if (p >= b.M) return;
     const int t = type_of(b.type_off, ds.T, p);
     const int w = p - b.type_off[t];
@@ -185,8 +269,7 @@ __global__ void pack_rows_slots_kernel(PackTables ds, PackBwdTables bw, PackBatc
     rows_msg[p] = remap_msg(ds, b, bw.rows_msg[q], k, g);
 }
 
-__global__ void pack_rows_rp_kernel(PackTables ds, PackBwdTables bw, PackBatch b, int* __restrict__ rows_rp) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_rows_rp(const PackTables& ds, const PackBwdTables& bw, const PackBatch& b, int r, int* __restrict__ rows_rp) {
     if (r == b.R) rows_rp[r] = b.M;
     if (r >= b.R) return;
     const int t = type_of(b.type_row_off, ds.T, r);
@@ -199,9 +282,9 @@ __global__ void pack_rows_rp_kernel(PackTables ds, PackBwdTables bw, PackBatch b
     rows_rp[r] = b.type_off[t] + b.msg_off[(size_t)t * (b.G + 1) + k] + (bw.rows_rp[q] - ds.type_off[t] - ds.e_off[(size_t)g * ds.T + t]);
 }
 
-__global__ void pack_node_rows_kernel(PackTables ds, PackBwdTables bw, PackBatch b, const int* __restrict__ gnl, const int* __restrict__ ptot,
-                                      int* __restrict__ node_rp, int* __restrict__ node_order) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_node_rows(const PackTables& ds, const PackBwdTables& bw, const PackBatch& b, int i,
+                                               const int* __restrict__ gnl, const int* __restrict__ ptot, int* __restrict__ node_rp,
+                                               int* __restrict__ node_order) {
     if (i <= b.V) {
         if (i == b.V) node_rp[i] = b.R;
         else {
@@ -216,6 +299,22 @@ __global__ void pack_node_rows_kernel(PackTables ds, PackBwdTables bw, PackBatch
     const int r_ds = bw.node_order[bw.node_rp[ds.node_ptr[g]] + (i - ptot[k])];
     const int t = type_of(ds.type_row_off, ds.T, r_ds);
     node_order[i] = b.type_row_off[t] + b.pair_off[(size_t)t * (b.G + 1) + k] + (r_ds - ds.type_row_off[t] - ds.p_off[(size_t)g * ds.T + t]);
+}
+
+struct PackBwdPlan { int e_rowptr, e_src, e_rows, e_rp; };                 // first block AFTER each task's range; the rest: node rows
+
+__global__ __launch_bounds__(256) void pack_batch_backward_kernel(PackTables ds, PackBwdTables bw, PackBatch b, PackBwdPlan plan,
+                                                                  const int* __restrict__ gnl, const int* __restrict__ ptot,
+                                                                  int* __restrict__ src_row_ptr, int* __restrict__ src_gather,
+                                                                  int* __restrict__ src_msg, int* __restrict__ rows_rp,
+                                                                  int* __restrict__ rows_gather, int* __restrict__ rows_msg,
+                                                                  int* __restrict__ node_rp, int* __restrict__ node_order) {
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    if (blk < plan.e_rowptr) pack_src_rowptr(ds, bw, b, (long long)blk * 256 + tid, gnl, src_row_ptr);
+    else if (blk < plan.e_src) pack_src_slots(ds, bw, b, (blk - plan.e_rowptr) * 256 + tid, src_gather, src_msg);
+    else if (blk < plan.e_rows) pack_rows_slots(ds, bw, b, (blk - plan.e_src) * 256 + tid, rows_gather, rows_msg);
+    else if (blk < plan.e_rp) pack_rows_rp(ds, bw, b, (blk - plan.e_rows) * 256 + tid, rows_rp);
+    else pack_node_rows(ds, bw, b, (blk - plan.e_rp) * 256 + tid, gnl, ptot, node_rp, node_order);
 }
 
 }  // namespace ggnn
@@ -268,18 +367,16 @@ extern "C" int ggnn_assemble_batch_backward(const void* const* ds_tables, const 
                    "null output");
     hipStream_t st = (hipStream_t)stream;
     const long long nvt = (long long)V * T + 1;
-    hipLaunchKernelGGL(pack_src_rowptr_kernel, dim3((unsigned)((nvt + 255) / 256)), dim3(256), 0, st, ds, bw, b, graph_nodes_list, src_row_ptr);
-    GGNN_CHECK_HIP(hipGetLastError());
-    if (M) {
-        hipLaunchKernelGGL(pack_src_slots_kernel, dim3((M + 255) / 256), dim3(256), 0, st, ds, bw, b, src_gather, src_msg);
-        GGNN_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(pack_rows_slots_kernel, dim3((M + 255) / 256), dim3(256), 0, st, ds, bw, b, rows_gather, rows_msg);
-        GGNN_CHECK_HIP(hipGetLastError());
-    }
-    hipLaunchKernelGGL(pack_rows_rp_kernel, dim3((R + 1 + 255) / 256), dim3(256), 0, st, ds, bw, b, rows_rp);
-    GGNN_CHECK_HIP(hipGetLastError());
+    GGNN_CHECK_ARG(nvt < (1LL << 31) - 256, "V*T overflows int32");
+    PackBwdPlan plan{};
+    plan.e_rowptr = (int)((nvt + 255) / 256);
+    plan.e_src = plan.e_rowptr + (M + 255) / 256;
+    plan.e_rows = plan.e_src + (M + 255) / 256;
+    plan.e_rp = plan.e_rows + (R + 1 + 255) / 256;
     const int nn = (V > R ? V : R) + 1;
-    hipLaunchKernelGGL(pack_node_rows_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, ds, bw, b, graph_nodes_list, ptot, node_rp, node_order);
+    const int blocks = plan.e_rp + (nn + 255) / 256;
+    hipLaunchKernelGGL(pack_batch_backward_kernel, dim3(blocks), dim3(256), 0, st, ds, bw, b, plan, graph_nodes_list, ptot, src_row_ptr,
+                       src_gather, src_msg, rows_rp, rows_gather, rows_msg, node_rp, node_order);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
@@ -298,24 +395,35 @@ extern "C" int ggnn_assemble_batch(const void* const* ds_tables, int A, int T, c
     int* gather_c = static_cast<int*>(out[9]);
     GGNN_CHECK_ARG(graph_ptr && row_ptr && (V == 0 || (h0 && gnl && nin)) && (M == 0 || (adj && gather_row && msg_perm)), "null output");
     GGNN_CHECK_ARG(!compact || M == 0 || (gather_c && (R == 0 || pair_node)), "null compaction output");
+    int4* heads = reinterpret_cast<int4*>(out[10]);
+    GGNN_CHECK_ARG(!heads || aligned16(heads), "slot heads must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int nv = (V > G ? V : G) + 1;
-    hipLaunchKernelGGL(pack_nodes_kernel, dim3((nv + 255) / 256), dim3(256), 0, st, ds, b, gnl, graph_ptr, nin, row_ptr);
+    const long long n4 = (long long)V * (D / 4);
+    GGNN_CHECK_ARG((n4 + 255) / 256 < (1LL << 30), "batch too large");
+    PackPlan plan{};
+    plan.e_nodes = (nv + 255) / 256;
+    plan.e_states = plan.e_nodes + (int)((n4 + 255) / 256);
+    plan.e_msgs = plan.e_states + (M + 255) / 256;
+    plan.e_slots = plan.e_msgs + (M + 255) / 256;
+    plan.e_pairs = plan.e_slots + (compact ? (R + 255) / 256 : 0);
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(plan.e_pairs), dim3(256), 0, st, ds, b, plan, h0, gnl, graph_ptr, nin, adj, row_ptr, gather_row,
+                       msg_perm, pair_node, compact ? gather_c : nullptr, heads);
     GGNN_CHECK_HIP(hipGetLastError());
-    if (V) {
-        const long long n4 = (long long)V * (D / 4);
-        hipLaunchKernelGGL(pack_states_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, ds, b, (const int*)gnl, h0);
-        GGNN_CHECK_HIP(hipGetLastError());
-    }
-    if (M) {
-        hipLaunchKernelGGL(pack_messages_kernel, dim3((M + 255) / 256), dim3(256), 0, st, ds, b, adj);
-        GGNN_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(pack_slots_kernel, dim3((M + 255) / 256), dim3(256), 0, st, ds, b, gather_row, msg_perm, compact ? gather_c : nullptr);
-        GGNN_CHECK_HIP(hipGetLastError());
-    }
-    if (compact && R) {
-        hipLaunchKernelGGL(pack_pairs_kernel, dim3((R + 255) / 256), dim3(256), 0, st, ds, b, pair_node);
-        GGNN_CHECK_HIP(hipGetLastError());
-    }
+    return GGNN_OK;
+}
+
+extern "C" int ggnn_pack_batch_tables(const int32_t* counts_t, int Gd, int rows, const int64_t* gids, int G, const float* targets,
+                                      const float* label_mask, int num_targets, const int64_t* task_ids, int K, int32_t* batch_tab,
+                                      float* target_values, float* target_mask, ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(Gd >= 0 && rows > 0 && G >= 0 && K >= 0 && num_targets >= 0, "bad sizes Gd=%d rows=%d G=%d K=%d", Gd, rows, G, K);
+    GGNN_CHECK_ARG(batch_tab && (G == 0 || (counts_t && gids)), "null pointer");
+    GGNN_CHECK_ARG(K == 0 || G == 0 || (targets && task_ids && target_values && target_mask), "null label pointer");
+    const long long nlab = (long long)K * G;
+    const int blocks = rows + (int)((nlab + 1023) / 1024);
+    hipLaunchKernelGGL(pack_tables_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, counts_t, Gd, rows,
+                       reinterpret_cast<const long long*>(gids), G, batch_tab, targets, label_mask, num_targets,
+                       reinterpret_cast<const long long*>(task_ids), K, target_values, target_mask);
+    GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }

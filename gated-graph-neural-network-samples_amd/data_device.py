@@ -93,6 +93,14 @@ class DeviceMoleculeSet:
         return hit
 
 
+    def arange_i32(self, n: int) -> torch.Tensor:
+        """arange(n) int32 on the device, cut from one cached ramp (the identity row list of the backward's compacted transform:
+        one launch less per training batch)."""
+        ramp = getattr(self, "_ramp", None)
+        if ramp is None or ramp.numel() < n:
+            ramp = self._ramp = torch.arange(max(n, 1 << 18), dtype=torch.int32, device=self.device)
+        return ramp[:n]
+
     def task_ids_dev(self, task_ids) -> torch.Tensor:
         key = tuple(int(t) for t in task_ids)
         if getattr(self, "_tids", (None, None))[0] != key:
@@ -163,10 +171,12 @@ class DeviceMoleculeSet:
 
 
 def _assemble_from_tables(dms: DeviceMoleculeSet, tab: dict, gids_h: np.ndarray, hidden_size: int, training: bool = False,
-                          gids_dev: Optional[torch.Tensor] = None):
+                          gids_dev: Optional[torch.Tensor] = None, task_ids: Sequence[int] = (0,)):
     """h0, graph_nodes_list, graph_ptr, nin and the batch's MessageIndex (+ compacted sources, slot heads) gathered from the
-    dataset-level tables: the (graph, type) prefix sums come from per-molecule count tables on the host, go up in one small copy,
-    and ggnn_assemble_batch does the rest in five launches."""
+    dataset-level tables: the (graph, type) prefix sums come from per-molecule count tables, and ggnn_assemble_batch does the rest
+    in ONE launch.  With the graph ids on the device (an epoch's order is uploaded once) the prefix sums and the batch's labels are
+    formed there too (ggnn_pack_batch_tables, one launch): a batch is two dependent launches (+ one for the backward structures).
+    Returns (h0, gnl, graph_ptr, nin, index, type_off, labels) with labels = (target_values, target_mask) or None (host path)."""
     lib = _lib.load()
     dev = dms.device
     T, A = tab["T"], tab["A"]
@@ -175,22 +185,37 @@ def _assemble_from_tables(dms: DeviceMoleculeSet, tab: dict, gids_h: np.ndarray,
     n = dms.nodes_per_graph[gids_h].astype(np.int64)
     mg = tab["msgs_gt"][gids_h].reshape(G, T)
     pg = tab["pairs_gt"][gids_h].reshape(G, T) if compact else np.zeros((G, T), np.int64)
-    incl = lambda c: np.concatenate([np.zeros((1,) + c.shape[1:], np.int64), np.cumsum(c, axis=0)])
-    node_off, slot_off, msg_off, pair_off = incl(n), incl(mg.sum(axis=1)), incl(mg), incl(pg)
-    V, M, R = int(node_off[-1]), int(slot_off[-1]), int(pair_off[-1].sum())
-    type_off = [0] + [int(x) for x in np.cumsum(msg_off[-1])]
-    type_row_off = [0] + [int(x) for x in np.cumsum(pair_off[-1])]
+    if gids_dev is not None:
+        V, M = int(n.sum()), int(mg.sum())
+        tsum, psum = mg.sum(axis=0), pg.sum(axis=0)
+        R = int(psum.sum())
+        type_off = [0] + [int(x) for x in np.cumsum(tsum)]
+        type_row_off = [0] + [int(x) for x in np.cumsum(psum)]
+    else:
+        incl = lambda c: np.concatenate([np.zeros((1,) + c.shape[1:], np.int64), np.cumsum(c, axis=0)])
+        node_off, slot_off, msg_off, pair_off = incl(n), incl(mg.sum(axis=1)), incl(mg), incl(pg)
+        V, M, R = int(node_off[-1]), int(slot_off[-1]), int(pair_off[-1].sum())
+        type_off = [0] + [int(x) for x in np.cumsum(msg_off[-1])]
+        type_row_off = [0] + [int(x) for x in np.cumsum(pair_off[-1])]
     if V * T >= 2 ** 31 - 1 or V * hidden_size >= 2 ** 31 - 1:
         raise ValueError("batch too large for 32-bit indices")
+    st = torch.cuda.current_stream().cuda_stream
+    labels = None
     if gids_dev is not None:
         # the graph ids are on the device already (pack_batches_device uploads an epoch's order once): the prefix sums are formed
         # there too -- a host->device copy per batch would make the host wait for everything queued on the stream, i.e. for
         # the previous batch's whole forward pass (tools/h2d_probe.py)
         ct = tab["counts_dev_t"]                                                # [2 + 2T + 1, Gd]
-        pre = torch.zeros((ct.shape[0], G + 1), dtype=torch.int32, device=dev)
-        if G:
-            torch.cumsum(torch.index_select(ct, 1, gids_dev), 1, dtype=torch.int32, out=pre[:, 1:])     # (scans along contiguous rows)
-        bt = torch.cat([gids_dev.to(torch.int32), pre.reshape(-1)])
+        rows = ct.shape[0]
+        bt = torch.empty(G + rows * (G + 1), dtype=torch.int32, device=dev)
+        tids = dms.task_ids_dev(task_ids)
+        K = int(tids.numel())
+        tv = torch.empty((K, G), dtype=torch.float32, device=dev)
+        tm = torch.empty((K, G), dtype=torch.float32, device=dev)
+        _lib.check(lib.ggnn_pack_batch_tables(ct.data_ptr(), ct.shape[1], rows, gids_dev.data_ptr(), G, dms.targets.data_ptr(),
+                                              None if dms.label_mask is None else dms.label_mask.data_ptr(), dms.targets.shape[1],
+                                              tids.data_ptr(), K, bt.data_ptr(), tv.data_ptr(), tm.data_ptr(), st))
+        labels = (tv, tm)
     else:
         batch_tab = np.concatenate([gids_h, node_off, slot_off, msg_off.T.ravel(), pair_off.T.ravel(), pair_off.sum(axis=1)]).astype(np.int32)
         bt = torch.from_numpy(batch_tab).to(dev)
@@ -199,33 +224,36 @@ def _assemble_from_tables(dms: DeviceMoleculeSet, tab: dict, gids_h: np.ndarray,
     gnl, graph_ptr, nin = i32(V), i32(G + 1), torch.empty((V, T), dtype=torch.float32, device=dev)
     adj, row_ptr, gather_row, msg_perm = i32(M, 2), i32(V + 1), i32(M), i32(M)
     pair_node, gather_c = (i32(max(R, 1)), i32(M)) if compact else (None, None)
-    outs = [h0, gnl, graph_ptr, nin, adj, row_ptr, gather_row, msg_perm, pair_node, gather_c]
-    c_out = (ctypes.c_void_p * 10)(*[None if t is None or t.numel() == 0 else t.data_ptr() for t in outs])
+    heads = i32(V, 4) if (ops.USE_SLOT_HEADS and V and M) else None
+    outs = [h0, gnl, graph_ptr, nin, adj, row_ptr, gather_row, msg_perm, pair_node, gather_c, heads]
+    c_out = (ctypes.c_void_p * 11)(*[None if t is None or t.numel() == 0 else t.data_ptr() for t in outs])
     c_to = (ctypes.c_int64 * (T + 1))(*type_off)
     c_tro = (ctypes.c_int64 * (T + 1))(*type_row_off)
     _lib.check(lib.ggnn_assemble_batch(tab["ptrs"], A, T, tab["c_type_off"], tab["c_type_row_off"], bt.data_ptr(), G, V, M, R,
-                                       hidden_size, c_to, c_tro, c_out, torch.cuda.current_stream().cuda_stream))
+                                       hidden_size, c_to, c_tro, c_out, st))
     index = ops.MessageIndex(adj, type_off, row_ptr, gather_row, msg_perm, V, T)
+    if heads is not None and not compact:
+        index._slot_heads = (gather_row, heads)
     if compact and M:
         comp = index._compact = ops.CompactSources(pair_node[:max(R, 1)], type_row_off, gather_c)
-        ops.slot_heads(comp, row_ptr, gather_c, V)
+        if heads is not None:
+            comp._slot_heads = (gather_c, heads)
         btab = dms.static_backward_tables(T, tab["tie"]) if training and R else None
         if btab is not None:
-            # the backward's transpose structures, gathered as well (ggnn_assemble_batch_backward: five more launches)
+            # the backward's transpose structures, gathered as well (ggnn_assemble_batch_backward: one more launch)
             src_rp, src_g, src_m = i32(V * T + 1), i32(M), i32(M)
             rows_rp, rows_g, rows_m, node_rp, node_order = i32(R + 1), i32(M), i32(M), i32(V + 1), i32(R)
             c_bout = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in (src_rp, src_g, src_m, rows_rp, rows_g, rows_m, node_rp, node_order)])
             _lib.check(lib.ggnn_assemble_batch_backward(tab["ptrs"], btab["bwd_ptrs"], A, T, tab["c_type_off"], tab["c_type_row_off"],
-                                                        bt.data_ptr(), gnl.data_ptr(), G, V, M, R, hidden_size, c_to, c_tro, c_bout,
-                                                        torch.cuda.current_stream().cuda_stream))
+                                                        bt.data_ptr(), gnl.data_ptr(), G, V, M, R, hidden_size, c_to, c_tro, c_bout, st))
             index._source_index = ops.MessageIndex(adj, type_off, src_rp, src_g, src_m, V * T, T)
             bwd = object.__new__(ops.CompactBackward)
             bwd.rows_index = ops.SegmentIndex(rows_rp, rows_g, R, rows_m)
             bwd.source_node_index = ops.SegmentIndex(src_rp[::T].contiguous(), src_g, V, src_m)
             bwd.node_index = ops.SegmentIndex(node_rp, node_order, V)
-            bwd.identity = ops.CompactSources(torch.arange(max(R, 1), dtype=torch.int32, device=dev), type_row_off, gather_c)
+            bwd.identity = ops.CompactSources(dms.arange_i32(max(R, 1)), type_row_off, gather_c)
             comp._bwd = bwd
-    return h0, gnl, graph_ptr, nin, index, type_off
+    return h0, gnl, graph_ptr, nin, index, type_off, labels
 
 
 def _ranges(starts: torch.Tensor, lengths: torch.Tensor, total: int) -> torch.Tensor:
@@ -257,14 +285,19 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
         raise IndexError("edge type outside [0, num_edge_types)")
     gids = torch.from_numpy(gids_h).to(dev) if graph_ids_dev is None else graph_ids_dev      # (int64, the batch's graphs on the device)
     tids = dms.task_ids_dev(task_ids)
-    tv = dms.targets[gids][:, tids].t().contiguous()                                # :335
-    tm = torch.ones_like(tv) if dms.label_mask is None else dms.label_mask[gids][:, tids].t().contiguous()
-    tv = tv * tm                                                                    # masked labels feed 0. (:319-321)
+
+    def labels_torch():
+        tv = dms.targets[gids][:, tids].t().contiguous()                            # :335
+        tm = torch.ones_like(tv) if dms.label_mask is None else dms.label_mask[gids][:, tids].t().contiguous()
+        return tv * tm, tm                                                          # masked labels feed 0. (:319-321)
+
     want_compact = bool(compact and ops.compact_supported(hidden_size))
     tab = dms.static_tables(T, tie_fwd_bkwd, want_compact) if (USE_STATIC_TABLES if static is None else static) else None
     if tab is not None:
-        # gathered from the dataset-level tables: no sort, no scan, five launches (ggnn_assemble_batch)
-        h0, gnl, graph_ptr, nin, index, type_off = _assemble_from_tables(dms, tab, gids_h, hidden_size, training, graph_ids_dev)
+        # gathered from the dataset-level tables: no sort, no scan, two launches (ggnn_pack_batch_tables, ggnn_assemble_batch)
+        h0, gnl, graph_ptr, nin, index, type_off, labels = _assemble_from_tables(dms, tab, gids_h, hidden_size, training, graph_ids_dev,
+                                                                                 task_ids)
+        tv, tm = labels if labels is not None else labels_torch()
         adjacency = [index.adj[type_off[t]:type_off[t + 1]] for t in range(T)]
         return {
             'initial_node_representation': h0, 'adjacency_lists': adjacency, 'num_incoming_edges_per_type': nin,
@@ -272,6 +305,7 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
             'message_index': ops.prepare_message_index(index, hidden_size, compact, training), 'graph_nodes_sorted': True,
             'graph_ids': gids,
         }
+    tv, tm = labels_torch()
     n = dms.node_ptr[gids + 1] - dms.node_ptr[gids]
     offs = torch.cumsum(n, 0) - n                                                   # node offset of each graph (:297)
     nsel = _ranges(dms.node_ptr[gids], n, V)

@@ -105,21 +105,30 @@ class ThreadedIterator:
 
 
 class StreamPrefetcher:
-    """Software pipeline over HIP streams, on ONE host thread: element i+1 of the wrapped iterator (a batch assembled on the GPU,
-    data_device.pack_batches_device) is produced on a side stream right after element i has been handed out, i.e. while the
-    consumer's kernels for element i run; the consumer's work goes round-robin onto `consumer_streams` (independent batches: the
-    tail of one batch's kernels is back-filled by the next batch's).  Yields (element, stream): the stream already waits for the
-    element's packing; the caller queues its work on it (`with torch.cuda.stream(stream)`).  An element is kept alive until the
-    work queued on its stream up to the next hand-out has completed (its memory belongs to the packing stream's pool).
+    """Software pipeline over HIP streams, on ONE host thread: the next `depth` elements of the wrapped iterator (batches assembled
+    on the GPU, data_device.pack_batches_device) are produced on side streams while the consumer's kernels for the current element
+    run; the consumer's work goes round-robin onto `consumer_streams` (independent batches: the tail of one batch's kernels is
+    back-filled by the next batch's).  Yields (element, stream): the stream already waits for the element's packing; the caller
+    queues its work on it (`with torch.cuda.stream(stream)`).  An element is kept alive until the work queued on its stream up
+    to the next hand-out has completed (its memory belongs to a packing stream's pool).
+
+    Packing a batch is a CHAIN of ~15 small dependent launches.  Next to a forward pass whose persistent workgroups own every CU
+    for the length of a launch, each link waits for a launch boundary, so one chain takes longer than a forward pass: the
+    packing streams are created with high priority (their kernels are dispatched first when workgroup slots free up) and
+    `depth` chains are kept in flight on `pack_streams` separate streams, so that a batch has `depth` forward passes' time to
+    come together.
 
     The reference overlaps host-side packing with sess.run through a producer thread (utils.py:16-36, ThreadedIterator above);
-    with packing on the device a thread is not needed to overlap it -- only a second stream -- and the launching thread keeps
-    the interpreter lock to itself."""
+    with packing on the device a thread is not needed to overlap it -- only more streams -- and the launching thread keeps the
+    interpreter lock to itself."""
 
-    def __init__(self, original_iterator, device, consumer_streams=None, pack_stream=None):
+    def __init__(self, original_iterator, device, consumer_streams=None, pack_streams=2, depth=3, priority=-1):
         self._it = original_iterator
         self._device = torch.device(device)
-        self._pack = pack_stream if pack_stream is not None else torch.cuda.Stream(self._device)
+        if isinstance(pack_streams, int):
+            pack_streams = [torch.cuda.Stream(self._device, priority=priority) for _ in range(max(1, pack_streams))]
+        self._packs = list(pack_streams)
+        self._depth = max(1, int(depth))
         self._streams = list(consumer_streams) if consumer_streams else [None]
         self._retired = collections.deque()
 
@@ -133,19 +142,31 @@ class StreamPrefetcher:
 
     def __iter__(self):
         it = iter(self._it)
-        prev, prev_stream, k = None, None, 0
+        queue = collections.deque()
+        prev, prev_stream, k, produced, exhausted = None, None, 0, 0, False
         start = torch.cuda.Event()
         start.record()                                   # whatever built the resident dataset is ordered before the first pack
-        self._pack.wait_event(start)
+        for ps in self._packs:
+            ps.wait_event(start)
         try:
             while True:
-                with torch.cuda.stream(self._pack):
-                    try:
-                        element = next(it)
-                    except StopIteration:
-                        break
-                    ready = torch.cuda.Event()
-                    ready.record()
+                # the first element is handed out as soon as it is packed; the queue then fills up two elements per hand-out (the
+                # consumer's kernels are running by then) -- packing `depth` batches up front would leave the GPU idle for as long
+                want = 1 if k == 0 else min(self._depth, len(queue) + 2)
+                while not exhausted and len(queue) < want:
+                    with torch.cuda.stream(self._packs[produced % len(self._packs)]):
+                        try:
+                            element = next(it)
+                        except StopIteration:
+                            exhausted = True
+                            break
+                        ready = torch.cuda.Event()
+                        ready.record()
+                    queue.append((element, ready))
+                    produced += 1
+                if not queue:
+                    break
+                element, ready = queue.popleft()
                 self._retire(prev, prev_stream)
                 stream = self._streams[k % len(self._streams)] or torch.cuda.current_stream(self._device)
                 stream.wait_event(ready)

@@ -440,7 +440,10 @@ int ggnn_clip_adam_f32(float* const* param_ptrs, const int32_t* var_numel, const
  *     the batch's graphs, in batch order);  type_off / type_row_off: host [T+1] of the batch.
  *   out [10]: 0 h0 f32[V,D] (annotation, zero-padded: :300-302)  1 graph_nodes_list i32[V]  2 graph_ptr i32[G+1]  3 nin f32[V,T]
  *     4 adj i32[M,2]  5 row_ptr i32[V+1]  6 gather_row i32[M]  7 msg_perm i32[M]  8 pair_node i32[R]  9 compact gather rows i32[M]
- *   -- exactly what ggnn_build_target_csr + ggnn_build_compact_sources + ggnn_remap_gather_rows produce for the batch. */
+ *     10 slot heads i32[V,4] (may be NULL): what ggnn_build_slot_heads gives for (5, 9) -- for (5, 6) without compaction
+ *   -- exactly what ggnn_build_target_csr + ggnn_build_compact_sources + ggnn_remap_gather_rows produce for the batch.
+ *   ONE launch (the gathers are independent; block ranges of one grid work on nodes / state rows / messages / slots / compact rows):
+ *   next to a running forward pass every dependent launch of the packer waits for a launch boundary of the forward stream. */
 /* ... and the transpose structures of the backward pass for the same batch (graph_nodes_list = out[1] of ggnn_assemble_batch; batch_tab
  * carries one more array at its end: ptot[G+1], compact rows of the graphs before k over all types).
  *   bwd_tables [8]: 0 by-(src*T+type) row_ptr i32[Nd*T+1]  1 slot -> dst  2 slot -> message id  3 compact row -> first message slot
@@ -453,6 +456,16 @@ int ggnn_assemble_batch_backward(const void* const* ds_tables, const void* const
 int ggnn_assemble_batch(const void* const* ds_tables, int A, int T, const int64_t* ds_type_off, const int64_t* ds_type_row_off,
                         const int32_t* batch_tab, int G, int V, int M, int R, int D, const int64_t* type_off,
                         const int64_t* type_row_off, void* const* out, ggnn_stream_t stream);
+/* batch_tab of the two calls above, formed on the device from the batch's graph ids (no host->device copy per batch: it would make
+ * the host wait for everything queued on the stream), together with the batch's labels -- one launch:
+ *   counts_t i32[rows][Gd]: per dataset graph the node count, message count, messages per type, compact rows per type, compact rows
+ *     (rows = 2 + 2T + 1);  gids i64[G] dataset graph ids in batch order;
+ *   batch_tab out i32[G + rows*(G+1)] = gid | exclusive prefix sums of every counts row over the batch's graphs;
+ *   targets f32[Gd, num_targets], label_mask f32[Gd, num_targets] or NULL (all ones), task_ids i64[K] (device):
+ *   target_values[i][j] = targets[gid[j]][task_ids[i]] * mask, target_mask[i][j] = mask   (chem_tensorflow_sparse.py:319-321, 335). */
+int ggnn_pack_batch_tables(const int32_t* counts_t, int Gd, int rows, const int64_t* gids, int G, const float* targets,
+                           const float* label_mask, int num_targets, const int64_t* task_ids, int K, int32_t* batch_tab,
+                           float* target_values, float* target_mask, ggnn_stream_t stream);
 
 /* ---- tf.nn.dropout with a counter-based mask (chem_tensorflow_sparse.py:91 edge-weight dropout, :113-114 DropoutWrapper on the
  * new node state; chem_tensorflow_dense.py:104; utils.py:68 readout weights) ------------------------------------------------------
