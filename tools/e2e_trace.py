@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("gated-graph-neural-network-samples_amd")
 dd = pkg.data_device
 dev = torch.device("cuda:0")
-ms = pkg.synthetic_qm9(int(100000 / 18 * 1.02 + 8) * 6, mean_nodes=18, seed=1000)
+ms = pkg.synthetic_qm9(int(os.environ.get("MOLS", "133885")), mean_nodes=18, seed=1000)
 model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": None, "valid_data": ms})
 T, params = model.num_edge_types, model.params
 model.prepare_resident_data(model.valid_data, False)
