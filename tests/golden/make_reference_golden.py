@@ -63,17 +63,22 @@ CASES = {
                                     "task_sample_ratios": {"1": 0.5}, "batch_size": 150, "random_seed": 2}, 2),
     # (sparse with tie_fwd_bkwd=False is not a case: the reference raises IndexError in its own packer, sparse:268-272
     #  offsets backward types by the already doubled num_edge_types -- verified by running it under this harness)
+    # BASELINE.json configs[0]: chem_tensorflow_sparse.py on 1000 QM9-sized molecules, 1 task (mu), h=100, every parameter at the
+    # reference's default (5 layers / 8 steps / residuals, batch_size 100000: the 1000 molecules are ONE batch) -- the reference's
+    # CPU plumbing end to end on the JSON schema of get_data.py:82-86; two Adam steps of its own train op on that batch
+    "sparse_config0": ("sparse", {"random_seed": 0}, 2, {"train": (1000, 9, 31), "valid": (100, 9, 32)}),
     "dense_default": ("dense", {"batch_size": 4, "random_seed": 5}, 3),     # dense drops incomplete batches (dense:160)
     "dense_untied": ("dense", {"tie_fwd_bkwd": False, "num_timesteps": 2, "batch_size": 5}, 0),
 }
 WEIGHT_SEED = 20
 
 
-def run_case(name, kind, params, train_steps, pkg, tf, models):
+def run_case(name, kind, params, train_steps, pkg, tf, models, data=None):
     tmp = tempfile.mkdtemp(prefix="ggnn_ref_")
     num_tasks = max(params.get("task_ids", [0])) + 1
-    train_ms = pkg.synthetic_qm9(40, mean_nodes=9, seed=11, num_tasks=num_tasks)
-    valid_ms = pkg.synthetic_qm9(24, mean_nodes=9, seed=12, num_tasks=num_tasks)
+    data = data or {"train": (40, 9, 11), "valid": (24, 9, 12)}           # (molecules, mean atoms, generator seed)
+    train_ms = pkg.synthetic_qm9(data["train"][0], mean_nodes=data["train"][1], seed=data["train"][2], num_tasks=num_tasks)
+    valid_ms = pkg.synthetic_qm9(data["valid"][0], mean_nodes=data["valid"][1], seed=data["valid"][2], num_tasks=num_tasks)
     for fn, ms in (("molecules_train.json", train_ms), ("molecules_valid.json", valid_ms)):
         with open(os.path.join(tmp, fn), "w") as f:
             json.dump(ms.to_json(), f)
@@ -200,9 +205,9 @@ def main():
         from chem_tensorflow_sparse import SparseGGNNChemModel
         models = {"sparse": SparseGGNNChemModel, "dense": DenseGGNNChemModel}
         only = sys.argv[1:]
-        for name, (kind, params, steps) in CASES.items():
+        for name, spec in CASES.items():
             if not only or name in only:
-                run_case(name, kind, params, steps, pkg, tf, models)
+                run_case(name, spec[0], spec[1], spec[2], pkg, tf, models, spec[3] if len(spec) > 3 else None)
         for name, (kind, params) in LOOP_CASES.items():
             if not only or name in only:
                 run_loop_case(name, kind, params, pkg, tf, models)

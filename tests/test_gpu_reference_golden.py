@@ -14,7 +14,7 @@ import torch
 import reference_golden as RG
 
 pytestmark = pytest.mark.gpu
-STATE_TOL = dict(rtol=1e-4, atol=2e-5)
+STATE_TOL = dict(rtol=1e-4, atol=1e-5)          # north_star / SURVEY 8c: final states after 8 steps, atol 1e-5 / rtol 1e-4
 
 
 def _np(x):
