@@ -36,7 +36,8 @@ def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tens
     assert ew_mask is None
     D = h.shape[1]
     # same choice as the native driver (ggnn_propagate.hip): segment sum gathered inside the GRU kernel
-    gather_in_gru = len(residual_states) + 1 <= int(ops.FUSE_GATHER) and ops.gru_gather_fused(D) and edge_biases is None
+    nx = len(residual_states) + 1
+    gather_in_gru = nx <= min(int(ops.FUSE_GATHER), ops.GRU_FUSED_MAX_INPUTS) and ops.gru_gather_fused(D) and edge_biases is None
     if USE_COMPACT_TRANSFORM and ops.compact_supported(D):
         # transform only the (node, type) pairs that emit a message; the pair list is built once per batch
         comp = getattr(index, "_compact", None)
@@ -59,7 +60,7 @@ def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tens
         return ops.gru_packed_gather(list(residual_states), h, packed, cell.gates_bias, cell.candidate_bias, Hrows, index,
                                      gather_row, nin if use_avg else None, activation)
     xs = list(residual_states) + [incoming]
-    if ops.gru_is_fused(D):
+    if ops.gru_is_fused(D) and nx <= ops.GRU_FUSED_MAX_INPUTS:     # (more inputs: the generic two-launch GRU below)
         packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, len(xs), D)
         return ops.gru_packed(xs, h, packed, cell.gates_bias, cell.candidate_bias, activation)
     return ops.gru(xs, h, cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias, activation)

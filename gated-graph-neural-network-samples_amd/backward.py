@@ -208,7 +208,7 @@ class PropagationStepFn(torch.autograd.Function):
             ew = edge_weights if edge_weights.is_contiguous() else edge_weights.contiguous()
             H = ops.msg_transform_compact_packed(h, _PACKED.edge(ew), ew.shape[0], comp)
             edge_weights = ew
-            if TRAIN_GATHER_IN_GRU and edge_biases is None and ops.gru_gather_fused(D):
+            if TRAIN_GATHER_IN_GRU and edge_biases is None and ops.gru_gather_fused(D) and len(residuals) + 1 <= ops.GRU_FUSED_MAX_INPUTS:
                 # the segment sum gathered inside the GRU launch, as on the inference path; the kernel also writes r, u, c and the
                 # gathered segment, which the backward pass needs (one launch and one pass over `incoming` less per timestep)
                 save = {}
@@ -246,7 +246,7 @@ class PropagationStepFn(torch.autograd.Function):
         act = ops.ACT_IDS[ctx.activation]
         xs = list(residuals) + [incoming]
 
-        if ops.gru_bwd_is_fused(D):
+        if ops.gru_bwd_is_fused(D) and nx <= ops.GRU_FUSED_MAX_INPUTS:
             # ---- 1.-5. in ONE launch: gate algebra, dX products, mean aggregation; dpc / dpg / r*h written for the dW products
             from .autograd import _PACKED
             dpc, dpg, rh, dh, dxs = ops.gru_bwd_fused(g, h, r, u, c, _PACKED.gru_bwd(Wg, Wc, nx, D), nin, ctx.use_avg, nx, ctx.activation)

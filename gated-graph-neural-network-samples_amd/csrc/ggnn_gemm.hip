@@ -85,7 +85,7 @@ extern "C" int ggnn_msg_transform_f32(const float* h, int ldh, const float* W, f
 extern "C" int ggnn_gemm_f32(const float* const* a_segs, int nseg, int D, int lda, const float* B, int ldb, float* C,
                              int ldc, int M, int N, ggnn_stream_t stream) {
     if (int rc = check_common(M, D)) return rc;
-    GGNN_CHECK_ARG(nseg >= 1 && nseg <= 4, "nseg %d outside 1..4", nseg);
+    GGNN_CHECK_ARG(nseg >= 1 && nseg <= kGemmMaxSeg, "nseg %d outside 1..%d", nseg, kGemmMaxSeg);
     GGNN_CHECK_ARG(lda >= D && lda % 4 == 0, "lda %d must be >= D and a multiple of 4", lda);
     GGNN_CHECK_ARG(N > 0 && N % 4 == 0 && ldb >= N && ldb % 4 == 0 && ldc >= N && ldc % 4 == 0,
                    "N/ldb/ldc must be multiples of 4 with ldb,ldc >= N");
@@ -109,7 +109,9 @@ extern "C" size_t ggnn_gru_workspace_bytes(int V, int D) {
 
 static int gru_args_check(const float* const* x_segs, int nx, const float* h, int V, int D) {
     if (int rc = check_common(V, D)) return rc;
-    GGNN_CHECK_ARG(nx >= 1 && nx <= 3, "nx %d outside 1..3 (residual inputs + aggregated messages)", nx);
+    // the reference concatenates any number of residual inputs (chem_tensorflow_sparse.py:139-145,211-212); the generic kernels
+    // take kGemmMaxSeg - 1 = 7 input segments (6 residual inputs + the aggregated messages), the fused single-launch kernels 3
+    GGNN_CHECK_ARG(nx >= 1 && nx <= kGemmMaxSeg - 1, "nx %d outside 1..%d (residual inputs + aggregated messages)", nx, kGemmMaxSeg - 1);
     if (V == 0) return GGNN_OK;
     GGNN_CHECK_ARG(x_segs && h && aligned16(h), "null or misaligned pointer");
     for (int s = 0; s < nx; ++s) GGNN_CHECK_ARG(x_segs[s] && aligned16(x_segs[s]), "x segment %d null or misaligned", s);
@@ -162,7 +164,7 @@ extern "C" int ggnn_gru_f32(const float* const* x_segs, int nx, const float* h, 
         return fail(GGNN_E_WORKSPACE, "GRU workspace too small: %zu < %zu", ws_bytes, ggnn_gru_workspace_bytes(V, D));
     GGNN_CHECK_ARG(act == GGNN_ACT_TANH || act == GGNN_ACT_RELU, "unknown activation %d", act);
     GGNN_CHECK_ARG(Wg && bg && Wc && bc && h_out && h_out != h, "null pointer or h_out aliases h");
-    if (gru_fused_supported(D)) {     // one launch: gates -> r*h -> candidate -> blend chained in registers
+    if (gru_fused_supported(D) && nx <= kGruFusedMaxNx) {     // one launch: gates -> r*h -> candidate -> blend chained in registers
         GGNN_CHECK_ARG(aligned16(Wg) && aligned16(bg) && aligned16(Wc) && aligned16(bc) && aligned16(h_out),
                        "pointers must be 16-byte aligned");
         GruFusedArgs a{};
@@ -196,6 +198,7 @@ extern "C" int ggnn_gru_packed_f32(const float* const* x_segs, int nx, const flo
                                    const float* bc, float* h_out, float* save_r, float* save_u, float* save_c, int V, int D,
                                    int act, int32_t* tile_counter, ggnn_stream_t stream) {
     if (int rc = gru_args_check(x_segs, nx, h, V, D)) return rc;
+    GGNN_CHECK_ARG(nx <= kGruFusedMaxNx, "nx %d: the fused GRU takes at most %d input segments (ggnn_gru_f32 takes more)", nx, kGruFusedMaxNx);
     GGNN_CHECK_ARG(act == GGNN_ACT_TANH || act == GGNN_ACT_RELU, "unknown activation %d", act);
     if (!gru_fused_supported(D)) return fail(GGNN_E_UNSUPPORTED, "no fused GRU for hidden size %d", D);
     if (V == 0) return GGNN_OK;
@@ -345,7 +348,7 @@ extern "C" int ggnn_gru_packed_gather_train_f32(const float* const* x_segs, int 
 extern "C" int ggnn_gru_bwd_dx_cand_f32(const float* dpc, const float* WcT, const float* h, const float* r, float* dx, float* dh,
                                         float* dpg, int nx, int V, int D, ggnn_stream_t stream) {
     if (int rc = check_common(V, D)) return rc;
-    GGNN_CHECK_ARG(nx >= 1 && nx <= 3, "nx %d outside 1..3", nx);
+    GGNN_CHECK_ARG(nx >= 1 && nx <= kGemmMaxSeg - 1, "nx %d outside 1..%d", nx, kGemmMaxSeg - 1);
     if (V == 0) return GGNN_OK;
     GGNN_CHECK_ARG(dpc && WcT && h && r && dx && dh && dpg, "null pointer");
     GGNN_CHECK_ARG(aligned16(dpc) && aligned16(WcT) && aligned16(h) && aligned16(r) && aligned16(dx) && aligned16(dh) && aligned16(dpg),
@@ -363,7 +366,7 @@ extern "C" int ggnn_gru_bwd_dx_cand_f32(const float* dpc, const float* WcT, cons
 extern "C" int ggnn_gru_bwd_dx_gates_f32(const float* dpg, const float* WgT, float* dx, float* dinc, const float* nin, int T,
                                          int use_avg, float* dh, int nx, int V, int D, ggnn_stream_t stream) {
     if (int rc = check_common(V, D)) return rc;
-    GGNN_CHECK_ARG(nx >= 1 && nx <= 3, "nx %d outside 1..3", nx);
+    GGNN_CHECK_ARG(nx >= 1 && nx <= kGemmMaxSeg - 1, "nx %d outside 1..%d", nx, kGemmMaxSeg - 1);
     if (V == 0) return GGNN_OK;
     GGNN_CHECK_ARG(dpg && WgT && dx && dinc && dh && (!use_avg || nin), "null pointer");
     GGNN_CHECK_ARG(aligned16(dpg) && aligned16(WgT) && aligned16(dx) && aligned16(dinc) && aligned16(dh), "pointers must be 16-byte aligned");

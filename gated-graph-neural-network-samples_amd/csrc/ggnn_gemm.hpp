@@ -23,9 +23,12 @@
 
 namespace ggnn {
 
+constexpr int kGemmMaxSeg = 8;   // K segments of one product: up to 6 residual inputs + aggregated messages + h (the fused kernels: 3 + h)
+constexpr int kGruFusedMaxNx = 3;
+
 struct GemmOperands {
-    const float* A[4];     // segment base pointers, each [M, D] with row stride lda[s]
-    int lda[4];
+    const float* A[kGemmMaxSeg];     // segment base pointers, each [M, D] with row stride lda[s]
+    int lda[kGemmMaxSeg];
     int nseg;              // K = nseg * D
     int D;
     const float* B;        // B(k,n) = B[(n / b_blk_cols) * b_blk_stride + k * ldb + (n % b_blk_cols)]

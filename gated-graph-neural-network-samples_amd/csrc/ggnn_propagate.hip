@@ -71,8 +71,10 @@ extern "C" int ggnn_sparse_propagate_f32(
     states[0] = h0;
     for (int l = 0; l < num_layers; ++l) {
         const int nres = res_ptr[l + 1] - res_ptr[l];
-        GGNN_CHECK_ARG(nres >= 0 && nres <= 2, "layer %d has %d residual inputs (max 2)", l, nres);
-        const float* xs[3];
+        // any number of residual inputs in the reference (:139-145); here up to 6 (the generic GEMM's 8 K segments = 6 + messages
+        // + h); the fused single-launch GRU kernels take 2, layers with more run the two-launch generic GRU
+        GGNN_CHECK_ARG(nres >= 0 && nres <= 6, "layer %d has %d residual inputs (max 6)", l, nres);
+        const float* xs[7];
         for (int i = 0; i < nres; ++i) {
             const int src = res_idx[res_ptr[l] + i];
             GGNN_CHECK_ARG(src >= 0 && src <= l, "layer %d: residual index %d refers to a later layer", l, src);
@@ -84,7 +86,7 @@ extern "C" int ggnn_sparse_propagate_f32(
         const float* cur = states[l];              // :152
         const int steps = layer_timesteps[l];
         const float* bias_l = edge_bias ? edge_bias[l] : nullptr;
-        const bool packed_gru = gru_packed && gru_packed[l] && ggnn_gru_is_fused(D);
+        const bool packed_gru = gru_packed && gru_packed[l] && ggnn_gru_is_fused(D) && nx <= 3;
         // fuse_gather = the largest number of concatenated GRU inputs (residuals + messages) for which the segment sum
         // is gathered inside the GRU kernel; 0 = never.
         const bool gather_in_gru = fuse_gather > 0 && nx <= fuse_gather && packed_gru && ggnn_gru_is_fused(D) == 1 && bias_l == nullptr &&
@@ -115,9 +117,11 @@ extern "C" int ggnn_sparse_propagate_f32(
                 if (packed_gru)
                     rc = ggnn_gru_packed_f32(xs, nx, cur, gru_packed[l], bg[l], bc[l], out, nullptr, nullptr, nullptr, V, D, act,
                                              counter, stream);
-                else
+                else {
+                    GGNN_CHECK_ARG(Wg && Wc && Wg[l] && Wc[l], "layer %d needs raw GRU weights (no packed images for it)", l);
                     rc = ggnn_gru_f32(xs, nx, cur, Wg[l], bg[l], Wc[l], bc[l], out, gru_ws, gru_ws_bytes, nullptr, nullptr,
                                       nullptr, V, D, act, stream);
+                }
             }
             if (rc) return rc;
             cur = out;

@@ -25,6 +25,25 @@ from . import _lib
 from ._lib import check
 
 ACT_IDS = {"tanh": 0, "relu": 1}
+GRU_FUSED_MAX_INPUTS = 3        # input segments (residual inputs + aggregated messages) of the single-launch GRU kernels
+GRU_MAX_INPUTS = 7              # ... of the generic two-launch GRU (8 K segments of the generic GEMM: 7 inputs + h)
+
+
+def kernel_width(D: int) -> int:
+    """Width at which node states of hidden size D live in HBM.  Hidden sizes the kernels take as they are (multiples of 32, 64
+    or 100) keep their width; any other size -- the reference accepts every hidden_size (chem_tensorflow_sparse.py:46-50) -- is
+    zero-padded to the next width that has single-launch kernels (32, 64, 100, 128, 192, 256), beyond that to a multiple of 32.
+    Zero columns stay zero through every propagation step when the weights are padded with zeros (padded rows contribute 0 to
+    every product; a padded state column is u*0 + (1-u)*act(0) = 0 for tanh and ReLU), so the model is unchanged."""
+    D = int(D)
+    if D <= 0:
+        raise ValueError("hidden_size must be positive")
+    if D % 32 == 0 or D % 100 == 0:
+        return D
+    for w in (32, 64, 100, 128, 192, 256):
+        if D <= w:
+            return w
+    return (D + 31) // 32 * 32
 # sparse_propagate: gather the segment sum inside the fused GRU (2 launches per timestep instead of 3) for layers with at
 # most FUSE_GATHER concatenated GRU inputs (3 = every layer (default: +1.8 % over 1 on MI355X), 1 = only layers without
 # residual inputs, 0 = never)
@@ -341,6 +360,22 @@ def xty(x_segs: Sequence[torch.Tensor], dy: torch.Tensor, x_rows: Optional[torch
     lib = _lib.load()
     nseg = len(x_segs)
     Dseg = x_segs[0].shape[1]
+    if nseg > 4:
+        # the kernel takes 4 column segments of X: more (layers with more than 2 residual inputs) are row blocks of the product
+        if row_off is not None or x_rows is not None:
+            raise ValueError("batched / row-gathered products take at most 4 segments")
+        N = dy.shape[1]
+        groups = [list(x_segs[i:i + 4]) for i in range(0, nseg, 4)]
+        if add_to is not None:
+            dst = add_to.view(nseg * Dseg, N)
+            k0 = 0
+            for gi, grp in enumerate(groups):
+                last = gi == len(groups) - 1
+                xty(grp, dy, ones_row=ones_row and last, add_to=dst[k0:k0 + len(grp) * Dseg], add_bias_to=add_bias_to if last else None)
+                k0 += len(grp) * Dseg
+            return None
+        parts = [xty(grp, dy, ones_row=ones_row and gi == len(groups) - 1) for gi, grp in enumerate(groups)]
+        return torch.cat(parts, dim=0)
     for i, x in enumerate(x_segs):
         if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != Dseg or (x.shape[0] > 1 and x.stride(1) != 1):
             raise TypeError("x_segs[%d] must be a [M, %d] float32 CUDA/HIP tensor with unit column stride" % (i, Dseg))

@@ -86,18 +86,21 @@ class SparseGGNNChemModel(ChemModel):
         """chem_tensorflow_sparse.py:63-115.  Placeholders become dict slots filled by feed(); the
         variables are created here with the reference's shapes and initialisers."""
         h_dim = self.params['hidden_size']
-        # Limits of the HIP kernels behind this model (the reference accepts any hidden size and any number of residual
-        # inputs): rows are moved as 16-byte vectors, and a GRU launch concatenates at most 3 input segments.
-        if h_dim <= 0 or h_dim % 4 != 0:
-            raise ValueError("hidden_size %r is not supported by the gfx950 kernels: it must be a positive multiple of 4 "
-                             "(node-state rows are read and written as 16-byte vectors)" % (h_dim,))
+        # The reference accepts any hidden size and any number of residual inputs per layer (chem_tensorflow_sparse.py:46-50,
+        # 139-145, 211-212).  Hidden sizes the kernels do not take as they are run zero-padded to ops.kernel_width(h_dim) (states
+        # and weight blocks; the variables keep the reference's shapes); layers with more than 2 residual inputs run the generic
+        # two-launch GRU instead of the single-launch kernels (up to 6 residual inputs: 8 K segments with the messages and h).
+        if h_dim <= 0:
+            raise ValueError("hidden_size %r must be positive" % (h_dim,))
+        self._kw = ops.kernel_width(h_dim)
+        self._padded_cache = {}
         if self.annotation_size > h_dim:
             raise ValueError("annotation_size %d exceeds hidden_size %d" % (self.annotation_size, h_dim))
         for layer_idx in range(len(self.params['layer_timesteps'])):
             res = self.params['residual_connections'].get(str(layer_idx)) or []
-            if len(res) > 2:
-                raise ValueError("layer %d has %d residual inputs; the GRU kernels take at most 2 (plus the aggregated "
-                                 "messages)" % (layer_idx, len(res)))
+            if len(res) + 1 > ops.GRU_MAX_INPUTS:
+                raise ValueError("layer %d has %d residual inputs; the GRU kernels take at most %d (plus the aggregated "
+                                 "messages)" % (layer_idx, len(res), ops.GRU_MAX_INPUTS - 1))
             for r in res:
                 if not 0 <= int(r) <= layer_idx:
                     raise ValueError("layer %d: residual connection %r refers to a layer that is not computed yet" % (layer_idx, r))
@@ -176,12 +179,54 @@ class SparseGGNNChemModel(ChemModel):
                 for (key, _, _, _), t in zip(CELL_SPECS[self.cell_type][1], cell):
                     t.copy_(as_t(L[key]))
 
+    # ---- parameters at the kernel width -----------------------------------------------------------------------
+    @staticmethod
+    def _pad_blocks(W: torch.Tensor, D: int, Dk: int) -> torch.Tensor:
+        """[rb*D, cb*D] (or [cb*D]) -> [rb*Dk, cb*Dk] ([cb*Dk]): every D x D block (D-vector) zero-padded to Dk.  Differentiable
+        (the gradient of a padded tensor is sliced back to the variable's shape)."""
+        import torch.nn.functional as F
+        if W.dim() == 1:
+            cb = W.shape[0] // D
+            return F.pad(W.view(cb, D), (0, Dk - D)).reshape(cb * Dk)
+        rb, cb = W.shape[0] // D, W.shape[1] // D
+        return F.pad(W.view(rb, D, cb, D), (0, Dk - D, 0, 0, 0, Dk - D)).reshape(rb * Dk, cb * Dk)
+
+    def _kernel_layer(self, layer_idx: int, need_grad: bool):
+        """(edge weight variable viewed [T, Dk, Dk], edge biases [T, Dk] | None, attention weights | None, cell tensors) of one
+        layer at the kernel width Dk = ops.kernel_width(hidden_size).  Dk == hidden_size: the variables themselves.  Otherwise
+        zero-padded copies: rebuilt with autograd when training, cached per weight version otherwise (so that the packed LDS
+        images derived from them are reused from batch to batch)."""
+        D, Dk, T = self.params['hidden_size'], self._kw, self.num_edge_types
+        ew_var = self._edge_weight_vars[layer_idx]
+        eb = self.gnn_weights.edge_biases[layer_idx] if self.params['use_edge_bias'] else None
+        attn = self.gnn_weights.edge_type_attention_weights[layer_idx] if self.params['use_propagation_attention'] else None
+        cell = self.gnn_weights.rnn_cells[layer_idx]
+        if Dk == D:
+            return ew_var.view(T, D, D), eb, attn, cell
+        src = [ew_var] + ([eb] if eb is not None else []) + list(cell)
+        versions = tuple(t._version for t in src)
+        if not need_grad:
+            hit = self._padded_cache.get(layer_idx)
+            if hit is not None and hit[0] == versions:
+                return hit[1]
+        import torch.nn.functional as F
+        ew = self._pad_blocks(ew_var, D, Dk).view(T, Dk, Dk)
+        ebp = None if eb is None else F.pad(eb, (0, Dk - D))
+        out = (ew, ebp, attn, type(cell)(*[self._pad_blocks(t, D, Dk) for t in cell]))
+        if not need_grad:
+            self._padded_cache[layer_idx] = (versions, out)
+        return out
+
     # ---- the hot path -----------------------------------------------------------------------------------
     def compute_final_node_representations(self) -> torch.Tensor:
         """chem_tensorflow_sparse.py:117-218."""
         from .autograd import propagation_step
         ph = self.placeholders
         h0 = ph['initial_node_representation']
+        h_dim, Dk = self.params['hidden_size'], self._kw
+        if h0.shape[1] != Dk:                                                     # (see ops.kernel_width: zero columns stay zero)
+            import torch.nn.functional as F
+            h0 = F.pad(h0, (0, Dk - h0.shape[1])).contiguous()
         node_states_per_layer = [h0]                                              # :118-119
         index = ph.get('message_index')
         if index is None:                                                         # :120-129
@@ -197,7 +242,8 @@ class SparseGGNNChemModel(ChemModel):
 
         if not variant and not need_grad and ew_keep >= 1.0 and st_keep >= 1.0 and ops._timing is None:
             # inference: the whole layer/timestep loop below runs inside ONE native call
-            return self._propagate_native(h0, index, nin, use_avg, act)
+            final = self._propagate_native(h0, index, nin, use_avg, act)
+            return final if Dk == h_dim else final[:, :h_dim].contiguous()
 
         for (layer_idx, num_timesteps) in enumerate(self.params['layer_timesteps']):   # :131
             layer_residual_connections = self.params['residual_connections'].get(str(layer_idx))   # :140
@@ -206,41 +252,44 @@ class SparseGGNNChemModel(ChemModel):
             else:
                 layer_residual_states = [node_states_per_layer[residual_layer_idx]
                                          for residual_layer_idx in layer_residual_connections]
+            ew_var, edge_biases, attn_w, cell = self._kernel_layer(layer_idx, need_grad)
             # :91 one weight-dropout mask per layer per run, shared by the layer's timesteps
-            # (a fresh view of the [T*D, D] variable, :90, so autograd sees the variable when training)
-            h_dim = self.params['hidden_size']
-            ew_var = self._edge_weight_vars[layer_idx].view(self.num_edge_types, h_dim, h_dim)
             ew_mask = None
             if ew_keep < 1.0:
                 ew_mask = (ew_keep, self.dropout_seed('edge_weights', layer_idx))
             plain_step = not variant
-            if ew_mask is None or (plain_step and need_grad):
+            if ew_mask is None:
+                edge_weights = ew_var
+            elif Dk != h_dim:
+                # padded width: the mask is drawn on the VARIABLE (reference shape), the masked weights are padded
+                edge_weights = self._pad_blocks(tf_dropout(self._edge_weight_vars[layer_idx], ew_mask[0], ew_mask[1]), h_dim,
+                                                Dk).view(self.num_edge_types, Dk, Dk)
+                ew_mask = None
+            elif plain_step and need_grad:
                 # (training on the default cell: the propagation step gets the variable AND the mask, so that its weight
                 # gradient can be accumulated unmasked and masked once per layer -- backward.PropagationStepFn)
                 edge_weights = ew_var
             else:
                 edge_weights = tf_dropout(ew_var, ew_mask[0], ew_mask[1])
-            edge_biases = self.gnn_weights.edge_biases[layer_idx] if self.params['use_edge_bias'] else None
-            cell = self.gnn_weights.rnn_cells[layer_idx]
             cur = node_states_per_layer[-1]                                        # :152
             for step in range(num_timesteps):                                      # :153
                 if variant and need_grad:
                     # non-default switches, training: HIP forward, autograd-derived backward (variants.py)
                     from .variants import variant_step
-                    attn = (self.gnn_weights.edge_type_attention_weights[layer_idx]
-                            if self.params['use_propagation_attention'] else None)
-                    cur = variant_step(cur, index, nin, edge_weights, edge_biases, attn, use_avg, layer_residual_states,
+                    cur = variant_step(cur, index, nin, edge_weights, edge_biases, attn_w, use_avg, layer_residual_states,
                                        self.cell_type, tuple(cell), act)
                 elif variant:
-                    cur = self._variant_step(cur, index, nin, edge_weights.contiguous(), edge_biases, use_avg,
-                                             layer_residual_states, layer_idx, act)
+                    cur = self._variant_step(cur, index, nin, edge_weights.contiguous(), edge_biases, attn_w, use_avg,
+                                             layer_residual_states, cell, act)
                 else:
                     cur = propagation_step(cur, index, nin, edge_weights, edge_biases, use_avg,
-                                           layer_residual_states, cell, act, need_grad, ew_mask if need_grad else None)
+                                           layer_residual_states, cell, act, need_grad,
+                                           ew_mask if (need_grad and plain_step) else None)
                 if st_keep < 1.0:                                                  # :113-114 DropoutWrapper(state)
                     cur = tf_dropout(cur, st_keep, self.dropout_seed('state', layer_idx, step), self._node_uid())
             node_states_per_layer.append(cur)
-        return node_states_per_layer[-1]                                           # :218
+        final = node_states_per_layer[-1]                                          # :218
+        return final if Dk == h_dim else final[:, :h_dim].contiguous()
 
     def _node_uid(self) -> Optional[torch.Tensor]:
         """int64 [V]: (dataset graph id << 20) + node index within its graph -- the row keys of the state-dropout mask, so
@@ -256,17 +305,15 @@ class SparseGGNNChemModel(ChemModel):
             ph['node_uid'] = uid = uid.contiguous()
         return uid
 
-    def _variant_step(self, h, index, nin, edge_weights, edge_biases, use_avg, residual_states, layer_idx, act):
+    def _variant_step(self, h, index, nin, edge_weights, edge_biases, attn_w, use_avg, residual_states, cell, act):
         """One timestep with the non-default switches of chem_tensorflow_sparse.py: propagation attention
         (:147-149, 170-196) and/or the BasicRNNCell / CudnnCompatibleGRUCell cells (:105-110).  Dense transform."""
         H = ops.msg_transform(h, edge_weights)
         if self.params['use_propagation_attention']:
-            incoming = ops.gather_segment_sum_attn(H, h, index, self.gnn_weights.edge_type_attention_weights[layer_idx],
-                                                   nin, edge_biases, use_avg)
+            incoming = ops.gather_segment_sum_attn(H, h, index, attn_w, nin, edge_biases, use_avg)
         else:
             incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
         xs = list(residual_states) + [incoming]
-        cell = self.gnn_weights.rnn_cells[layer_idx]
         if self.cell_type == 'gru':
             return ops.gru(xs, h, cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias, act)
         if self.cell_type == 'rnn':
@@ -277,21 +324,24 @@ class SparseGGNNChemModel(ChemModel):
         """compute_final_node_representations through ggnn_sparse_propagate_f32 (the loop of :131-218 in C):
         source-compacted transform and pre-packed weight images where the hidden size supports them."""
         from .autograd import USE_COMPACT_TRANSFORM, _PACKED
-        D, T = self.params['hidden_size'], self.num_edge_types
+        D, T = self._kw, self.num_edge_types
         L = len(self.params['layer_timesteps'])
         comp = None
         if USE_COMPACT_TRANSFORM and ops.compact_supported(D):
             comp = getattr(index, "_compact", None)
             if comp is None:
                 comp = index._compact = ops.build_compact_sources(index)
-        edge_w = [self._edge_weight_vars[l].view(T, D, D) for l in range(L)]
+        layers = [self._kernel_layer(l, False) for l in range(L)]
+        edge_w = [lay[0].contiguous() for lay in layers]
         edge_packed = [_PACKED.edge(w) for w in edge_w] if comp is not None else None
-        edge_bias = list(self.gnn_weights.edge_biases) if self.params['use_edge_bias'] else None
-        cells = self.gnn_weights.rnn_cells
+        edge_bias = [lay[1] for lay in layers] if self.params['use_edge_bias'] else None
+        cells = [lay[3] for lay in layers]
         residuals = [self.params['residual_connections'].get(str(l)) or [] for l in range(L)]
         gru_packed = None
         if ops.gru_is_fused(D):
-            gru_packed = [_PACKED.gru(c.gates_kernel, c.candidate_kernel, len(residuals[l]) + 1, D) for l, c in enumerate(cells)]
+            # (layers with more inputs than the single-launch kernels take run the generic GRU on the raw weights)
+            gru_packed = [_PACKED.gru(c.gates_kernel, c.candidate_kernel, len(residuals[l]) + 1, D)
+                          if len(residuals[l]) + 1 <= ops.GRU_FUSED_MAX_INPUTS else None for l, c in enumerate(cells)]
         outs = ops.sparse_propagate(h0, index, comp, nin, use_avg, self.params['layer_timesteps'], residuals,
                                     edge_w, edge_packed, edge_bias,
                                     [c.gates_kernel for c in cells], [c.gates_bias for c in cells],
@@ -316,16 +366,23 @@ class SparseGGNNChemModel(ChemModel):
         """gated_regression (chem_tensorflow_sparse.py:220-231) and the masked sums of chem_tensorflow.py:161-166 in one
         fused, differentiable, deterministic unit (autograd.readout_loss).  None when the fused kernels do not apply."""
         from .autograd import readout_loss
-        if not last_h.is_cuda or self.params['hidden_size'] > 256 or not self._graph_nodes_sorted():
+        D, Dk = self.params['hidden_size'], self._kw
+        if not last_h.is_cuda or Dk > 256 or not self._graph_nodes_sorted():
             return None
-        keep = float(self.placeholders.get('out_layer_dropout_keep_prob', 1.0))
         g, t = regression_gate.params, regression_transform.params
         if len(g["weights"]) != 1 or len(t["weights"]) != 1:
             return None
         ph = self.placeholders
-        out, num, ab, ms = readout_loss(last_h, ph['initial_node_representation'], ph['graph_nodes_list'], ph.get('graph_ptr'), None,
-                                        ph['num_graphs'], regression_gate.dropped_weight(0), g["biases"][0],
-                                        regression_transform.dropped_weight(0), t["biases"][0],    # utils.py:68 dropout on W
+        h0 = ph['initial_node_representation']
+        gW, tW = regression_gate.dropped_weight(0), regression_transform.dropped_weight(0)       # utils.py:68 dropout on W
+        if Dk != D:
+            # hidden sizes the kernels run zero-padded (ops.kernel_width): states and the [hT | h0] / hT weight vectors at width Dk
+            import torch.nn.functional as F
+            last_h = F.pad(last_h, (0, Dk - D))
+            h0 = h0 if h0.shape[1] == Dk else F.pad(h0, (0, Dk - h0.shape[1]))
+            gW, tW = self._pad_blocks(gW.reshape(-1), D, Dk), self._pad_blocks(tW.reshape(-1), D, Dk)
+        out, num, ab, ms = readout_loss(last_h, h0.contiguous(), ph['graph_nodes_list'], ph.get('graph_ptr'), None,
+                                        ph['num_graphs'], gW, g["biases"][0], tW, t["biases"][0],
                                         target_values.contiguous(), target_mask.contiguous())
         self.output = out
         return out, num, ab, ms
@@ -334,21 +391,29 @@ class SparseGGNNChemModel(ChemModel):
         """chem_tensorflow_sparse.py:220-231."""
         from .autograd import segment_sum_rows
         keep = float(self.placeholders.get('out_layer_dropout_keep_prob', 1.0))
+        D, Dk = self.params['hidden_size'], self._kw
+        h0 = self.placeholders['initial_node_representation']
         if not (self.training and torch.is_grad_enabled()) and keep >= 1.0 and last_h.is_cuda:
             # inference: one fused HIP pass (no [V,2D] concat, no per-node intermediates); deterministic segmented sum for
             # batcher output, the atomic form only for an unsorted graph_nodes_list
             g, t = regression_gate.params, regression_transform.params
             ph = self.placeholders
-            if self._graph_nodes_sorted() and self.params['hidden_size'] <= 256:
-                output = ops.readout_loss_fwd(last_h.contiguous(), ph['initial_node_representation'], ph['graph_nodes_list'],
-                                              ph.get('graph_ptr'), None, ph['num_graphs'], g["weights"][0].reshape(-1),
-                                              g["biases"][0], t["weights"][0].reshape(-1), t["biases"][0], None, None)[0]
+            gW, tW = g["weights"][0].reshape(-1), t["weights"][0].reshape(-1)
+            hT = last_h.contiguous()
+            if Dk != D:                                                             # zero-padded width, see ops.kernel_width
+                import torch.nn.functional as F
+                hT = F.pad(hT, (0, Dk - D))
+                h0 = (h0 if h0.shape[1] == Dk else F.pad(h0, (0, Dk - h0.shape[1]))).contiguous()
+                gW, tW = self._pad_blocks(gW, D, Dk), self._pad_blocks(tW, D, Dk)
+            if self._graph_nodes_sorted() and Dk <= 256:
+                output = ops.readout_loss_fwd(hT, h0, ph['graph_nodes_list'], ph.get('graph_ptr'), None, ph['num_graphs'], gW,
+                                              g["biases"][0], tW, t["biases"][0], None, None)[0]
             else:
-                output = ops.gated_readout(last_h.contiguous(), ph['initial_node_representation'], ph['graph_nodes_list'],
-                                           ph['num_graphs'], g["weights"][0], g["biases"][0], t["weights"][0], t["biases"][0])
+                output = ops.gated_readout(hT, h0, ph['graph_nodes_list'], ph['num_graphs'], gW.reshape(-1, 1), g["biases"][0],
+                                           tW.reshape(-1, 1), t["biases"][0])
             self.output = output
             return output
-        gate_input = torch.cat([last_h, self.placeholders['initial_node_representation']], dim=-1)   # [v x 2h]
+        gate_input = torch.cat([last_h, h0[:, :D]], dim=-1)                                          # [v x 2h]
         gated_outputs = torch.sigmoid(regression_gate(gate_input)) * regression_transform(last_h)    # [v x 1]
         # Sum up all nodes per-graph
         graph_representations = segment_sum_rows(gated_outputs, self.placeholders['graph_nodes_list'],
@@ -432,12 +497,16 @@ class SparseGGNNChemModel(ChemModel):
         from . import backward
         compact = (not is_training) or backward.USE_COMPACT_TRANSFORM
 
+        # (a hidden size the kernels run zero-padded: the annotations are zero-padded anyway, :300-302, so the batches are packed at
+        # the kernel width right away -- 'initial_node_representation' is then [V, ops.kernel_width(hidden_size)])
+        pack_params = self.params if self._kw == self.params['hidden_size'] else dict(self.params, hidden_size=self._kw)
+
         def epoch_batches(order):
             if on_device:
-                return pack_batches_device(data["molecules_dev"], self.params, self.num_edge_types, order, rank, world, compact,
+                return pack_batches_device(data["molecules_dev"], pack_params, self.num_edge_types, order, rank, world, compact,
                                            training=is_training and compact)
             return (self.to_device_batch(b, compact) for b in
-                    pack_batches(ms, self.params, self.num_edge_types, order, data["label_mask"], rank, world))
+                    pack_batches(ms, pack_params, self.num_edge_types, order, data["label_mask"], rank, world))
 
         if is_training:
             # :281-282 np.random.shuffle(data) shuffles the reference's graph list IN PLACE, so the orders of successive

@@ -159,7 +159,7 @@ def _hip_backward(ctx, g, h, nin, W, bias, attn, cell, residuals, extra):
     # ---- cell: d state, d inputs (the last input = aggregated messages, mean aggregation undone), weight / bias gradients ------
     if ctx.cell_type == 'gru':
         r, u, c = extra[1:4]
-        if ops.gru_bwd_is_fused(D):
+        if (ops.gru_bwd_is_fused(D) and nx <= ops.GRU_FUSED_MAX_INPUTS):
             dpc, dpg, rh, dh, dxs = ops.gru_bwd_fused(g, h, r, u, c, _PACKED.gru_bwd(cell[0], cell[2], nx, D), nin, ctx.use_avg, nx,
                                                       ctx.activation)
             dinc, d_res = dxs[-1], dxs[:-1]

@@ -146,7 +146,8 @@ def _model_and_feed(pkg, oracle, ms, config=None, seed=0):
 
 def _oracle_states(oracle, feed, layers, params, dtype=np.float64):
     adj = [a.cpu().numpy() for a in feed["adjacency_lists"]]
-    return oracle.sparse_propagate(feed["initial_node_representation"].cpu().numpy(), adj,
+    # (hidden sizes that run zero-padded are packed at the kernel width: the oracle gets the reference's [V, hidden_size])
+    return oracle.sparse_propagate(feed["initial_node_representation"].cpu().numpy()[:, :params["hidden_size"]], adj,
                                    feed["num_incoming_edges_per_type"].cpu().numpy(), layers, params, dtype=dtype)
 
 
@@ -208,6 +209,48 @@ def test_random_model_shapes_match_oracle(pkg, oracle, cuda, seed):
                 np.testing.assert_allclose(got, want, err_msg=str(config), **MODEL_TOL)
     finally:
         pkg.ops.FUSE_GATHER = old
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_model_shapes_any_hidden_size_and_residual_fan_in(pkg, oracle, cuda, seed):
+    """The sweep above over what the reference accepts beyond the kernels' native shapes (chem_tensorflow_sparse.py:46-50,
+    139-145, 211-212): hidden sizes 20 / 52 / 84 / 116 (zero-padded to 32 / 64 / 100 / 128 inside the engine), 50 (not even a
+    multiple of 4) and 100, and layers with up to 4 residual inputs (the generic two-launch GRU beyond 2)."""
+    rng = np.random.default_rng(5000 + seed)
+    n_graphs = int(rng.choice([1, 17, 60, 200]))
+    n_layers = int(rng.integers(3, 6))
+    timesteps = [int(rng.integers(1, 3)) for _ in range(n_layers)]
+    residuals = {}
+    for l in range(1, n_layers):
+        k = int(rng.integers(0, min(l + 1, 4) + 1))
+        if k:
+            residuals[str(l)] = sorted(int(x) for x in rng.choice(l + 1, size=k, replace=False))
+    D = int([20, 52, 84, 116, 50, 100][seed % 6])
+    config = {"hidden_size": D, "layer_timesteps": timesteps, "residual_connections": residuals,
+              "use_edge_bias": bool(rng.integers(0, 2)), "use_edge_msg_avg_aggregation": bool(rng.integers(0, 2)),
+              "graph_rnn_activation": str(rng.choice(["tanh", "ReLU"])), "batch_size": int(rng.choice([700, 100000]))}
+    if seed % 5 == 4:
+        config["graph_rnn_cell"] = str(rng.choice(["RNN", "CudnnCompatibleGRUCell"]))
+        config["graph_rnn_activation"] = "tanh"
+    ms = pkg.synthetic_qm9(n_graphs, mean_nodes=float(rng.choice([4, 9, 14])), seed=seed)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms, config, seed=seed)
+    assert model._kw == pkg.ops.kernel_width(D)
+    with torch.no_grad():
+        for feed in feeds[:2]:
+            model.feed(feed)
+            got = model.compute_final_node_representations().cpu().numpy()
+            assert got.shape[1] == D
+            want = _oracle_states(oracle, feed, layers, model.params)
+            np.testing.assert_allclose(got, want, err_msg=str(config), **MODEL_TOL)
+            # ... and through the readout + loss (fused kernels at the padded width) against the oracle's
+            loss = float(model.forward_batch(feed))
+            gate, tr = model.weights["regression_gate_task0"].params, model.weights["regression_transform_task0"].params
+            h0 = feed["initial_node_representation"].cpu().numpy()[:, :D]
+            pred = oracle.gated_regression(want, h0, feed["graph_nodes_list"].cpu().numpy(), feed["num_graphs"],
+                                           gate["weights"][0].cpu().numpy(), gate["biases"][0].cpu().numpy(),
+                                           tr["weights"][0].cpu().numpy(), tr["biases"][0].cpu().numpy())
+            want_loss = oracle.task_loss(pred, feed["target_values"].cpu().numpy()[0], feed["target_mask"].cpu().numpy()[0])[0]
+            assert abs(loss - want_loss) <= 2e-4 * max(1.0, abs(want_loss)), (loss, want_loss, config)
 
 
 @pytest.mark.parametrize("tie", [True, False])

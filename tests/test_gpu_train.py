@@ -81,6 +81,42 @@ def test_gradients_match_oracle_autograd(pkg, oracle, oracle_torch, cuda, config
         v.requires_grad_(False); v.grad = None
 
 
+@pytest.mark.parametrize("config", [
+    {"hidden_size": 52, "layer_timesteps": [1, 1, 1, 2], "residual_connections": {"2": [0, 1], "3": [0, 1, 2]}},
+    {"hidden_size": 100, "layer_timesteps": [1, 1, 1, 1, 1], "residual_connections": {"3": [0, 1, 2], "4": [0, 1, 2, 3]}, "use_edge_bias": True},
+    {"hidden_size": 84, "layer_timesteps": [2, 1], "residual_connections": {"1": [0]}, "use_edge_msg_avg_aggregation": False},
+    {"hidden_size": 30, "layer_timesteps": [2], "residual_connections": {}},
+])
+def test_gradients_any_hidden_size_and_residual_fan_in(pkg, oracle, oracle_torch, cuda, config):
+    """Training on what the reference accepts beyond the kernels' native shapes: hidden sizes that run zero-padded (the gradient
+    of a padded weight block is sliced back to the variable) and layers with 3 / 4 residual inputs (unfused GRU backward, weight
+    gradient products over more than 4 column segments) -- against the oracle's float64 autograd."""
+    model, layers, feed = _setup(pkg, oracle, config)
+    want_loss, want = _oracle_loss_and_grads(oracle_torch, model, layers, dict(feed, initial_node_representation=feed["initial_node_representation"][:, :config["hidden_size"]]))
+    variables = model.trainable_variables
+    for v in variables.values():
+        v.requires_grad_(True); v.grad = None
+    model.training = True
+    loss = model.forward_batch(feed)
+    loss.backward()
+    model.training = False
+    assert abs(float(loss) - want_loss) < 1e-5 * max(1.0, abs(want_loss))
+    assert set(want) == set(variables)
+    for name, v in variables.items():
+        assert v.grad is not None and tuple(v.grad.shape) == tuple(v.shape), name
+        got = v.grad.detach().cpu().double().reshape(want[name].shape)
+        scale = float(want[name].abs().max()) + 1e-12
+        err = float((got - want[name]).abs().max())
+        assert err <= 2e-4 * scale + 1e-7, (name, err, scale)
+        v.requires_grad_(False); v.grad = None
+    # ... and a whole optimisation step runs (flat gradient buffer, clip + Adam) and lowers the loss on the batch
+    feed = dict(feed); feed["out_layer_dropout_keep_prob"] = 1.0
+    first = float(model.train_batch(feed))
+    for _ in range(5):
+        last = float(model.train_batch(feed))
+    assert last < first
+
+
 def test_train_step_matches_restated_tf_adam(pkg, oracle, oracle_torch, cuda):
     """One train step == oracle grads -> per-variable clip_by_norm (chem_tensorflow.py:186-190) -> TF-1.3 Adam."""
     model, layers, feed = _setup(pkg, oracle, {})

@@ -166,13 +166,27 @@ def test_feed_drops_index_derived_from_previous_batch(pkg):
     assert m.placeholders["message_index"] == "again"
 
 
-def test_unsupported_hidden_size_and_residual_count_fail_early(pkg):
+def test_any_hidden_size_and_residual_fan_in_are_accepted(pkg):
+    """The reference takes any hidden_size and any number of residual inputs per layer (chem_tensorflow_sparse.py:46-50, 139-145,
+    211-212).  Sizes the kernels do not take as they are run zero-padded to ops.kernel_width (variables keep the reference's
+    shapes); up to 6 residual inputs per layer; what cannot run fails at construction, not in the first batch."""
     ms = pkg.synthetic_qm9(12, mean_nodes=6, seed=2)
     base = {"--quiet": True, "--device": "cpu", "train_data": None, "valid_data": ms}
-    with pytest.raises(ValueError, match="multiple of 4"):
-        pkg.SparseGGNNChemModel(dict(base, **{"--config": {"hidden_size": 30}}))
+    assert [pkg.ops.kernel_width(d) for d in (20, 30, 52, 84, 100, 116, 96, 200, 260)] == [32, 32, 64, 100, 100, 128, 96, 200, 288]
+    m = pkg.SparseGGNNChemModel(dict(base, **{"--config": {"hidden_size": 30}}))
+    assert m._kw == 32 and m._edge_weight_vars[0].shape == (m.num_edge_types * 30, 30)
+    assert m.gnn_weights.rnn_cells[0].gates_kernel.shape == (60, 60)
+    ew, eb, attn, cell = m._kernel_layer(4, False)                       # layer 4: residual inputs [0, 2] -> 3 x + h row blocks
+    assert ew.shape == (m.num_edge_types, 32, 32) and cell.gates_kernel.shape == (4 * 32, 64) and cell.candidate_bias.shape == (32,)
+    Wg = m.gnn_weights.rnn_cells[4].gates_kernel
+    assert torch.equal(cell.gates_kernel[32:62, 32:62], Wg[30:60, 30:60]) and float(cell.gates_kernel[30:32].abs().sum()) == 0.0
+    assert m._kernel_layer(4, False)[0] is ew                            # cached per weight version
+    m6 = pkg.SparseGGNNChemModel(dict(base, **{"--config": {"layer_timesteps": [1] * 7, "residual_connections": {"6": [0, 1, 2, 3, 4, 5]}}}))
+    assert m6.gnn_weights.rnn_cells[6].gates_kernel.shape == (8 * 100, 200)
     with pytest.raises(ValueError, match="residual"):
-        pkg.SparseGGNNChemModel(dict(base, **{"--config": {"residual_connections": {"4": [0, 1, 2]}}}))
+        pkg.SparseGGNNChemModel(dict(base, **{"--config": {"layer_timesteps": [1] * 8, "residual_connections": {"7": [0, 1, 2, 3, 4, 5, 6]}}}))
+    with pytest.raises(ValueError, match="not computed yet"):
+        pkg.SparseGGNNChemModel(dict(base, **{"--config": {"residual_connections": {"1": [2]}}}))
 
 
 def test_dense_task_sample_ratios_mask_labels(pkg):
