@@ -49,6 +49,9 @@ USE_TN_KERNEL = os.environ.get("GGNN_TN_KERNEL", "0") != "0"
 # spends a third of each pass waiting for HBM; the products are matrix-pipe bound).  The sums are the ones autograd would have
 # formed, in the same order (timesteps in backward order, one in-order stream), so the result is bit-identical.
 USE_WGRAD_STREAM = os.environ.get("GGNN_WGRAD_STREAM", "1") != "0"
+# The whole optimisation step of the default model on the native launch sequences (train_native.py / csrc/ggnn_train.hip);
+# GGNN_NATIVE_STEP=0: through torch.autograd (this file), which stays the path of every other model variant
+USE_NATIVE_STEP = os.environ.get("GGNN_NATIVE_STEP", "1") != "0"
 # Training forward with the segment sum gathered inside the GRU launch (ggnn_gru_packed_gather_train_f32); 0: separate launch
 TRAIN_GATHER_IN_GRU = os.environ.get("GGNN_TRAIN_GATHER_IN_GRU", "1") != "0"
 

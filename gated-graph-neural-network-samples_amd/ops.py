@@ -1086,9 +1086,12 @@ def readout_loss_fwd(last_h: torch.Tensor, h0: torch.Tensor, graph_nodes_list: t
 
 
 def readout_loss_bwd(last_h, h0, graph_nodes_list, node_mask, num_graphs, gate_W, transform_W, gate, val, out, target, mask,
-                     d_out: Optional[torch.Tensor], d_stats: Optional[torch.Tensor], d_last_h: Optional[torch.Tensor] = None):
+                     d_out: Optional[torch.Tensor], d_stats: Optional[torch.Tensor], d_last_h: Optional[torch.Tensor] = None,
+                     grad_out: Optional[Sequence[torch.Tensor]] = None):
     """Backward of readout_loss_fwd: -> (d_last_h [V,D], d_gate_W [2D], d_gate_b [1], d_transform_W [D], d_transform_b [1]).
-    d_last_h given: the gradient is ADDED to it (further tasks of a multi-task model)."""
+    d_last_h given: the gradient is ADDED to it (further tasks of a multi-task model).
+    grad_out: four contiguous float32 buffers (2D, 1, D, 1 elements) that receive the weight gradients (the optimizer's flat
+    gradient views) instead of fresh tensors."""
     lib = _lib.load()
     V, D = last_h.shape
     G = int(num_graphs)
@@ -1096,8 +1099,14 @@ def readout_loss_bwd(last_h, h0, graph_nodes_list, node_mask, num_graphs, gate_W
     accumulate = d_last_h is not None
     if d_last_h is None:
         d_last_h = torch.empty_like(last_h) if V and G else torch.zeros_like(last_h)
-    dgW = torch.empty(2 * D, dtype=torch.float32, device=dev); dgb = torch.empty(1, dtype=torch.float32, device=dev)
-    dtW = torch.empty(D, dtype=torch.float32, device=dev); dtb = torch.empty(1, dtype=torch.float32, device=dev)
+    if grad_out is not None:
+        dgW, dgb, dtW, dtb = grad_out
+        for t, n in ((dgW, 2 * D), (dgb, 1), (dtW, D), (dtb, 1)):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+                raise TypeError("grad_out buffers must be contiguous float32 CUDA/HIP tensors of 2D, 1, D and 1 elements")
+    else:
+        dgW = torch.empty(2 * D, dtype=torch.float32, device=dev); dgb = torch.empty(1, dtype=torch.float32, device=dev)
+        dtW = torch.empty(D, dtype=torch.float32, device=dev); dtb = torch.empty(1, dtype=torch.float32, device=dev)
     ws_bytes = lib.ggnn_readout_workspace_bytes(V, D, G)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _launch("readout_loss_bwd", lambda: lib.ggnn_readout_loss_bwd_f32(

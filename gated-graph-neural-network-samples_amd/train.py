@@ -213,6 +213,10 @@ def train_step(model, batch_data) -> torch.Tensor:
     sum(0.5*diff^2) / (sum(mask) + 1e-7) over the whole batch (chem_tensorflow.py:161-169), so shards
     are combined by all-reducing the loss numerator-gradients and the mask count, not by averaging
     per-rank losses (see parallel.DataParallelContext.reduce_gradients)."""
+    from . import train_native
+    if train_native.eligible(model, batch_data):
+        # the default model: forward, backward and weight-gradient products as native launch sequences (csrc/ggnn_train.hip)
+        return train_native.native_train_step(model, batch_data)
     variables = list(model.trainable_variables.values())
     for v in variables:
         v.requires_grad_(True)

@@ -467,6 +467,37 @@ int ggnn_pack_batch_tables(const int32_t* counts_t, int Gd, int rows, const int6
                            const float* label_mask, int num_targets, const int64_t* task_ids, int K, int32_t* batch_tab,
                            float* target_values, float* target_mask, ggnn_stream_t stream);
 
+/* ---- the optimisation step of the default sparse model as native launch sequences (chem_tensorflow.py:183-191 over
+ * chem_tensorflow_sparse.py:117-218; ggnn_train.hip) -----------------------------------------------------------------------------
+ * Default cell (GRU), no edge bias, no attention, a hidden size with the gather-fused GRU and the compacted transform (32, 64, 100),
+ * at most 2 residual inputs and at least one timestep per layer.  Layer description as in ggnn_sparse_propagate_f32.
+ *   forward:  per timestep the compacted transform + ggnn_gru_packed_gather_train_f32; every timestep's state and r / u / c /
+ *     incoming stay in `ws` (ggnn_sparse_train_workspace_bytes, 256-byte aligned) for the backward call on the SAME ws.
+ *     edge_packed[l]: stage images of the (weight-dropout-masked) edge weights (ggnn_edge_weights_pack_f32), gru_packed[l]:
+ *     ggnn_gru_pack_weights_f32.  *final_state_offset: byte offset inside ws of the final node states [V,D].
+ *   backward: d_final [V,D] = dL/d(final states) (from ggnn_readout_loss_bwd_f32).  Per timestep, last to first: the fused GRU
+ *     backward, the transpose segment sum over (rows_rp, rows_gather[, rows_heads]) (segments = compact rows, gather = target node),
+ *     the compacted transform with the images of W^T (edge_packed_t[l]) on identity_rows = 0..R-1, the per-node sum over
+ *     (node_rp, node_order[, node_heads]); on `side_stream` the weight-gradient products, ADDED into g_edge[l] [T,D,D], g_Wg[l]
+ *     [(nx+1)D, 2D], g_bg[l] [2D], g_Wc[l] [(nx+1)D, D], g_bc[l] [D] (the caller zeroes them; under weight dropout it masks g_edge
+ *     afterwards).  d_state_ws[l] [V,D] (l < num_layers): scratch for the gradients of the layer inputs.  Returns with `stream`
+ *     ordered behind the side stream's last product.  Events come from a per-device pool the library creates on first use. */
+size_t ggnn_sparse_train_workspace_bytes(int V, int D, int T, int64_t compact_rows, int total_steps);
+int ggnn_sparse_train_forward_f32(const float* h0, int V, int D, int T, const int32_t* row_ptr, const int32_t* gather_row_c,
+                                  const int32_t* pair_node, const int64_t* type_row_off, const float* nin, int use_avg, int num_layers,
+                                  const int32_t* layer_timesteps, const int32_t* res_ptr, const int32_t* res_idx,
+                                  const float* const* edge_packed, const float* const* bg, const float* const* bc,
+                                  const float* const* gru_packed, int act, void* ws, size_t ws_bytes, int64_t* final_state_offset,
+                                  ggnn_stream_t stream);
+int ggnn_sparse_train_backward_f32(const float* h0, int V, int D, int T, const int32_t* pair_node, const int64_t* type_row_off,
+                                   const float* nin, int use_avg, int num_layers, const int32_t* layer_timesteps,
+                                   const int32_t* res_ptr, const int32_t* res_idx, const int32_t* rows_rp, const int32_t* rows_gather,
+                                   const int32_t* rows_heads, const int32_t* node_rp, const int32_t* node_order,
+                                   const int32_t* node_heads, const int32_t* identity_rows, const float* const* edge_packed_t,
+                                   const float* const* gru_bwd_packed, int act, float* const* g_edge, float* const* g_Wg,
+                                   float* const* g_bg, float* const* g_Wc, float* const* g_bc, float* d_final, float* const* d_state_ws,
+                                   void* ws, size_t ws_bytes, ggnn_stream_t stream, ggnn_stream_t side_stream);
+
 /* ---- tf.nn.dropout with a counter-based mask (chem_tensorflow_sparse.py:91 edge-weight dropout, :113-114 DropoutWrapper on the
  * new node state; chem_tensorflow_dense.py:104; utils.py:68 readout weights) ------------------------------------------------------
  *   out[r,c] = x[r,c] / keep_prob * floor(keep_prob + U),   U = (Philox4x32-10(counter, key)[c % 4] >> 8) * 2^-24

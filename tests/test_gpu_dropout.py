@@ -93,6 +93,7 @@ def test_edge_weight_gradients_go_through_the_sink_and_are_masked_once(pkg, orac
     (mask * (dW_1 + dW_2) / keep), autograd sums the masked products (dW_1 / keep + dW_2 / keep on the kept entries): the same
     gradient up to one rounding per addend, and exactly zero on the dropped entries either way."""
     results = []
+    monkeypatch.setattr(pkg.backward, "USE_NATIVE_STEP", False)          # (the autograd path is the one with the sink)
     for side in (True, False):
         monkeypatch.setattr(pkg.backward, "USE_WGRAD_STREAM", side)
         model, layers, feed = _model(pkg, oracle, cfg, n=300, seed=4)

@@ -146,6 +146,7 @@ def test_side_stream_weight_gradients_are_bit_identical(pkg, oracle, cuda, confi
     on a second stream (backward.weight_gradient_sink) instead of returning them to autograd: three steps from the same
     weights give the same weights, bit for bit, with the sink switched off."""
     results = []
+    monkeypatch.setattr(pkg.backward, "USE_NATIVE_STEP", False)          # (the autograd path is the one with the sink)
     for side in (True, False):
         monkeypatch.setattr(pkg.backward, "USE_WGRAD_STREAM", side)
         model, layers, feed = _setup(pkg, oracle, config, n=300, seed=4)
@@ -254,3 +255,51 @@ def test_stream_prefetcher_matches_sequential_packing(pkg, oracle, cuda):
             assert len(got) == len(want)
             for a, b in zip(got, want):
                 assert torch.equal(a.cpu(), b)
+
+
+@pytest.mark.parametrize("config,keeps", [
+    ({}, (1.0, 1.0)),                                                                  # the reference's default model
+    ({}, (0.8, 0.9)),                                                                  # its training recipe: weight dropout, + readout dropout
+    ({"hidden_size": 64, "layer_timesteps": [2, 1, 2], "residual_connections": {"1": [0], "2": [0, 1]},
+      "use_edge_msg_avg_aggregation": False, "graph_rnn_activation": "ReLU"}, (0.8, 1.0)),
+    ({"layer_timesteps": [1, 2], "residual_connections": {"1": [1, 0]}, "task_ids": [0, 1], "task_sample_ratios": {"1": 0.5}}, (1.0, 1.0)),
+])
+def test_native_training_step_equals_autograd_path(pkg, oracle, cuda, config, keeps, monkeypatch):
+    """train_native (two C calls per step: csrc/ggnn_train.hip) against the torch.autograd path it replaces for the default
+    model: the same losses and, after three optimisation steps from the same weights, the same weights -- the two paths launch
+    the same kernels on the same operands; only the order in which gradient contributions of shared layer inputs are added
+    differs (fp32 rounding)."""
+    results = []
+    for native in (True, False):
+        monkeypatch.setattr(pkg.backward, "USE_NATIVE_STEP", native)
+        ms = pkg.synthetic_qm9(300, mean_nodes=10, seed=4, num_tasks=max(config.get("task_ids", [0])) + 1)
+        cfg = dict(config)
+        model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms, "--config": cfg})
+        model.set_graph_weights(oracle.make_sparse_layers(np.random.default_rng(4), model.params, model.num_edge_types, random_bias=True))
+        feed = dict(next(iter(model.make_minibatch_iterator(model.train_data, is_training=False))))
+        feed["edge_weight_dropout_keep_prob"], feed["out_layer_dropout_keep_prob"] = keeps
+        assert pkg.train_native.eligible(model, feed) == native
+        losses = [float(model.train_batch(feed)) for _ in range(3)]
+        torch.cuda.synchronize()
+        results.append((losses, {k: v.detach().clone() for k, v in model.trainable_variables.items()},
+                        float(model.ops["accuracy_task0"]), model.ops["final_node_representations"].detach().clone()))
+    (l1, w1, a1, f1), (l0, w0, a0, f0) = results
+    np.testing.assert_allclose(l1, l0, rtol=2e-6)
+    assert abs(a1 - a0) <= 2e-6 * max(1.0, abs(a0))
+    assert float((f1 - f0).abs().max()) < 2e-5
+    for k in w0:
+        assert float((w1[k] - w0[k]).abs().max()) < 2e-5, k       # three Adam steps of ~1e-3: <1 % of one step
+
+
+def test_native_training_step_is_not_taken_by_other_variants(pkg, cuda):
+    ms = pkg.synthetic_qm9(40, mean_nodes=8, seed=1)
+    for cfg in ({"use_edge_bias": True}, {"graph_rnn_cell": "RNN"}, {"use_propagation_attention": True}, {"hidden_size": 84},
+                {"layer_timesteps": [1, 1, 1, 1], "residual_connections": {"3": [0, 1, 2]}}):
+        model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms, "--config": cfg})
+        feed = dict(next(iter(model.make_minibatch_iterator(model.train_data, is_training=False))))
+        assert not pkg.train_native.eligible(model, feed), cfg
+        assert np.isfinite(float(model.train_batch(feed)))
+    model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms})
+    feed = dict(next(iter(model.make_minibatch_iterator(model.train_data, is_training=False))))
+    assert pkg.train_native.eligible(model, feed)
+    assert not pkg.train_native.eligible(model, dict(feed, graph_state_keep_prob=0.9))
