@@ -284,24 +284,37 @@ __global__ __launch_bounds__(kXtyWaves * 64) void xty_kernel(XtyArgs a) {
 // go to C [nbatch][K][N] and the ones row to Cb [nbatch][N]; accumulate: the sums are ADDED to what the destinations hold (the
 // gradient buffers of the training step: one launch less per product, and no torch add on the side stream).
 struct XtyReduceArgs { int wg_off[kXtyMaxBatch + 1]; };
-__global__ void xty_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, float* __restrict__ Cb, int KN, int KwN,
-                                  int nbatch, int accumulate, XtyReduceArgs ra) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)KN * nbatch) return;
-    const int b = (int)(i / KN), j = (int)(i - (long long)b * KN);
-    // eight independent chains (row p goes to chain p % 8), combined pairwise: a fixed order with 1/8 of the dependent loads
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int S = ra.wg_off[b + 1] - ra.wg_off[b];
-    const float* src = part + (size_t)ra.wg_off[b] * KN + j;
-    int p = 0;
-    for (; p + 8 <= S; p += 8) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s[q] += src[(size_t)(p + q) * KN];
+// A block = 32 consecutive output elements x the 8 chains: thread (c, q) sums the partials of the workgroup rows p == q (mod 8) of
+// its element in row order, the chains are combined pairwise through LDS -- the same sums in the same order as one thread walking
+// eight interleaved chains (the first form of this kernel), but 8x the threads: the reduction of a 201 x 200 product over 256
+// workgroup rows is 41 MB read by 1256 blocks instead of 157 (it had become the largest single line of the training step's profile:
+// 24 launches of 31-59 us next to the fused GRU backward, for 11 us of memory traffic).
+__global__ __launch_bounds__(256) void xty_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, float* __restrict__ Cb,
+                                                         int KN, int KwN, int nbatch, int accumulate, XtyReduceArgs ra) {
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + c;
+    const bool on = i < (long long)KN * nbatch;
+    float s = 0.f;
+    int b = 0, j = 0;
+    if (on) {
+        b = (int)(i / KN); j = (int)(i - (long long)b * KN);
+        const int S = ra.wg_off[b + 1] - ra.wg_off[b];
+        const float* src = part + (size_t)ra.wg_off[b] * KN + j;
+        int p = q;
+        for (; p + 24 < S; p += 32) {                      // four loads in flight per thread; the adds stay in row order
+            const float v0 = src[(size_t)p * KN], v1 = src[(size_t)(p + 8) * KN], v2 = src[(size_t)(p + 16) * KN], v3 = src[(size_t)(p + 24) * KN];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; p < S; p += 8) s += src[(size_t)p * KN];
     }
-    for (int q = 0; p < S; ++p, ++q) s[q] += src[(size_t)p * KN];
-    const float v = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-    float* dst = (Cb && j >= KwN) ? Cb + (size_t)b * (KN - KwN) + (j - KwN) : C + (size_t)b * (Cb ? KwN : KN) + j;
-    *dst = accumulate ? *dst + v : v;
+    red[q][c] = s;
+    __syncthreads();
+    if (q == 0 && on) {
+        const float v = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
+        float* dst = (Cb && j >= KwN) ? Cb + (size_t)b * (KN - KwN) + (j - KwN) : C + (size_t)b * (Cb ? KwN : KN) + j;
+        *dst = accumulate ? *dst + v : v;
+    }
 }
 
 struct XtyPlan { int rows, kb_tiles, n_tiles, kblocks, px, py, wg_rows; size_t lds; int wg_off[kXtyMaxBatch + 1]; };
@@ -350,7 +363,7 @@ static int launch_xty(const XtyArgs& a, const XtyPlan& p, float* C, float* Cb, i
     XtyReduceArgs ra;
     for (int b = 0; b <= kXtyMaxBatch; ++b) ra.wg_off[b] = a.wg_off[b <= a.nbatch ? b : a.nbatch];
     const long long total = (long long)a.Kout * a.N * a.nbatch;
-    hipLaunchKernelGGL(xty_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)a.part, C, Cb, a.Kout * a.N,
+    hipLaunchKernelGGL(xty_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, (const float*)a.part, C, Cb, a.Kout * a.N,
                        a.K * a.N, a.nbatch, accumulate, ra);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
