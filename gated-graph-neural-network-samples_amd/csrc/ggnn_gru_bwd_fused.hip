@@ -72,7 +72,18 @@ __device__ __forceinline__ void store_frag(float* base, int row, int kq, const F
         *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + ((unsigned)row * (unsigned)D + 16u * NC + 4u * q + (unsigned)kq) * 4u) = f.r[q];
 }
 
-template <int D, int NX, int NW, bool PREFETCH, int RING>
+// PREFETCH: 0 = a tile's inputs are fetched at the top of its pass; 1 = under the last stage of the previous pass (same registers);
+// 2 = a WHOLE pass ahead, into a second register set, one fragment per stage (g, u, c, h, r under stages 0..4) -- for the 4-wave
+// form (NW = 4: one wave per SIMD, so a wave may use the whole 512-entry register file of its SIMD lane; the compiler places
+// ~200 values in the accumulation half).  MEASURED (tools/gru_bwd_bench.py, tools/gru_bwd_timeline.py, round 3): the head of a
+// pass shrinks from 22-41k to 2k clocks, but a stage of ONE tile per SIMD is 5.6k clocks of matrix-pipe work and takes 7-10k:
+// the barrier that closes a stage waits for the LDS-DMA of the next image and -- the load counter is in order -- for the
+// fragment issued before it, and neither a 48 KiB image nor a 6.4 KB-per-wave HBM fragment lands in 5.6k clocks.  58k clocks per
+// 4 tiles against 60.5k in form 0: 200 vs 205 us.  Staging the images through registers instead of LDS-DMA (exact counter waits)
+// does not help either: the image's loads are younger than the fragment's, waiting for them waits for it (245 us, and the
+// register file overflows: 276 B of scratch).  Hiding the loads needs a load path whose completion is not ordered with the
+// weights' -- a loader wave would do, but a fifth wave halves the register budget of the other four.
+template <int D, int NX, int NW, int PREFETCH, int RING>
 __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs a, const float* __restrict__ packed) {
     using C = StageCfg<D>;
     constexpr int NT = C::NT, NC = C::NC, NR = C::NR;
@@ -101,16 +112,19 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
     // last stage of the previous pass, when only dpu of the current tile is still live -- so that no pass starts with an
     // exposed load phase; the first tile's are fetched before the loop.
     struct Raw { Frag<D> g, u, c, h, r; };
-    auto fetch_raw = [&](Raw& x, int t, int part) {           // part 0: g, u, c, h;  part 1: r
+    auto fetch_piece = [&](Raw& x, int t, int piece) {        // piece 0..4: g, u, c, h, r
         const int tile = tile_of(t);
         const int r0 = (tile >= 0 ? tile : 0) * 16 + li;
         const int rc = r0 < a.V ? r0 : a.V - 1;
-        if (part == 0) {
-            load_frag<D>(x.g, a.g, rc, kq); load_frag<D>(x.u, a.u, rc, kq); load_frag<D>(x.c, a.c, rc, kq);
-            load_frag<D>(x.h, a.h, rc, kq);
-        } else {
-            load_frag<D>(x.r, a.r, rc, kq);
-        }
+        if (piece == 0) load_frag<D>(x.g, a.g, rc, kq);
+        else if (piece == 1) load_frag<D>(x.u, a.u, rc, kq);
+        else if (piece == 2) load_frag<D>(x.c, a.c, rc, kq);
+        else if (piece == 3) load_frag<D>(x.h, a.h, rc, kq);
+        else load_frag<D>(x.r, a.r, rc, kq);
+    };
+    auto fetch_raw = [&](Raw& x, int t, int part) {           // part 0: g, u, c, h;  part 1: r
+        if (part == 0) { fetch_piece(x, t, 0); fetch_piece(x, t, 1); fetch_piece(x, t, 2); fetch_piece(x, t, 3); }
+        else fetch_piece(x, t, 4);
     };
     // value of accumulator-layout tile NC (the D % 16 remainder columns 16NC .. +3, held by the kq == 0 lanes) from a fragment:
     // column 16NC + e is the remainder element of lane (li, kq' = e)
@@ -125,8 +139,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
 
     int cur = 0;
     if constexpr (RING == 2) dma_stage_image<D, NW>(packed, ring, wave, lane);
-    Raw raw;
-    if (PREFETCH && (int)blockIdx.x < n_tk) { fetch_raw(raw, blockIdx.x, 0); fetch_raw(raw, blockIdx.x, 1); }
+    Raw raw_a, raw_b;                                            // (raw_b: PREFETCH == 2 only, the tile after the current one)
+    if (PREFETCH && (int)blockIdx.x < n_tk) { fetch_raw(raw_a, blockIdx.x, 0); fetch_raw(raw_a, blockIdx.x, 1); }
     __syncthreads();
 
     // A wave has tiles in a PREFIX of its workgroup's passes (full tickets, then possibly a thin tail ticket), so the passes run
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
     int pass_no = 0;
 #define GGNN_BT(K) if (a.tdbg && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && pass_no < 8) \
         a.tdbg[(pass_no * 2 + (wave >> 2)) * 16 + (K)] = __builtin_amdgcn_s_memtime();
-    auto run_pass = [&](auto active_c) {
+    auto run_pass = [&](auto active_c, Raw& raw, Raw& raw_next) {
         const int tile = tile_of(tk);
         const bool last_pass = tk + nb >= n_tk;
         GGNN_BT(0)
@@ -151,6 +165,9 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
                 const float* nsrc = packed + (size_t)nidx * C::IMG;
                 float* ndst = ring + (cur ^ 1) * C::IMG;
                 before();
+                if constexpr (PREFETCH == 2) {
+                    if (ACT && !last_pass && img_idx < 5) fetch_piece(raw_next, tk + nb, img_idx);
+                }
                 if constexpr (RING == 1) {
                     // one image in LDS (two of these 4-wave workgroups share a CU and run out of phase: the DMA wait and the
                     // load / epilogue phases of one are covered by the MFMAs of the other)
@@ -266,8 +283,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
             // (g, u, c, h before the burst of the last stage -- dpc, dpr are dead by then; r after it, when dpu is dead too:
             //  all five at once overflow the register file by ~60 values)
             GGNN_BT(6)
-            auto fetch_next_a = [&] { if (PREFETCH && ACT && !last_pass) fetch_raw(raw, tk + nb, 0); };
-            auto fetch_next_b = [&] { if (PREFETCH && ACT && !last_pass) fetch_raw(raw, tk + nb, 1); };
+            auto fetch_next_a = [&] { if (PREFETCH == 1 && ACT && !last_pass) fetch_raw(raw, tk + nb, 0); };
+            auto fetch_next_b = [&] { if (PREFETCH == 1 && ACT && !last_pass) fetch_raw(raw, tk + nb, 1); };
 #define GGNN_BWD_SEG(S)                                                                                             \
             if constexpr ((S) < NX) {                                                                               \
                 stage(std::true_type{}, acc, dpc, 3 + 3 * (S), nothing, nothing);                                   \
@@ -303,8 +320,19 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
         }
         ++pass_no;
     };
-    for (; tk < n_tk && tile_of(tk) >= 0; tk += nb) run_pass(std::true_type{});
-    for (; tk < n_tk; tk += nb) run_pass(std::false_type{});
+    if constexpr (PREFETCH == 2) {
+        // the two register sets swap roles from pass to pass: the loop is unrolled by two instead of copying 125 registers
+        while (tk < n_tk && tile_of(tk) >= 0) {
+            run_pass(std::true_type{}, raw_a, raw_b);
+            tk += nb;
+            if (!(tk < n_tk && tile_of(tk) >= 0)) break;
+            run_pass(std::true_type{}, raw_b, raw_a);
+            tk += nb;
+        }
+    } else {
+        for (; tk < n_tk && tile_of(tk) >= 0; tk += nb) run_pass(std::true_type{}, raw_a, raw_a);
+    }
+    for (; tk < n_tk; tk += nb) run_pass(std::false_type{}, raw_a, raw_a);
 }
 
 // (A "pipelined" form -- g, u, c of the next tile fetched under the last three stages, h and r under stage 0, every store issued in
@@ -313,7 +341,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
 //  share of HBM (6 TB/s / 256 CUs = 10 B/clock) is 28k clocks; hiding it takes a full pass of prefetch distance, i.e. 125 more
 //  registers per wave or 256 KB of LDS per CU.  tools/gru_bwd_timeline.py, tools/gru_bwd_bench.py)
 
-template <int D, int NX, int NW, bool PREFETCH, int RING>
+template <int D, int NX, int NW, int PREFETCH, int RING>
 static int launch_gru_bwd_variant(const GruBwdArgs& a, const float* packed, hipStream_t st) {
     using C = StageCfg<D>;
     const size_t lds = (size_t)RING * C::IMG_BYTES;
@@ -339,10 +367,13 @@ static int launch_gru_bwd(const GruBwdArgs& a, const float* Wg, const float* Wc,
     // GGNN_BWD_FORM: 0 = one 8-wave workgroup per CU, 2-image ring, inputs fetched at the top of a pass;
     //                1 = the same with the next tile's inputs prefetched under the last stage;
     //                2 = two 4-wave workgroups per CU, one image each
+    //                3 = one 4-wave workgroup per CU (a wave per SIMD, 256 + ~200 registers), the next tile's inputs fetched a
+    //                    whole pass ahead into a second register set, one fragment per stage (see the kernel's header)
     const int form = [] { const char* e = getenv("GGNN_BWD_FORM"); return e ? atoi(e) : 0; }();   // (read per call: tools/gru_bwd_bench.py)
-    if (form == 1) return launch_gru_bwd_variant<D, NX, 8, true, 2>(a, packed, st);
-    if (form == 2) return launch_gru_bwd_variant<D, NX, 4, false, 1>(a, packed, st);
-    return launch_gru_bwd_variant<D, NX, 8, false, 2>(a, packed, st);
+    if (form == 1) return launch_gru_bwd_variant<D, NX, 8, 1, 2>(a, packed, st);
+    if (form == 2) return launch_gru_bwd_variant<D, NX, 4, 0, 1>(a, packed, st);
+    if (form == 3) return launch_gru_bwd_variant<D, NX, 4, 2, 2>(a, packed, st);
+    return launch_gru_bwd_variant<D, NX, 8, 0, 2>(a, packed, st);
 }
 
 template <int D>
