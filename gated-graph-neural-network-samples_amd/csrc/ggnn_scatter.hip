@@ -189,42 +189,68 @@ __global__ void slot_heads_kernel(const int* __restrict__ row_ptr, const int* __
 }
 
 // One lane per (node, float4 column), slot heads: same sums, same order, same epilogue as gather_segment_sum_flat_kernel.
+// A thread works on ITEMS (node, column) items, 256 apart, in three phases -- all head records, then all (up to 4 ITEMS) source
+// rows, then the adds and stores -- so that it has ITEMS times the loads in flight per dependent level and the launch has
+// 1 / ITEMS of the workgroups: with one item per thread the 25 us launch at QM9 shape spent a third of its time ramping up and
+// draining 9,766 tiny workgroups.
+template <int ITEMS>
 __global__ __launch_bounds__(256) void gather_segment_sum_heads_kernel(
         const float* __restrict__ H, const int* __restrict__ row_ptr, const int* __restrict__ gidx, const int4* __restrict__ heads,
         const float* __restrict__ nin, const float* __restrict__ bias, int use_avg, float* __restrict__ out,
         long long total4, int D, int T, int accumulate) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total4) return;
     const int D4 = D >> 2;
-    const int v = (int)(i / D4);
-    const int c4 = (int)(i - (long long)v * D4);
-    const int4 hd = heads[v];
-    const int beg = row_ptr[v], end = row_ptr[v + 1];           // (independent of the head record: only the tail loop needs them)
-    const float* hcol = H + 4 * c4;
-    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0, r3 = r0;
-    if (hd.x >= 0) r0 = *reinterpret_cast<const f32x4*>(hcol + (size_t)hd.x * D);
-    if (hd.y >= 0) r1 = *reinterpret_cast<const f32x4*>(hcol + (size_t)hd.y * D);
-    if (hd.z >= 0) r2 = *reinterpret_cast<const f32x4*>(hcol + (size_t)hd.z * D);
-    if (hd.w >= 0) r3 = *reinterpret_cast<const f32x4*>(hcol + (size_t)hd.w * D);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc += r0;                                                  // slot order = reference accumulation order
-    if (hd.y >= 0) acc += r1;
-    if (hd.z >= 0) acc += r2;
-    if (hd.w >= 0) acc += r3;
-    for (int e = beg + 4; e < end; ++e) acc += *reinterpret_cast<const f32x4*>(hcol + (size_t)gidx[e] * D);
-    if (bias || use_avg) {
-        float deg = 0.f;
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < T; ++t) {
-            const float n = nin[(size_t)v * T + t];
-            deg += n;
-            if (bias) b += n * *reinterpret_cast<const f32x4*>(bias + (size_t)t * D + 4 * c4);
-        }
-        if (bias) acc += b;
-        if (use_avg) acc = acc / (deg + 1e-7f);
+    const long long i0 = ((long long)blockIdx.x * ITEMS) * 256 + threadIdx.x;
+    int v[ITEMS], c4[ITEMS];
+    bool on[ITEMS];
+    int4 hd[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const long long i = i0 + (long long)k * 256;
+        on[k] = i < total4;
+        const long long ic = on[k] ? i : 0;
+        v[k] = (int)(ic / D4);
+        c4[k] = (int)(ic - (long long)v[k] * D4);
+        hd[k] = heads[v[k]];
+        if (!on[k]) hd[k] = make_int4(-1, -1, -1, -1);
     }
-    if (accumulate) acc += *reinterpret_cast<const f32x4*>(out + (size_t)v * D + 4 * c4);
-    *reinterpret_cast<f32x4*>(out + (size_t)v * D + 4 * c4) = acc;
+    f32x4 r[ITEMS][4];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const float* hcol = H + 4 * c4[k];
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        r[k][0] = hd[k].x >= 0 ? *reinterpret_cast<const f32x4*>(hcol + (size_t)hd[k].x * D) : z;
+        r[k][1] = hd[k].y >= 0 ? *reinterpret_cast<const f32x4*>(hcol + (size_t)hd[k].y * D) : z;
+        r[k][2] = hd[k].z >= 0 ? *reinterpret_cast<const f32x4*>(hcol + (size_t)hd[k].z * D) : z;
+        r[k][3] = hd[k].w >= 0 ? *reinterpret_cast<const f32x4*>(hcol + (size_t)hd[k].w * D) : z;
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        if (!on[k]) continue;
+        const float* hcol = H + 4 * c4[k];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc += r[k][0];                                             // slot order = reference accumulation order
+        if (hd[k].y >= 0) acc += r[k][1];
+        if (hd[k].z >= 0) acc += r[k][2];
+        if (hd[k].w >= 0) {
+            acc += r[k][3];
+            const int beg = row_ptr[v[k]], end = row_ptr[v[k] + 1];     // (only a node with more than four slots walks the slot list)
+            for (int e = beg + 4; e < end; ++e) acc += *reinterpret_cast<const f32x4*>(hcol + (size_t)gidx[e] * D);
+        }
+        if (bias || use_avg) {
+            float deg = 0.f;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < T; ++t) {
+                const float n = nin[(size_t)v[k] * T + t];
+                deg += n;
+                if (bias) b += n * *reinterpret_cast<const f32x4*>(bias + (size_t)t * D + 4 * c4[k]);
+            }
+            if (bias) acc += b;
+            if (use_avg) acc = acc / (deg + 1e-7f);
+        }
+        float* o = out + (size_t)v[k] * D + 4 * c4[k];
+        if (accumulate) acc += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = acc;
+    }
 }
 
 // ---- propagation attention (chem_tensorflow_sparse.py:147-149, 170-196) fused into the segment sum ---------
@@ -487,8 +513,19 @@ static int gather_segment_sum_impl(const float* Hrows, const int32_t* row_ptr, c
     const bool flat = flat_env >= 0 ? flat_env != 0 : (D4 < 64 && (64 % D4) != 0);
     if (heads && flat) {   // (the sub-wave kernels keep their own slot-index broadcast: at D = 256 / in-degree 10 they measure 155 vs 179 us)
         const long long total4 = (long long)V * D4;
-        hipLaunchKernelGGL(gather_segment_sum_heads_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, Hrows, row_ptr,
-                           gather_row, reinterpret_cast<const int4*>(heads), nin, bias, use_avg, out, total4, D, T, accumulate);
+        static const int items = [] { const char* e = getenv("GGNN_K2_ITEMS"); return e ? atoi(e) : 2; }();
+        if (items == 1)
+            hipLaunchKernelGGL(gather_segment_sum_heads_kernel<1>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, Hrows, row_ptr,
+                               gather_row, reinterpret_cast<const int4*>(heads), nin, bias, use_avg, out, total4, D, T, accumulate);
+        else if (items == 2)
+            hipLaunchKernelGGL(gather_segment_sum_heads_kernel<2>, dim3((unsigned)((total4 + 511) / 512)), dim3(256), 0, st, Hrows, row_ptr,
+                               gather_row, reinterpret_cast<const int4*>(heads), nin, bias, use_avg, out, total4, D, T, accumulate);
+        else if (items == 8)
+            hipLaunchKernelGGL(gather_segment_sum_heads_kernel<8>, dim3((unsigned)((total4 + 2047) / 2048)), dim3(256), 0, st, Hrows, row_ptr,
+                               gather_row, reinterpret_cast<const int4*>(heads), nin, bias, use_avg, out, total4, D, T, accumulate);
+        else
+            hipLaunchKernelGGL(gather_segment_sum_heads_kernel<4>, dim3((unsigned)((total4 + 1023) / 1024)), dim3(256), 0, st, Hrows, row_ptr,
+                               gather_row, reinterpret_cast<const int4*>(heads), nin, bias, use_avg, out, total4, D, T, accumulate);
     } else if (flat) {
         const long long total4 = (long long)V * D4;
         hipLaunchKernelGGL(gather_segment_sum_flat_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, Hrows,

@@ -1,4 +1,4 @@
-"""Stand-alone segment sum (K2) at the config-2 shape for the GGNN_K2_ILP settings (env read once per process: run per value)."""
+"""Stand-alone segment sum (K2) at the config-2 shape for the GGNN_K2_ITEMS settings (items per thread of the slot-head kernel) (env read once per process: run per value)."""
 import importlib, os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("gated-graph-neural-network-samples_amd")
@@ -16,4 +16,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(200): out = run()
 e1.record(); torch.cuda.synchronize()
-print("GGNN_K2_ILP=%s: %.2f us  (V=%d, M=%d)  checksum %.6f" % (os.environ.get("GGNN_K2_ILP", "default"), e0.elapsed_time(e1) * 5, V, idx.num_messages, float(out.double().sum())))
+print("GGNN_K2_ITEMS=%s: %.2f us  (V=%d, M=%d)  checksum %.6f" % (os.environ.get("GGNN_K2_ITEMS", "default"), e0.elapsed_time(e1) * 5, V, idx.num_messages, float(out.double().sum())))
