@@ -93,6 +93,31 @@ class DeviceMoleculeSet:
         return hit
 
 
+    def upload_order(self, order: np.ndarray) -> torch.Tensor:
+        """An epoch's graph order on the device (int64 [G]).  The identity order (validation, inference) is cached; a shuffled
+        order goes through a pinned staging buffer on a copy stream of its own -- a pageable
+        `torch.from_numpy(order).to(device)` on the packing stream is a staged synchronous copy behind everything queued there and
+        held the launching thread for ~2 ms at every epoch start while the queues ran dry (tools/e2e_trace.py)."""
+        G = int(order.shape[0])
+        if G == self.host.num_graphs and G and order[0] == 0 and order[-1] == G - 1 and bool((np.diff(order) == 1).all()):
+            ident = getattr(self, "_identity_order", None)
+            if ident is None:
+                ident = self._identity_order = torch.arange(G, dtype=torch.int64, device=self.device)
+            return ident
+        if self.device.type != "cuda":
+            return torch.from_numpy(order).to(self.device)
+        stage = getattr(self, "_order_stage", None)
+        if stage is None or stage[0].numel() < G:
+            stage = self._order_stage = (torch.empty(max(G, 1), dtype=torch.int64, pin_memory=True), torch.cuda.Stream(self.device))
+        pinned, up = stage
+        pinned[:G].copy_(torch.from_numpy(order))
+        dev_order = torch.empty(G, dtype=torch.int64, device=self.device)
+        # on a stream of its own, so that waiting for the copy waits for nothing else; complete on return (any stream may read it)
+        with torch.cuda.stream(up):
+            dev_order.copy_(pinned[:G], non_blocking=True)
+        up.synchronize()
+        return dev_order
+
     def arange_i32(self, n: int) -> torch.Tensor:
         """arange(n) int32 on the device, cut from one cached ramp (the identity row list of the backward's compacted transform:
         one launch less per training batch)."""
@@ -370,7 +395,7 @@ def pack_batches_device(dms: DeviceMoleculeSet, params: dict, num_edge_types: in
     bounds = batch_boundaries(dms.nodes_per_graph[order], params["batch_size"])
     nb = len(bounds) - 1
     steps = (nb + world_size - 1) // world_size
-    order_dev = torch.from_numpy(order).to(dms.device)          # ONE upload per epoch: the batches slice it on the device
+    order_dev = dms.upload_order(order)                         # ONE upload per epoch: the batches slice it on the device
     for s in range(steps):
         i = s * world_size + rank
         ids = order[bounds[i]:bounds[i + 1]] if i < nb else np.zeros(0, np.int64)

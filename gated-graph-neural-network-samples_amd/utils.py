@@ -148,30 +148,38 @@ class StreamPrefetcher:
         start.record()                                   # whatever built the resident dataset is ordered before the first pack
         for ps in self._packs:
             ps.wait_event(start)
+        def produce(n):
+            nonlocal produced, exhausted
+            for _ in range(n):
+                if exhausted:
+                    return
+                with torch.cuda.stream(self._packs[produced % len(self._packs)]):
+                    try:
+                        element = next(it)
+                    except StopIteration:
+                        exhausted = True
+                        return
+                    ready = torch.cuda.Event()
+                    ready.record()
+                queue.append((element, ready))
+                produced += 1
+
         try:
             while True:
-                # the first element is handed out as soon as it is packed; the queue then fills up two elements per hand-out (the
-                # consumer's kernels are running by then) -- packing `depth` batches up front would leave the GPU idle for as long
-                want = 1 if k == 0 else min(self._depth, len(queue) + 2)
-                while not exhausted and len(queue) < want:
-                    with torch.cuda.stream(self._packs[produced % len(self._packs)]):
-                        try:
-                            element = next(it)
-                        except StopIteration:
-                            exhausted = True
-                            break
-                        ready = torch.cuda.Event()
-                        ready.record()
-                    queue.append((element, ready))
-                    produced += 1
+                # An element is handed out as soon as one is ready; the queue is topped up (two elements per hand-out, up to
+                # `depth`) AFTER the consumer has queued its kernels for it -- packing `depth` batches up front, or setting up the
+                # next epoch (graph order upload, batch boundaries) in front of a hand-out, leaves the GPU idle for as long.
                 if not queue:
-                    break
+                    produce(1)
+                    if not queue:
+                        break
                 element, ready = queue.popleft()
                 self._retire(prev, prev_stream)
                 stream = self._streams[k % len(self._streams)] or torch.cuda.current_stream(self._device)
                 stream.wait_event(ready)
                 prev, prev_stream, k = element, stream, k + 1
                 yield element, stream
+                produce(min(2, self._depth - len(queue)))
         finally:
             self._retire(prev, prev_stream)
             for ev, _ in self._retired:
