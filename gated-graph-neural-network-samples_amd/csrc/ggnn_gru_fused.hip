@@ -256,7 +256,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             if constexpr (G_NEXT) {
                 g_ptrs(r0c, on);
                 if (on) { g_index(); g_rows0(xf[0]); g_rows(xf[0], 2); g_rows(xf[0], 3); g_finish(xf[0]); }
-                if constexpr (SAVE) { if (on && r0 < a.V) store_x(xf[0], r0); }
+                if constexpr (SAVE) { if (on && r0 < a.V && a.save_x) store_x(xf[0], r0); }
             } else {
                 if constexpr (G_U - 5 < 0) g_ptrs(r0c, on);
                 if constexpr (G_U - 4 < 0) g_index();         // (also for a wave without a tile: its slots -> row 0)
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         {                                                                                                \
             GGNN_T(POS, 0)                                                                               \
             if constexpr (GATHER && (POS) == G_U % NSTAGE) {                                             \
-                if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVE) { if (row < a.V) store_x(xf[GBUF], row); } } \
+                if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVE) { if (row < a.V && a.save_x) store_x(xf[GBUF], row); } } \
             }                                                                                            \
             if constexpr ((POS) + TWD < NSTAGE) {                                                        \
                 if (wave < NT) load_tile_weights<D>(tw[((POS) + TWD) % (TWD + 1)],                       \
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             float* ndst_ = ring + (cur ^ 1) * C::IMG;                                                    \
             GGNN_T(POS, 0)                                                                               \
             if constexpr (GATHER && (POS) == G_U % NSTAGE) {   /* the fragment this stage multiplies */  \
-                if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVE) { if (row < a.V) store_x(xf[GBUF], row); } } \
+                if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVE) { if (row < a.V && a.save_x) store_x(xf[GBUF], row); } } \
             }                                                                                            \
             /* Side work of the stage (prefetches, the DMA of the whole next image): the LATE waves do it  \
                before their MFMA burst, the EARLY waves after theirs, so its memory instructions issue      \
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                 if constexpr (COOP_REGS) hv = hv_pre;
                 else hv = ld4_b(a.h, ((unsigned)rowc * D + col) * 4u);
                 if constexpr (SAVE) {
-                    if (row < a.V) {
+                    if (row < a.V && a.save_r) {
                         st4_b(a.save_r, ((unsigned)row * D + col) * 4u, r);
                         st4_b(a.save_u, ((unsigned)row * D + col) * 4u, u);
                     }
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                     const f32x4 u = sigmoid4_scaled(acc_u[nt], ld4(bias_s + D + col));
                     acc_r[nt] = r; acc_u[nt] = u;
                     if constexpr (SAVE) {
-                        if (row < a.V) {
+                        if (row < a.V && a.save_r) {
                             st4_b(a.save_r, ((unsigned)row * D + col) * 4u, r);
                             st4_b(a.save_u, ((unsigned)row * D + col) * 4u, u);
                         }
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                 }
                 const f32x4 u = acc_u[0], hv = acc_r[0];
                 st4_b(a.h_out, ((unsigned)row * D + col) * 4u, u * hv + (1.0f - u) * c);
-                if constexpr (SAVE) st4_b(a.save_c, ((unsigned)row * D + col) * 4u, c);
+                if constexpr (SAVE) { if (a.save_c) st4_b(a.save_c, ((unsigned)row * D + col) * 4u, c); }
             }
             return;
         }
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                     }
                     const f32x4 u = acc_u[nt];
                     st4_b(a.h_out, ((unsigned)row * D + col) * 4u, u * hv + (1.0f - u) * c);
-                    if constexpr (SAVE) st4_b(a.save_c, ((unsigned)row * D + col) * 4u, c);
+                    if constexpr (SAVE) { if (a.save_c) st4_b(a.save_c, ((unsigned)row * D + col) * 4u, c); }
                 }
             }
         }
@@ -598,6 +598,11 @@ static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t
     return GGNN_OK;
 }
 
+static bool nosave_kernel() {
+    static const bool v = [] { const char* e = getenv("GGNN_GRU_NOSAVE_KERNEL"); return e && atoi(e) != 0; }();
+    return v;
+}
+
 template <int D>
 static int dispatch_nx(const GruFusedArgs& a, float* packed, hipStream_t st) {
     const bool save = a.save_r || a.save_u || a.save_c;
@@ -607,8 +612,11 @@ static int dispatch_nx(const GruFusedArgs& a, float* packed, hipStream_t st) {
         if (save && !a.save_x) return fail(GGNN_E_INVALID, "the gather-fused GRU saves r/u/c together with the gathered segment (save_x)");
         switch (a.nx) {
             case 1: return save ? launch_gru_fused<D, 1, 8, true, true>(a, packed, st) : launch_gru_fused<D, 1, 8, false, true>(a, packed, st);
-            case 2: return save ? launch_gru_fused<D, 2, 8, true, true>(a, packed, st) : launch_gru_fused<D, 2, 8, false, true>(a, packed, st);
-            case 3: return save ? launch_gru_fused<D, 3, 8, true, true>(a, packed, st) : launch_gru_fused<D, 3, 8, false, true>(a, packed, st);
+            // With residual inputs the inference kernels (SAVE = false) come out of the register allocator with 36-40 B of scratch per
+            // lane, the training instantiations (SAVE = true: the same code plus stores) with none -- so those run both, the
+            // stores skipped at run time when no save buffers are given (a uniform branch).  GGNN_GRU_NOSAVE_KERNEL=1: the others.
+            case 2: return (save || !nosave_kernel()) ? launch_gru_fused<D, 2, 8, true, true>(a, packed, st) : launch_gru_fused<D, 2, 8, false, true>(a, packed, st);
+            case 3: return (save || !nosave_kernel()) ? launch_gru_fused<D, 3, 8, true, true>(a, packed, st) : launch_gru_fused<D, 3, 8, false, true>(a, packed, st);
             default: return fail(GGNN_E_INVALID, "nx %d outside 1..3", a.nx);
         }
     }

@@ -1,0 +1,25 @@
+"""Per-kernel HIP-event timing of one 8-step forward at the headline shape (bench.py's roofline leg on its own)."""
+import importlib, os, sys, json
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("gated-graph-neural-network-samples_amd")
+ms = pkg.synthetic_qm9(5700 * 2, mean_nodes=18, seed=1000)
+model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": None, "valid_data": ms})
+feeds = list(model.make_minibatch_iterator(model.valid_data, False))[:2]
+for f in feeds:
+    f["initial_node_representation"] = torch.rand_like(f["initial_node_representation"]) * 2 - 1
+with torch.no_grad():
+    for i in range(6):
+        model.feed(feeds[i % 2]); model.compute_final_node_representations()
+    with pkg.ops.kernel_timing() as kt:
+        for i in range(10):
+            model.feed(feeds[i % 2]); model.compute_final_node_representations()
+    res = kt.results()
+    print({k: round(float(np.mean(v)) * 1e3, 1) for k, v in res.items()})
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for i in range(100):
+        model.feed(feeds[i % 2]); model.compute_final_node_representations()
+    torch.cuda.synchronize()
+    print("one stream: %.3f ms per forward" % ((time.perf_counter() - t0) * 10))
