@@ -115,6 +115,9 @@ SYMBOLS = {
     "ggnn_gemm_tn_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ggnn_pack_batch_tables": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
+    "ggnn_sparse_train_prepare_f32": (c_int, [c_int, c_int, c_int, POINTER(c_int32), POINTER(c_void_p), c_float, POINTER(c_uint64),
+                                              POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                              POINTER(c_void_p), c_void_p]),
     "ggnn_sparse_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int64, c_int]),
     "ggnn_sparse_train_forward_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p,
                                               c_int, c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_void_p),

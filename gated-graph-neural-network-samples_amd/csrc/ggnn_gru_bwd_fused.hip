@@ -39,26 +39,8 @@ struct GruBwdArgs {
 //   3 + 3s + {0,1,2}: the same three for x segment s (rows s*D + n)
 template <int D>
 __global__ void gru_bwd_pack_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx, float* __restrict__ out) {
-    using C = StageCfg<D>;
     const int i = blockIdx.y;
-    const int seg = i < 3 ? nx : (i - 3) / 3, which = i < 3 ? i : (i - 3) % 3;
-    const float* W = which == 0 ? Wc : Wg;
-    const int ldw = which == 0 ? D : 2 * D;
-    const int c0 = which == 2 ? D : 0;
-    float* img = out + (size_t)i * C::IMG;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < C::IMG; j += gridDim.x * blockDim.x) {
-        float v = 0.f;
-        int k = -1, n = 0;
-        if (j < C::MAIN) {
-            const int e = j & 3; n = (j >> 2) % C::BN; const int ck = (j >> 2) / C::BN;
-            k = 4 * ck + e;
-        } else if (j < C::MAIN + C::REM) {
-            const int jj = j - C::MAIN;
-            n = jj % C::BN; k = 16 * C::NC + jj / C::BN;
-        }
-        if (k >= 0 && n < D) v = W[(size_t)(seg * D + n) * ldw + c0 + k];          // transposed read
-        img[j] = v;
-    }
+    gru_bwd_image_pack<D>(Wg, Wc, nx, i, out + (size_t)i * StageCfg<D>::IMG, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 template <int D>

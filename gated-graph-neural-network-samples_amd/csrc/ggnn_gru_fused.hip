@@ -54,18 +54,8 @@ template <int D>
 __global__ void gru_pack_weights_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx,
                                         float* __restrict__ out) {
     const int ci = blockIdx.y;
-    const float* W; int r0, c0, ldw;
-    int c_alt = -1, c_alt2 = -1, r0_2 = 0;
-    if (ci < 2 * (nx + 1)) {
-        W = Wg; r0 = (ci >> 1) * D; c0 = (ci & 1) * D; ldw = 2 * D;
-        // r images carry the u gate's last (partly filled) tile in their padding columns: the u stages then skip it;
-        // the r images of the x segments also carry the candidate's last tile (same input rows; NOT the h segment,
-        // whose candidate rows multiply r*h)
-        if (StageCfg<D>::TAILPACK && (ci & 1) == 0) c_alt = D + (D / 16) * 16;
-        if (StageCfg<D>::TAILPACK3 && (ci & 1) == 0 && (ci >> 1) < nx) { c_alt2 = (D / 16) * 16; r0_2 = (ci >> 1) * D; }
-    } else { W = Wc; r0 = (ci - 2 * (nx + 1)) * D; c0 = 0; ldw = D; }
-    pack_stage_image<D>(W, r0, c0, ldw, out + (size_t)ci * StageCfg<D>::IMG, blockIdx.x * blockDim.x + threadIdx.x,
-                        gridDim.x * blockDim.x, c_alt, Wc, r0_2, D, c_alt2);
+    gru_fwd_image_pack<D>(Wg, Wc, nx, ci, out + (size_t)ci * StageCfg<D>::IMG, blockIdx.x * blockDim.x + threadIdx.x,
+                          gridDim.x * blockDim.x);
 }
 
 // position in the per-pass stage sequence -> packed image (segment s = pos / 3; 0,1: its r / u gate columns, 2: candidate)

@@ -65,6 +65,48 @@ __device__ __forceinline__ void pack_stage_image(const float* __restrict__ W, in
     }
 }
 
+// Image ci of the fused GRU's packed weights (ggnn_gru_fused.hip): gates (s = 0..nx) x {r,u}, then candidate (s = 0..nx).
+// r images carry the u gate's last (partly filled) tile in their padding columns (the u stages then skip it); the r images of
+// the x segments also carry the candidate's last tile (same input rows; NOT the h segment, whose candidate rows multiply r*h).
+template <int D>
+__device__ __forceinline__ void gru_fwd_image_pack(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx, int ci,
+                                                   float* __restrict__ img, int first, int stride) {
+    const float* W; int r0, c0, ldw;
+    int c_alt = -1, c_alt2 = -1, r0_2 = 0;
+    if (ci < 2 * (nx + 1)) {
+        W = Wg; r0 = (ci >> 1) * D; c0 = (ci & 1) * D; ldw = 2 * D;
+        if (StageCfg<D>::TAILPACK && (ci & 1) == 0) c_alt = D + (D / 16) * 16;
+        if (StageCfg<D>::TAILPACK3 && (ci & 1) == 0 && (ci >> 1) < nx) { c_alt2 = (D / 16) * 16; r0_2 = (ci >> 1) * D; }
+    } else { W = Wc; r0 = (ci - 2 * (nx + 1)) * D; c0 = 0; ldw = D; }
+    pack_stage_image<D>(W, r0, c0, ldw, img, first, stride, c_alt, Wc, r0_2, D, c_alt2);
+}
+
+// Image i of the fused GRU backward's packed weights (ggnn_gru_bwd_fused.hip; image[k][n] = B(k, n), out[:, n] = sum_k A[:, k] B(k, n)):
+//   0: Wc^T h block  B(k,n) = Wc[nx*D + n][k]    1: Wg_r^T h block  B(k,n) = Wg[nx*D + n][k]    2: Wg_u^T h block  B(k,n) = Wg[nx*D + n][D + k]
+//   3 + 3s + {0,1,2}: the same three for x segment s (rows s*D + n)
+template <int D>
+__device__ __forceinline__ void gru_bwd_image_pack(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx, int i,
+                                                   float* __restrict__ img, int first, int stride) {
+    using C = StageCfg<D>;
+    const int seg = i < 3 ? nx : (i - 3) / 3, which = i < 3 ? i : (i - 3) % 3;
+    const float* W = which == 0 ? Wc : Wg;
+    const int ldw = which == 0 ? D : 2 * D;
+    const int c0 = which == 2 ? D : 0;
+    for (int j = first; j < C::IMG; j += stride) {
+        float v = 0.f;
+        int k = -1, n = 0;
+        if (j < C::MAIN) {
+            const int e = j & 3; n = (j >> 2) % C::BN; const int ck = (j >> 2) / C::BN;
+            k = 4 * ck + e;
+        } else if (j < C::MAIN + C::REM) {
+            const int jj = j - C::MAIN;
+            n = jj % C::BN; k = 16 * C::NC + jj / C::BN;
+        }
+        if (k >= 0 && n < D) v = W[(size_t)(seg * D + n) * ldw + c0 + k];          // transposed read
+        img[j] = v;
+    }
+}
+
 template <int D>
 struct Frag {
     f32x4 v[StageCfg<D>::NC > 0 ? StageCfg<D>::NC : 1];

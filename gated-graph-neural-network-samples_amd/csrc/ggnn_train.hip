@@ -13,7 +13,8 @@
 // Cross-stream hazards: everything a side-stream product reads (dpc, dpg, r*h, incoming, states, dHc) has its own buffer per
 // timestep, so the main stream never waits for the side stream inside a step; the call ends with the main stream waiting for the
 // side stream's last product, which orders the next step's forward (it reuses the workspace) behind them.
-#include "ggnn_common.h"
+#include "ggnn_stage.hpp"
+#include "ggnn_philox.hpp"
 #include <mutex>
 
 namespace ggnn {
@@ -101,6 +102,60 @@ int add_inplace(float* dst, const float* src, long long n, hipStream_t st) {
     return GGNN_OK;
 }
 
+// ---- a step's weight images in ONE launch ------------------------------------------------------------------------------------------
+// Every optimisation step changes every weight, so every step rebuilds every stage image: per layer the T edge-weight images and
+// the T images of their transposes (both of the weight-dropout-MASKED weights, the mask applied on the fly: ggnn_philox.hpp), the
+// 3(nx+1) images of the fused GRU and the 3(nx+1) of its backward -- ~120 images of 48 KiB for the default model.  Driven layer by
+// layer from the host that was 30 launches of 4 us each at the head of the step (mask, transpose copy, four pack kernels per layer).
+constexpr int kPrepMaxLayers = 16;
+struct PrepArgs {
+    const float* edge_w[kPrepMaxLayers]; const float* Wg[kPrepMaxLayers]; const float* Wc[kPrepMaxLayers];
+    float* edge_img[kPrepMaxLayers]; float* edge_img_t[kPrepMaxLayers]; float* gru_img[kPrepMaxLayers]; float* gru_bwd_img[kPrepMaxLayers];
+    unsigned long long seed[kPrepMaxLayers];
+    int nx[kPrepMaxLayers];
+    int T; float keep;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void train_prepare_kernel(PrepArgs a) {
+    using C = StageCfg<D>;
+    const int l = blockIdx.z, i = blockIdx.y;
+    const int first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    const int T = a.T, ng = 3 * (a.nx[l] + 1);
+    if (i < 2 * T) {
+        // edge-weight image of type t (i < T), or of its transpose (the backward's Z = dHc W_t^T); masked like ggnn_dropout_f32 masks
+        // the [T*D, D] variable: row key = t*D + (row of W_t), column = column of W_t
+        const bool tr = i >= T;
+        const int t = tr ? i - T : i;
+        const float* W = a.edge_w[l] + (size_t)t * D * D;
+        float* img = (tr ? a.edge_img_t[l] : a.edge_img[l]) + (size_t)t * C::IMG;
+        const float keep = a.keep;
+        const unsigned long long seed = a.seed[l];
+        for (int j = first; j < C::IMG; j += stride) {
+            float v = 0.f;
+            int k = -1, n = 0;
+            if (j < C::MAIN) {
+                const int e = j & 3; n = (j >> 2) % C::BN; k = 4 * ((j >> 2) / C::BN) + e;
+            } else if (j < C::MAIN + C::REM) {
+                const int jj = j - C::MAIN;
+                n = jj % C::BN; k = 16 * C::NC + jj / C::BN;
+            }
+            if (k >= 0 && n < D) {
+                const int r = tr ? n : k, c = tr ? k : n;                 // image[k][n] = W_t[k][n], or W_t[n][k]
+                v = W[(size_t)r * D + c];
+                if (keep < 1.0f) v = dropout_apply(v, keep, seed, (unsigned long long)(t * D + r), c);
+            }
+            img[j] = v;
+        }
+    } else if (i < 2 * T + ng) {
+        const int ci = i - 2 * T;
+        gru_fwd_image_pack<D>(a.Wg[l], a.Wc[l], a.nx[l], ci, a.gru_img[l] + (size_t)ci * C::IMG, first, stride);
+    } else if (i < 2 * T + 2 * ng) {
+        const int bi = i - 2 * T - ng;
+        gru_bwd_image_pack<D>(a.Wg[l], a.Wc[l], a.nx[l], bi, a.gru_bwd_img[l] + (size_t)bi * C::IMG, first, stride);
+    }
+}
+
 struct LayerPlan { int first_step, steps, nres; int res[kMaxNx]; };
 
 int plan_layers(int num_layers, const int32_t* layer_timesteps, const int32_t* res_ptr, const int32_t* res_idx, LayerPlan* plan,
@@ -127,6 +182,38 @@ int plan_layers(int num_layers, const int32_t* layer_timesteps, const int32_t* r
 }  // namespace ggnn
 
 using namespace ggnn;
+
+extern "C" int ggnn_sparse_train_prepare_f32(int num_layers, int T, int D, const int32_t* nx, const float* const* edge_w, float keep_prob,
+                                             const uint64_t* seeds, const float* const* Wg, const float* const* Wc,
+                                             float* const* edge_packed, float* const* edge_packed_t, float* const* gru_packed,
+                                             float* const* gru_bwd_packed, ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(num_layers > 0 && num_layers <= kPrepMaxLayers, "num_layers %d outside 1..%d", num_layers, kPrepMaxLayers);
+    GGNN_CHECK_ARG(T > 0 && T <= 64 && nx && edge_w && Wg && Wc && edge_packed && edge_packed_t && gru_packed && gru_bwd_packed, "bad arguments");
+    GGNN_CHECK_ARG(keep_prob > 0.0f && keep_prob <= 1.0f && (keep_prob >= 1.0f || seeds), "keep_prob %g outside (0, 1] or seeds missing", (double)keep_prob);
+    if (ggnn_gru_is_fused(D) != 1 || !ggnn_gru_bwd_is_fused(D) || !ggnn_msg_transform_compact_supported(D))
+        return fail(GGNN_E_UNSUPPORTED, "no whole-block stage images for hidden size %d", D);
+    PrepArgs a{};
+    a.T = T; a.keep = keep_prob;
+    int max_images = 0;
+    for (int l = 0; l < num_layers; ++l) {
+        GGNN_CHECK_ARG(nx[l] >= 1 && nx[l] <= kMaxNx, "layer %d: nx %d outside 1..%d", l, nx[l], kMaxNx);
+        GGNN_CHECK_ARG(edge_w[l] && Wg[l] && Wc[l] && edge_packed[l] && edge_packed_t[l] && gru_packed[l] && gru_bwd_packed[l], "layer %d: null pointer", l);
+        a.edge_w[l] = edge_w[l]; a.Wg[l] = Wg[l]; a.Wc[l] = Wc[l];
+        a.edge_img[l] = edge_packed[l]; a.edge_img_t[l] = edge_packed_t[l]; a.gru_img[l] = gru_packed[l]; a.gru_bwd_img[l] = gru_bwd_packed[l];
+        a.seed[l] = seeds ? seeds[l] : 0ULL; a.nx[l] = nx[l];
+        const int images = 2 * T + 6 * (nx[l] + 1);
+        if (images > max_images) max_images = images;
+    }
+    const dim3 grid(8, max_images, num_layers);
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 100: hipLaunchKernelGGL(train_prepare_kernel<100>, grid, dim3(256), 0, st, a); break;
+        case 64: hipLaunchKernelGGL(train_prepare_kernel<64>, grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(train_prepare_kernel<32>, grid, dim3(256), 0, st, a); break;
+    }
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
 
 extern "C" size_t ggnn_sparse_train_workspace_bytes(int V, int D, int T, int64_t compact_rows, int total_steps) {
     if (V < 0 || D <= 0 || T <= 0 || total_steps <= 0) return 0;

@@ -22,6 +22,12 @@ from ._lib import check
 from .utils import SMALL_NUMBER
 
 
+import os
+
+# all of a step's weight images in one launch (GGNN_FUSED_PREPARE=0: mask / transpose / pack layer by layer through the caches of ops.py)
+USE_FUSED_PREPARE = os.environ.get("GGNN_FUSED_PREPARE", "1") != "0"
+
+
 def _ptrs(tensors):
     return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
@@ -121,18 +127,35 @@ def native_train_step(model, batch_data: Dict[str, Any]) -> torch.Tensor:
     with torch.no_grad():
         # ---- this step's weights: masked edge weights (:91, one mask per layer and step) and the kernels' stage images ----
         ew_keep = float(ph.get('edge_weight_dropout_keep_prob', 1.0))
-        masks, edge_packed, edge_packed_t, gru_packed, gru_bwd_packed = [], [], [], [], []
         cells = model.gnn_weights.rnn_cells
-        for l in range(L):
-            W = model._edge_weight_vars[l].view(T, D, D)
-            if ew_keep < 1.0:
-                masks.append((ew_keep, model.dropout_seed('edge_weights', l)))
-                W = backward._MASKED.get(W, masks[-1][0], masks[-1][1])
-            edge_packed.append(_PACKED.edge(W))
-            edge_packed_t.append(_PACKED.edge(backward._TRANSPOSED.get(W, (1, 2))))
-            nx = len(residuals[l]) + 1
-            gru_packed.append(_PACKED.gru(cells[l].gates_kernel, cells[l].candidate_kernel, nx, D))
-            gru_bwd_packed.append(_PACKED.gru_bwd(cells[l].gates_kernel, cells[l].candidate_kernel, nx, D))
+        masks = [(ew_keep, model.dropout_seed('edge_weights', l)) for l in range(L)] if ew_keep < 1.0 else []
+        nxs = [len(residuals[l]) + 1 for l in range(L)]
+        if L <= 16 and USE_FUSED_PREPARE:
+            # all ~120 images of the step in ONE launch, the weight-dropout mask applied on the fly (ggnn_sparse_train_prepare_f32)
+            imgs = getattr(model, "_native_images", None)
+            if imgs is None:
+                f32 = lambda nbytes: torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+                eb = lib.ggnn_msg_transform_compact_workspace_bytes(D, T)
+                imgs = model._native_images = (
+                    [f32(eb) for _ in range(L)], [f32(eb) for _ in range(L)],
+                    [f32(lib.ggnn_gru_packed_bytes(D, nxs[l])) for l in range(L)],
+                    [f32(lib.ggnn_gru_bwd_packed_bytes(D, nxs[l])) for l in range(L)])
+            edge_packed, edge_packed_t, gru_packed, gru_bwd_packed = imgs
+            seeds = (ctypes.c_uint64 * L)(*[m[1] for m in masks]) if masks else None
+            check(lib.ggnn_sparse_train_prepare_f32(
+                L, T, D, _i32(nxs), _ptrs(model._edge_weight_vars), ew_keep if masks else 1.0, seeds,
+                _ptrs([c.gates_kernel for c in cells]), _ptrs([c.candidate_kernel for c in cells]), _ptrs(edge_packed),
+                _ptrs(edge_packed_t), _ptrs(gru_packed), _ptrs(gru_bwd_packed), st.cuda_stream))
+        else:
+            edge_packed, edge_packed_t, gru_packed, gru_bwd_packed = [], [], [], []
+            for l in range(L):
+                W = model._edge_weight_vars[l].view(T, D, D)
+                if masks:
+                    W = backward._MASKED.get(W, masks[l][0], masks[l][1])
+                edge_packed.append(_PACKED.edge(W))
+                edge_packed_t.append(_PACKED.edge(backward._TRANSPOSED.get(W, (1, 2))))
+                gru_packed.append(_PACKED.gru(cells[l].gates_kernel, cells[l].candidate_kernel, nxs[l], D))
+                gru_bwd_packed.append(_PACKED.gru_bwd(cells[l].gates_kernel, cells[l].candidate_kernel, nxs[l], D))
 
         # ---- forward ------------------------------------------------------------------------------------------------------
         ws_bytes = lib.ggnn_sparse_train_workspace_bytes(V, D, T, R, steps)

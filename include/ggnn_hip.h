@@ -481,7 +481,16 @@ int ggnn_pack_batch_tables(const int32_t* counts_t, int Gd, int rows, const int6
  *     (node_rp, node_order[, node_heads]); on `side_stream` the weight-gradient products, ADDED into g_edge[l] [T,D,D], g_Wg[l]
  *     [(nx+1)D, 2D], g_bg[l] [2D], g_Wc[l] [(nx+1)D, D], g_bc[l] [D] (the caller zeroes them; under weight dropout it masks g_edge
  *     afterwards).  d_state_ws[l] [V,D] (l < num_layers): scratch for the gradients of the layer inputs.  Returns with `stream`
- *     ordered behind the side stream's last product.  Events come from a per-device pool the library creates on first use. */
+ *     ordered behind the side stream's last product.  Events come from a per-device pool the library creates on first use.
+ *   prepare: ALL of a step's stage images in one launch (the weights change every step): per layer l the T edge-weight images
+ *     (edge_packed[l], ggnn_msg_transform_compact_workspace_bytes) and those of the transposed weights (edge_packed_t[l]) -- of the
+ *     variable edge_w[l] [T*D, D] masked on the fly like ggnn_dropout_f32(keep_prob, seeds[l]) masks it (keep_prob 1: unmasked) --,
+ *     the fused GRU's images (gru_packed[l], ggnn_gru_packed_bytes(D, nx[l])) and its backward's (gru_bwd_packed[l]).  num_layers <= 16;
+ *     nx, seeds, and the pointer arrays are HOST arrays. */
+int ggnn_sparse_train_prepare_f32(int num_layers, int T, int D, const int32_t* nx, const float* const* edge_w, float keep_prob,
+                                  const uint64_t* seeds, const float* const* Wg, const float* const* Wc, float* const* edge_packed,
+                                  float* const* edge_packed_t, float* const* gru_packed, float* const* gru_bwd_packed,
+                                  ggnn_stream_t stream);
 size_t ggnn_sparse_train_workspace_bytes(int V, int D, int T, int64_t compact_rows, int total_steps);
 int ggnn_sparse_train_forward_f32(const float* h0, int V, int D, int T, const int32_t* row_ptr, const int32_t* gather_row_c,
                                   const int32_t* pair_node, const int64_t* type_row_off, const float* nin, int use_avg, int num_layers,

@@ -303,3 +303,39 @@ def test_native_training_step_is_not_taken_by_other_variants(pkg, cuda):
     feed = dict(next(iter(model.make_minibatch_iterator(model.train_data, is_training=False))))
     assert pkg.train_native.eligible(model, feed)
     assert not pkg.train_native.eligible(model, dict(feed, graph_state_keep_prob=0.9))
+
+
+@pytest.mark.parametrize("keep", [1.0, 0.8])
+def test_fused_weight_preparation_equals_per_layer_packing(pkg, oracle, cuda, keep):
+    """ggnn_sparse_train_prepare_f32 (all of a step's stage images in one launch, weight-dropout mask on the fly) against the
+    per-layer path: ggnn_dropout_f32 on the variable, a transpose copy, ggnn_edge_weights_pack_f32 twice, ggnn_gru_pack_weights_f32,
+    the backward's pack -- bit for bit."""
+    import ctypes
+    ms = pkg.synthetic_qm9(30, mean_nodes=8, seed=1)
+    model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms})
+    model.set_graph_weights(oracle.make_sparse_layers(np.random.default_rng(1), model.params, model.num_edge_types, random_bias=True))
+    lib = pkg._lib.load()
+    T, D, L = model.num_edge_types, model.params["hidden_size"], len(model.params["layer_timesteps"])
+    cells = model.gnn_weights.rnn_cells
+    nxs = [len(model.params["residual_connections"].get(str(l)) or []) + 1 for l in range(L)]
+    f32 = lambda nbytes: torch.full((nbytes // 4,), float("nan"), device=cuda)
+    eb = lib.ggnn_msg_transform_compact_workspace_bytes(D, T)
+    imgs = ([f32(eb) for _ in range(L)], [f32(eb) for _ in range(L)], [f32(lib.ggnn_gru_packed_bytes(D, nxs[l])) for l in range(L)],
+            [f32(lib.ggnn_gru_bwd_packed_bytes(D, nxs[l])) for l in range(L)])
+    ptrs = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    seeds = [model.dropout_seed("edge_weights", l) for l in range(L)]
+    pkg._lib.check(lib.ggnn_sparse_train_prepare_f32(
+        L, T, D, (ctypes.c_int32 * L)(*nxs), ptrs(model._edge_weight_vars), keep, (ctypes.c_uint64 * L)(*seeds),
+        ptrs([c.gates_kernel for c in cells]), ptrs([c.candidate_kernel for c in cells]), ptrs(imgs[0]), ptrs(imgs[1]), ptrs(imgs[2]),
+        ptrs(imgs[3]), torch.cuda.current_stream().cuda_stream))
+    packed = pkg.ops.PackedWeights()
+    for l in range(L):
+        W = model._edge_weight_vars[l].view(T, D, D)
+        if keep < 1.0:
+            W = pkg.ops.dropout(W.contiguous(), keep, seeds[l])
+        want = [packed.edge(W), packed.edge(W.transpose(1, 2).contiguous()),
+                packed.gru(cells[l].gates_kernel, cells[l].candidate_kernel, nxs[l], D),
+                packed.gru_bwd(cells[l].gates_kernel, cells[l].candidate_kernel, nxs[l], D)]
+        for k in range(4):
+            n = want[k].numel()
+            assert torch.equal(imgs[k][l][:n], want[k]), (l, k)
