@@ -518,6 +518,79 @@ def main():
         "graphs_per_sec": total_graphs / elapsed,
     }
 
+    # ---- index prep / packing outside the timed region, and the rate with them inside (rank 0) ----------------------
+    # (before the training leg: after a few seconds of training steps the same leg measures ~4 % lower -- clocks, not code)
+    if rank == 0 and not headline_train:
+        ops = pkg.ops
+        for warm in (True, False):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for f in feeds:
+                ops.prepare_message_index(ops.build_message_index(f["adjacency_lists"], f["initial_node_representation"].shape[0],
+                                                                  validate=False), D)
+            torch.cuda.synchronize()
+            idx_ms = (time.perf_counter() - t0) / len(feeds) * 1e3
+        dms = model.valid_data["molecules_dev"]
+        from importlib import import_module
+        dd = import_module(PKG + ".data_device")
+        list(dd.pack_batches_device(dms, params, T, None))                         # warm
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        packed = list(dd.pack_batches_device(dms, params, T, None))
+        torch.cuda.synchronize()
+        pack_ms = (time.perf_counter() - t0) / len(packed) * 1e3
+        del packed
+        e2e_streams = [None] * max(args.streams, 1)
+        e2e_packs = [None, None]
+        # the end-to-end leg runs whole epochs over a FULL-QM9-sized dataset (133,885 molecules, ~25 batches: configs[1]), so that
+        # the pipeline's fill and drain weigh what they weigh in an epoch of the real dataset (6-batch epochs overstate them 4x)
+        ms_full = pkg.synthetic_qm9(133885, mean_nodes=args.mean_nodes, seed=2000 + rank)
+        dms_e2e = dd.DeviceMoleculeSet(ms_full, dev, None)
+        dms_e2e.static_tables(T, params.get("tie_fwd_bkwd", True), pkg.ops.compact_supported(D))
+        e2e_batches = len(pkg.data.batch_boundaries(dms_e2e.nodes_per_graph, params["batch_size"])) - 1
+
+        e2e_data = {"molecules": ms_full, "molecules_dev": dms_e2e, "label_mask": None}
+        pool = torch.rand((max(params["batch_size"], max(nodes)), D), device=dev) * 2 - 1     # dense random states, as above
+
+        def dense_states(fb):
+            fb["initial_node_representation"] = pool[:fb["initial_node_representation"].shape[0]]
+
+        def fresh_epochs(reps, pipelined):
+            """`reps` passes over the dataset, every batch packed fresh.  pipelined: SparseGGNNChemModel.forward_dataset -- batch
+            i+1.. assembled on side streams while batch i's forward runs, forwards alternating over the compute streams
+            (utils.StreamPrefetcher); else: packing and forward in sequence on one stream."""
+            nn = 0
+            with torch.no_grad():
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for rep in range(reps):
+                    if pipelined:
+                        for fb, states, st in model.forward_dataset(e2e_data, num_streams=max(args.streams, 1), feed_hook=dense_states):
+                            nn += states.shape[0]
+                    else:
+                        for fb in dd.pack_batches_device(dms_e2e, params, T, None):
+                            dense_states(fb)
+                            model.feed(fb)
+                            nn += model.compute_final_node_representations().shape[0]
+                torch.cuda.synchronize()
+            return nn, time.perf_counter() - t0
+
+        gc.collect(); gc.freeze(); gc.disable()
+        fresh_epochs(1, True)                                                       # warm (the side stream's allocator pool)
+        nn1, e2e1 = fresh_epochs(1, False)
+        reps = max(2, int(np.ceil(0.25 / max(e2e1, 1e-3))))
+        nn, e2e = fresh_epochs(reps, True)
+        gc.enable()
+        del dms_e2e, e2e_data, pool
+        out["index_build_ms_per_batch"] = idx_ms
+        out["pack_ms_per_batch"] = pack_ms
+        out["end_to_end_fresh_batch"] = {
+            "value": nn * n_prop / e2e, "unit": "node-state updates/s", "hip_streams": "%d compute + %d packing" % (len(e2e_streams), len(e2e_packs)),
+            "epochs_timed": reps, "batches_per_epoch": e2e_batches, "molecules": ms_full.num_graphs, "seconds": e2e,
+            "one_stream_value": nn1 * n_prop / e2e1,
+            "what": "whole epochs over a full-QM9-sized synthetic dataset; every step assembles a fresh ~100k-node batch on the GPU from graph ids (chem_tensorflow_sparse.py:278-350: h0, "
+                    "adjacency lists, in-degree table, graph_nodes_list, plus the message index of :120-129 and the source-pair "
+                    "compaction) and runs the 8-step forward on it; batch i+1 is assembled on a side stream under batch i's forward, "
+                    "forwards alternate over the compute streams (SparseGGNNChemModel.forward_dataset / utils.StreamPrefetcher; the pipeline "
+                    "fills and drains once per epoch); one_stream_value: packing and forward in sequence on one stream"}
+
     # ---- the other mode, short: forward runs get a `train` object, train runs a `forward` object (all ranks: it holds the collective)
     if not args.no_secondary:
         o_steps = max(4, min(args.steps, 12))
@@ -549,86 +622,6 @@ def main():
                "allreduce_bytes": int(sum(v.numel() for v in variables) * 4), "backend": "nccl (RCCL)"}
         out.setdefault("train", {}).update(rec) if not headline_train else out.update({"collective": rec})
         out["allreduce_us"] = rec["allreduce_us"]
-
-    # ---- index prep / packing outside the timed region, and the rate with them inside (rank 0) ----------------------
-    if rank == 0 and not headline_train:
-        ops = pkg.ops
-        for warm in (True, False):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            for f in feeds:
-                ops.prepare_message_index(ops.build_message_index(f["adjacency_lists"], f["initial_node_representation"].shape[0],
-                                                                  validate=False), D)
-            torch.cuda.synchronize()
-            idx_ms = (time.perf_counter() - t0) / len(feeds) * 1e3
-        dms = model.valid_data["molecules_dev"]
-        from importlib import import_module
-        dd = import_module(PKG + ".data_device")
-        list(dd.pack_batches_device(dms, params, T, None))                         # warm
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        packed = list(dd.pack_batches_device(dms, params, T, None))
-        torch.cuda.synchronize()
-        pack_ms = (time.perf_counter() - t0) / len(packed) * 1e3
-        del packed
-        pool = torch.rand((max(params["batch_size"], max(nodes)), D), device=dev) * 2 - 1     # dense random states, as above
-        e2e_streams = streams if streams is not None else [torch.cuda.current_stream()]
-        # the end-to-end leg runs whole epochs over a FULL-QM9-sized dataset (133,885 molecules, ~25 batches: configs[1]), so that
-        # the pipeline's fill and drain weigh what they weigh in an epoch of the real dataset (6-batch epochs overstate them 4x)
-        ms_full = pkg.synthetic_qm9(133885, mean_nodes=args.mean_nodes, seed=2000 + rank)
-        dms_e2e = dd.DeviceMoleculeSet(ms_full, dev, None)
-        dms_e2e.static_tables(T, params.get("tie_fwd_bkwd", True), pkg.ops.compact_supported(D))
-        e2e_batches = len(pkg.data.batch_boundaries(dms_e2e.nodes_per_graph, params["batch_size"])) - 1
-
-        def fresh_epochs(reps, pipelined, chained=False):
-            """`reps` passes over the dataset, every batch packed fresh.  pipelined: batch i+1 is assembled on a side stream while
-            batch i's forward runs, forwards alternate over the compute streams (utils.StreamPrefetcher); else: one stream.
-            chained: the epochs go through ONE prefetcher (the next epoch's first batches are packed under the last forwards of
-            the current one); else the pipeline fills and drains once per epoch."""
-            import itertools
-            nn = 0
-            with torch.no_grad():
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                for rep in range(1 if chained else reps):
-                    gen = dd.pack_batches_device(dms_e2e, params, T, None)
-                    if chained:
-                        gen = itertools.chain.from_iterable(dd.pack_batches_device(dms_e2e, params, T, None) for _ in range(reps))
-                    if pipelined:
-                        for fb, st in pkg.utils.StreamPrefetcher(gen, dev, consumer_streams=e2e_streams):
-                            Vf = fb["initial_node_representation"].shape[0]
-                            with torch.cuda.stream(st):
-                                fb["initial_node_representation"] = pool[:Vf]
-                                model.feed(fb)
-                                model.compute_final_node_representations()
-                            nn += Vf
-                    else:
-                        for fb in gen:
-                            Vf = fb["initial_node_representation"].shape[0]
-                            fb["initial_node_representation"] = pool[:Vf]
-                            model.feed(fb)
-                            model.compute_final_node_representations()
-                            nn += Vf
-                torch.cuda.synchronize()
-            return nn, time.perf_counter() - t0
-
-        gc.collect(); gc.freeze(); gc.disable()
-        fresh_epochs(1, True)                                                       # warm (the side stream's allocator pool)
-        nn1, e2e1 = fresh_epochs(1, False)
-        reps = max(2, int(np.ceil(0.25 / max(e2e1, 1e-3))))
-        nn, e2e = fresh_epochs(reps, True, chained=True)
-        nn2, e2e2 = fresh_epochs(reps, True)
-        gc.enable()
-        del pool, dms_e2e
-        out["index_build_ms_per_batch"] = idx_ms
-        out["pack_ms_per_batch"] = pack_ms
-        out["end_to_end_fresh_batch"] = {
-            "value": nn * n_prop / e2e, "unit": "node-state updates/s", "hip_streams": "%d compute + 1 packing" % len(e2e_streams),
-            "epochs_timed": reps, "batches_per_epoch": e2e_batches, "molecules": ms_full.num_graphs, "seconds": e2e,
-            "per_epoch_value": nn2 * n_prop / e2e2, "one_stream_value": nn1 * n_prop / e2e1,
-            "what": "whole epochs over a full-QM9-sized synthetic dataset; every step assembles a fresh ~100k-node batch on the GPU from graph ids (chem_tensorflow_sparse.py:278-350: h0, "
-                    "adjacency lists, in-degree table, graph_nodes_list, plus the message index of :120-129 and the source-pair "
-                    "compaction) and runs the 8-step forward on it; batch i+1 is assembled on a side stream under batch i's forward, "
-                    "forwards alternate over the compute streams (utils.StreamPrefetcher); value: the epochs follow each other through one "
-                    "prefetcher; per_epoch_value: the pipeline fills and drains once per epoch (setup, first pack, last forward alone); "
-                    "one_stream_value: packing and forward in sequence on one stream"}
 
     # ---- roofline leg: per-launch HIP-event timing of every kernel (rank 0) -----------------------------
     if rank == 0 and not args.no_roofline and not headline_train:

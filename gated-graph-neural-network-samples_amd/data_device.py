@@ -44,6 +44,7 @@ class DeviceMoleculeSet:
         self.bonds_per_graph = np.diff(ms.bond_ptr)
         self.max_bond_type = int(ms.bonds[:, 1].max()) if len(ms.bonds) else 0
         self.min_bond_type = int(ms.bonds[:, 1].min()) if len(ms.bonds) else 1
+        self._identity_epoch = {}                              # batch_size -> (order, batch boundaries, order on the device) of the dataset order
         self._type_counts = {}                                 # (T, tie) -> per-graph message / source-pair counts per type
         self._static = {}                                      # (T, tie, compact) -> dataset-level tables of ggnn_assemble_batch
         # Bond endpoints come from the data file: check them ONCE against their graph's node count, so that the per-batch
@@ -391,11 +392,20 @@ def pack_batches_device(dms: DeviceMoleculeSet, params: dict, num_edge_types: in
     boundaries, same rank assignment, same empty padding batches)."""
     ms = dms.host
     G = ms.num_graphs
-    order = np.arange(G, dtype=np.int64) if order is None else np.asarray(order, np.int64)
-    bounds = batch_boundaries(dms.nodes_per_graph[order], params["batch_size"])
+    if order is None:
+        # dataset order (validation, inference): order, batch boundaries and the device copy of the order are the same every epoch
+        cached = dms._identity_epoch.get(int(params["batch_size"]))
+        if cached is None:
+            ident = np.arange(G, dtype=np.int64)
+            cached = dms._identity_epoch[int(params["batch_size"])] = (ident, batch_boundaries(dms.nodes_per_graph, params["batch_size"]),
+                                                                      dms.upload_order(ident))
+        order, bounds, order_dev = cached
+    else:
+        order = np.asarray(order, np.int64)
+        bounds = batch_boundaries(dms.nodes_per_graph[order], params["batch_size"])
+        order_dev = dms.upload_order(order)                     # ONE upload per epoch: the batches slice it on the device
     nb = len(bounds) - 1
     steps = (nb + world_size - 1) // world_size
-    order_dev = dms.upload_order(order)                         # ONE upload per epoch: the batches slice it on the device
     for s in range(steps):
         i = s * world_size + rank
         ids = order[bounds[i]:bounds[i + 1]] if i < nb else np.zeros(0, np.int64)

@@ -526,6 +526,32 @@ class SparseGGNNChemModel(ChemModel):
             feed['edge_weight_dropout_keep_prob'] = edge_weights_dropout_keep_prob
             yield feed
 
+    def forward_dataset(self, data: Any, num_streams: int = 2, feed_hook=None):
+        """Inference over a whole dataset with every batch assembled fresh on the GPU, pipelined: batch i+1.. are packed on
+        high-priority side streams under batch i's forward, the forwards alternate over `num_streams` compute streams
+        (utils.StreamPrefetcher; the reference overlaps its host-side packer with sess.run through a producer thread,
+        chem_tensorflow.py:219).  Yields (feed, final node representations, stream): the states are valid on `stream` -- work
+        queued there sees them; to read them from the host, synchronise it.  Streams are kept for later calls.
+        feed_hook(feed): called on the consumer stream before the forward (bench.py swaps in dense random initial states)."""
+        from .utils import StreamPrefetcher
+        self.prepare_resident_data(data, False)
+        pipe = getattr(self, '_pipeline_streams', None)
+        if pipe is None or len(pipe[0]) != num_streams:
+            pipe = self._pipeline_streams = ([torch.cuda.Stream(self.device) for _ in range(num_streams)],
+                                             [torch.cuda.Stream(self.device, priority=-1) for _ in range(2)])
+        pack_params = self.params if self._kw == self.params['hidden_size'] else dict(self.params, hidden_size=self._kw)
+        gen = pack_batches_device(data["molecules_dev"], pack_params, self.num_edge_types, None, 0, 1, True)
+        cur = torch.cuda.current_stream(self.device)
+        for st in pipe[0]:
+            st.wait_stream(cur)
+        with torch.no_grad():
+            for feed, st in StreamPrefetcher(gen, self.device, consumer_streams=pipe[0], pack_streams=pipe[1]):
+                with torch.cuda.stream(st):
+                    if feed_hook is not None:
+                        feed_hook(feed)
+                    self.feed(feed)
+                    yield feed, self.compute_final_node_representations(), st
+
     def evaluate_one_batch(self, data):
         """chem_tensorflow_sparse.py:352-362."""
         outs = []

@@ -255,6 +255,10 @@ def test_stream_prefetcher_matches_sequential_packing(pkg, oracle, cuda):
             assert len(got) == len(want)
             for a, b in zip(got, want):
                 assert torch.equal(a.cpu(), b)
+        # the product entry point of the same pipeline
+        got = [states for _, states, _ in model.forward_dataset(model.valid_data, num_streams=2)]
+        torch.cuda.synchronize()
+        assert len(got) == len(want) and all(torch.equal(a.cpu(), b) for a, b in zip(got, want))
 
 
 @pytest.mark.parametrize("config,keeps", [
