@@ -562,13 +562,18 @@ def main():
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 for rep in range(reps):
                     if pipelined:
-                        for fb, states, st in model.forward_dataset(e2e_data, num_streams=max(args.streams, 1), feed_hook=dense_states):
+                        for fb, states, st in model.forward_dataset(e2e_data, num_streams=max(args.streams, 1), feed_hook=dense_states,
+                                                                   consumer_streams=streams):
                             nn += states.shape[0]
                     else:
                         for fb in dd.pack_batches_device(dms_e2e, params, T, None):
                             dense_states(fb)
                             model.feed(fb)
                             nn += model.compute_final_node_representations().shape[0]
+                    if dbg_steps:
+                        torch.cuda.synchronize()
+                        print("[bench] fresh epoch %d (%s): %.2f ms since start" % (rep, "pipelined" if pipelined else "one stream",
+                                                                                   (time.perf_counter() - t0) * 1e3), file=sys.stderr)
                 torch.cuda.synchronize()
             return nn, time.perf_counter() - t0
 

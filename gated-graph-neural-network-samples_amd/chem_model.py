@@ -348,9 +348,8 @@ class ChemModel(object):
         while the following step is being enqueued (1.1 ms of a 7.2 ms fresh-batch step).  Returns (host tensor, event)."""
         if not stats.is_cuda:
             return (stats, None)
-        if getattr(self, '_readback_stream', None) is None:
-            self._readback_stream = torch.cuda.Stream(stats.device)
-        rb = self._readback_stream
+        from .backward import side_stream
+        rb = side_stream(stats.device)          # (shared with the weight-gradient products: they are done before the step's end)
         ready = torch.cuda.Event()
         ready.record()
         host = torch.empty(stats.shape, dtype=stats.dtype, device='cpu', pin_memory=True)

@@ -526,19 +526,25 @@ class SparseGGNNChemModel(ChemModel):
             feed['edge_weight_dropout_keep_prob'] = edge_weights_dropout_keep_prob
             yield feed
 
-    def forward_dataset(self, data: Any, num_streams: int = 2, feed_hook=None):
+    def forward_dataset(self, data: Any, num_streams: int = 2, feed_hook=None, consumer_streams=None):
         """Inference over a whole dataset with every batch assembled fresh on the GPU, pipelined: batch i+1.. are packed on
         high-priority side streams under batch i's forward, the forwards alternate over `num_streams` compute streams
         (utils.StreamPrefetcher; the reference overlaps its host-side packer with sess.run through a producer thread,
         chem_tensorflow.py:219).  Yields (feed, final node representations, stream): the states are valid on `stream` -- work
         queued there sees them; to read them from the host, synchronise it.  Streams are kept for later calls.
-        feed_hook(feed): called on the consumer stream before the forward (bench.py swaps in dense random initial states)."""
+        feed_hook(feed): called on the consumer stream before the forward (bench.py swaps in dense random initial states).
+        consumer_streams: compute streams to use instead of the model's own.  (A process should stay frugal with streams: the
+        runtime multiplexes them onto a handful of hardware queues -- 4 by default -- and two streams that land on the same queue
+        do not overlap: with bench.py's two headline streams still alive, two more compute streams plus two packing streams ran
+        this pipeline at exactly the one-stream rate.)"""
         from .utils import StreamPrefetcher
         self.prepare_resident_data(data, False)
         pipe = getattr(self, '_pipeline_streams', None)
-        if pipe is None or len(pipe[0]) != num_streams:
-            pipe = self._pipeline_streams = ([torch.cuda.Stream(self.device) for _ in range(num_streams)],
+        if pipe is None or (consumer_streams is None and len(pipe[0]) != num_streams):
+            pipe = self._pipeline_streams = ([] if consumer_streams is not None else [torch.cuda.Stream(self.device) for _ in range(num_streams)],
                                              [torch.cuda.Stream(self.device, priority=-1) for _ in range(2)])
+        if consumer_streams is not None:
+            pipe = (list(consumer_streams), pipe[1])
         pack_params = self.params if self._kw == self.params['hidden_size'] else dict(self.params, hidden_size=self._kw)
         gen = pack_batches_device(data["molecules_dev"], pack_params, self.num_edge_types, None, 0, 1, True)
         cur = torch.cuda.current_stream(self.device)

@@ -118,10 +118,9 @@ def native_train_step(model, batch_data: Dict[str, Any]) -> torch.Tensor:
         res_idx.extend(r)
         res_ptr.append(len(res_idx))
     st = torch.cuda.current_stream()
-    if getattr(model, "_native_side_stream", None) is None:
-        model._native_side_stream = torch.cuda.Stream(h0.device)
+    if getattr(model, "_native_ws", None) is None:
         model._native_ws = _Workspace()
-    side = model._native_side_stream
+    side = backward.side_stream(h0.device)
     dev = h0.device
 
     with torch.no_grad():

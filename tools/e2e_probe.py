@@ -47,3 +47,21 @@ for kw in ({"pack_streams": 1, "depth": 1, "priority": 0}, {"pack_streams": 1, "
     run(1, **kw)
     r = run(8, **kw)
     print(kw, "-> %.1f M node-updates/s, host in pack %.0f %%, in forward %.0f %%" % (r[0], 100 * r[1], 100 * r[2]), flush=True)
+
+
+def run_fd(reps):
+    """the same epochs through SparseGGNNChemModel.forward_dataset"""
+    nn = 0
+    hook = lambda fb: fb.__setitem__("initial_node_representation", pool[:fb["initial_node_representation"].shape[0]])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        for fb, states, st in model.forward_dataset(model.valid_data, num_streams=2, feed_hook=hook):
+            nn += states.shape[0]
+    torch.cuda.synchronize()
+    return nn * 8 / (time.perf_counter() - t0) / 1e6
+
+
+run_fd(1)
+print("forward_dataset: %.1f M node-updates/s" % run_fd(8), flush=True)
+r = run(8, pack_streams=2, depth=3, priority=-1)
+print("manual loop again: %.1f" % r[0], flush=True)
