@@ -7,15 +7,7 @@ or through the alias module `ggnn_amd` at the repo root.  Sub-modules are import
 registered under both names.
 """
 import importlib as _importlib
-import os as _os
 import sys as _sys
-
-# HIP multiplexes a process's streams onto a handful of hardware queues (4 by default), and two streams that share a queue do
-# not overlap: a pipelined forward over 2 compute + 2 packing streams next to 3 older streams ran at exactly the one-stream
-# rate (tools/e2e_probe.py, DESIGN.md K10).  Ask for 8 queues unless the user chose a number; only effective when this import
-# precedes the process's first HIP call (torch initialises HIP lazily, so it normally does).  The package itself stays frugal:
-# one side stream for weight-gradient products and read-backs, one packing stream per producer.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _ALIAS = "ggnn_amd"
 _SUBMODULES = ["_lib", "data", "utils", "ops", "data_device", "autograd", "backward", "train", "train_native", "chem_model", "sparse_model",

@@ -534,9 +534,10 @@ class SparseGGNNChemModel(ChemModel):
         queued there sees them; to read them from the host, synchronise it.  Streams are kept for later calls.
         feed_hook(feed): called on the consumer stream before the forward (bench.py swaps in dense random initial states).
         consumer_streams: compute streams to use instead of the model's own.  (A process should stay frugal with streams: the
-        runtime multiplexes them onto a handful of hardware queues -- 4 by default -- and two streams that land on the same queue
-        do not overlap: with bench.py's two headline streams still alive, two more compute streams plus two packing streams ran
-        this pipeline at exactly the one-stream rate.)"""
+        runtime multiplexes them onto a handful of hardware queues -- GPU_MAX_HW_QUEUES, 4 by default; with 1 or 2 every
+        multi-stream number of bench.py falls to its one-stream value -- and which streams end up sharing a queue is not under
+        the program's control: with bench.py's two headline streams still alive, two MORE compute streams plus two packing
+        streams ran this pipeline at exactly the one-stream rate; re-using the two existing ones runs it at full rate.)"""
         from .utils import StreamPrefetcher
         self.prepare_resident_data(data, False)
         pipe = getattr(self, '_pipeline_streams', None)
