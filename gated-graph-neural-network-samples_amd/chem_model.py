@@ -286,7 +286,14 @@ class ChemModel(object):
         shard_stats, shard_graphs = [], []
         pending = None
         batch_iterator = self.make_minibatch_iterator(data, is_training)
-        if is_training and self.params.get('threaded_batches', True):
+        threaded = self.params.get('threaded_batches', 'auto')
+        if threaded == 'auto':
+            # The producer thread pays when the launching thread is the bottleneck (the autograd path: ~4 ms of Python per step);
+            # with the native step the host has slack, packing a batch inline costs 0.3 ms of it, and a second thread only takes
+            # the interpreter lock away from the launches (5.8 vs 6.05 ms per step, tools/bench_extra.py epoch).
+            from . import train_native
+            threaded = not train_native.model_eligible(self)
+        if is_training and threaded:
             # chem_tensorflow.py:219 ThreadedIterator(..., max_queue_size=5): the next batches are packed while this one trains
             # (validation batches are packed once and stay resident: nothing to prefetch).  Two ahead is enough here.
             from .utils import ThreadedIterator

@@ -36,19 +36,21 @@ def _i32(xs):
     return (ctypes.c_int32 * max(len(xs), 1))(*[int(x) for x in xs])
 
 
-def eligible(model, batch_data: Dict[str, Any]) -> bool:
-    """True when this step can run on the native sequences (see the module docstring)."""
+def model_eligible(model) -> bool:
+    """The part of `eligible` that depends on the model only (run_epoch uses it to choose how batches are prefetched)."""
     p = getattr(model, "params", None)
     if p is None or not hasattr(model, "_edge_weight_vars") or not torch.cuda.is_available():
         return False
-    if not backward.USE_NATIVE_STEP or not backward.USE_COMPACT_TRANSFORM or not backward.TRAIN_GATHER_IN_GRU or ops._timing is not None:
+    if not backward.USE_NATIVE_STEP or not backward.USE_COMPACT_TRANSFORM or not backward.TRAIN_GATHER_IN_GRU:
         return False
     D = p['hidden_size']
     if getattr(model, "cell_type", None) != 'gru' or p['use_propagation_attention'] or p['use_edge_bias'] or not p['use_graph']:
         return False
+    if torch.device(model.device).type != 'cuda':
+        return False
     if model._kw != D or not ops.gru_gather_fused(D) or not ops.compact_supported(D) or D > 104 or not ops.gru_bwd_is_fused(D):
         return False
-    if float(batch_data.get('graph_state_keep_prob', 1.0)) < 1.0:
+    if float(p.get('graph_state_dropout_keep_prob', 1.0)) < 1.0:
         return False
     L = len(p['layer_timesteps'])
     if L > 60 or any(int(s) < 1 for s in p['layer_timesteps']):
@@ -62,15 +64,25 @@ def eligible(model, batch_data: Dict[str, Any]) -> bool:
     have = {v.data_ptr() for v in variables}
     if any(v.data_ptr() not in have for v in model.named_variables().values()):        # (--freeze-graph-model)
         return False
+    for task_id in p['task_ids']:
+        if len(model.weights['regression_gate_task%i' % task_id].params["weights"]) != 1:
+            return False
+    return True
+
+
+def eligible(model, batch_data: Dict[str, Any]) -> bool:
+    """True when this step can run on the native sequences (see the module docstring)."""
+    if ops._timing is not None or not model_eligible(model):
+        return False
+    D = model.params['hidden_size']
+    if float(batch_data.get('graph_state_keep_prob', 1.0)) < 1.0:
+        return False
     h0 = batch_data.get('initial_node_representation')
     index = batch_data.get('message_index')
     if h0 is None or index is None or not h0.is_cuda or h0.shape[0] == 0 or h0.shape[1] != D or index.num_messages == 0:
         return False
     if batch_data.get('graph_nodes_sorted') is not True or int(batch_data['num_graphs']) == 0:
         return False
-    for task_id in p['task_ids']:
-        if len(model.weights['regression_gate_task%i' % task_id].params["weights"]) != 1:
-            return False
     return True
 
 
