@@ -35,18 +35,21 @@ struct TrainLayout {
 TrainLayout train_layout(int V, int D, int T, int64_t R, int steps) {
     TrainLayout L{};
     L.steps = steps;
-    L.vd = al256((size_t)V * D * sizeof(float));
+    // per-timestep buffers follow each other WITHOUT padding (V*D*4 is a multiple of 16): the buffers of consecutive timesteps then
+    // form one [S*V, D] matrix, which lets the weight-gradient products of a layer's timesteps run as ONE product over S*V rows
+    L.vd = (size_t)V * D * sizeof(float);
     L.rd = al256((size_t)(R > 0 ? R : 1) * D * sizeof(float));
     size_t p = 0;
     auto take = [&](size_t bytes) { const size_t at = p; p += al256(bytes); return at; };
     L.Hc = take(L.rd);
-    L.state = take(L.vd * steps); L.r = take(L.vd * steps); L.u = take(L.vd * steps); L.c = take(L.vd * steps);
+    L.state = take(L.vd * (steps + 1));                  // slot 0: a copy of h0; slot k+1: the state after timestep k
+    L.r = take(L.vd * steps); L.u = take(L.vd * steps); L.c = take(L.vd * steps);
     L.inc = take(L.vd * steps);
     L.counters = take((size_t)steps * sizeof(int32_t));
     L.dpc = take(L.vd * steps); L.rh = take(L.vd * steps); L.dh = take(L.vd * steps); L.dpg = take(2 * L.vd * steps);
     L.dx = take(L.vd * steps * kMaxNx);
     L.dHc = take(L.rd * steps); L.Z = take(L.rd);
-    L.xty = take(ggnn_xty_workspace_bytes(V > R ? V : (int)R, 4 * D, 2 * D, T));
+    L.xty = take(ggnn_xty_workspace_bytes((V > R ? V : (int)R) * (steps > 1 ? steps : 1), 4 * D, 2 * D, T));
     L.total = p + 256;
     (void)T;
     return L;
@@ -156,6 +159,12 @@ __global__ __launch_bounds__(256) void train_prepare_kernel(PrepArgs a) {
     }
 }
 
+// GGNN_TRAIN_MERGE_PRODUCTS=0: the GRU weight-gradient products timestep by timestep also for layers without residual inputs
+bool merge_products() {
+    static const bool v = [] { const char* e = getenv("GGNN_TRAIN_MERGE_PRODUCTS"); return !e || atoi(e) != 0; }();
+    return v;
+}
+
 struct LayerPlan { int first_step, steps, nres; int res[kMaxNx]; };
 
 int plan_layers(int num_layers, const int32_t* layer_timesteps, const int32_t* res_ptr, const int32_t* res_idx, LayerPlan* plan,
@@ -247,6 +256,8 @@ extern "C" int ggnn_sparse_train_forward_f32(
     auto buf = [&](size_t off, int step) { return reinterpret_cast<float*>(base + off + (size_t)step * L.vd); };
     const float* states[kMaxLayers + 1];
     states[0] = h0;
+    // (the backward's merged products read the input state of every timestep from the state array: slot 0 holds h0)
+    GGNN_CHECK_HIP(hipMemcpyAsync(buf(L.state, 0), h0, L.vd, hipMemcpyDeviceToDevice, st));
     const size_t edge_img_bytes = ggnn_msg_transform_compact_workspace_bytes(D, T);
     for (int l = 0; l < num_layers; ++l) {
         const LayerPlan& P = plan[l];
@@ -259,7 +270,7 @@ extern "C" int ggnn_sparse_train_forward_f32(
             const int k = P.first_step + s;
             if (int rc = ggnn_msg_transform_compact_f32(cur, nullptr, pair_node, type_row_off, Hc, const_cast<float*>(edge_packed[l]),
                                                         edge_img_bytes, V, D, T, stream)) return rc;
-            float* out = buf(L.state, k);
+            float* out = buf(L.state, k + 1);
             if (int rc = ggnn_gru_packed_gather_train_f32(xs, nx, cur, gru_packed[l], bg[l], bc[l], out, Hc, row_ptr, gather_row_c,
                                                           use_avg ? nin : nullptr, T, use_avg ? 1 : 0, buf(L.r, k), buf(L.u, k),
                                                           buf(L.c, k), buf(L.inc, k), V, D, act, counters + k, stream)) return rc;
@@ -308,8 +319,9 @@ extern "C" int ggnn_sparse_train_backward_f32(
 
     // forward states by layer (the forward pass's buffers) and the gradients flowing into them
     const float* states[kMaxLayers + 1];
-    states[0] = h0;
-    for (int l = 0; l < num_layers; ++l) states[l + 1] = buf(L.state, plan[l].first_step + plan[l].steps - 1);
+    states[0] = buf(L.state, 0);                          // (the forward's copy of h0)
+    for (int l = 0; l < num_layers; ++l) states[l + 1] = buf(L.state, plan[l].first_step + plan[l].steps);
+    (void)h0;
     float* dstate[kMaxLayers + 1];
     bool has[kMaxLayers + 1];
     for (int l = 0; l < num_layers; ++l) { dstate[l] = d_state_ws[l]; has[l] = false; GGNN_CHECK_ARG(dstate[l], "d_state_ws[%d] is null", l); }
@@ -326,7 +338,7 @@ extern "C" int ggnn_sparse_train_backward_f32(
         const float* g = dstate[l + 1];
         for (int s = P.steps - 1; s >= 0; --s) {
             const int k = P.first_step + s;
-            const float* h_in = s == 0 ? states[l] : buf(L.state, k - 1);
+            const float* h_in = buf(L.state, k);              // input state of timestep k (slot k; slot 0 = h0)
             // where this timestep's gradients go: straight into an empty accumulator, else into a temporary that is added afterwards
             float* dh_dst = buf(L.dh, k);
             bool dh_direct = false;
@@ -351,8 +363,24 @@ extern "C" int ggnn_sparse_train_backward_f32(
             if (dh_direct) has[l] = true;
 
             // ---- GRU weight gradients, side stream: dWc += [x.. | incoming | r*h]^T dpc, dWg += [x.. | incoming | h]^T dpg
-            if (int rc = order_after(side, st)) return rc;
-            {
+            // A layer WITHOUT residual inputs runs them once for all its timesteps: incoming, r*h, dpc, dpg and the input states of
+            // consecutive timesteps are consecutive [V,D] ([V,2D]) buffers, i.e. one matrix of S*V rows each -- one product
+            // instead of S, and its fixed part (prologue, partial store, reduction launch: ~20 us of ~100) paid once.
+            const bool merged = P.nres == 0 && P.steps > 1 && merge_products();
+            if (merged) {
+                if (s == 0) {                               // (the layer's first timestep is the last one processed)
+                    if (int rc = order_after(side, st)) return rc;
+                    const int k0 = P.first_step;
+                    int32_t row_off_m[2] = {0, V * P.steps};
+                    const float* X[2] = {buf(L.inc, k0), buf(L.rh, k0)}; int32_t ldx[2] = {D, D};
+                    if (int rc = ggnn_xty_acc_f32(X, 2, D, ldx, nullptr, buf(L.dpc, k0), D, g_Wc[l], g_bc[l], 1, 2 * D, D, 1, row_off_m, 1,
+                                                  xty_ws, xty_ws_bytes, side)) return rc;
+                    X[1] = buf(L.state, k0);
+                    if (int rc = ggnn_xty_acc_f32(X, 2, D, ldx, nullptr, reinterpret_cast<float*>(base + L.dpg + (size_t)k0 * 2 * L.vd), 2 * D,
+                                                  g_Wg[l], g_bg[l], 1, 2 * D, 2 * D, 1, row_off_m, 1, xty_ws, xty_ws_bytes, side)) return rc;
+                }
+            } else {
+                if (int rc = order_after(side, st)) return rc;
                 const float* X[4]; int32_t ldx[4];
                 for (int i = 0; i < P.nres; ++i) { X[i] = states[P.res[i]]; ldx[i] = D; }
                 X[nx - 1] = buf(L.inc, k); ldx[nx - 1] = D;
