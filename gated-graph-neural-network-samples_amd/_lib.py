@@ -11,12 +11,14 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libggnn_hip.so")
+# GGNN_LIB_VARIANT=<tag>: load libggnn_hip_<tag>.so (kernel experiments built by tools/variant_lib.sh; never set in production)
+LIB_PATH = os.path.join(_HERE, "libggnn_hip%s.so" % ("_" + os.environ["GGNN_LIB_VARIANT"] if os.environ.get("GGNN_LIB_VARIANT") else ""))
 ABI_VERSION = 1
 
 # every symbol include/ggnn_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "ggnn_abi_version": (c_int, []),
+    "ggnn_matrix_path_is_split": (c_int, []),
     "ggnn_last_error": (c_char_p, []),
     "ggnn_csr_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "ggnn_build_target_csr": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int, c_int64, c_void_p, c_void_p,

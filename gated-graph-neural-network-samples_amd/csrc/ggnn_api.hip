@@ -1,6 +1,7 @@
 // ABI version, thread-local error text, device properties.
 #include "ggnn_common.h"
 #include <atomic>
+#include <cstdlib>
 
 namespace ggnn {
 
@@ -29,7 +30,15 @@ int num_cus() {
     return n;
 }
 
+// Matrix path of the fused kernels (ggnn_split.hpp): "bf16x3" (default) = f32 products as six bf16 MFMA products of 3-way split
+// operands; GGNN_MATRIX=f32 = the f32 MFMA forms.  Read once: packed weight images are in the format of the mode.
+bool split_matrix_path() {
+    static const bool v = [] { const char* e = getenv("GGNN_MATRIX"); return !(e && (e[0] == 'f' || e[0] == 'F')); }();
+    return v;
+}
+
 }  // namespace ggnn
 
+extern "C" int ggnn_matrix_path_is_split(void) { return ggnn::split_matrix_path() ? 1 : 0; }
 extern "C" int ggnn_abi_version(void) { return GGNN_ABI_VERSION; }
 extern "C" const char* ggnn_last_error(void) { return ggnn::error_buffer(); }

@@ -25,7 +25,7 @@
 // so each x fragment is read from memory once and dies after its third stage; the fragment of the next
 // segment (or of the next pass's first segment) is fetched while the current one is being multiplied.
 // All accumulation orders are those of the plain [x|h] / [x|r*h] products (segments in order, h last).
-#include "ggnn_stage.hpp"
+#include "ggnn_split.hpp"
 #include <type_traits>
 
 #ifndef GGNN_COOP_DEPTH
@@ -41,21 +41,23 @@ int gru_panel_dispatch(const GruFusedArgs& a, int D, float* packed, hipStream_t 
 
 int gru_pack_floats(int D, int nx) {
     if (gru_panel_supported(D)) return gru_panel_pack_floats(D, nx);
+    const bool sp = split_matrix_path();
     switch (D) {
-        case 100: return 3 * (nx + 1) * StageCfg<100>::IMG;
-        case 64: return 3 * (nx + 1) * StageCfg<64>::IMG;
-        case 32: return 3 * (nx + 1) * StageCfg<32>::IMG;
+        case 100: return 3 * (nx + 1) * (sp ? ImgCfg<100, true>::IMG : ImgCfg<100, false>::IMG);
+        case 64: return 3 * (nx + 1) * (sp ? ImgCfg<64, true>::IMG : ImgCfg<64, false>::IMG);
+        case 32: return 3 * (nx + 1) * (sp ? ImgCfg<32, true>::IMG : ImgCfg<32, false>::IMG);
         default: return 0;
     }
 }
 
 // image ci of the packed weights: gates (s = 0..nx) x {r,u}, then candidate (s = 0..nx)
-template <int D>
+template <int D, bool SPLIT>
 __global__ void gru_pack_weights_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx,
                                         float* __restrict__ out) {
     const int ci = blockIdx.y;
-    gru_fwd_image_pack<D>(Wg, Wc, nx, ci, out + (size_t)ci * StageCfg<D>::IMG, blockIdx.x * blockDim.x + threadIdx.x,
-                          gridDim.x * blockDim.x);
+    float* img = out + (size_t)ci * ImgCfg<D, SPLIT>::IMG;
+    if constexpr (SPLIT) gru_fwd_image_pack_split<D>(Wg, Wc, nx, ci, img, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    else gru_fwd_image_pack<D>(Wg, Wc, nx, ci, img, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // position in the per-pass stage sequence -> packed image (segment s = pos / 3; 0,1: its r / u gate columns, 2: candidate)
@@ -88,13 +90,14 @@ __device__ __forceinline__ void frag_add(Frag<D>& f, const Frag<D>& t) {
 // gather_row -> rows); it is software-pipelined over the stage boundaries BEFORE the stage that consumes it: every
 // level is issued at the start of a stage and has landed by that stage's closing barrier, so the MFMAs never wait
 // for it (only slots beyond the pipelined depth, 4 per row = the largest valence in QM9, are fetched synchronously).
-template <int D, int NX, int NW, bool SAVE, bool GATHER>
+// SPLIT: the products run on the bf16 matrix pipe in 3-way split form (ggnn_split.hpp) -- same stages, same fragments, same
+// accumulators; the stage images are the split ones and every activation fragment is split in registers before its first stage.
+template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a, const float* __restrict__ packed) {
     using C = StageCfg<D>;
+    using I = ImgCfg<D, SPLIT>;
     constexpr int NT = C::NT, NC = C::NC, NR = C::NR;
     constexpr int NSTAGE = 3 * (NX + 1);
-    constexpr int DMA_PER_WAVE = C::IMG_BYTES / (NW * 1024);
-    static_assert(DMA_PER_WAVE <= C::NC * ((NT + 3) / 4), "more DMA pieces than MFMA groups to hide them behind");
     extern __shared__ __attribute__((aligned(16))) float lds_[];    // [biases | ring [2][IMG]]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     float* ring = lds_ + BIAS_FLOATS;
     int* tk_slot = reinterpret_cast<int*>(bias_s + 4 * D);
     constexpr int RHP = C::BN + 4;                     // row pitch of the r*h exchange block (cooperative tail pass)
-    float* rh_x = ring + 2 * C::IMG;                   // [16][RHP], behind the ring
+    float* rh_x = ring + 2 * I::IMG;                   // [16][RHP], behind the ring
     for (int i = tid; i < 4 * D; i += NW * 64)
         bias_s[i] = i < 2 * D ? -kLog2e * a.bg[i] : (i < 3 * D ? 2.0f * kLog2e * a.bc[i - 2 * D] : a.bc[i - 3 * D]);
     // The two waves of a SIMD (w and w + NW/2) do not interleave on the matrix pipe: the older one issues its whole
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     if (a.tickets && tid == 0) *tk_slot = nb + atomicAdd(a.tickets, 1);
 
     int cur = 0;
-    dma_stage_image<D, NW>(packed, ring, wave, lane);
+    dma_image<I::IMG_BYTES, NW>(packed, ring, wave, lane);
 
     // ---- the pipelined gather of the aggregated-messages segment (GATHER) --------------------------------------
     // Phases, each issued at a stage start and landed by that stage's closing barrier (U = the stage that consumes
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     // straight from the images in global memory into registers (no ring, no per-stage barrier).  The register form
     // needs 2 x 25 more VGPRs; with residual inputs (NX >= 2) that pushes loop invariants of the ordinary passes into
     // scratch (measured: NX = 3 launch 224 -> 240 us), so only the single-input kernel uses it (121 -> 120 us).
-    constexpr bool COOP_REGS = (NX == 1);
+    constexpr bool COOP_REGS = (NX == 1) && !SPLIT;
     const int n_dma = (coop_tail && COOP_REGS) ? n_main : n_tk; // passes that need the ring filled
     auto run_pass = [&](auto coop_c, const int p) {
         const int tile_ = tile_of(tk);
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             }                                                                                            \
             if constexpr ((POS) + TWD < NSTAGE) {                                                        \
                 if (wave < NT) load_tile_weights<D>(tw[((POS) + TWD) % (TWD + 1)],                       \
-                                                    packed + (size_t)gru_stage_image<NX>((POS) + TWD) * C::IMG, li, kq, wave); \
+                                                    packed + (size_t)gru_stage_image<NX>((POS) + TWD) * I::IMG, li, kq, wave); \
             }                                                                                            \
             prefetch(std::integral_constant<int, (POS)>{});                                              \
             if constexpr ((POS) == 3 * NX) {   /* h columns of this wave's tile, for the two epilogues */ \
@@ -347,8 +350,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         {                                                                                                \
             constexpr int npos_ = (POS) + 1;                                                             \
             const bool more_ = (npos_ < NSTAGE) || tk_next < n_dma;                                      \
-            const float* nsrc_ = packed + (size_t)gru_stage_image<NX>(npos_ < NSTAGE ? npos_ : 0) * C::IMG; \
-            float* ndst_ = ring + (cur ^ 1) * C::IMG;                                                    \
+            const float* nsrc_ = packed + (size_t)gru_stage_image<NX>(npos_ < NSTAGE ? npos_ : 0) * I::IMG; \
+            float* ndst_ = ring + (cur ^ 1) * I::IMG;                                                    \
             GGNN_T(POS, 0)                                                                               \
             if constexpr (GATHER && (POS) == G_U % NSTAGE) {   /* the fragment this stage multiplies */  \
                 if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVE) { if (row < a.V && a.save_x) store_x(xf[GBUF], row); } } \
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                via the stage_mma hook measured slower.) */                                                \
             if (late) {                                                                                  \
                 prefetch(std::integral_constant<int, (POS)>{});                                          \
-                if (more_) dma_stage_image<D, NW>(nsrc_, ndst_, wave, lane);                             \
+                if (more_ && !(a.dbg & 8)) dma_image<I::IMG_BYTES, NW>(nsrc_, ndst_, wave, lane);                             \
             }                                                                                            \
             GGNN_T(POS, 1)                                                                               \
             __builtin_amdgcn_sched_barrier(0);   /* keep the side work on its side of the MFMA block */  \
@@ -369,18 +372,27 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             constexpr int ntl_ = ((C::TAILPACK && (POS) % 3 == 1) ||                                     \
                                   (C::TAILPACK3 && (POS) % 3 == 2 && (POS) < 3 * NX)) ? NT - 1 : NT;     \
             /* stages 0..2 open the three accumulator sets: they start from the constant 0 */            \
+            /* SPLIT: a fragment is split into its bf16 planes before the first of its stages */         \
+            if constexpr (SPLIT && ((POS) % 3 == 0 || (POS) == NSTAGE - 1)) { if (active && !(a.dbg & 16)) split_frag<D>(sf, FRAG); } \
             if (active && !(a.dbg & 1)) {                                                                \
-                if constexpr (!coop) stage_mma<D, NoHook, ntl_, ((POS) < 3)>(ACC, FRAG, ring + cur * C::IMG, li, kq); \
-                else if (C::TAILPACK3 && (POS) == NSTAGE - 1 && wave == NT - 1) {                        \
+                const float* img_ = ring + cur * I::IMG;                                                 \
+                if constexpr (!coop) {                                                                   \
+                    if constexpr (SPLIT) stage_mma_split<D, ntl_, ((POS) < 3)>(ACC, sf, FRAG, img_, li, kq); \
+                    else stage_mma<D, NoHook, ntl_, ((POS) < 3)>(ACC, FRAG, img_, li, kq);               \
+                } else if (C::TAILPACK3 && (POS) == NSTAGE - 1 && wave == NT - 1) {                      \
                     f32x4 t_;        /* (same association as the tail-packed ordinary passes, see GGNN_COOP_STAGE) */ \
-                    stage_mma_one<D, true>(t_, FRAG, ring + cur * C::IMG, li, kq, wave);                 \
+                    if constexpr (SPLIT) stage_mma_one_split<D, true>(t_, sf, FRAG, img_, li, kq, wave); \
+                    else stage_mma_one<D, true>(t_, FRAG, img_, li, kq, wave);                           \
                     ACC[0] = ACC[0] + t_;                                                                \
-                } else { if (wave < NT) stage_mma_one<D, ((POS) < 3)>(ACC[0], FRAG, ring + cur * C::IMG, li, kq, wave); } \
+                } else if (wave < NT) {                                                                  \
+                    if constexpr (SPLIT) stage_mma_one_split<D, ((POS) < 3)>(ACC[0], sf, FRAG, img_, li, kq, wave); \
+                    else stage_mma_one<D, ((POS) < 3)>(ACC[0], FRAG, img_, li, kq, wave);                \
+                }                                                                                        \
             }                                                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                           \
             if (!late) {                                                                                 \
                 prefetch(std::integral_constant<int, (POS)>{});                                          \
-                if (more_) dma_stage_image<D, NW>(nsrc_, ndst_, wave, lane);                             \
+                if (more_ && !(a.dbg & 8)) dma_image<I::IMG_BYTES, NW>(nsrc_, ndst_, wave, lane);                             \
             }                                                                                            \
             GGNN_T(POS, 2)                                                                               \
             __syncthreads();                                                                             \
@@ -389,6 +401,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         }
 
         f32x4 acc_r[NT], acc_u[NT], acc_c[NT];       // opened by stages 0, 1, 2 (first MFMA of each tile: C = 0)
+        SFrag<D> sf;                                 // (SPLIT) bf16 planes of the fragment the current stages multiply
         constexpr int TWD = GGNN_COOP_DEPTH;         // (cooperative tail pass, COOP_REGS) stages of weight look-ahead
         TileWeights<D> tw[TWD + 1];                  // this wave's column-tile weights of stages POS .. POS+TWD
         f32x4 hv_pre = {0.f, 0.f, 0.f, 0.f};
@@ -554,21 +567,22 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     }
 }
 
-template <int D, int NX, int NW, bool SAVE, bool GATHER>
-static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t st) {
+template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT>
+static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream_t st) {
     using C = StageCfg<D>;
+    using I = ImgCfg<D, SPLIT>;
     GruFusedArgs a = a_in;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GGNN_GRU_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     { const char* e = getenv("GGNN_GRU_TPTR"); a.tdbg = e ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
     if (a.Wg) {   // raw weights given: build the stage images first (skipped when the caller pre-packed them)
-        hipLaunchKernelGGL((gru_pack_weights_kernel<D>), dim3(8, 3 * (NX + 1)), dim3(256), 0, st, a.Wg, a.Wc, NX, packed);
+        hipLaunchKernelGGL((gru_pack_weights_kernel<D, SPLIT>), dim3(8, 3 * (NX + 1)), dim3(256), 0, st, a.Wg, a.Wc, NX, packed);
         GGNN_CHECK_HIP(hipGetLastError());
     }
     if (a.h == nullptr) return GGNN_OK;   // pack-only call
     if ((unsigned long long)a.V * D >= (1ULL << 30) || (a.g_H && (unsigned long long)a.V * a.g_T * D >= (1ULL << 30)))
         return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit byte offsets: V*D (and V*T*D for the gathered rows) "
                                         "must be < 2^30 (V=%d, D=%d)", a.V, D);
-    const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)((4 * D + 4 + 63) / 64 * 64) * sizeof(float)    // biases, ticket slots + ring
+    const size_t lds = (size_t)2 * I::IMG_BYTES + (size_t)((4 * D + 4 + 63) / 64 * 64) * sizeof(float)    // biases, ticket slots + ring
                      + (size_t)16 * (C::BN + 4) * sizeof(float);                                          // + r*h exchange block
     const int wt_total = (a.V + 15) / 16;
     // one workgroup per CU; with fewer than NW tiles per CU the tiles are spread over ALL CUs as thin tickets (the
@@ -582,10 +596,16 @@ static int launch_gru_fused(const GruFusedArgs& a_in, float* packed, hipStream_t
     static const int coop_small = [] { const char* e = getenv("GGNN_GRU_COOP_SMALL"); return e ? atoi(e) : 1; }();
     if (coop_small && wt_total > nb && wt_total <= 2 * nb && StageCfg<D>::NT <= NW) nb = wt_total;
     static std::atomic<unsigned long long> lds_ok{0};        // (one per template instantiation)
-    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER>, lds, lds_ok));
-    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
+    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT>, lds, lds_ok));
+    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
+}
+
+template <int D, int NX, int NW, bool SAVE, bool GATHER>
+static int launch_gru_fused(const GruFusedArgs& a, float* packed, hipStream_t st) {
+    if constexpr (SplitCfg<D>::OK) { if (split_matrix_path()) return launch_gru_fused_m<D, NX, NW, SAVE, GATHER, true>(a, packed, st); }
+    return launch_gru_fused_m<D, NX, NW, SAVE, GATHER, false>(a, packed, st);
 }
 
 static bool nosave_kernel() {
@@ -593,6 +613,7 @@ static bool nosave_kernel() {
     return v;
 }
 
+#ifndef GGNN_PROBE_NX
 template <int D>
 static int dispatch_nx(const GruFusedArgs& a, float* packed, hipStream_t st) {
     const bool save = a.save_r || a.save_u || a.save_c;
@@ -618,10 +639,15 @@ static int dispatch_nx(const GruFusedArgs& a, float* packed, hipStream_t st) {
     }
 }
 
+#endif
+
 // 1: whole-block stage images, with a gather-fused variant; 2: column-panel kernel (no gather-fused variant); 0: none
 int gru_fused_supported(int D) { return (D == 100 || D == 64 || D == 32) ? 1 : (gru_panel_supported(D) ? 2 : 0); }
 
 int gru_fused_dispatch(const GruFusedArgs& a, int D, float* packed, hipStream_t st) {
+#ifdef GGNN_PROBE_NX   // register-allocation probe (tools/kernel_regs.sh ... -DGGNN_PROBE_NX=1 -DGGNN_PROBE_SAVE=false): one instantiation
+    return launch_gru_fused_m<100, GGNN_PROBE_NX, 8, GGNN_PROBE_SAVE, true, true>(a, packed, st);
+#else
     if (gru_panel_supported(D)) return gru_panel_dispatch(a, D, packed, st);
     switch (D) {
         case 100: return dispatch_nx<100>(a, packed, st);
@@ -629,6 +655,7 @@ int gru_fused_dispatch(const GruFusedArgs& a, int D, float* packed, hipStream_t 
         case 32: return dispatch_nx<32>(a, packed, st);
         default: return fail(GGNN_E_UNSUPPORTED, "no fused GRU for hidden size %d", D);
     }
+#endif
 }
 
 }  // namespace ggnn

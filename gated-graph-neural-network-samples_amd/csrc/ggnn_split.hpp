@@ -1,0 +1,291 @@
+// FP32 products on the BF16 matrix pipe: the "3-way split" form of the stage product of ggnn_stage.hpp.
+//
+// gfx950 multiplies f32 operands on the matrix cores at the f32 VECTOR rate (v_mfma_f32_16x16x4_f32: 1024 MACs per 32
+// clocks per SIMD, 157 TF) -- 1/16 of what the same cores do with bf16 operands (v_mfma_f32_16x16x32_bf16: 8192 MACs per
+// 16 clocks, 2.5 PF), and there is no TF32-like middle.  An f32 value is EXACTLY the sum of three bf16 values
+//     a = a_hi + a_mid + a_lo        (8 + 8 + 8 significand bits; bf16 has the f32 exponent range)
+// so the f32 product a*b is the sum of nine bf16 x bf16 products, each of which is exact in f32 (16-bit significands).
+// Dropping the three smallest (a_mid*b_lo, a_lo*b_mid, a_lo*b_lo: < 2^-23 |a b| together) leaves SIX products
+//     a_hi b_hi + (a_hi b_mid + a_mid b_hi) + (a_mid b_mid + a_hi b_lo + a_lo b_hi)
+// accumulated in f32 by the MFMA: 6 MFMAs of k = 32 do the work of 8 MFMAs of k = 4 x 32 clocks -- 96 clocks instead of
+// 256 per 16 x 16 x 32 block -- with an error bound no worse than the f32 FMA chain's (one rounding per k there, one per
+// 32-k dot product here; tests/test_gpu_split_precision.py measures both against an f64 product).
+//
+// Layout.  v_mfma_f32_16x16x32_bf16: lane (i = lane & 15, g = lane >> 4) holds, for BOTH operands, the 8 k values
+// 8g .. 8g+7 of its row / column; the output mapping is that of the f32 form (lane holds 4 consecutive output columns of
+// one row when the WEIGHT fragment is the first operand).  k order inside a 32-chunk is free as long as both operands
+// agree, so slot j of lane group g in chunk c2 is
+//     k = 32 c2 + 16 (j >> 2) + 4 g + (j & 3)
+// i.e. the float4 pair Frag::v[2 c2], Frag::v[2 c2 + 1] of the f32 activation fragment: fragments are loaded, gathered and
+// chained (output tile nt == activation chunk nt) exactly as in the f32 kernels, and split in registers.  The D % 16
+// remainder k indices (4 at D = 100) stay on the f32 MFMA.
+//
+// Stage image (one D x D block; BN = 16 ceil(D/16) columns):
+//     plane p in {hi, mid, lo}:  [c2][g][n][8 x bf16]   one ds_read_b128 = the weight operand of (c2, tile of n)
+//     rem (f32): [q][g][n] = W[16 NC + 4q + g][n]       as in the f32 image
+#pragma once
+#include "ggnn_stage.hpp"
+
+namespace ggnn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// Process-wide choice of the matrix path of the fused kernels (read once): GGNN_MATRIX=f32 selects the f32 MFMA forms.
+bool split_matrix_path();
+
+template <int D>
+struct SplitCfg {
+    using S = StageCfg<D>;
+    static constexpr bool OK = (S::NC % 2 == 0) && S::NC > 0;
+    static constexpr int NC2 = S::NC / 2;
+    static constexpr int PLANE_BYTES = NC2 * 4 * S::BN * 16;
+    static constexpr int MAIN_BYTES = 3 * PLANE_BYTES;
+    static constexpr int REM_BYTES = S::NR * 4 * S::BN * 4;
+    static constexpr int IMG_BYTES = (MAIN_BYTES + REM_BYTES + 8191) / 8192 * 8192;
+    static constexpr int IMG = IMG_BYTES / 4;
+};
+
+// image geometry of a fused kernel: the f32 stage image or the split one
+template <int D, bool SPLIT>
+struct ImgCfg {
+    static constexpr int IMG_BYTES = SPLIT ? SplitCfg<D>::IMG_BYTES : StageCfg<D>::IMG_BYTES;
+    static constexpr int IMG = IMG_BYTES / 4;
+};
+
+__device__ __forceinline__ float trunc_bf16_f(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+// piece p (0 hi, 1 mid, 2 lo) of x as bf16 bits.  Truncation: every piece takes the next 8 significand bits, the three
+// together all 24 -- the split is exact and each residual subtraction is exact.
+__device__ __forceinline__ unsigned split_piece_bits(float x, int p) {
+    const float hi = trunc_bf16_f(x);
+    if (p == 0) return __float_as_uint(hi) >> 16;
+    const float r1 = x - hi, mid = trunc_bf16_f(r1);
+    if (p == 1) return __float_as_uint(mid) >> 16;
+    return __float_as_uint(r1 - mid) >> 16;
+}
+
+// The (k, n) -> value rule of a stage image (pack_stage_image's, see there): the block itself, plus the partly filled last
+// tiles of up to two other blocks riding in the padding columns.
+template <int D>
+struct StageValue {
+    const float* W; int r0, c0, ldw, c_alt;
+    const float* W2; int r0_2, ldw2, c_alt2;
+    __device__ __forceinline__ float operator()(int k, int n) const {
+        constexpr int TC = D % 16;
+        if (n < D) return W[(size_t)(r0 + k) * ldw + c0 + n];
+        if (c_alt >= 0 && n < D + TC) return W[(size_t)(r0 + k) * ldw + c_alt + (n - D)];
+        if (W2 && c_alt2 >= 0 && n >= D + TC && n < D + 2 * TC) return W2[(size_t)(r0_2 + k) * ldw2 + c_alt2 + (n - D - TC)];
+        return 0.f;
+    }
+};
+
+// transposed block (the backward kernels' images): B(k, n) = W[(r0 + n) * ldw + c0 + k]
+template <int D>
+struct StageValueT {
+    const float* W; int r0, c0, ldw;
+    __device__ __forceinline__ float operator()(int k, int n) const { return n < D ? W[(size_t)(r0 + n) * ldw + c0 + k] : 0.f; }
+};
+
+template <int D, class Value>
+__device__ __forceinline__ void pack_split_image(const Value& value, float* __restrict__ img, int first, int stride) {
+    using C = SplitCfg<D>;
+    using S = StageCfg<D>;
+    constexpr int PW = C::PLANE_BYTES / 4, MW = C::MAIN_BYTES / 4, RW = C::REM_BYTES / 4;
+    for (int i = first; i < C::IMG; i += stride) {
+        unsigned out = 0u;
+        if (i < MW) {
+            const int plane = i / PW, w = i % PW;
+            const int slot = w >> 2, pr = w & 3;                 // 16-byte slot (c2, g, n); bf16 pair (j = 2 pr, 2 pr + 1)
+            const int n = slot % S::BN, cg = slot / S::BN, c2 = cg >> 2, g = cg & 3;
+            const int j0 = 2 * pr;
+            const int k0 = 32 * c2 + 16 * (j0 >> 2) + 4 * g + (j0 & 3);
+            out = split_piece_bits(value(k0, n), plane) | (split_piece_bits(value(k0 + 1, n), plane) << 16);
+        } else if (i < MW + RW) {
+            const int j = i - MW;
+            out = __float_as_uint(value(16 * S::NC + j / S::BN, j % S::BN));       // j / BN = q*4 + g
+        }
+        img[i] = __uint_as_float(out);
+    }
+}
+
+// Image ci of the fused GRU's packed weights in split form: the same blocks and tail-riding columns as gru_fwd_image_pack.
+template <int D>
+__device__ __forceinline__ void gru_fwd_image_pack_split(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx, int ci,
+                                                         float* __restrict__ img, int first, int stride) {
+    StageValue<D> v{nullptr, 0, 0, 0, -1, Wc, 0, D, -1};
+    if (ci < 2 * (nx + 1)) {
+        v.W = Wg; v.r0 = (ci >> 1) * D; v.c0 = (ci & 1) * D; v.ldw = 2 * D;
+        if (StageCfg<D>::TAILPACK && (ci & 1) == 0) v.c_alt = D + (D / 16) * 16;
+        if (StageCfg<D>::TAILPACK3 && (ci & 1) == 0 && (ci >> 1) < nx) { v.c_alt2 = (D / 16) * 16; v.r0_2 = (ci >> 1) * D; }
+    } else { v.W = Wc; v.r0 = (ci - 2 * (nx + 1)) * D; v.c0 = 0; v.ldw = D; }
+    pack_split_image<D>(v, img, first, stride);
+}
+
+// the three bf16 planes of an activation fragment's 32-chunks (the remainder floats stay in the Frag)
+template <int D>
+struct SFrag {
+    u32x4 hi[SplitCfg<D>::NC2 > 0 ? SplitCfg<D>::NC2 : 1];
+    u32x4 mid[SplitCfg<D>::NC2 > 0 ? SplitCfg<D>::NC2 : 1];
+    u32x4 lo[SplitCfg<D>::NC2 > 0 ? SplitCfg<D>::NC2 : 1];
+};
+
+// two floats -> one register of each plane (element 0 in the low half): 3 v_perm + 4 v_and + 4 v_sub
+__device__ __forceinline__ void split_pair(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = a0 - __uint_as_float(u0 & 0xffff0000u), r1 = a1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+template <int D>
+__device__ __forceinline__ void split_frag(SFrag<D>& s, const Frag<D>& f) {
+#pragma unroll
+    for (int c2 = 0; c2 < SplitCfg<D>::NC2; ++c2) {
+        const f32x4 a = f.v[2 * c2], b = f.v[2 * c2 + 1];
+        unsigned h[4], m[4], l[4];
+        split_pair(a.x, a.y, h[0], m[0], l[0]);
+        split_pair(a.z, a.w, h[1], m[1], l[1]);
+        split_pair(b.x, b.y, h[2], m[2], l[2]);
+        split_pair(b.z, b.w, h[3], m[3], l[3]);
+        s.hi[c2] = u32x4{h[0], h[1], h[2], h[3]};
+        s.mid[c2] = u32x4{m[0], m[1], m[2], m[3]};
+        s.lo[c2] = u32x4{l[0], l[1], l[2], l[3]};
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 w, u32x4 a, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+}
+
+// the six products of one (32-chunk, tile), smallest terms first; FIRST: the accumulator is opened with C = 0
+template <bool FIRST>
+__device__ __forceinline__ f32x4 split_products(f32x4 acc, u32x4 wh, u32x4 wm, u32x4 wl, u32x4 ah, u32x4 am, u32x4 al) {
+    f32x4 c = FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc;
+    c = mfma_bf16(wl, ah, c);
+    c = mfma_bf16(wh, al, c);
+    c = mfma_bf16(wm, am, c);
+    c = mfma_bf16(wm, ah, c);
+    c = mfma_bf16(wh, am, c);
+    c = mfma_bf16(wh, ah, c);
+    return c;
+}
+
+// acc[nt] (+)= A-fragment x split stage image: the counterpart of stage_mma (same tiles, same remainder handling).
+// Per 32-chunk and group of G tiles: 3G ds_read_b128 feed 6G MFMAs; the reads of group gi+1 are issued before the MFMAs
+// of group gi; inside a group the tiles alternate so that consecutive MFMAs write different accumulators.
+#ifndef GGNN_SPLIT_G
+#define GGNN_SPLIT_G 1
+#endif
+template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false>
+__device__ __forceinline__ void stage_mma_split(f32x4 (&acc)[StageCfg<D>::NT], const SFrag<D>& a, const Frag<D>& af,
+                                                const float* img, int li, int kq) {
+    using S = StageCfg<D>;
+    using C = SplitCfg<D>;
+    constexpr int G = GGNN_SPLIT_G;
+    constexpr int GPC = (NTILES + G - 1) / G;
+    constexpr int NG = C::NC2 * GPC;
+    constexpr int PL = C::PLANE_BYTES / 16;                           // plane pitch in 16-byte slots
+    const u32x4* base = reinterpret_cast<const u32x4*>(img) + kq * S::BN + li;
+    u32x4 w[2][G][3];
+    float wr[S::NR > 0 ? S::NR : 1][S::NT];
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+        if (j < NTILES) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) w[0][j][p] = base[p * PL + j * 16];
+        }
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int c2 = gi / GPC, g0 = (gi % GPC) * G;
+        if (gi + 1 < NG) {
+            const int cn = (gi + 1) / GPC, gn = ((gi + 1) % GPC) * G;
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                if (gn + j < NTILES) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) w[(gi + 1) & 1][j][p] = base[p * PL + cn * 4 * S::BN + (gn + j) * 16];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < S::NR; ++q)
+#pragma unroll
+                for (int nt = 0; nt < NTILES; ++nt) wr[q][nt] = img[C::MAIN_BYTES / 4 + (q * 4 + kq) * S::BN + li + nt * 16];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // product-major over the group's tiles: tile j's next MFMA is G issue slots behind its previous one
+        u32x4 (&wg)[G][3] = w[gi & 1];
+        const bool first = ZERO && c2 == 0;
+#define GGNN_SPLIT_STEP(WP, AP, OPEN)                                                                     \
+        _Pragma("unroll") for (int j = 0; j < G; ++j) if (g0 + j < NTILES) {                               \
+            const f32x4 cin = ((OPEN) && first) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[g0 + j];                 \
+            acc[g0 + j] = mfma_bf16(wg[j][WP], a.AP[c2], cin);                                             \
+        }
+        GGNN_SPLIT_STEP(2, hi, true)
+        GGNN_SPLIT_STEP(0, lo, false)
+        GGNN_SPLIT_STEP(1, mid, false)
+        GGNN_SPLIT_STEP(1, hi, false)
+        GGNN_SPLIT_STEP(0, mid, false)
+        GGNN_SPLIT_STEP(0, hi, false)
+#undef GGNN_SPLIT_STEP
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 0; q < S::NR; ++q)
+#pragma unroll
+        for (int nt = 0; nt < NTILES; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q][nt], af.r[q], acc[nt], 0, 0, 0);
+}
+
+// ONE output tile (wave-uniform, run time) of the same product: the cooperative tail pass
+template <int D, bool ZERO>
+__device__ __forceinline__ void stage_mma_one_split(f32x4& acc, const SFrag<D>& a, const Frag<D>& af, const float* img, int li,
+                                                    int kq, int tile) {
+    using S = StageCfg<D>;
+    using C = SplitCfg<D>;
+    constexpr int PL = C::PLANE_BYTES / 16;
+    const u32x4* base = reinterpret_cast<const u32x4*>(img) + kq * S::BN + li + tile * 16;
+    f32x4 cin = acc;
+    if constexpr (ZERO) cin = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 w0 = base[0], w1 = base[PL], w2 = base[2 * PL];
+#pragma unroll
+    for (int c2 = 0; c2 < C::NC2; ++c2) {
+        const int cn = c2 + 1 < C::NC2 ? c2 + 1 : c2;
+        const u32x4 n0 = base[cn * 4 * S::BN], n1 = base[PL + cn * 4 * S::BN], n2 = base[2 * PL + cn * 4 * S::BN];
+        cin = split_products<false>(cin, w0, w1, w2, a.hi[c2], a.mid[c2], a.lo[c2]);
+        w0 = n0; w1 = n1; w2 = n2;
+    }
+#pragma unroll
+    for (int q = 0; q < S::NR; ++q) {
+        const float wr = img[C::MAIN_BYTES / 4 + (q * 4 + kq) * S::BN + li + tile * 16];
+        cin = __builtin_amdgcn_mfma_f32_16x16x4f32(wr, af.r[q], cin, 0, 0, 0);
+    }
+    acc = cin;
+}
+
+// LDS-DMA of BYTES (a multiple of NW KiB) from src into LDS at dst by an NW-wave workgroup (dma_stage_image for any image size)
+template <int BYTES, int NW>
+__device__ __forceinline__ void dma_image(const float* src, float* dst, int wave, int lane) {
+    constexpr int PER_WAVE = BYTES / (NW * 1024);
+    static_assert(BYTES % (NW * 1024) == 0, "image must split into whole KiB per wave");
+    char* d = reinterpret_cast<char*>(dst) + (size_t)wave * PER_WAVE * 1024;
+    const unsigned voff = (unsigned)lane * 16u;
+#pragma unroll
+    for (int i0 = 0; i0 < PER_WAVE; i0 += 4) {
+        const unsigned long long sb = reinterpret_cast<unsigned long long>(src) + (unsigned long long)wave * PER_WAVE * 1024 + (unsigned long long)i0 * 1024;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+        const char* s = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+        lds_void* dl = (lds_void*)(d + i0 * 1024);
+        if (i0 + 0 < PER_WAVE) __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 0, 0);
+        if (i0 + 1 < PER_WAVE) __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 1024, 0);
+        if (i0 + 2 < PER_WAVE) __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 2048, 0);
+        if (i0 + 3 < PER_WAVE) __builtin_amdgcn_global_load_lds((glb_void*)(s + voff), dl, 16, 3072, 0);
+    }
+}
+
+}  // namespace ggnn

@@ -13,7 +13,7 @@
 // Cross-stream hazards: everything a side-stream product reads (dpc, dpg, r*h, incoming, states, dHc) has its own buffer per
 // timestep, so the main stream never waits for the side stream inside a step; the call ends with the main stream waiting for the
 // side stream's last product, which orders the next step's forward (it reuses the workspace) behind them.
-#include "ggnn_stage.hpp"
+#include "ggnn_split.hpp"
 #include "ggnn_philox.hpp"
 #include <mutex>
 
@@ -119,7 +119,8 @@ struct PrepArgs {
     int T; float keep;
 };
 
-template <int D>
+// SF: the fused GRU forward's images in split form (ggnn_split.hpp)
+template <int D, bool SF>
 __global__ __launch_bounds__(256) void train_prepare_kernel(PrepArgs a) {
     using C = StageCfg<D>;
     const int l = blockIdx.z, i = blockIdx.y;
@@ -152,7 +153,9 @@ __global__ __launch_bounds__(256) void train_prepare_kernel(PrepArgs a) {
         }
     } else if (i < 2 * T + ng) {
         const int ci = i - 2 * T;
-        gru_fwd_image_pack<D>(a.Wg[l], a.Wc[l], a.nx[l], ci, a.gru_img[l] + (size_t)ci * C::IMG, first, stride);
+        float* img = a.gru_img[l] + (size_t)ci * ImgCfg<D, SF>::IMG;
+        if constexpr (SF) gru_fwd_image_pack_split<D>(a.Wg[l], a.Wc[l], a.nx[l], ci, img, first, stride);
+        else gru_fwd_image_pack<D>(a.Wg[l], a.Wc[l], a.nx[l], ci, img, first, stride);
     } else if (i < 2 * T + 2 * ng) {
         const int bi = i - 2 * T - ng;
         gru_bwd_image_pack<D>(a.Wg[l], a.Wc[l], a.nx[l], bi, a.gru_bwd_img[l] + (size_t)bi * C::IMG, first, stride);
@@ -215,11 +218,15 @@ extern "C" int ggnn_sparse_train_prepare_f32(int num_layers, int T, int D, const
     }
     const dim3 grid(8, max_images, num_layers);
     hipStream_t st = (hipStream_t)stream;
+    const bool sf = split_matrix_path();
+#define GGNN_PREP(DD) if (sf) hipLaunchKernelGGL((train_prepare_kernel<DD, true>), grid, dim3(256), 0, st, a); \
+                      else hipLaunchKernelGGL((train_prepare_kernel<DD, false>), grid, dim3(256), 0, st, a);
     switch (D) {
-        case 100: hipLaunchKernelGGL(train_prepare_kernel<100>, grid, dim3(256), 0, st, a); break;
-        case 64: hipLaunchKernelGGL(train_prepare_kernel<64>, grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL(train_prepare_kernel<32>, grid, dim3(256), 0, st, a); break;
+        case 100: GGNN_PREP(100) break;
+        case 64: GGNN_PREP(64) break;
+        default: GGNN_PREP(32) break;
     }
+#undef GGNN_PREP
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }

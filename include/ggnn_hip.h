@@ -45,6 +45,12 @@ typedef void* ggnn_stream_t;     /* hipStream_t */
 
 int ggnn_abi_version(void);
 const char* ggnn_last_error(void);
+/* Matrix path of the fused kernels, fixed per process (environment GGNN_MATRIX, read at the first call):
+ *   1 (default)  f32 products as six bf16 MFMA products of operands split exactly into three bf16 pieces (csrc/ggnn_split.hpp):
+ *                f32 inputs, f32 accumulation, error bound of an f32 FMA chain, 2.5x the f32 matrix rate of gfx950;
+ *   0 (GGNN_MATRIX=f32)  the f32 MFMA forms (v_mfma_f32_16x16x4_f32).
+ * Packed weight images (ggnn_*_pack_*) are in the format of the mode and sized by the *_bytes functions. */
+int ggnn_matrix_path_is_split(void);
 
 /* ---- (a-1) message index prep: chem_tensorflow_sparse.py:120-129 -------------------------------
  * The reference concatenates the per-type target columns into message_targets[M] (type ascending,

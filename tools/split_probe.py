@@ -1,0 +1,39 @@
+"""Error of the fused GRU launch against an f64 evaluation, and its duration, in the process's matrix mode
+(GGNN_MATRIX=f32 | default bf16x3 split).  Run once per mode and compare:
+    GGNN_MATRIX=f32 python tools/split_probe.py; python tools/split_probe.py
+"""
+import importlib, os, sys, json
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("gated-graph-neural-network-samples_amd")
+ops = pkg.ops
+lib = pkg._lib.load()
+mode = "bf16x3" if lib.ggnn_matrix_path_is_split() else "f32"
+dev = "cuda:0"
+out = {"mode": mode}
+for D, nx, V in ((100, 1, 40000), (100, 3, 20000), (64, 2, 20000), (32, 1, 20000)):
+    g = torch.Generator(device="cpu").manual_seed(5 + D + nx)
+    xs = [(torch.rand(V, D, generator=g) * 2 - 1) for _ in range(nx)]
+    h = torch.rand(V, D, generator=g) * 2 - 1
+    s = 1.0 / np.sqrt((nx + 1) * D)
+    Wg = (torch.rand((nx + 1) * D, 2 * D, generator=g) * 2 - 1) * (3 * s)
+    Wc = (torch.rand((nx + 1) * D, D, generator=g) * 2 - 1) * (3 * s)
+    bg = torch.rand(2 * D, generator=g) - 0.5
+    bc = torch.rand(D, generator=g) - 0.5
+    # f64 evaluation
+    X = torch.cat(xs + [h], 1).double()
+    ru = torch.sigmoid(X @ Wg.double() + bg.double())
+    r, u = ru[:, :D], ru[:, D:]
+    c = torch.tanh(torch.cat([x.double() for x in xs] + [r * h.double()], 1) @ Wc.double() + bc.double())
+    want = u * h.double() + (1 - u) * c
+    # pre-activation magnitudes: the error of the products is relative to sum |a b|
+    dx = [t.to(dev) for t in xs]; dh = h.to(dev)
+    save = {}
+    got = ops.gru(dx, dh, Wg.to(dev), bg.to(dev), Wc.to(dev), bc.to(dev), "tanh", save=save)
+    e = (got.double().cpu() - want).abs()
+    er = (save["r"].double().cpu() - r).abs()
+    ec = (save["c"].double().cpu() - c).abs()
+    key = "D%d_nx%d" % (D, nx)
+    out[key] = {"h_max": float(e.max()), "h_rms": float((e ** 2).mean().sqrt()), "r_max": float(er.max()),
+                "c_max": float(ec.max()), "c_rms": float((ec ** 2).mean().sqrt())}
+print(json.dumps(out))
