@@ -39,6 +39,12 @@ int gru_panel_supported(int D);
 int gru_panel_pack_floats(int D, int nx);
 int gru_panel_dispatch(const GruFusedArgs& a, int D, float* packed, hipStream_t st);
 
+// This source is compiled TWICE: as itself (the f32-MFMA instantiations, the dispatch, the C entry points) and, through
+// ggnn_gru_fused_split.hip (GGNN_GRU_TU_SPLIT), for the SPLIT instantiations -- that translation unit is built without
+// packed-f32 vector instructions (build.py: a v_pk_* instruction beside the partner wave's bf16 MFMAs stalls the SIMD).
+int gru_split_launch(int D, int nx, bool save, bool gather, const GruFusedArgs& a, float* packed, hipStream_t st);
+
+#ifndef GGNN_GRU_TU_SPLIT
 int gru_pack_floats(int D, int nx) {
     if (gru_panel_supported(D)) return gru_panel_pack_floats(D, nx);
     const bool sp = split_matrix_path();
@@ -49,6 +55,7 @@ int gru_pack_floats(int D, int nx) {
         default: return 0;
     }
 }
+#endif
 
 // image ci of the packed weights: gates (s = 0..nx) x {r,u}, then candidate (s = 0..nx)
 template <int D, bool SPLIT>
@@ -154,7 +161,13 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     if (a.tickets && tid == 0) *tk_slot = nb + atomicAdd(a.tickets, 1);
 
     int cur = 0;
-    dma_image<I::IMG_BYTES, NW>(packed, ring, wave, lane);
+    // SPLIT: the DMA goes out through inline assembly and is waited for explicitly (dma_image_asm, ggnn_split.hpp)
+    auto dma = [&](const float* src, float* dst) {
+        if constexpr (SPLIT) dma_image_asm<I::IMG_BYTES, NW>(src, dst, wave, lane);
+        else dma_image<I::IMG_BYTES, NW>(src, dst, wave, lane);
+    };
+    auto publish = [&]() { if constexpr (SPLIT) dma_wait(); __syncthreads(); };
+    dma(packed, ring);
 
     // ---- the pipelined gather of the aggregated-messages segment (GATHER) --------------------------------------
     // Phases, each issued at a stage start and landed by that stage's closing barrier (U = the stage that consumes
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             load_frag<D>(xf[0], a.x[0], r0c, kq);
         }
     }
-    __syncthreads();          // (drains the DMA: hipcc emits vmcnt(0) before the barrier while an LDS-DMA is in flight)
+    publish();                // (f32: hipcc emits vmcnt(0) before the barrier while an LDS-DMA is in flight)
 
     if (a.tickets) tk_next = __builtin_amdgcn_readfirstlane(*tk_slot);
 
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
                via the stage_mma hook measured slower.) */                                                \
             if (late) {                                                                                  \
                 prefetch(std::integral_constant<int, (POS)>{});                                          \
-                if (more_ && !(a.dbg & 8)) dma_image<I::IMG_BYTES, NW>(nsrc_, ndst_, wave, lane);                             \
+                if (more_ && !(a.dbg & 8)) dma(nsrc_, ndst_);                             \
             }                                                                                            \
             GGNN_T(POS, 1)                                                                               \
             __builtin_amdgcn_sched_barrier(0);   /* keep the side work on its side of the MFMA block */  \
@@ -392,10 +405,10 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             __builtin_amdgcn_sched_barrier(0);                                                           \
             if (!late) {                                                                                 \
                 prefetch(std::integral_constant<int, (POS)>{});                                          \
-                if (more_ && !(a.dbg & 8)) dma_image<I::IMG_BYTES, NW>(nsrc_, ndst_, wave, lane);                             \
+                if (more_ && !(a.dbg & 8)) dma(nsrc_, ndst_);                             \
             }                                                                                            \
             GGNN_T(POS, 2)                                                                               \
-            __syncthreads();                                                                             \
+            publish();                                                                                   \
             GGNN_T(POS, 3)                                                                               \
             cur ^= 1;                                                                                    \
         }
@@ -602,9 +615,45 @@ static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream
     return GGNN_OK;
 }
 
+#ifdef GGNN_GRU_TU_SPLIT
+// SAVE is a run-time matter in the kernel's epilogues (uniform branches on the save pointers): the training instantiation
+// serves inference too (it is also the one that comes out of the register allocator with less scratch).
+template <int D>
+static int split_launch_d(int nx, bool gather, const GruFusedArgs& a, float* packed, hipStream_t st) {
+    if constexpr (SplitCfg<D>::OK) {
+        if (gather) {
+            switch (nx) {
+                case 1: return launch_gru_fused_m<D, 1, 8, true, true, true>(a, packed, st);
+                case 2: return launch_gru_fused_m<D, 2, 8, true, true, true>(a, packed, st);
+                case 3: return launch_gru_fused_m<D, 3, 8, true, true, true>(a, packed, st);
+            }
+        } else {
+            switch (nx) {
+                case 1: return launch_gru_fused_m<D, 1, 8, true, false, true>(a, packed, st);
+                case 2: return launch_gru_fused_m<D, 2, 8, true, false, true>(a, packed, st);
+                case 3: return launch_gru_fused_m<D, 3, 8, true, false, true>(a, packed, st);
+            }
+        }
+    }
+    return fail(GGNN_E_INVALID, "nx %d outside 1..3", nx);
+}
+int gru_split_launch(int D, int nx, bool save, bool gather, const GruFusedArgs& a, float* packed, hipStream_t st) {
+    (void)save;
+#ifdef GGNN_PROBE_NX   // register-allocation probe (tools/kernel_regs.sh .../ggnn_gru_fused_split.hip . -DGGNN_PROBE_NX=2): one instantiation
+    return launch_gru_fused_m<100, GGNN_PROBE_NX, 8, true, true, true>(a, packed, st);
+#else
+    switch (D) {
+        case 100: return split_launch_d<100>(nx, gather, a, packed, st);
+        case 64: return split_launch_d<64>(nx, gather, a, packed, st);
+        case 32: return split_launch_d<32>(nx, gather, a, packed, st);
+        default: return fail(GGNN_E_UNSUPPORTED, "no split-form fused GRU for hidden size %d", D);
+    }
+#endif
+}
+#else
 template <int D, int NX, int NW, bool SAVE, bool GATHER>
 static int launch_gru_fused(const GruFusedArgs& a, float* packed, hipStream_t st) {
-    if constexpr (SplitCfg<D>::OK) { if (split_matrix_path()) return launch_gru_fused_m<D, NX, NW, SAVE, GATHER, true>(a, packed, st); }
+    if (SplitCfg<D>::OK && split_matrix_path()) return gru_split_launch(D, NX, SAVE, GATHER, a, packed, st);
     return launch_gru_fused_m<D, NX, NW, SAVE, GATHER, false>(a, packed, st);
 }
 
@@ -613,7 +662,6 @@ static bool nosave_kernel() {
     return v;
 }
 
-#ifndef GGNN_PROBE_NX
 template <int D>
 static int dispatch_nx(const GruFusedArgs& a, float* packed, hipStream_t st) {
     const bool save = a.save_r || a.save_u || a.save_c;
@@ -639,15 +687,10 @@ static int dispatch_nx(const GruFusedArgs& a, float* packed, hipStream_t st) {
     }
 }
 
-#endif
-
 // 1: whole-block stage images, with a gather-fused variant; 2: column-panel kernel (no gather-fused variant); 0: none
 int gru_fused_supported(int D) { return (D == 100 || D == 64 || D == 32) ? 1 : (gru_panel_supported(D) ? 2 : 0); }
 
 int gru_fused_dispatch(const GruFusedArgs& a, int D, float* packed, hipStream_t st) {
-#ifdef GGNN_PROBE_NX   // register-allocation probe (tools/kernel_regs.sh ... -DGGNN_PROBE_NX=1 -DGGNN_PROBE_SAVE=false): one instantiation
-    return launch_gru_fused_m<100, GGNN_PROBE_NX, 8, GGNN_PROBE_SAVE, true, true>(a, packed, st);
-#else
     if (gru_panel_supported(D)) return gru_panel_dispatch(a, D, packed, st);
     switch (D) {
         case 100: return dispatch_nx<100>(a, packed, st);
@@ -655,9 +698,11 @@ int gru_fused_dispatch(const GruFusedArgs& a, int D, float* packed, hipStream_t 
         case 32: return dispatch_nx<32>(a, packed, st);
         default: return fail(GGNN_E_UNSUPPORTED, "no fused GRU for hidden size %d", D);
     }
-#endif
 }
+#endif   // !GGNN_GRU_TU_SPLIT
 
 }  // namespace ggnn
 
+#ifndef GGNN_GRU_TU_SPLIT
 extern "C" int ggnn_gru_is_fused(int D) { return ggnn::gru_fused_supported(D); }
+#endif

@@ -288,4 +288,41 @@ __device__ __forceinline__ void dma_image(const float* src, float* dst, int wave
     }
 }
 
+// The same transfer issued through inline assembly, so that the COMPILER does not know an LDS-DMA is in flight: with the builtin
+// it puts s_waitcnt vmcnt(0) in front of every LDS read that follows (any ds_read might alias the destination) and in front of
+// every barrier -- a wave that issues its DMA pieces and then starts its MFMA burst first waits for the pieces to land, which
+// at 16-clock MFMAs is a sizeable part of a stage.  The kernel waits explicitly instead: dma_wait() before the barrier that
+// publishes the image.  (The compiler's own vmcnt bookkeeping stays safe: the counter is in-order and these loads only add to
+// it, so its waits can only be longer than needed.)
+template <int BYTES, int NW>
+__device__ __forceinline__ void dma_image_asm(const float* src, float* dst, int wave, int lane) {
+    constexpr int PER_WAVE = BYTES / (NW * 1024);
+    static_assert(BYTES % (NW * 1024) == 0, "image must split into whole KiB per wave");
+    const unsigned voff = (unsigned)lane * 16u;
+    const unsigned lbase = (unsigned)(unsigned long)(lds_void*)dst + (unsigned)wave * (PER_WAVE * 1024);
+    const unsigned long long sb0 = reinterpret_cast<unsigned long long>(src) + (unsigned long long)wave * PER_WAVE * 1024;
+#pragma unroll
+    for (int i0 = 0; i0 < PER_WAVE; i0 += 4) {
+        const unsigned long long sb = sb0 + (unsigned long long)i0 * 1024;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+        const unsigned long long s = ((unsigned long long)hi << 32) | lo;
+        const unsigned l = __builtin_amdgcn_readfirstlane(lbase + (unsigned)i0 * 1024u);
+        constexpr int n = PER_WAVE;
+        if (i0 + 3 < n)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072" :: "s"(l), "v"(voff), "s"(s) : "memory");
+        else if (i0 + 2 < n)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:2048" :: "s"(l), "v"(voff), "s"(s) : "memory");
+        else if (i0 + 1 < n)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
+                         :: "s"(l), "v"(voff), "s"(s) : "memory");
+        else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(l), "v"(voff), "s"(s) : "memory");
+    }
+}
+// every load this wave has issued (DMA pieces included) has landed
+__device__ __forceinline__ void dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 }  // namespace ggnn

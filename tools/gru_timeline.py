@@ -28,8 +28,10 @@ for p in range(4):
     for s in range(NSTAGE):
         w = t[p, s, 0] - t0
         allw_mma = t[p, s, :, 2] - t0
-        print(p, s, "| %8d  pre+%5d  mma+%6d  bar+%5d | mma_done over waves: min %d max %d" % (
-            w[0], w[1] - w[0], w[2] - w[1], w[3] - w[2], allw_mma.min() - w[0], allw_mma.max() - w[0]))
+        w4 = t[p, s, 4] - t0
+        print(p, s, "| %8d  pre+%5d  mma+%6d  bar+%5d | mma_done over waves: min %d max %d | wave4: +%5d +%5d bar+%5d" % (
+            w[0], w[1] - w[0], w[2] - w[1], w[3] - w[2], allw_mma.min() - w[0], allw_mma.max() - w[0],
+            w4[1] - w4[0], w4[2] - w4[1], w4[3] - w4[2]))
     if p < 3:
         print("   epilogue/pass gap: %d" % (t[p + 1, 0, 0, 0] - t[p, NSTAGE - 1, 0, 3]))
 b = raw[4096:].reshape(256, 4)
