@@ -24,7 +24,7 @@ namespace ggnn {
 struct DenseGraphArgs {
     const float* h0;        // [b, v, D]
     const float* A;         // [b, E, v, v]  A[g,e,dst,src]
-    const float* eimg;      // E stage images of W_e            (ggnn_edge_weights_pack_f32)
+    const float* eimg;      // E stage images of W_e            (ggnn_dense_edge_pack_f32)
     const float* gimg;      // 6 stage images: Wg[x,r] Wg[h,r] Wg[x,u] Wg[h,u] Wc[x] Wc[h]   (dense_gru_pack_kernel)
     const float* ebias;     // [E, D] or NULL
     const float* bg;        // [2D]
@@ -287,6 +287,38 @@ extern "C" int ggnn_dense_propagate_supported(int v, int E, int D) {
     const int bn = (D + 15) / 16 * 16;
     const size_t ldsb = ((size_t)(E + 3) * 32 * (bn + 4) + (size_t)E * 32 * 33 + (size_t)E * 32 + (size_t)E * bn) * sizeof(float);   // M_e, exchange block, adjacency rows, in-degrees, biases
     return ldsb <= (size_t)160 * 1024;
+}
+
+// The E edge-weight stage images of the graph-resident kernel: always the f32 stage image (this kernel reads its weights as f32
+// register tiles; ggnn_edge_weights_pack_f32 writes the format of the process's matrix path, which may be the split one).
+template <int D>
+__global__ void dense_edge_pack_kernel(const float* __restrict__ W, float* __restrict__ out) {
+    const int t = blockIdx.y;
+    pack_stage_image<D>(W + (size_t)t * D * D, 0, 0, D, out + (size_t)t * StageCfg<D>::IMG, blockIdx.x * blockDim.x + threadIdx.x,
+                        gridDim.x * blockDim.x);
+}
+
+extern "C" size_t ggnn_dense_edge_packed_bytes(int D, int T) {
+    if (T <= 0) return 0;
+    switch (D) {
+        case 100: return (size_t)T * StageCfg<100>::IMG * sizeof(float);
+        case 64: return (size_t)T * StageCfg<64>::IMG * sizeof(float);
+        case 32: return (size_t)T * StageCfg<32>::IMG * sizeof(float);
+        default: return 0;
+    }
+}
+
+extern "C" int ggnn_dense_edge_pack_f32(const float* W, int T, int D, float* packed, ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(W && packed && aligned16(packed) && T > 0 && T <= 64, "null or misaligned pointer, or T = %d outside 1..64", T);
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 100: hipLaunchKernelGGL((dense_edge_pack_kernel<100>), dim3(8, T), dim3(256), 0, st, W, packed); break;
+        case 64: hipLaunchKernelGGL((dense_edge_pack_kernel<64>), dim3(8, T), dim3(256), 0, st, W, packed); break;
+        case 32: hipLaunchKernelGGL((dense_edge_pack_kernel<32>), dim3(8, T), dim3(256), 0, st, W, packed); break;
+        default: return fail(GGNN_E_UNSUPPORTED, "no graph-resident dense kernel for hidden size %d", D);
+    }
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
 }
 
 extern "C" size_t ggnn_dense_gru_packed_bytes(int D) {

@@ -640,7 +640,10 @@ static int split_launch_d(int nx, bool gather, const GruFusedArgs& a, float* pac
 int gru_split_launch(int D, int nx, bool save, bool gather, const GruFusedArgs& a, float* packed, hipStream_t st) {
     (void)save;
 #ifdef GGNN_PROBE_NX   // register-allocation probe (tools/kernel_regs.sh .../ggnn_gru_fused_split.hip . -DGGNN_PROBE_NX=2): one instantiation
-    return launch_gru_fused_m<100, GGNN_PROBE_NX, 8, true, true, true>(a, packed, st);
+#ifndef GGNN_PROBE_SAVE
+#define GGNN_PROBE_SAVE true
+#endif
+    return launch_gru_fused_m<100, GGNN_PROBE_NX, 8, GGNN_PROBE_SAVE, true, true>(a, packed, st);
 #else
     switch (D) {
         case 100: return split_launch_d<100>(nx, gather, a, packed, st);

@@ -9,7 +9,7 @@
 // GEMM per type, all types in one launch -- and the segment-sum gathers compact rows.
 // Same arithmetic per message as the dense form (identical fmaf chains), ~3.3x fewer flops, and the
 // transformed-state buffer shrinks from V*T*D to R*D floats (fits the 256 MiB Infinity Cache).
-#include "ggnn_stage.hpp"
+#include "ggnn_split.hpp"
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
 
@@ -55,11 +55,13 @@ static size_t scan_temp_bytes(long long n) {
 }
 
 // ---- weights -> stage images ------------------------------------------------------------------------------
-template <int D>
+template <int D, bool SPLIT>
 __global__ void edge_weight_pack_kernel(const float* __restrict__ W, float* __restrict__ out) {
     const int t = blockIdx.y;
-    pack_stage_image<D>(W + (size_t)t * D * D, 0, 0, D, out + (size_t)t * StageCfg<D>::IMG,
-                        blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    float* img = out + (size_t)t * ImgCfg<D, SPLIT>::IMG;
+    const int first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if constexpr (SPLIT) pack_split_image<D>(StageValue<D>{W + (size_t)t * D * D, 0, 0, D, -1, nullptr, 0, 0, -1}, img, first, stride);
+    else pack_stage_image<D>(W + (size_t)t * D * D, 0, 0, D, img, first, stride);
 }
 
 // ---- the transform: persistent workgroups, each bound to ONE edge type ---------------------------------------
@@ -71,11 +73,13 @@ __global__ void edge_weight_pack_kernel(const float* __restrict__ W, float* __re
 // Two workgroups fit a CU (LDS 2 x 48 KiB, <= 128 VGPRs): 4 waves per SIMD keep the matrix pipe fed while others
 // store and fetch.  The host sizes the per-type workgroup counts so that every wave gets the same number of tiles
 // (+-1) across ALL types (launch_compact).
-template <int D, int NW>
-__global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per CU */ void msg_transform_compact_kernel(const float* __restrict__ h, const int* __restrict__ pair_node,
-                                                                           TypeRows tr, const float* __restrict__ packed,
-                                                                           float* __restrict__ Hc) {
+// SPLIT: the product on the bf16 matrix pipe in 3-way split form (ggnn_split.hpp): the type's image is the 72 KiB split one, a
+// tile's rows are split in registers before its MFMAs.
+template <int D, int NW, bool SPLIT>
+__global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per CU */ void msg_transform_compact_kernel(
+        const float* __restrict__ h, const int* __restrict__ pair_node, TypeRows tr, const float* __restrict__ packed, float* __restrict__ Hc) {
     using C = StageCfg<D>;
+    using I = ImgCfg<D, SPLIT>;
     constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) float img[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -99,9 +103,11 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
     int node_0 = 0, node_n = 0;
     if (idx < n_wt) node_0 = pair_node[row_of(idx)];
     if (idx + stride < n_wt) node_n = pair_node[row_of(idx + stride)];
-    dma_stage_image<D, NW>(packed + (size_t)t * C::IMG, img, wave, lane);
+    if constexpr (SPLIT) dma_image_asm<I::IMG_BYTES, NW>(packed + (size_t)t * I::IMG, img, wave, lane);
+    else dma_stage_image<D, NW>(packed + (size_t)t * C::IMG, img, wave, lane);
     if (idx < n_wt) load_frag<D>(a, h, node_0, kq);
     K1C_T(1)
+    if constexpr (SPLIT) dma_wait();
     __syncthreads();                                        // the image has landed (vmcnt(0) + barrier)
     K1C_T(2)
     int tcount = 0;
@@ -112,8 +118,14 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
         if (idx_n + stride < n_wt) node_n = pair_node[row_of(idx_n + stride)];
         f32x4 acc[NT];
         __builtin_amdgcn_sched_barrier(0);                  // the fetches are issued BEFORE the MFMA block
-        stage_mma<D, NoHook, NT, true>(acc, a, img, li, kq);    // (first MFMA of each tile starts from C = 0)
-        stage_tail_reduce<D>(acc);
+        if constexpr (SPLIT) {
+            SFrag<D> sf;
+            split_frag<D>(sf, a);
+            stage_mma_split<D, NT, true>(acc, sf, a, img, li, kq);
+        } else {
+            stage_mma<D, NoHook, NT, true>(acc, a, img, li, kq);    // (first MFMA of each tile starts from C = 0)
+            stage_tail_reduce<D>(acc);
+        }
         const int r = row_beg + idx * 16 + li;
         if (r < row_end) {
 #pragma unroll
@@ -130,16 +142,16 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
     K1C_T(7)
 }
 
-template <int D>
-static int launch_compact(const float* h, const float* W, const int* pair_node, TypeRows& tr, float* packed, float* Hc,
-                          hipStream_t st) {
+template <int D, bool SPLIT>
+static int launch_compact_m(const float* h, const float* W, const int* pair_node, TypeRows& tr, float* packed, float* Hc,
+                            hipStream_t st) {
     // waves per workgroup: 8, two workgroups per CU.  (One 16-wave workgroup per CU halves the image DMA and evens out
     // the prologues -- the second workgroup of a CU otherwise starts 5 us late behind the first one's MFMA bursts --
     // but measures the same alone (32.8 us) and 2 % slower with two streams: 608 vs 621 M node-updates/s.)
     constexpr int NW = 8;
-    using C = StageCfg<D>;
+    using C = ImgCfg<D, SPLIT>;
     if (W) {      // raw [T,D,D] weights given: build the T stage images (skipped when the caller pre-packed them)
-        hipLaunchKernelGGL((edge_weight_pack_kernel<D>), dim3(8, tr.T), dim3(256), 0, st, W, packed);
+        hipLaunchKernelGGL((edge_weight_pack_kernel<D, SPLIT>), dim3(8, tr.T), dim3(256), 0, st, W, packed);
         GGNN_CHECK_HIP(hipGetLastError());
     }
     if (tr.row_off[tr.T] == 0 || h == nullptr) return GGNN_OK;
@@ -150,7 +162,9 @@ static int launch_compact(const float* h, const float* W, const int* pair_node, 
     // two workgroups per CU, then ceil(wave tiles of the type / (R * NW)) workgroups for each type.
     long long total_wt = 0;
     for (int t = 0; t < tr.T; ++t) total_wt += (tr.row_off[t + 1] - tr.row_off[t] + 15) / 16;
-    const long long budget = (long long)(16 / NW) * num_cus();     // 16 waves per CU
+    // workgroups per CU: 2 (16 waves; both forms stay below 128 registers and 2 x 72 KiB of images fit the LDS); GGNN_K1_WG_PER_CU=1 to compare
+    static const int wg_per_cu = [] { const char* e = getenv("GGNN_K1_WG_PER_CU"); return e && atoi(e) == 1 ? 1 : 2; }();
+    const long long budget = (long long)wg_per_cu * num_cus();
     long long R = total_wt / (budget * NW);
     if (R < 1) R = 1;
     for (;; ++R) {
@@ -162,12 +176,18 @@ static int launch_compact(const float* h, const float* W, const int* pair_node, 
     for (int t = 0; t < tr.T; ++t)
         tr.tile_off[t + 1] = tr.tile_off[t] + (int)(((tr.row_off[t + 1] - tr.row_off[t] + 15) / 16 + R * NW - 1) / (R * NW));
     static std::atomic<unsigned long long> lds_ok{0};
-    if (C::IMG_BYTES > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&msg_transform_compact_kernel<D, NW>, C::IMG_BYTES, lds_ok));
+    if (C::IMG_BYTES > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&msg_transform_compact_kernel<D, NW, SPLIT>, C::IMG_BYTES, lds_ok));
     { const char* e = getenv("GGNN_K1C_TPTR"); tr.tdbg = e ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
-    hipLaunchKernelGGL((msg_transform_compact_kernel<D, NW>), dim3(tr.tile_off[tr.T]), dim3(NW * 64), C::IMG_BYTES, st, h, pair_node,
+    hipLaunchKernelGGL((msg_transform_compact_kernel<D, NW, SPLIT>), dim3(tr.tile_off[tr.T]), dim3(NW * 64), C::IMG_BYTES, st, h, pair_node,
                        tr, (const float*)packed, Hc);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
+}
+
+template <int D>
+static int launch_compact(const float* h, const float* W, const int* pair_node, TypeRows& tr, float* packed, float* Hc, hipStream_t st) {
+    if (SplitCfg<D>::OK && split_matrix_path()) return launch_compact_m<D, true>(h, W, pair_node, tr, packed, Hc, st);
+    return launch_compact_m<D, false>(h, W, pair_node, tr, packed, Hc, st);
 }
 
 int gru_panel_supported(int D);      // ggnn_panel.hip: hidden sizes handled on column panels
@@ -176,10 +196,11 @@ int transform_panel_dispatch(const float* h, const float* W, const int* pair_nod
 
 static int stage_img_floats(int D) {
     if (gru_panel_supported(D)) return D * D;            // NP panel images of D x 64
+    const bool sp = split_matrix_path();
     switch (D) {
-        case 100: return StageCfg<100>::IMG;
-        case 64: return StageCfg<64>::IMG;
-        case 32: return StageCfg<32>::IMG;
+        case 100: return sp ? ImgCfg<100, true>::IMG : ImgCfg<100, false>::IMG;
+        case 64: return sp ? ImgCfg<64, true>::IMG : ImgCfg<64, false>::IMG;
+        case 32: return sp ? ImgCfg<32, true>::IMG : ImgCfg<32, false>::IMG;
         default: return 0;
     }
 }

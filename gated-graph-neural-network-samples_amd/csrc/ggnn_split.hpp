@@ -166,79 +166,62 @@ template <bool FIRST>
 __device__ __forceinline__ f32x4 split_products(f32x4 acc, u32x4 wh, u32x4 wm, u32x4 wl, u32x4 ah, u32x4 am, u32x4 al) {
     f32x4 c = FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc;
     c = mfma_bf16(wl, ah, c);
-    c = mfma_bf16(wh, al, c);
     c = mfma_bf16(wm, am, c);
     c = mfma_bf16(wm, ah, c);
+    c = mfma_bf16(wh, al, c);
     c = mfma_bf16(wh, am, c);
     c = mfma_bf16(wh, ah, c);
     return c;
 }
 
 // acc[nt] (+)= A-fragment x split stage image: the counterpart of stage_mma (same tiles, same remainder handling).
-// Per 32-chunk and group of G tiles: 3G ds_read_b128 feed 6G MFMAs; the reads of group gi+1 are issued before the MFMAs
-// of group gi; inside a group the tiles alternate so that consecutive MFMAs write different accumulators.
-#ifndef GGNN_SPLIT_G
-#define GGNN_SPLIT_G 1
-#endif
+// One (32-chunk, tile) unit = 3 ds_read_b128 (the lo / mid / hi planes of the weight fragment) feeding 6 MFMAs.  The planes are
+// consumed in the order lo (1 product), mid (2), hi (3) and each plane's registers are refilled with the NEXT unit's fragment as
+// soon as its last product has issued: 12 weight registers in flight instead of 24 for a double buffer, the lo and mid fragments
+// of the next unit a full unit ahead, the hi fragment three MFMAs ahead (the partner wave's MFMAs cover what that leaves).
 template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false>
 __device__ __forceinline__ void stage_mma_split(f32x4 (&acc)[StageCfg<D>::NT], const SFrag<D>& a, const Frag<D>& af,
                                                 const float* img, int li, int kq) {
     using S = StageCfg<D>;
     using C = SplitCfg<D>;
-    constexpr int G = GGNN_SPLIT_G;
-    constexpr int GPC = (NTILES + G - 1) / G;
-    constexpr int NG = C::NC2 * GPC;
+    constexpr int NU = C::NC2 * NTILES;                               // units, chunk-major
     constexpr int PL = C::PLANE_BYTES / 16;                           // plane pitch in 16-byte slots
     const u32x4* base = reinterpret_cast<const u32x4*>(img) + kq * S::BN + li;
-    u32x4 w[2][G][3];
-    float wr[S::NR > 0 ? S::NR : 1][S::NT];
+    auto slot = [&](int u, int p) { return base[p * PL + (u / NTILES) * 4 * S::BN + (u % NTILES) * 16]; };
+    u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
 #pragma unroll
-    for (int j = 0; j < G; ++j)
-        if (j < NTILES) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) w[0][j][p] = base[p * PL + j * 16];
-        }
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-        const int c2 = gi / GPC, g0 = (gi % GPC) * G;
-        if (gi + 1 < NG) {
-            const int cn = (gi + 1) / GPC, gn = ((gi + 1) % GPC) * G;
-#pragma unroll
-            for (int j = 0; j < G; ++j)
-                if (gn + j < NTILES) {
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) w[(gi + 1) & 1][j][p] = base[p * PL + cn * 4 * S::BN + (gn + j) * 16];
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-#pragma unroll
-            for (int q = 0; q < S::NR; ++q)
-#pragma unroll
-                for (int nt = 0; nt < NTILES; ++nt) wr[q][nt] = img[C::MAIN_BYTES / 4 + (q * 4 + kq) * S::BN + li + nt * 16];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // product-major over the group's tiles: tile j's next MFMA is G issue slots behind its previous one
-        u32x4 (&wg)[G][3] = w[gi & 1];
-        const bool first = ZERO && c2 == 0;
-#define GGNN_SPLIT_STEP(WP, AP, OPEN)                                                                     \
-        _Pragma("unroll") for (int j = 0; j < G; ++j) if (g0 + j < NTILES) {                               \
-            const f32x4 cin = ((OPEN) && first) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[g0 + j];                 \
-            acc[g0 + j] = mfma_bf16(wg[j][WP], a.AP[c2], cin);                                             \
-        }
-        GGNN_SPLIT_STEP(2, hi, true)
-        GGNN_SPLIT_STEP(0, lo, false)
-        GGNN_SPLIT_STEP(1, mid, false)
-        GGNN_SPLIT_STEP(1, hi, false)
-        GGNN_SPLIT_STEP(0, mid, false)
-        GGNN_SPLIT_STEP(0, hi, false)
-#undef GGNN_SPLIT_STEP
+    for (int u = 0; u < NU; ++u) {
+        const int c2 = u / NTILES, nt = u % NTILES;
+        const bool more = u + 1 < NU;
+        f32x4 c = (ZERO && c2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt];
+        c = mfma_bf16(wl, a.hi[c2], c);
         __builtin_amdgcn_sched_barrier(0);
+        if (more) wl = slot(u + 1, 2);
+        c = mfma_bf16(wm, a.mid[c2], c);
+        c = mfma_bf16(wm, a.hi[c2], c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wm = slot(u + 1, 1);
+        c = mfma_bf16(wh, a.lo[c2], c);
+        c = mfma_bf16(wh, a.mid[c2], c);
+        c = mfma_bf16(wh, a.hi[c2], c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wh = slot(u + 1, 0);
+        acc[nt] = c;
     }
+    // the D % 16 remainder k values on the f32 MFMA, their weights two tiles ahead (2 registers in flight)
+    if constexpr (S::NR > 0) {
+        constexpr int NRM = S::NR * NTILES;
+        auto rw = [&](int i) { return img[C::MAIN_BYTES / 4 + ((i / NTILES) * 4 + kq) * S::BN + li + (i % NTILES) * 16]; };
+        float w0 = rw(0), w1 = NRM > 1 ? rw(1) : 0.f;
 #pragma unroll
-    for (int q = 0; q < S::NR; ++q)
-#pragma unroll
-        for (int nt = 0; nt < NTILES; ++nt)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[q][nt], af.r[q], acc[nt], 0, 0, 0);
+        for (int i = 0; i < NRM; ++i) {
+            const int q = i / NTILES, nt = i % NTILES;
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, af.r[q], acc[nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            w0 = w1;
+            if (i + 2 < NRM) w1 = rw(i + 2);
+        }
+    }
 }
 
 // ONE output tile (wave-uniform, run time) of the same product: the cooperative tail pass

@@ -119,7 +119,7 @@ struct PrepArgs {
     int T; float keep;
 };
 
-// SF: the fused GRU forward's images in split form (ggnn_split.hpp)
+// SF: the edge-weight images and the fused GRU forward's images in split form (ggnn_split.hpp)
 template <int D, bool SF>
 __global__ __launch_bounds__(256) void train_prepare_kernel(PrepArgs a) {
     using C = StageCfg<D>;
@@ -132,24 +132,30 @@ __global__ __launch_bounds__(256) void train_prepare_kernel(PrepArgs a) {
         const bool tr = i >= T;
         const int t = tr ? i - T : i;
         const float* W = a.edge_w[l] + (size_t)t * D * D;
-        float* img = (tr ? a.edge_img_t[l] : a.edge_img[l]) + (size_t)t * C::IMG;
         const float keep = a.keep;
         const unsigned long long seed = a.seed[l];
-        for (int j = first; j < C::IMG; j += stride) {
-            float v = 0.f;
-            int k = -1, n = 0;
-            if (j < C::MAIN) {
-                const int e = j & 3; n = (j >> 2) % C::BN; k = 4 * ((j >> 2) / C::BN) + e;
-            } else if (j < C::MAIN + C::REM) {
-                const int jj = j - C::MAIN;
-                n = jj % C::BN; k = 16 * C::NC + jj / C::BN;
+        auto value = [&](int k, int n) -> float {                         // image[k][n] = W_t[k][n], or W_t[n][k]
+            if (n >= D) return 0.f;
+            const int r = tr ? n : k, c = tr ? k : n;
+            float v = W[(size_t)r * D + c];
+            if (keep < 1.0f) v = dropout_apply(v, keep, seed, (unsigned long long)(t * D + r), c);
+            return v;
+        };
+        float* img = (tr ? a.edge_img_t[l] : a.edge_img[l]) + (size_t)t * ImgCfg<D, SF>::IMG;
+        if constexpr (SF) {
+            pack_split_image<D>(value, img, first, stride);
+        } else {
+            for (int j = first; j < C::IMG; j += stride) {
+                float v = 0.f;
+                if (j < C::MAIN) {
+                    const int e = j & 3, n = (j >> 2) % C::BN, k = 4 * ((j >> 2) / C::BN) + e;
+                    v = value(k, n);
+                } else if (j < C::MAIN + C::REM) {
+                    const int jj = j - C::MAIN;
+                    v = value(16 * C::NC + jj / C::BN, jj % C::BN);
+                }
+                img[j] = v;
             }
-            if (k >= 0 && n < D) {
-                const int r = tr ? n : k, c = tr ? k : n;                 // image[k][n] = W_t[k][n], or W_t[n][k]
-                v = W[(size_t)r * D + c];
-                if (keep < 1.0f) v = dropout_apply(v, keep, seed, (unsigned long long)(t * D + r), c);
-            }
-            img[j] = v;
         }
     } else if (i < 2 * T + ng) {
         const int ci = i - 2 * T;

@@ -103,7 +103,7 @@ class DenseGGNNChemModel(ChemModel):
                 and ops.dense_propagate_supported(int(v), self.num_edge_types, h_dim):
             # all timesteps in ONE launch: a graph's states stay on its CU (ggnn_dense_propagate_f32)
             W = self.weights['edge_weights'].contiguous()
-            return ops.dense_propagate(h.reshape(b, int(v), h_dim), A.contiguous(), _PACKED.edge(W),
+            return ops.dense_propagate(h.reshape(b, int(v), h_dim), A.contiguous(), _PACKED.dense_edge(W),
                                        _PACKED.dense_gru(cell.gates_kernel, cell.candidate_kernel, h_dim), bias,
                                        cell.gates_bias, cell.candidate_bias, self.params['num_timesteps'])
         packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, 1, h_dim) if ops.gru_is_fused(h_dim) else None

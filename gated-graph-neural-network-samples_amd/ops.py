@@ -619,7 +619,7 @@ def dense_propagate_supported(v: int, E: int, D: int) -> bool:
 def dense_propagate(h0: torch.Tensor, adjacency: torch.Tensor, edge_packed: torch.Tensor, gru_packed: torch.Tensor,
                     edge_biases: Optional[torch.Tensor], bg: torch.Tensor, bc: torch.Tensor, steps: int) -> torch.Tensor:
     """The whole dense forward (chem_tensorflow_dense.py:93-117) in one launch, graph-resident (ggnn_dense_propagate_f32).
-    h0 [b,v,D], adjacency [b,e,v,v]; edge_packed = PackedWeights.edge(W [e,D,D]); gru_packed = PackedWeights.dense_gru(Wg, Wc)."""
+    h0 [b,v,D], adjacency [b,e,v,v]; edge_packed = PackedWeights.dense_edge(W [e,D,D]); gru_packed = PackedWeights.dense_gru(Wg, Wc)."""
     lib = _lib.load()
     _req(h0, torch.float32, "h0"); _req(adjacency, torch.float32, "adjacency")
     b, v, D = h0.shape
@@ -882,6 +882,21 @@ class PackedWeights:
             packed = torch.empty(lib.ggnn_gru_packed_bytes(D, nx) // 4, dtype=torch.float32, device=Wg.device)
             check(lib.ggnn_gru_pack_weights_f32(_ptr(Wg), _ptr(Wc), nx, D, _ptr(packed), _stream()))
             hit = self._store(self._gru, key, (Wg, Wc), packed)
+        return hit
+
+    def dense_edge(self, W: torch.Tensor) -> torch.Tensor:
+        """The E f32 stage images of the graph-resident dense kernel (ggnn_dense_edge_pack_f32), once per weight version."""
+        lib = _lib.load()
+        if not hasattr(self, "_dense_edge"):
+            self._dense_edge = {}
+        key = self._key(W)
+        hit = self._lookup(self._dense_edge, key, (W,))
+        if hit is None:
+            _req(W, torch.float32, "edge_weights")
+            T, D = W.shape[0], W.shape[1]
+            packed = torch.empty(lib.ggnn_dense_edge_packed_bytes(D, T) // 4, dtype=torch.float32, device=W.device)
+            check(lib.ggnn_dense_edge_pack_f32(_ptr(W), T, D, _ptr(packed), _stream()))
+            hit = self._store(self._dense_edge, key, (W,), packed)
         return hit
 
     def dense_gru(self, Wg: torch.Tensor, Wc: torch.Tensor, D: int) -> torch.Tensor:

@@ -43,7 +43,7 @@ def test_graph_resident_dense_forward(pkg, oracle, cuda, b, v, E, D, bias, steps
     P = pkg.ops.PackedWeights()
     dW, dWg, dWc = dev(W, cuda), dev(gru["Wg"], cuda), dev(gru["Wc"], cuda)
     dbias = None if eb is None else dev(eb.reshape(E, D), cuda)
-    run = lambda: pkg.ops.dense_propagate(dev(h0, cuda), dev(A, cuda), P.edge(dW), P.dense_gru(dWg, dWc, D), dbias,
+    run = lambda: pkg.ops.dense_propagate(dev(h0, cuda), dev(A, cuda), P.dense_edge(dW), P.dense_gru(dWg, dWc, D), dbias,
                                           dev(gru["bg"], cuda), dev(gru["bc"], cuda), steps)
     got = run()
     want = oracle.dense_propagate(h0, A, W, eb, gru, steps)

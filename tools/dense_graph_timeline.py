@@ -10,7 +10,7 @@ A = t(rng.random((b, E, v, v)) < 2.0 / v); h0 = t(rng.uniform(-1, 1, (b, v, D)))
 W = t(rng.uniform(-.1, .1, (E, D, D))); Wg = t(rng.uniform(-.1, .1, (2 * D, 2 * D))); Wc = t(rng.uniform(-.1, .1, (2 * D, D)))
 eb = t(rng.normal(0, .1, (E, D))); bg = t(np.ones(2 * D)); bc = t(np.zeros(D))
 P = pkg.ops.PackedWeights()
-run = lambda: pkg.ops.dense_propagate(h0, A, P.edge(W), P.dense_gru(Wg, Wc, D), eb, bg, bc, steps)
+run = lambda: pkg.ops.dense_propagate(h0, A, P.dense_edge(W), P.dense_gru(Wg, Wc, D), eb, bg, bc, steps)
 for _ in range(3): run()
 torch.cuda.synchronize()
 tb = torch.zeros(8 * 2 * 8, dtype=torch.int64, device=dev)
