@@ -60,6 +60,12 @@ sys.path.insert(0, ROOT)
 PKG = "gated-graph-neural-network-samples_amd"
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 dense (2495 measured)
+# Kernels that multiply in 3-way split form (csrc/ggnn_split.hpp: every f32 product = 6 bf16 MFMA products, f32 accumulation)
+# when the library runs its default matrix path: their ceiling on the bf16 pipe is its peak / 6 f32-equivalent flops.
+SPLIT_PRODUCTS = 6
+SPLIT_KERNELS = ("msg_transform_compact", "gru_fused")
+SPLIT_ACTIVE = False               # set from ggnn_matrix_path_is_split() in main()
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 HBM_COPY_GBPS = 6290.0
 
@@ -169,6 +175,13 @@ def kernel_table(res, reps, V, M, D, T, R=None):
                          "max_us": float(np.max(times)) * 1e3, "launches_per_step": len(times) / reps,
                          "time_share": None, "traffic": None, "algorithmic_bytes": by,
                          "hbm_frac": by / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        if bound == "mfma" and SPLIT_ACTIVE and name.startswith(SPLIT_KERNELS) and D in (32, 64, 100):
+            # `peak` stays the chip's f32 matrix peak (the dtype's peak: what an f32-MFMA kernel could reach at most);
+            # `pipe_peak` is what the pipe this kernel actually runs on offers for the same f32-equivalent flops
+            pipe = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+            kernels[name].update({"matrix_path": "bf16x3 split: f32 operands as 3 bf16 pieces each, 6 bf16 MFMA products per f32 product, "
+                                                 "f32 accumulation (error bound of an f32 FMA chain)",
+                                  "pipe_peak": pipe, "pipe_frac": ach / pipe})
     tot_ms = sum(float(np.sum(res[n])) for n in kernels)
     for name in kernels:
         kernels[name]["time_share"] = float(np.sum(res[name])) / tot_ms if tot_ms else None
@@ -390,6 +403,8 @@ def main():
         return dry_run(args, pkg, dist_ctx)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU implementation)"
     dev = dist_ctx.device
+    global SPLIT_ACTIVE
+    SPLIT_ACTIVE = bool(pkg._lib.load().ggnn_matrix_path_is_split())
 
     # ---- data: enough QM9-shaped molecules for `batches` distinct ~100k-node batches per rank ------
     mols_per_batch = int(100000 / args.mean_nodes * 1.02) + 8
@@ -505,7 +520,9 @@ def main():
         "metric": "node-state updates/sec on QM9-shaped graphs, h=100, 4 edge types" + (" (training step)" if headline_train else ""),
         "value": value, "unit": "node-state updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / steps_timed * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen(dist_ctx), "allreduce_us": None,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "matrix_path": ("bf16x3 split (f32 in, f32 accumulate; every f32 product = 6 exact bf16 MFMA products of 3-way split operands; "
+                        "GGNN_MATRIX=f32 selects the f32 MFMA kernels)" if SPLIT_ACTIVE else "f32 MFMA"), "ranks_seen": ranks_seen(dist_ctx), "allreduce_us": None,
         "steps_timed": steps_timed, "timed_repeats": repeats, "timed_seconds": elapsed,
         "config": {"workload": what + ", full-QM9-sized synthetic batches (configs[%d])" % (3 if world > 1 else 1),
                    "mode": args.mode, "hidden_size": D, "num_edge_types": T, "propagation_steps": n_prop,

@@ -19,7 +19,7 @@
 //
 // Stage order per tile:   h block of Wc^T (-> drh, dpr);  h blocks of Wg_r^T, Wg_u^T (-> dh);
 //                         then per x segment: Wc^T, Wg_r^T, Wg_u^T blocks (-> dx_s)
-#include "ggnn_stage.hpp"
+#include "ggnn_split.hpp"
 #include <type_traits>
 
 namespace ggnn {
@@ -37,10 +37,13 @@ struct GruBwdArgs {
 //   0: Wc^T h block      B(k,n) = Wc[nx*D + n][k]
 //   1: Wg_r^T h block    B(k,n) = Wg[nx*D + n][k]          2: Wg_u^T h block   B(k,n) = Wg[nx*D + n][D + k]
 //   3 + 3s + {0,1,2}: the same three for x segment s (rows s*D + n)
-template <int D>
+template <int D, bool SPLIT>
 __global__ void gru_bwd_pack_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx, float* __restrict__ out) {
     const int i = blockIdx.y;
-    gru_bwd_image_pack<D>(Wg, Wc, nx, i, out + (size_t)i * StageCfg<D>::IMG, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    float* img = out + (size_t)i * ImgCfg<D, SPLIT>::IMG;
+    const int first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if constexpr (SPLIT) gru_bwd_image_pack_split<D>(Wg, Wc, nx, i, img, first, stride);
+    else gru_bwd_image_pack<D>(Wg, Wc, nx, i, img, first, stride);
 }
 
 template <int D>
@@ -65,9 +68,13 @@ __device__ __forceinline__ void store_frag(float* base, int row, int kq, const F
 // does not help either: the image's loads are younger than the fragment's, waiting for them waits for it (245 us, and the
 // register file overflows: 276 B of scratch).  Hiding the loads needs a load path whose completion is not ordered with the
 // weights' -- a loader wave would do, but a fifth wave halves the register budget of the other four.
-template <int D, int NX, int NW, int PREFETCH, int RING>
+// SPLIT: the products on the bf16 matrix pipe in 3-way split form (ggnn_split.hpp); dpc, dpr, dpu are split once, when complete,
+// and their planes serve all 1 + NX stages that multiply them.
+template <int D, int NX, int NW, int PREFETCH, int RING, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs a, const float* __restrict__ packed) {
     using C = StageCfg<D>;
+    using I = ImgCfg<D, SPLIT>;
+    static_assert(!SPLIT || RING == 2, "the split form runs the two-image ring");
     constexpr int NT = C::NT, NC = C::NC, NR = C::NR;
     constexpr int NSTAGE = 3 * (NX + 1);
     extern __shared__ __attribute__((aligned(16))) float ring[];    // [2][IMG]
@@ -120,10 +127,15 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
     static_assert(NR <= 1, "remainder handling covers D % 16 in {0, 4}");
 
     int cur = 0;
-    if constexpr (RING == 2) dma_stage_image<D, NW>(packed, ring, wave, lane);
+    auto dma = [&](const float* src, float* dst) {
+        if constexpr (SPLIT) dma_image_asm<I::IMG_BYTES, NW>(src, dst, wave, lane);
+        else dma_stage_image<D, NW>(src, dst, wave, lane);
+    };
+    auto publish = [&]() { if constexpr (SPLIT) dma_wait(); __syncthreads(); };
+    if constexpr (RING == 2) dma(packed, ring);
     Raw raw_a, raw_b;                                            // (raw_b: PREFETCH == 2 only, the tile after the current one)
     if (PREFETCH && (int)blockIdx.x < n_tk) { fetch_raw(raw_a, blockIdx.x, 0); fetch_raw(raw_a, blockIdx.x, 1); }
-    __syncthreads();
+    publish();
 
     // A wave has tiles in a PREFIX of its workgroup's passes (full tickets, then possibly a thin tail ticket), so the passes run
     // as two loops -- with a tile, without -- instead of one loop with a branch: the prefetched raw fragments are carried from
@@ -141,11 +153,15 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
             const int row = (ACT ? tile : 0) * 16 + li;
             const bool row_ok = ACT && row < a.V;
 
-            auto stage = [&](auto zero_c, f32x4 (&acc)[NT], const Frag<D>& A, int img_idx, auto&& before, auto&& after) {
+            auto mma = [&](auto zero_c, f32x4 (&acc)[NT], const Frag<D>& A, const SFrag<D>& S, const float* img) {
+                if constexpr (SPLIT) stage_mma_split<D, NT, decltype(zero_c)::value>(acc, S, A, img, li, kq);
+                else stage_mma<D, NoHook, NT, decltype(zero_c)::value>(acc, A, img, li, kq);
+            };
+            auto stage = [&](auto zero_c, f32x4 (&acc)[NT], const Frag<D>& A, const SFrag<D>& S, int img_idx, auto&& before, auto&& after) {
                 const int nidx = img_idx + 1 < NSTAGE ? img_idx + 1 : 0;
                 const bool more = (img_idx + 1 < NSTAGE) || !last_pass;
-                const float* nsrc = packed + (size_t)nidx * C::IMG;
-                float* ndst = ring + (cur ^ 1) * C::IMG;
+                const float* nsrc = packed + (size_t)nidx * I::IMG;
+                float* ndst = ring + (cur ^ 1) * I::IMG;
                 before();
                 if constexpr (PREFETCH == 2) {
                     if (ACT && !last_pass && img_idx < 5) fetch_piece(raw_next, tk + nb, img_idx);
@@ -154,18 +170,18 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
                     // one image in LDS (two of these 4-wave workgroups share a CU and run out of phase: the DMA wait and the
                     // load / epilogue phases of one are covered by the MFMAs of the other)
                     __syncthreads();                                   // the previous stage's image has been consumed
-                    dma_stage_image<D, NW>(packed + (size_t)img_idx * C::IMG, ring, wave, lane);
+                    dma_stage_image<D, NW>(packed + (size_t)img_idx * I::IMG, ring, wave, lane);
                     __syncthreads();                                   // (vmcnt(0) + barrier: landed)
-                    if constexpr (ACT) stage_mma<D, NoHook, NT, decltype(zero_c)::value>(acc, A, ring, li, kq);
+                    if constexpr (ACT) mma(zero_c, acc, A, S, ring);
                     after();
                 } else {
-                    if (late && more) dma_stage_image<D, NW>(nsrc, ndst, wave, lane);
+                    if (late && more) dma(nsrc, ndst);
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (ACT) stage_mma<D, NoHook, NT, decltype(zero_c)::value>(acc, A, ring + cur * C::IMG, li, kq);
+                    if constexpr (ACT) mma(zero_c, acc, A, S, ring + cur * I::IMG);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (!late && more) dma_stage_image<D, NW>(nsrc, ndst, wave, lane);
+                    if (!late && more) dma(nsrc, ndst);
                     after();
-                    __syncthreads();
+                    publish();
                     cur ^= 1;
                 }
             };
@@ -173,6 +189,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
 
             // ---- element-wise head, in place on the raw fragments: g -> dpc, c -> dpu, u -> g*u, h -> h*r*(1-r) (r stays) ----------
             Frag<D> dpc, dpu, gu, rf, hrr, dpr;
+            SFrag<D> sdpc, sdpr, sdpu;                              // (SPLIT) their bf16 planes
             if constexpr (ACT) {
                 if constexpr (!PREFETCH) { fetch_raw(raw, tk, 0); fetch_raw(raw, tk, 1); }
                 auto dact = [&](float cv) { return a.act == GGNN_ACT_TANH ? 1.0f - cv * cv : (cv > 0.f ? 1.0f : 0.f); };
@@ -207,10 +224,11 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
                 }
             }
 
+            if constexpr (SPLIT && ACT) { split_frag<D>(sdpc, dpc); split_frag<D>(sdpu, dpu); }
             // ---- stage 0: drh = dpc Wc^T[h block]; dpr = drh h r (1-r); dh_part = drh r  (accumulator layout) ----------------
             f32x4 acc[NT];
             GGNN_BT(1)
-            stage(std::true_type{}, acc, dpc, 0, nothing, nothing);
+            stage(std::true_type{}, acc, dpc, sdpc, 0, nothing, nothing);
             GGNN_BT(2)
             if constexpr (ACT) {
                 // accumulator tile nt == fragment chunk nt (same lanes, same columns); the remainder tile through rem_tile().
@@ -245,11 +263,12 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
                 }
             }
 
+            if constexpr (SPLIT && ACT) split_frag<D>(sdpr, dpr);
             // ---- stages 1, 2: the h blocks of Wg^T -> dh = g u + drh r + dpr Wg_r^T + dpu Wg_u^T ------------------------------------
             GGNN_BT(3)
-            stage(std::false_type{}, acc, dpr, 1, nothing, nothing);
+            stage(std::false_type{}, acc, dpr, sdpr, 1, nothing, nothing);
             GGNN_BT(4)
-            stage(std::false_type{}, acc, dpu, 2, nothing, nothing);
+            stage(std::false_type{}, acc, dpu, sdpu, 2, nothing, nothing);
             GGNN_BT(5)
             if constexpr (ACT) {
                 if (row_ok) {
@@ -269,12 +288,12 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
             auto fetch_next_b = [&] { if (PREFETCH == 1 && ACT && !last_pass) fetch_raw(raw, tk + nb, 1); };
 #define GGNN_BWD_SEG(S)                                                                                             \
             if constexpr ((S) < NX) {                                                                               \
-                stage(std::true_type{}, acc, dpc, 3 + 3 * (S), nothing, nothing);                                   \
+                stage(std::true_type{}, acc, dpc, sdpc, 3 + 3 * (S), nothing, nothing);                             \
                 if ((S) == 0) { GGNN_BT(8) }                                                                        \
-                stage(std::false_type{}, acc, dpr, 4 + 3 * (S), nothing, nothing);                                  \
+                stage(std::false_type{}, acc, dpr, sdpr, 4 + 3 * (S), nothing, nothing);                            \
                 if ((S) == 0) { GGNN_BT(9) }                                                                        \
-                if constexpr ((S) == NX - 1) stage(std::false_type{}, acc, dpu, 5 + 3 * (S), fetch_next_a, fetch_next_b); \
-                else stage(std::false_type{}, acc, dpu, 5 + 3 * (S), nothing, nothing);                             \
+                if constexpr ((S) == NX - 1) stage(std::false_type{}, acc, dpu, sdpu, 5 + 3 * (S), fetch_next_a, fetch_next_b); \
+                else stage(std::false_type{}, acc, dpu, sdpu, 5 + 3 * (S), nothing, nothing);                       \
                 if ((S) == 0) { GGNN_BT(10) }                                                                       \
                 if constexpr (ACT) {                                                                                \
                     if (row_ok) {                                                                                   \
@@ -323,29 +342,77 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
 //  share of HBM (6 TB/s / 256 CUs = 10 B/clock) is 28k clocks; hiding it takes a full pass of prefetch distance, i.e. 125 more
 //  registers per wave or 256 KB of LDS per CU.  tools/gru_bwd_timeline.py, tools/gru_bwd_bench.py)
 
-template <int D, int NX, int NW, int PREFETCH, int RING>
+template <int D, int NX, int NW, int PREFETCH, int RING, bool SPLIT = false>
 static int launch_gru_bwd_variant(const GruBwdArgs& a, const float* packed, hipStream_t st) {
-    using C = StageCfg<D>;
+    using C = ImgCfg<D, SPLIT>;
     const size_t lds = (size_t)RING * C::IMG_BYTES;
     const int wt_total = (a.V + 15) / 16;
     int nb = num_cus() * (RING == 1 ? 2 : 1);                  // single-image form: two 4-wave workgroups per CU
     if (nb > wt_total) nb = wt_total;
     static std::atomic<unsigned long long> lds_ok{0};
-    if (lds > 64 * 1024) GGNN_CHECK_HIP((allow_dynamic_lds(&ggnn_gru_bwd_fused_kernel<D, NX, NW, PREFETCH, RING>, lds, lds_ok)));
-    hipLaunchKernelGGL((ggnn_gru_bwd_fused_kernel<D, NX, NW, PREFETCH, RING>), dim3(nb), dim3(NW * 64), lds, st, a, packed);
+    if (lds > 64 * 1024) GGNN_CHECK_HIP((allow_dynamic_lds(&ggnn_gru_bwd_fused_kernel<D, NX, NW, PREFETCH, RING, SPLIT>, lds, lds_ok)));
+    hipLaunchKernelGGL((ggnn_gru_bwd_fused_kernel<D, NX, NW, PREFETCH, RING, SPLIT>), dim3(nb), dim3(NW * 64), lds, st, a, packed);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
 
-template <int D, int NX>
-static int launch_gru_bwd(const GruBwdArgs& a, const float* Wg, const float* Wc, float* packed, hipStream_t st) {
+// This source is compiled twice, like ggnn_gru_fused.hip: as itself (f32 MFMA) and through ggnn_gru_bwd_fused_split.hip
+// (GGNN_GRU_BWD_TU_SPLIT: the split instantiations, built without packed-f32 vector instructions).
+int gru_bwd_split_launch(int D, int nx, const GruBwdArgs& a, const float* Wg, const float* Wc, float* packed, hipStream_t st);
+
+template <int D, int NX, bool SPLIT>
+static int gru_bwd_prepare(const GruBwdArgs& a, const float* Wg, const float* Wc, float* packed, hipStream_t st, bool* done) {
+    *done = true;
     if (Wg) {
-        hipLaunchKernelGGL((gru_bwd_pack_kernel<D>), dim3(8, 3 * (NX + 1)), dim3(256), 0, st, Wg, Wc, NX, packed);
+        hipLaunchKernelGGL((gru_bwd_pack_kernel<D, SPLIT>), dim3(8, 3 * (NX + 1)), dim3(256), 0, st, Wg, Wc, NX, packed);
         GGNN_CHECK_HIP(hipGetLastError());
     }
     if (a.g == nullptr || a.V == 0) return GGNN_OK;
     if ((unsigned long long)a.V * 2 * D >= (1ULL << 30))
         return fail(GGNN_E_UNSUPPORTED, "fused GRU backward indexes with 32-bit byte offsets: V*2D must be < 2^30 (V=%d, D=%d)", a.V, D);
+    *done = false;
+    return GGNN_OK;
+}
+
+#ifdef GGNN_GRU_BWD_TU_SPLIT
+template <int D, int NX>
+static int launch_gru_bwd_split(const GruBwdArgs& a, const float* Wg, const float* Wc, float* packed, hipStream_t st) {
+    bool done;
+    if (int rc = gru_bwd_prepare<D, NX, true>(a, Wg, Wc, packed, st, &done); rc != GGNN_OK || done) return rc;
+    // GGNN_BWD_FORM=1: the next tile's inputs prefetched under the last stage
+    const int form = [] { const char* e = getenv("GGNN_BWD_FORM"); return e ? atoi(e) : 0; }();
+    if (form == 1) return launch_gru_bwd_variant<D, NX, 8, 1, 2, true>(a, packed, st);
+    return launch_gru_bwd_variant<D, NX, 8, 0, 2, true>(a, packed, st);
+}
+template <int D>
+static int gru_bwd_split_d(int nx, const GruBwdArgs& a, const float* Wg, const float* Wc, float* packed, hipStream_t st) {
+    if constexpr (SplitCfg<D>::OK) {
+        switch (nx) {
+            case 1: return launch_gru_bwd_split<D, 1>(a, Wg, Wc, packed, st);
+            case 2: return launch_gru_bwd_split<D, 2>(a, Wg, Wc, packed, st);
+            case 3: return launch_gru_bwd_split<D, 3>(a, Wg, Wc, packed, st);
+        }
+    }
+    return fail(GGNN_E_INVALID, "nx %d outside 1..3", nx);
+}
+int gru_bwd_split_launch(int D, int nx, const GruBwdArgs& a, const float* Wg, const float* Wc, float* packed, hipStream_t st) {
+#ifdef GGNN_PROBE_NX
+    return launch_gru_bwd_split<100, GGNN_PROBE_NX>(a, Wg, Wc, packed, st);
+#else
+    switch (D) {
+        case 100: return gru_bwd_split_d<100>(nx, a, Wg, Wc, packed, st);
+        case 64: return gru_bwd_split_d<64>(nx, a, Wg, Wc, packed, st);
+        case 32: return gru_bwd_split_d<32>(nx, a, Wg, Wc, packed, st);
+        default: return fail(GGNN_E_UNSUPPORTED, "no split-form fused GRU backward for hidden size %d", D);
+    }
+#endif
+}
+#else
+template <int D, int NX>
+static int launch_gru_bwd(const GruBwdArgs& a, const float* Wg, const float* Wc, float* packed, hipStream_t st) {
+    if (SplitCfg<D>::OK && split_matrix_path()) return gru_bwd_split_launch(D, NX, a, Wg, Wc, packed, st);
+    bool done;
+    if (int rc = gru_bwd_prepare<D, NX, false>(a, Wg, Wc, packed, st, &done); rc != GGNN_OK || done) return rc;
     // GGNN_BWD_FORM: 0 = one 8-wave workgroup per CU, 2-image ring, inputs fetched at the top of a pass;
     //                1 = the same with the next tile's inputs prefetched under the last stage;
     //                2 = two 4-wave workgroups per CU, one image each
@@ -368,18 +435,22 @@ static int dispatch_gru_bwd(const GruBwdArgs& a, const float* Wg, const float* W
     }
 }
 
+#endif   // !GGNN_GRU_BWD_TU_SPLIT
+
 }  // namespace ggnn
 
+#ifndef GGNN_GRU_BWD_TU_SPLIT
 using namespace ggnn;
 
 extern "C" int ggnn_gru_bwd_is_fused(int D) { return D == 100 || D == 64 || D == 32; }
 
 extern "C" size_t ggnn_gru_bwd_packed_bytes(int D, int nx) {
     size_t img = 0;
+    const bool sp = split_matrix_path();
     switch (D) {
-        case 100: img = StageCfg<100>::IMG; break;
-        case 64: img = StageCfg<64>::IMG; break;
-        case 32: img = StageCfg<32>::IMG; break;
+        case 100: img = sp ? ImgCfg<100, true>::IMG : ImgCfg<100, false>::IMG; break;
+        case 64: img = sp ? ImgCfg<64, true>::IMG : ImgCfg<64, false>::IMG; break;
+        case 32: img = sp ? ImgCfg<32, true>::IMG : ImgCfg<32, false>::IMG; break;
         default: return 0;
     }
     return (size_t)3 * (nx + 1) * img * sizeof(float);
@@ -417,3 +488,4 @@ extern "C" int ggnn_gru_bwd_fused_f32(const float* g, const float* h, const floa
         default: return dispatch_gru_bwd<32>(a, Wg, Wc, packed, st);
     }
 }
+#endif

@@ -122,6 +122,14 @@ __device__ __forceinline__ void gru_fwd_image_pack_split(const float* __restrict
     pack_split_image<D>(v, img, first, stride);
 }
 
+// Image i of the fused GRU backward's packed weights in split form (blocks as gru_bwd_image_pack: transposed reads)
+template <int D>
+__device__ __forceinline__ void gru_bwd_image_pack_split(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx, int i,
+                                                         float* __restrict__ img, int first, int stride) {
+    const int seg = i < 3 ? nx : (i - 3) / 3, which = i < 3 ? i : (i - 3) % 3;
+    pack_split_image<D>(StageValueT<D>{which == 0 ? Wc : Wg, seg * D, which == 2 ? D : 0, which == 0 ? D : 2 * D}, img, first, stride);
+}
+
 // the three bf16 planes of an activation fragment's 32-chunks (the remainder floats stay in the Frag)
 template <int D>
 struct SFrag {

@@ -119,7 +119,7 @@ struct PrepArgs {
     int T; float keep;
 };
 
-// SF: the edge-weight images and the fused GRU forward's images in split form (ggnn_split.hpp)
+// SF: every image in split form (ggnn_split.hpp)
 template <int D, bool SF>
 __global__ __launch_bounds__(256) void train_prepare_kernel(PrepArgs a) {
     using C = StageCfg<D>;
@@ -164,7 +164,9 @@ __global__ __launch_bounds__(256) void train_prepare_kernel(PrepArgs a) {
         else gru_fwd_image_pack<D>(a.Wg[l], a.Wc[l], a.nx[l], ci, img, first, stride);
     } else if (i < 2 * T + 2 * ng) {
         const int bi = i - 2 * T - ng;
-        gru_bwd_image_pack<D>(a.Wg[l], a.Wc[l], a.nx[l], bi, a.gru_bwd_img[l] + (size_t)bi * C::IMG, first, stride);
+        float* img = a.gru_bwd_img[l] + (size_t)bi * ImgCfg<D, SF>::IMG;
+        if constexpr (SF) gru_bwd_image_pack_split<D>(a.Wg[l], a.Wc[l], a.nx[l], bi, img, first, stride);
+        else gru_bwd_image_pack<D>(a.Wg[l], a.Wc[l], a.nx[l], bi, img, first, stride);
     }
 }
 

@@ -110,6 +110,35 @@ def basic_rnn_cell(x, h, W, b, act=np.tanh):
 # ----------------------------------------------------------------------------------------------
 # One sparse propagation step and the layer/timestep driver
 # ----------------------------------------------------------------------------------------------
+# ---- the split matrix path of the HIP kernels (csrc/ggnn_split.hpp), restated -------------------------------------------
+# Not part of the reference: the kernels evaluate the reference's f32 products  x W  as six bf16 products of operands split into
+# three bf16 pieces.  This restatement pins the two claims the kernels rest on: the split is exact, and the six-product sum has
+# the error of an f32 evaluation.
+def bf16_split3(a):
+    """a (float32) -> (hi, mid, lo), each exactly representable in bf16 (low 16 bits zero), hi + mid + lo == a exactly.
+    Truncation split: every piece takes the next 8 significand bits."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    trunc = lambda x: (x.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    hi = trunc(a)
+    r1 = (a - hi).astype(np.float32)          # exact: a and hi share their leading bits
+    mid = trunc(r1)
+    lo = (r1 - mid).astype(np.float32)        # at most 8 significant bits are left: already a bf16 value
+    return hi, mid, lo
+
+
+def split6_matmul(A, W, chunk=32):
+    """A [M,K] x W [K,N] the way stage_mma_split accumulates it: per `chunk` of k, six dot products (lo-order terms first)
+    whose bf16 x bf16 products are exact, each added to an f32 accumulator (the MFMA's C operand)."""
+    a, w = bf16_split3(A), bf16_split3(W)
+    order = [(0, 2), (1, 1), (0, 1), (2, 0), (1, 0), (0, 0)]      # (piece of A, piece of W): w_lo a_hi | w_mid a_mid | w_mid a_hi | w_hi a_lo | ...
+    acc = np.zeros((A.shape[0], W.shape[1]), np.float32)
+    for c in range(0, A.shape[1], chunk):
+        for i, j in order:
+            d = a[i][:, c:c + chunk].astype(np.float64) @ w[j][c:c + chunk].astype(np.float64)
+            acc = (acc.astype(np.float64) + d).astype(np.float32)
+    return acc
+
+
 def philox4x32_10(counter, key):
     """Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123) on uint32 arrays:
     counter [..., 4], key [..., 2] -> [..., 4].  Pinned by Random123's published known-answer vectors (tests/test_oracle.py)."""

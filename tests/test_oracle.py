@@ -198,6 +198,34 @@ def test_golden_fixture(oracle):
         assert np.abs(s - g["state_%d" % i]).max() < 1e-12
 
 
+def test_split_matrix_path_arithmetic(oracle):
+    """csrc/ggnn_split.hpp in numpy: the 3-way bf16 split of an f32 value is exact, and six of the nine partial products reproduce
+    the f32 product to f32 accuracy (the three dropped ones are below 2^-23 of it)."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(4000).astype(np.float32) * s for s in (1e-20, 1e-3, 1.0, 1e4, 1e30)] +
+                       [np.array([0.0, -0.0, 1.0, -1.0, np.float32(2 ** -126), np.float32(3.4e38), 1 + 2 ** -23], np.float32)])
+    hi, mid, lo = oracle.bf16_split3(x)
+    for p in (hi, mid, lo):
+        assert not np.any(p.view(np.uint32) & np.uint32(0xFFFF))           # each piece is a bf16 value
+    assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), x.astype(np.float64))
+    # a GRU-sized product: K = 300, operands of the model's size
+    A = rng.uniform(-1, 1, (512, 300)).astype(np.float32)
+    W = rng.uniform(-0.2, 0.2, (300, 100)).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64)
+    scale = np.abs(A.astype(np.float64)) @ np.abs(W.astype(np.float64))
+    chain = np.zeros((512, 100), np.float32)                                # the f32 MFMA's arithmetic: one rounding per k
+    for k in range(300):
+        chain = (chain.astype(np.float64) + A[:, k:k + 1].astype(np.float64) * W[k:k + 1].astype(np.float64)).astype(np.float32)
+    e_split = np.abs(oracle.split6_matmul(A, W) - ref)
+    e_chain = np.abs(chain - ref)
+    assert (e_split / scale).max() < 2e-7 and (e_chain / scale).max() < 4e-7
+    assert np.sqrt((e_split ** 2).mean()) <= np.sqrt((e_chain ** 2).mean())      # fewer roundings: at least as accurate
+    # dropping the second-order terms as well (three products) would NOT be f32-accurate -- the reason there are six
+    a, w = oracle.bf16_split3(A), oracle.bf16_split3(W)
+    three = sum(a[i].astype(np.float64) @ w[j].astype(np.float64) for i, j in ((0, 0), (0, 1), (1, 0)))
+    assert (np.abs(three - ref) / scale).max() > 2e-6
+
+
 def test_philox_known_answers_and_counter_dropout(oracle):
     """The counter-based dropout mask (ggnn_dropout_f32) is Philox4x32-10: Random123's published known-answer vectors
     (kat_vectors: zero, all-ones, pi digits) pin the restatement; the mask keeps a fraction keep_prob, scales by 1/keep_prob, and

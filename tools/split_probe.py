@@ -36,4 +36,26 @@ for D, nx, V in ((100, 1, 40000), (100, 3, 20000), (64, 2, 20000), (32, 1, 20000
     key = "D%d_nx%d" % (D, nx)
     out[key] = {"h_max": float(e.max()), "h_rms": float((e ** 2).mean().sqrt()), "r_max": float(er.max()),
                 "c_max": float(ec.max()), "c_rms": float((ec ** 2).mean().sqrt())}
+# the compacted message transform (K1): rows h[pair_node] x W_type against an f64 product, error relative to sum |a||w|
+for D, V in ((100, 30000), (64, 9000)):
+    T = 4
+    g = torch.Generator(device="cpu").manual_seed(77 + D)
+    h = torch.rand(V, D, generator=g) * 2 - 1
+    W = (torch.rand(T, D, D, generator=g) * 2 - 1) * 0.3
+    src = torch.randint(0, V, (4 * V,), generator=g)
+    tgt = torch.randint(0, V, (4 * V,), generator=g)
+    adj = [torch.stack([src[t::T], tgt[t::T]], 1).to(torch.int32).to(dev) for t in range(T)]
+    index = ops.build_message_index(adj, V)
+    comp = ops.build_compact_sources(index)
+    Hc = ops.msg_transform_compact(h.to(dev), W.to(dev), comp).double().cpu()[:comp.num_rows]
+    pn = comp.pair_node.cpu().long()[:comp.num_rows]
+    want = torch.empty(comp.num_rows, D, dtype=torch.float64)
+    bound = torch.empty(comp.num_rows, D, dtype=torch.float64)
+    for t in range(T):
+        lo, hi = int(comp.type_row_off[t]), int(comp.type_row_off[t + 1])
+        rows = h[pn[lo:hi]].double()
+        want[lo:hi] = rows @ W[t].double()
+        bound[lo:hi] = rows.abs() @ W[t].double().abs()
+    e = (Hc - want).abs()
+    out["transform_D%d" % D] = {"max": float(e.max()), "rms": float((e ** 2).mean().sqrt()), "max_rel_to_sum_abs": float((e / bound).max())}
 print(json.dumps(out))
