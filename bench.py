@@ -232,11 +232,18 @@ def pmc_key(pmc, name, D):
         return next((k for k in pmc if k.startswith("gather_segment_sum") and "attn" not in k), None)
     if name.startswith("dense_propagate"):
         return next((k for k in pmc if k.startswith("dense_graph")), None)
-    if name.startswith("gru_fused"):                     # template args <D, NX, NW, SAVE, GATHER>
+    if name.startswith("gru_fused"):                     # template args <D, NX, NW, SAVE, GATHER, SPLIT>
         nx = name.split("nx=")[1].rstrip("]")
-        tail = "true>" if name.startswith("gru_fused_gather") else "false>"
-        return next((k for k in pmc if k.startswith("gru_fused<%d, %s," % (D, nx)) and k.endswith(tail) and k.count(",") == 4),
-                    None) or next((k for k in pmc if k.startswith("gru_panel<%d," % D)), None)
+        gather = "true" if name.startswith("gru_fused_gather") else "false"
+        hits = []
+        for k in pmc:
+            if k.startswith("gru_fused<") and k.endswith(">"):
+                t = [x.strip() for x in k[len("gru_fused<"):-1].split(",")]
+                if len(t) >= 5 and t[0] == str(D) and t[1] == nx and t[4] == gather:
+                    hits.append((len(t) > 5 and t[5] == ("true" if SPLIT_ACTIVE else "false"), pmc[k].get("launches", 0), k))
+        if hits:
+            return max(hits)[2]                          # the instantiation of this process's matrix path, the most-launched one
+        return next((k for k in pmc if k.startswith("gru_panel<%d," % D)), None)
     return None
 
 
