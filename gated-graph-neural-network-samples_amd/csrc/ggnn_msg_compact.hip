@@ -191,11 +191,12 @@ static int launch_compact(const float* h, const float* W, const int* pair_node, 
 }
 
 int gru_panel_supported(int D);      // ggnn_panel.hip: hidden sizes handled on column panels
+int transform_panel_image_floats(int D);
 int transform_panel_dispatch(const float* h, const float* W, const int* pair_node, const int* row_off, int T, int V, int D,
                              float* packed, float* Hc, hipStream_t st);
 
 static int stage_img_floats(int D) {
-    if (gru_panel_supported(D)) return D * D;            // NP panel images of D x 64
+    if (gru_panel_supported(D)) return (D / 64) * transform_panel_image_floats(D);      // NP panel images per type
     const bool sp = split_matrix_path();
     switch (D) {
         case 100: return sp ? ImgCfg<100, true>::IMG : ImgCfg<100, false>::IMG;

@@ -21,7 +21,7 @@
 //
 // The transform is the same stage loop without the chain: a persistent workgroup is bound to ONE (edge type, panel),
 // keeps that panel image in LDS and walks 16-row tiles of the type's active (source node, type) pairs.
-#include "ggnn_stage.hpp"
+#include "ggnn_split.hpp"
 #include <type_traits>
 
 namespace ggnn {
@@ -45,6 +45,73 @@ __device__ __forceinline__ void pack_panel_image(const float* __restrict__ W, in
     for (int i = first; i < C::IMG; i += stride) {
         const int e = i & 3, n = (i >> 2) % C::BN, ck = (i >> 2) / C::BN;
         img[i] = W[(size_t)(r0 + 4 * ck + e) * ldw + c0 + n];
+    }
+}
+
+// ---- the transform's panel in 3-way split form (ggnn_split.hpp): image = three bf16 planes [c2][g][n < 64][8 x bf16] -----------
+template <int D>
+struct PanelSplitCfg {
+    static constexpr int NC2 = D / 32;
+    static constexpr int PLANE_BYTES = NC2 * 4 * 64 * 16;          // D * 128
+    static constexpr int IMG_BYTES = 3 * PLANE_BYTES;              // 96 KiB at D = 256: ONE image per workgroup, no ring
+    static constexpr int IMG = IMG_BYTES / 4;
+};
+
+template <int D>
+__device__ __forceinline__ void pack_panel_split_image(const float* __restrict__ W, int r0, int c0, int ldw, float* __restrict__ img,
+                                                       int first, int stride) {
+    using C = PanelSplitCfg<D>;
+    constexpr int PW = C::PLANE_BYTES / 4;
+    for (int i = first; i < C::IMG; i += stride) {
+        const int plane = i / PW, w = i % PW;
+        const int slot = w >> 2, pr = w & 3;
+        const int n = slot % 64, cg = slot / 64, c2 = cg >> 2, g = cg & 3;
+        const int j0 = 2 * pr;
+        const int k0 = 32 * c2 + 16 * (j0 >> 2) + 4 * g + (j0 & 3);
+        const float v0 = W[(size_t)(r0 + k0) * ldw + c0 + n], v1 = W[(size_t)(r0 + k0 + 1) * ldw + c0 + n];
+        img[i] = __uint_as_float(split_piece_bits(v0, plane) | (split_piece_bits(v1, plane) << 16));
+    }
+}
+
+// acc[0..3] (+)= fragment x split panel image.  The fragment stays f32; the 8 values of a 32-chunk are split right before the
+// chunk's 24 MFMAs (the next chunk's while the current one multiplies); weight planes rotate through 12 registers (stage_mma_split).
+template <int D, bool ZERO>
+__device__ __forceinline__ void panel_mma_split(f32x4 (&acc)[4], const Frag<D>& a, const float* img, int li, int kq) {
+    using C = PanelSplitCfg<D>;
+    constexpr int NU = C::NC2 * 4;
+    constexpr int PL = C::PLANE_BYTES / 16;
+    const u32x4* base = reinterpret_cast<const u32x4*>(img) + kq * 64 + li;
+    auto slot = [&](int u, int p) { return base[p * PL + (u / 4) * 4 * 64 + (u % 4) * 16]; };
+    auto planes = [&](int c2, u32x4& hi, u32x4& mid, u32x4& lo) {
+        const f32x4 x = a.v[2 * c2], y = a.v[2 * c2 + 1];
+        unsigned h[4], m[4], l[4];
+        split_pair(x.x, x.y, h[0], m[0], l[0]); split_pair(x.z, x.w, h[1], m[1], l[1]);
+        split_pair(y.x, y.y, h[2], m[2], l[2]); split_pair(y.z, y.w, h[3], m[3], l[3]);
+        hi = u32x4{h[0], h[1], h[2], h[3]}; mid = u32x4{m[0], m[1], m[2], m[3]}; lo = u32x4{l[0], l[1], l[2], l[3]};
+    };
+    u32x4 ah, am, al, nh, nm, nl;
+    planes(0, ah, am, al);
+    u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int c2 = u / 4, j = u % 4;
+        const bool more = u + 1 < NU;
+        if (j == 0 && c2 + 1 < C::NC2) planes(c2 + 1, nh, nm, nl);      // (vector work of the next chunk, under this chunk's MFMAs)
+        f32x4 c = (ZERO && c2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j];
+        c = mfma_bf16(wl, ah, c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wl = slot(u + 1, 2);
+        c = mfma_bf16(wm, am, c);
+        c = mfma_bf16(wm, ah, c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wm = slot(u + 1, 1);
+        c = mfma_bf16(wh, al, c);
+        c = mfma_bf16(wh, am, c);
+        c = mfma_bf16(wh, ah, c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wh = slot(u + 1, 0);
+        acc[j] = c;
+        if (j == 3) { ah = nh; am = nm; al = nl; }
     }
 }
 
@@ -448,11 +515,12 @@ struct PanelRows {
 
 // workgroup (type t, panel p, j-th of the type's workgroups on that panel): keeps image (t, p) in LDS and walks 16-row tiles
 // j*NW + wave, + stride, ... of the type's active pairs; the rows of tile k+1 are fetched under the MFMAs of tile k.
-template <int D, int NW>
+template <int D, int NW, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void msg_transform_panel_kernel(const float* __restrict__ h, const int* __restrict__ pair_node,
                                                                       PanelRows pr, const float* __restrict__ packed,
                                                                       float* __restrict__ Hc) {
     using C = PanelCfg<D>;
+    constexpr int IMGF = SPLIT ? PanelSplitCfg<D>::IMG : C::IMG;
     constexpr int NP = C::NP;
     extern __shared__ __attribute__((aligned(16))) float img[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -473,8 +541,10 @@ __global__ __launch_bounds__(NW * 64) void msg_transform_panel_kernel(const floa
     int node_0 = 0, node_n = 0;
     if (idx < n_wt) node_0 = pair_node[row_of(idx)];
     if (idx + stride < n_wt) node_n = pair_node[row_of(idx + stride)];
-    dma_block<C::IMG_BYTES, NW>(packed + (size_t)(t * NP + p) * C::IMG, img, wave, lane);
+    if constexpr (SPLIT) dma_image_asm<PanelSplitCfg<D>::IMG_BYTES, NW>(packed + (size_t)(t * NP + p) * IMGF, img, wave, lane);
+    else dma_block<C::IMG_BYTES, NW>(packed + (size_t)(t * NP + p) * IMGF, img, wave, lane);
     if (idx < n_wt) load_frag<D>(a, h, node_0, kq);
+    if constexpr (SPLIT) dma_wait();
     __syncthreads();
 
     while (idx < n_wt) {
@@ -483,7 +553,8 @@ __global__ __launch_bounds__(NW * 64) void msg_transform_panel_kernel(const floa
         if (idx_n + stride < n_wt) node_n = pair_node[row_of(idx_n + stride)];
         f32x4 acc[4];
         __builtin_amdgcn_sched_barrier(0);
-        panel_mma<D, true>(acc, a, img, li, kq);
+        if constexpr (SPLIT) panel_mma_split<D, true>(acc, a, img, li, kq);
+        else panel_mma<D, true>(acc, a, img, li, kq);
         const int r = row_beg + idx * 16 + li;
         if (r < row_end) {
 #pragma unroll
@@ -494,21 +565,33 @@ __global__ __launch_bounds__(NW * 64) void msg_transform_panel_kernel(const floa
     }
 }
 
-template <int D>
+template <int D, bool SPLIT>
 __global__ void edge_weight_panel_pack_kernel(const float* __restrict__ W, float* __restrict__ out) {
     using C = PanelCfg<D>;
     const int t = blockIdx.y / C::NP, p = blockIdx.y % C::NP;
-    pack_panel_image<D>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * C::IMG,
-                        blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    const int first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if constexpr (SPLIT) pack_panel_split_image<D>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * PanelSplitCfg<D>::IMG, first, stride);
+    else pack_panel_image<D>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * C::IMG, first, stride);
 }
 
-template <int D>
-static int launch_transform_panel(const float* h, const float* W, const int* pair_node, const int* row_off, int T, int V,
+// floats of ONE (type, panel) image of the transform, in the process's matrix path
+int transform_panel_image_floats(int D) {
+    const bool sp = split_matrix_path();
+    switch (D) {
+        case 128: return sp ? PanelSplitCfg<128>::IMG : PanelCfg<128>::IMG;
+        case 192: return sp ? PanelSplitCfg<192>::IMG : PanelCfg<192>::IMG;
+        case 256: return sp ? PanelSplitCfg<256>::IMG : PanelCfg<256>::IMG;
+        default: return 0;
+    }
+}
+
+template <int D, bool SPLIT>
+static int launch_transform_panel_m(const float* h, const float* W, const int* pair_node, const int* row_off, int T, int V,
                                   float* packed, float* Hc, hipStream_t st) {
     using C = PanelCfg<D>;
     constexpr int NW = 8, NP = C::NP;
     if (W) {
-        hipLaunchKernelGGL((edge_weight_panel_pack_kernel<D>), dim3(8, T * NP), dim3(256), 0, st, W, packed);
+        hipLaunchKernelGGL((edge_weight_panel_pack_kernel<D, SPLIT>), dim3(8, T * NP), dim3(256), 0, st, W, packed);
         GGNN_CHECK_HIP(hipGetLastError());
     }
     const int R = row_off[T];
@@ -532,11 +615,19 @@ static int launch_transform_panel(const float* h, const float* W, const int* pai
     }
     pr.row_off[T] = R;
     static std::atomic<unsigned long long> lds_ok{0};
-    if (C::IMG_BYTES > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&msg_transform_panel_kernel<D, NW>, C::IMG_BYTES, lds_ok));
-    hipLaunchKernelGGL((msg_transform_panel_kernel<D, NW>), dim3(pr.wg_off[T]), dim3(NW * 64), C::IMG_BYTES, st, h, pair_node, pr,
+    constexpr size_t lds = SPLIT ? PanelSplitCfg<D>::IMG_BYTES : C::IMG_BYTES;
+    if (lds > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&msg_transform_panel_kernel<D, NW, SPLIT>, lds, lds_ok));
+    hipLaunchKernelGGL((msg_transform_panel_kernel<D, NW, SPLIT>), dim3(pr.wg_off[T]), dim3(NW * 64), lds, st, h, pair_node, pr,
                        (const float*)packed, Hc);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
+}
+
+template <int D>
+static int launch_transform_panel(const float* h, const float* W, const int* pair_node, const int* row_off, int T, int V,
+                                  float* packed, float* Hc, hipStream_t st) {
+    if (split_matrix_path()) return launch_transform_panel_m<D, true>(h, W, pair_node, row_off, T, V, packed, Hc, st);
+    return launch_transform_panel_m<D, false>(h, W, pair_node, row_off, T, V, packed, Hc, st);
 }
 
 int transform_panel_dispatch(const float* h, const float* W, const int* pair_node, const int* row_off, int T, int V, int D,

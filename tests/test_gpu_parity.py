@@ -392,13 +392,14 @@ def test_compact_transform_equals_dense_form(pkg, oracle, cuda, V, M, D, T):
     # Split path (default): the compacted transform multiplies on the bf16 pipe in 3-way split form, the dense form on the f32
     # MFMA -- two f32-faithful evaluations of the same product that differ in the last bits (test_gpu_split_precision.py).
     full = 0 if pkg._lib.load().ggnn_matrix_path_is_split() else (D // 16) * 16
+    atol = 2e-6 * max(1.0, D / 100.0)      # two f32-faithful evaluations of a D-term product (|h| <= 1, |w| <= 0.3) apart
     for r, (t, v) in enumerate(got_pairs[:2000]):
         assert np.array_equal(Hcn[r, :full], Hn[v, t, :full])
-        np.testing.assert_allclose(Hcn[r, full:], Hn[v, t, full:], atol=2e-6, rtol=1e-5)
+        np.testing.assert_allclose(Hcn[r, full:], Hn[v, t, full:], atol=atol, rtol=1e-5)
     a = pkg.ops.gather_segment_sum(H, index, nd, None, True)
     b = pkg.ops.gather_segment_sum_compact(Hc, index, comp, nd, None, True)
     assert torch.equal(a[:, :full], b[:, :full])
-    assert torch.allclose(a, b, atol=2e-6, rtol=1e-5)
+    assert torch.allclose(a, b, atol=atol, rtol=1e-5)
 
 
 @pytest.mark.parametrize("M,K,N,strided", [(1000, 100, 100, False), (33333, 200, 200, False), (70001, 400, 100, True),
