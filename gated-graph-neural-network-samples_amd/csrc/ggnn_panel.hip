@@ -115,6 +115,91 @@ __device__ __forceinline__ void panel_mma_split(f32x4 (&acc)[4], const Frag<D>& 
     }
 }
 
+// ---- the GRU's panels in split form: image [c2][plane][g][n < 64][8 x bf16], CHUNK-major, so that it can be brought in in PARTS --
+// A split 64-column panel of a 256-row block is 96 KiB: two of them do not fit the LDS.  The ring therefore holds PARTS of an
+// image (D = 256: 2 x 4 chunks = 48 KiB each; 192: 3 x 2 chunks = 24 KiB; 128: the whole 48 KiB image) and a stage is PARTS
+// DMA / MFMA / barrier rounds over the same accumulators.
+template <int D>
+struct PanelGruSplitCfg {
+    static constexpr int NC2 = D / 32;
+    static constexpr int CHUNK_BYTES = 3 * 4 * 64 * 16;            // 12 KiB per 32-chunk
+    static constexpr int PARTS = D == 256 ? 2 : (D == 192 ? 3 : 1);
+    static constexpr int CP = NC2 / PARTS;                         // chunks per part
+    static constexpr int PART_BYTES = CP * CHUNK_BYTES;
+    static constexpr int PART = PART_BYTES / 4;
+    static constexpr int IMG_BYTES = NC2 * CHUNK_BYTES;
+    static constexpr int IMG = IMG_BYTES / 4;
+    static_assert(NC2 % PARTS == 0 && PART_BYTES % 8192 == 0, "parts are whole chunks and whole KiB per wave of an 8-wave workgroup");
+};
+
+template <int D>
+__device__ __forceinline__ void pack_panel_gru_split_image(const float* __restrict__ W, int r0, int c0, int ldw, float* __restrict__ img,
+                                                           int first, int stride) {
+    using C = PanelGruSplitCfg<D>;
+    for (int i = first; i < C::IMG; i += stride) {
+        const int slot = i >> 2, pr = i & 3;                       // 16-byte slot ((c2*3 + plane)*4 + g)*64 + n
+        const int n = slot % 64, g = (slot / 64) % 4, plane = (slot / 256) % 3, c2 = slot / 768;
+        const int j0 = 2 * pr;
+        const int k0 = 32 * c2 + 16 * (j0 >> 2) + 4 * g + (j0 & 3);
+        const float v0 = W[(size_t)(r0 + k0) * ldw + c0 + n], v1 = W[(size_t)(r0 + k0 + 1) * ldw + c0 + n];
+        img[i] = __uint_as_float(split_piece_bits(v0, plane) | (split_piece_bits(v1, plane) << 16));
+    }
+}
+
+__device__ __forceinline__ void frag_planes(f32x4 x, f32x4 y, u32x4& hi, u32x4& mid, u32x4& lo) {
+    // The fragment is the same for every stage of its segment, so the compiler would split it ONCE and keep all planes live across
+    // the stages (96 registers at D = 256: ~450 B of scratch).  The empty asm makes the inputs opaque: the split is redone per stage,
+    // 44 vector instructions per 24 MFMAs, and only one chunk's planes are live.
+    asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w), "+v"(y.x), "+v"(y.y), "+v"(y.z), "+v"(y.w));
+    unsigned h[4], m[4], l[4];
+    split_pair(x.x, x.y, h[0], m[0], l[0]); split_pair(x.z, x.w, h[1], m[1], l[1]);
+    split_pair(y.x, y.y, h[2], m[2], l[2]); split_pair(y.z, y.w, h[3], m[3], l[3]);
+    hi = u32x4{h[0], h[1], h[2], h[3]}; mid = u32x4{m[0], m[1], m[2], m[3]}; lo = u32x4{l[0], l[1], l[2], l[3]};
+}
+
+// acc[0..3] (+)= chunks [part*CP, (part+1)*CP) of the fragment x the same chunks of a split panel image; `chunks` points at the
+// first of them (in LDS: a ring slot; GLOBAL: the image in L2, cooperative tail pass).  The fragment's 8 values of a chunk are split
+// right before the chunk's 24 MFMAs (the next chunk's under the current one's); weight planes rotate through 12 registers.
+template <int D, bool ZERO, bool GLOBAL, int part>
+__device__ __forceinline__ void panel_part_mma_split(f32x4 (&acc)[4], const Frag<D>& a, const float* chunks, int li, int kq) {
+    using C = PanelGruSplitCfg<D>;
+    constexpr int NU = C::CP * 4;
+    const unsigned voff = (unsigned)(kq * 64 + li) * 16u;
+    const unsigned long long gb = reinterpret_cast<unsigned long long>(chunks);
+    const float* sbase = chunks;
+    if constexpr (GLOBAL) {     // wave-uniform base in scalar registers + one 32-bit per-lane offset (see panel_mma_global)
+        const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gb), ghi = __builtin_amdgcn_readfirstlane((unsigned)(gb >> 32));
+        sbase = reinterpret_cast<const float*>(((unsigned long long)ghi << 32) | glo);
+    }
+    auto slot = [&](int u, int p) -> u32x4 {                        // unit u = (chunk cc, tile j), plane p
+        const unsigned off = voff + (unsigned)((((u / 4) * 3 + p) * 4) * 64 + (u % 4) * 16) * 16u;
+        if constexpr (GLOBAL) return __builtin_bit_cast(u32x4, ld4_b(sbase, off));
+        else return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(chunks) + off);
+    };
+    u32x4 ah, am, al;
+    u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int cc = u / 4, j = u % 4;
+        const bool more = u + 1 < NU;
+        if (j == 0) frag_planes(a.v[2 * (part * C::CP + cc)], a.v[2 * (part * C::CP + cc) + 1], ah, am, al);
+        f32x4 c = (ZERO && cc == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j];
+        c = mfma_bf16(wl, ah, c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wl = slot(u + 1, 2);
+        c = mfma_bf16(wm, am, c);
+        c = mfma_bf16(wm, ah, c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wm = slot(u + 1, 1);
+        c = mfma_bf16(wh, al, c);
+        c = mfma_bf16(wh, am, c);
+        c = mfma_bf16(wh, ah, c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wh = slot(u + 1, 0);
+        acc[j] = c;
+    }
+}
+
 // acc[0..3] (+)= fragment x panel image: per k chunk 4 ds_read_b128 feed 16 MFMAs; one chunk of read-ahead
 template <int D, bool ZERO>
 __device__ __forceinline__ void panel_mma(f32x4 (&acc)[4], const Frag<D>& a, const float* img, int li, int kq) {
@@ -205,7 +290,7 @@ __device__ __forceinline__ void dma_block(const float* src, float* dst, int wave
 //   phase UC:  p < NP:  for s < NX: U (Wg rows s, cols D + 64p ..), C (Wc rows s, cols 64p ..);  U (Wg rows h);  C (Wc rows h = r*h)
 __host__ __device__ constexpr int panel_gru_images(int D, int nx) { return 3 * (nx + 1) * (D / 64); }
 
-template <int D>
+template <int D, bool SPLIT>
 __global__ void gru_panel_pack_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx, float* __restrict__ out) {
     using C = PanelCfg<D>;
     const int ns = nx + 1, NP = C::NP;
@@ -218,12 +303,19 @@ __global__ void gru_panel_pack_kernel(const float* __restrict__ Wg, const float*
         if (q % 2 == 0) { W = Wg; r0 = s * D; c0 = D + p * C::BN; ldw = 2 * D; }
         else { W = Wc; r0 = s * D; c0 = p * C::BN; ldw = D; }
     }
-    pack_panel_image<D>(W, r0, c0, ldw, out + (size_t)i * C::IMG, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    const int first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if constexpr (SPLIT) pack_panel_gru_split_image<D>(W, r0, c0, ldw, out + (size_t)i * PanelGruSplitCfg<D>::IMG, first, stride);
+    else pack_panel_image<D>(W, r0, c0, ldw, out + (size_t)i * C::IMG, first, stride);
 }
 
-template <int D, int NX, int NW, bool SAVE>
+// SPLIT: the products on the bf16 pipe in 3-way split form; an image comes through the ring in PanelGruSplitCfg::PARTS parts.
+template <int D, int NX, int NW, bool SAVE, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a, const float* __restrict__ packed) {
     using C = PanelCfg<D>;
+    using SC = PanelGruSplitCfg<D>;
+    constexpr int IMGF = SPLIT ? SC::IMG : C::IMG;                   // floats per image in `packed`
+    constexpr int SLOTF = SPLIT ? SC::PART : C::IMG;                 // floats per ring slot
+    constexpr int PARTS = SPLIT ? SC::PARTS : 1;
     constexpr int NP = C::NP, NC = C::NC, NS = NX + 1;
     constexpr int NSTAGE = 3 * NS * NP;
     constexpr int R_STAGES = NS * NP;
@@ -266,11 +358,16 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
     };
 
     int cur = 0;
-    dma_block<C::IMG_BYTES, NW>(packed, ring, wave, lane);
+    auto dma = [&](const float* src, float* dst) {
+        if constexpr (SPLIT) dma_image_asm<SC::PART_BYTES, NW>(src, dst, wave, lane);
+        else dma_block<C::IMG_BYTES, NW>(src, dst, wave, lane);
+    };
+    auto publish = [&]() { if constexpr (SPLIT) dma_wait(); __syncthreads(); };
+    dma(packed, ring);
     Frag<D> af;                                // the ONE resident activation fragment (segment of the current stage)
     int tk = blockIdx.x;
     if (tk < n_main) load_frag<D>(af, a.x[0], row_of(tk), kq);
-    __syncthreads();
+    publish();
 
     for (; tk < n_main; tk += nb) {
         const int tile = tile_of(tk);
@@ -290,16 +387,28 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
             auto stage = [&](auto zero_c, f32x4 (&acc)[4], const Frag<D>& A, int img_idx, auto&& after) {
                 const int nidx = img_idx + 1 < NSTAGE ? img_idx + 1 : 0;
                 const bool more = (img_idx + 1 < NSTAGE) || !last_pass;
-                const float* nsrc = packed + (size_t)nidx * C::IMG;
-                float* ndst = ring + (cur ^ 1) * C::IMG;
-                if (late && more) dma_block<C::IMG_BYTES, NW>(nsrc, ndst, wave, lane);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (ACT) panel_mma<D, decltype(zero_c)::value>(acc, A, ring + cur * C::IMG, li, kq);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!late && more) dma_block<C::IMG_BYTES, NW>(nsrc, ndst, wave, lane);
-                if constexpr (ACT) after();
-                __syncthreads();
-                cur ^= 1;
+                auto round = [&](auto part_c) {
+                    constexpr int part = decltype(part_c)::value;
+                    // what the ring's other slot receives during this round: the next part of this image, or the first of the next
+                    const bool more_p = part + 1 < PARTS || more;
+                    const float* nsrc = part + 1 < PARTS ? packed + (size_t)img_idx * IMGF + (size_t)(part + 1) * SLOTF
+                                                         : packed + (size_t)nidx * IMGF;
+                    float* ndst = ring + (cur ^ 1) * SLOTF;
+                    if (late && more_p) dma(nsrc, ndst);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (ACT) {
+                        if constexpr (SPLIT) panel_part_mma_split<D, decltype(zero_c)::value && part == 0, false, part>(acc, A, ring + cur * SLOTF, li, kq);
+                        else panel_mma<D, decltype(zero_c)::value>(acc, A, ring + cur * SLOTF, li, kq);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!late && more_p) dma(nsrc, ndst);
+                    if constexpr (ACT) { if constexpr (part == PARTS - 1) after(); }
+                    publish();
+                    cur ^= 1;
+                };
+                round(std::integral_constant<int, 0>{});
+                if constexpr (PARTS > 1) round(std::integral_constant<int, 1>{});
+                if constexpr (PARTS > 2) round(std::integral_constant<int, 2>{});
             };
             auto nothing = [] {};
 
@@ -392,7 +501,14 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
         const int p = wave;                                     // this wave's panel
         const bool on = p < NP;
         float* rh_x = ring;
-        auto gimg = [&](int img_idx) { return packed + (size_t)img_idx * C::IMG; };
+        auto gimg = [&](int img_idx) { return packed + (size_t)img_idx * IMGF; };
+        auto gmma = [&](auto zero_c, f32x4 (&acc)[4], const Frag<D>& A, const float* img) {     // whole image, straight from L2
+            if constexpr (SPLIT) {
+                panel_part_mma_split<D, decltype(zero_c)::value, true, 0>(acc, A, img, li, kq);
+                if constexpr (SC::PARTS > 1) panel_part_mma_split<D, false, true, 1>(acc, A, img + (size_t)SC::PART, li, kq);
+                if constexpr (SC::PARTS > 2) panel_part_mma_split<D, false, true, 2>(acc, A, img + (size_t)2 * SC::PART, li, kq);
+            } else panel_mma_global<D, decltype(zero_c)::value>(acc, A, img, li, kq);
+        };
         Frag<D> rh;
         f32x4 accr[4];
         if (on) {
@@ -400,7 +516,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
 #define GGNN_CR_STAGE(S)                                                                                            \
             if constexpr ((S) < NS) {                                                                               \
                 load_frag<D>(af, (S) < NX ? a.x[(S) < NX ? (S) : 0] : a.h, rowc, kq);                               \
-                panel_mma_global<D, (S) == 0>(accr, af, gimg((S) * NP + p), li, kq);                                \
+                gmma(std::integral_constant<bool, (S) == 0>{}, accr, af, gimg((S) * NP + p));                       \
             }
             GGNN_CR_STAGE(0) GGNN_CR_STAGE(1) GGNN_CR_STAGE(2) GGNN_CR_STAGE(3)
 #undef GGNN_CR_STAGE
@@ -423,14 +539,14 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
 #define GGNN_CX_STAGES(S)                                                                                           \
             if constexpr ((S) < NX) {                                                                               \
                 load_frag<D>(af, a.x[(S)], rowc, kq);                                                               \
-                panel_mma_global<D, (S) == 0>(acc_u, af, gimg(img0 + 2 * (S)), li, kq);                             \
-                panel_mma_global<D, (S) == 0>(acc_c, af, gimg(img0 + 2 * (S) + 1), li, kq);                         \
+                gmma(std::integral_constant<bool, (S) == 0>{}, acc_u, af, gimg(img0 + 2 * (S)));                    \
+                gmma(std::integral_constant<bool, (S) == 0>{}, acc_c, af, gimg(img0 + 2 * (S) + 1));                \
             }
             GGNN_CX_STAGES(0) GGNN_CX_STAGES(1) GGNN_CX_STAGES(2)
 #undef GGNN_CX_STAGES
             load_frag<D>(af, a.h, rowc, kq);
-            panel_mma_global<D, false>(acc_u, af, gimg(img0 + 2 * NX), li, kq);
-            panel_mma_global<D, false>(acc_c, rh, gimg(img0 + 2 * NX + 1), li, kq);
+            gmma(std::false_type{}, acc_u, af, gimg(img0 + 2 * NX));
+            gmma(std::false_type{}, acc_c, rh, gimg(img0 + 2 * NX + 1));
             if (row < a.V) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
@@ -455,27 +571,36 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
     }
 }
 
-template <int D, int NX, bool SAVE>
-static int launch_gru_panel(const GruFusedArgs& a_in, float* packed, hipStream_t st) {
+template <int D, int NX, bool SAVE, bool SPLIT>
+static int launch_gru_panel_m(const GruFusedArgs& a_in, float* packed, hipStream_t st) {
     using C = PanelCfg<D>;
     constexpr int NW = 8;
     GruFusedArgs a = a_in;
     if (a.Wg) {   // raw weights given: build the stage images first
-        hipLaunchKernelGGL((gru_panel_pack_kernel<D>), dim3(8, panel_gru_images(D, NX)), dim3(256), 0, st, a.Wg, a.Wc, NX, packed);
+        hipLaunchKernelGGL((gru_panel_pack_kernel<D, SPLIT>), dim3(8, panel_gru_images(D, NX)), dim3(256), 0, st, a.Wg, a.Wc, NX, packed);
         GGNN_CHECK_HIP(hipGetLastError());
     }
     if (a.h == nullptr) return GGNN_OK;   // pack-only call
     if ((unsigned long long)a.V * D >= (1ULL << 30))
         return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit byte offsets: V*D must be < 2^30 (V=%d, D=%d)", a.V, D);
-    const size_t lds = (size_t)2 * C::IMG_BYTES + (size_t)((4 * D + 63) / 64 * 64) * sizeof(float);
+    // ring: two images (f32) / two parts of an image (split); the cooperative tail's r*h exchange block [16][D + 4] shares it
+    size_t ringb = (size_t)2 * (SPLIT ? PanelGruSplitCfg<D>::PART_BYTES : C::IMG_BYTES);
+    if (ringb < (size_t)16 * (D + 4) * sizeof(float)) ringb = (size_t)16 * (D + 4) * sizeof(float);
+    const size_t lds = ringb + (size_t)((4 * D + 63) / 64 * 64) * sizeof(float);
     const int wt_total = (a.V + 15) / 16;
     int nb = num_cus();
     if (nb > wt_total) nb = wt_total;
     static std::atomic<unsigned long long> lds_ok{0};
-    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_panel_kernel<D, NX, NW, SAVE>, lds, lds_ok));
-    hipLaunchKernelGGL((ggnn_gru_panel_kernel<D, NX, NW, SAVE>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
+    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_panel_kernel<D, NX, NW, SAVE, SPLIT>, lds, lds_ok));
+    hipLaunchKernelGGL((ggnn_gru_panel_kernel<D, NX, NW, SAVE, SPLIT>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
+}
+
+template <int D, int NX, bool SAVE>
+static int launch_gru_panel(const GruFusedArgs& a, float* packed, hipStream_t st) {
+    if (split_matrix_path()) return launch_gru_panel_m<D, NX, SAVE, true>(a, packed, st);
+    return launch_gru_panel_m<D, NX, SAVE, false>(a, packed, st);
 }
 
 template <int D>
@@ -494,7 +619,11 @@ static int dispatch_panel_nx(const GruFusedArgs& a, float* packed, hipStream_t s
 
 int gru_panel_supported(int D) { return D == 128 || D == 192 || D == 256; }
 
-int gru_panel_pack_floats(int D, int nx) { return gru_panel_supported(D) ? panel_gru_images(D, nx) * D * 64 : 0; }
+int gru_panel_pack_floats(int D, int nx) {
+    if (!gru_panel_supported(D)) return 0;
+    const int img = !split_matrix_path() ? D * 64 : (D == 128 ? PanelGruSplitCfg<128>::IMG : (D == 192 ? PanelGruSplitCfg<192>::IMG : PanelGruSplitCfg<256>::IMG));
+    return panel_gru_images(D, nx) * img;
+}
 
 int gru_panel_dispatch(const GruFusedArgs& a, int D, float* packed, hipStream_t st) {
     switch (D) {
