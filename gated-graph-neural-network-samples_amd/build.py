@@ -45,7 +45,7 @@ def _headers():
 # next to bf16 MFMAs of the partner wave a packed-f32 instruction stalls the SIMD for the length of the MFMA stream, a plain
 # v_fma_f32 does not (tools/mfma_overlap.hip -DBF16: 6400 FMAs beside 1600 MFMAs take 59.6k clocks unpacked, 71.7k = the sum packed).
 NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-PER_SOURCE_FLAGS = {"ggnn_gru_fused_split.hip": NO_PACKED_F32, "ggnn_gru_bwd_fused_split.hip": NO_PACKED_F32, "ggnn_msg_compact.hip": NO_PACKED_F32, "ggnn_panel.hip": NO_PACKED_F32}
+PER_SOURCE_FLAGS = {"ggnn_gru_fused_split.hip": NO_PACKED_F32, "ggnn_gru_bwd_fused_split.hip": NO_PACKED_F32, "ggnn_msg_compact.hip": NO_PACKED_F32, "ggnn_panel.hip": NO_PACKED_F32, "ggnn_bwd_gemm.hip": NO_PACKED_F32}
 
 
 def build(force: bool = False, verbose: bool = True) -> str:

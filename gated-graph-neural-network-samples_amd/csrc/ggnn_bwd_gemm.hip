@@ -20,7 +20,7 @@
 // SIMDs differs by at most one tile product (13 x 13 tiles: 43/42/42/42; the earlier one-wave-per-X-tile layout: 52/39/39/39).
 // A wave reads MT + NT <= 8 operand registers for MT * NT <= 16 MFMAs per 4-row step.
 #include "ggnn_gemm.hpp"
-#include "ggnn_stage.hpp"
+#include "ggnn_split.hpp"
 
 namespace ggnn {
 
@@ -280,6 +280,217 @@ __global__ __launch_bounds__(kXtyWaves * 64) void xty_kernel(XtyArgs a) {
 #undef GGNN_XT
 }
 
+
+// ---- X^T dY in 3-way split form (ggnn_split.hpp): both operands are activations, so both are split in flight ----------------------
+// Same slabs (raw f32 rows by LDS-DMA, same pitches), same partial products and reduction as xty_kernel; what differs:
+//   * the contraction step is 32 rows (v_mfma_f32_16x16x32_bf16): lane group g of an operand tile holds rows 4j + g, j = 0..7, of
+//     the step -- for a fixed j the four groups read four consecutive rows: the bank pattern of the f32 kernel's 4-row steps;
+//   * a tile's 8 values per lane are split into three bf16 planes in registers (44 vector instructions per tile and step) and a
+//     tile PAIR takes 6 MFMAs of 16 clocks where the f32 kernel issues 8 of 32 clocks;
+//   * 8 waves of 256 registers instead of 16 of 128: wave w owns X group w >> 1 (<= MTM tiles; its planes are split once per
+//     step and stay resident, 48 registers) and TWO dY groups, (w >> 1) + 2 (w & 1) and the next one (mod 4) (<= 2 NTM tiles,
+//     split tile by tile): <= 28 tile pairs = 112 accumulator registers.  Every (X group, dY group) pair exactly once; the two
+//     waves of a SIMD (w, w + 4) carry 46 / 45 / 39 / 39 pairs at 13 x 13 tiles.
+//   * the slab DMA goes out through inline assembly (the compiler does not see an LDS-DMA in flight, see dma_image_asm) and is
+//     waited for explicitly before the barrier that publishes the slab.
+constexpr int kXtySplitWaves = 8;
+constexpr int kXtySplitMaxI = 8;
+
+template <bool GATHER, int ROWS, int MTM, int NTM>
+__global__ __launch_bounds__(kXtySplitWaves * 64) void xty_split_kernel(XtyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float slab[];     // [2][ROWS][pitch_x] | [2][ROWS][pitch_y]
+    constexpr int nw = kXtySplitWaves;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    int batch = 0;
+    while (batch + 1 < a.nbatch && (int)blockIdx.y >= a.wg_off[batch + 1]) ++batch;
+    const int split = (int)blockIdx.y - a.wg_off[batch], splits = a.wg_off[batch + 1] - a.wg_off[batch];
+    const int rb = a.row_off[batch], re = a.row_off[batch + 1];
+    int rows_per = (re - rb + splits - 1) / splits;
+    rows_per = (rows_per + ROWS - 1) / ROWS * ROWS;
+    const int r_beg = rb + split * rows_per;
+    const int r_end = min(re, r_beg + rows_per);
+    const int kcol0 = blockIdx.x * a.kb_tiles * 16;
+    const int px = a.pitch_x, py = a.pitch_y;
+    float* sx = slab;
+    float* sy = slab + 2 * ROWS * px;
+    float* out = a.part + (size_t)blockIdx.y * a.Kout * a.N;
+
+    // this wave's tile groups
+    int kt0, my_mt, nta0, cnta, ntb0, cntb;
+    xty_group(a.kb_tiles, wave >> 1, kt0, my_mt);
+    const int ga = ((wave >> 1) + 2 * (wave & 1)) & 3;
+    xty_group(a.n_tiles, ga, nta0, cnta);
+    xty_group(a.n_tiles, (ga + 1) & 3, ntb0, cntb);
+    const int my_nt = cnta + cntb;
+
+    // ---- per-lane decode of the DMA chunks (as xty_kernel, 8 waves) --------------------------------------------------------------
+    constexpr int MAXI = kXtySplitMaxI;
+    const int cprx = px / 4, cpry = py / 4;
+    const int nix = ROWS * cprx / 64, niy = ROWS * cpry / 64;
+    unsigned mx[MAXI], my[MAXI];
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+        const int ix = j * nw + wave;
+        mx[j] = 0x80000000u; my[j] = 0x80000000u;
+        if (ix < nix) {
+            const int c = ix * 64 + lane, row = c / cprx, q = c - row * cprx;
+            int col = kcol0 + 4 * q;
+            const bool ones = a.Kout > a.K && col == a.K && 4 * q < a.kb_tiles * 16;
+            if (!(4 * q < a.kb_tiles * 16 && col < a.K)) col = 0;
+            const int seg = col / a.Dseg, within = col - seg * a.Dseg;
+            mx[j] = (unsigned)within | ((unsigned)seg << 16) | ((unsigned)row << 18) | (ones ? 0x40000000u : 0u);
+        }
+        if (ix < niy) {
+            const int c = ix * 64 + lane, row = c / cpry, q = c - row * cpry;
+            my[j] = (unsigned)(4 * q < a.N ? 4 * q : 0) | ((unsigned)row << 18);
+        }
+    }
+    auto xrow = [&](int r0, unsigned m) __attribute__((always_inline)) -> int {
+        int r = r0 + (int)((m >> 18) & 127u); r = r < r_end ? r : r_end - 1;
+        return r;
+    };
+    int rid[GATHER ? MAXI : 1];
+    auto fetch_rows = [&](int r0) __attribute__((always_inline)) {
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int j = 0; j < MAXI; ++j) rid[j] = (mx[j] >> 31) ? 0 : a.x_rows[xrow(r0 < r_end ? r0 : r_beg, mx[j])];
+        }
+    };
+    auto sgpr_ptr = [](const float* p) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
+    const float* X0 = sgpr_ptr(a.X[0]); const float* X1 = sgpr_ptr(a.X[1]);
+    const float* X2 = sgpr_ptr(a.X[2]); const float* X3 = sgpr_ptr(a.X[3]);
+    const int L0 = __builtin_amdgcn_readfirstlane(a.ldx[0]), L1 = __builtin_amdgcn_readfirstlane(a.ldx[1]);
+    const int L2 = __builtin_amdgcn_readfirstlane(a.ldx[2]), L3 = __builtin_amdgcn_readfirstlane(a.ldx[3]);
+    const float* Yb = sgpr_ptr(a.Y);
+    const int ldy = __builtin_amdgcn_readfirstlane(a.ldy);
+    // one 1-KiB LDS-DMA instruction with per-lane source addresses, through inline assembly (M0 = the wave's LDS destination)
+    auto dma1 = [&](const float* src, float* dst) __attribute__((always_inline)) {
+        const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void*)dst);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(l), "v"(src) : "memory");
+    };
+    auto issue = [&](int buf, int r0) __attribute__((always_inline)) {                             // uses rid[] (fetched one slab ahead)
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) {
+            if (!(mx[j] >> 31)) {
+                const unsigned m = mx[j];
+                const int seg = (int)((m >> 16) & 3u);
+                const float* xb = seg == 0 ? X0 : (seg == 1 ? X1 : (seg == 2 ? X2 : X3));
+                const int xl = seg == 0 ? L0 : (seg == 1 ? L1 : (seg == 2 ? L2 : L3));
+                const int xr = GATHER ? rid[GATHER ? j : 0] : xrow(r0, m);
+                const float* src = xb + (size_t)xr * xl + (m & 0xFFFFu);
+                if (m & 0x40000000u) src = kXtyOnesChunk;
+                if (r0 + (int)((m >> 18) & 127u) >= r_end) src = kXtyZeroChunk;
+                dma1(src, sx + buf * ROWS * px + (size_t)(j * nw + wave) * 256);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) {
+            if (!(my[j] >> 31)) {
+                const unsigned m = my[j];
+                int r = r0 + (int)((m >> 18) & 127u); r = r < r_end ? r : r_end - 1;
+                dma1(Yb + (size_t)r * ldy + (m & 0xFFFFu), sy + buf * ROWS * py + (size_t)(j * nw + wave) * 256);
+            }
+        }
+    };
+
+    // the slab loop, instantiated per (X tiles, dY tiles) of a wave and selected once (see xty_kernel)
+    auto run = [&](auto mt_c, auto nt_c) __attribute__((always_inline)) {
+        constexpr int MT = decltype(mt_c)::value, NT = decltype(nt_c)::value;
+        constexpr bool ON = MT > 0 && NT > 0;
+        f32x4 acc[ON ? MT : 1][ON ? NT : 1];
+#pragma unroll
+        for (int mt = 0; mt < (ON ? MT : 1); ++mt)
+#pragma unroll
+            for (int nt = 0; nt < (ON ? NT : 1); ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // dY tile t of this wave: column offset within the slab row
+        auto ycol = [&](int t) __attribute__((always_inline)) { return (t < cnta ? nta0 + t : ntb0 + (t - cnta)) * 16; };
+        if (r_beg < r_end) {
+            int buf = 0;
+            fetch_rows(r_beg);
+            issue(0, r_beg);
+            fetch_rows(r_beg + ROWS);
+            dma_wait();
+            __syncthreads();
+            for (int r0 = r_beg; r0 < r_end; r0 += ROWS) {
+                const bool has_next = r0 + ROWS < r_end;
+                if (has_next) { issue(buf ^ 1, r0 + ROWS); fetch_rows(r0 + 2 * ROWS); }
+                if constexpr (ON) {
+                    const float* bx = sx + buf * ROWS * px + kt0 * 16 + li;
+                    const float* by = sy + buf * ROWS * py + li;
+                    // 8 values of a tile column (rows 32 s + 4 j + kq) -> planes
+                    auto tile_planes = [&](const float* col, int pitch, int s, u32x4& hi, u32x4& mid, u32x4& lo) __attribute__((always_inline)) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = col[(size_t)(32 * s + 4 * j + kq) * pitch];
+                        unsigned h[4], m[4], l[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) split_pair(v[2 * q], v[2 * q + 1], h[q], m[q], l[q]);
+                        hi = u32x4{h[0], h[1], h[2], h[3]}; mid = u32x4{m[0], m[1], m[2], m[3]}; lo = u32x4{l[0], l[1], l[2], l[3]};
+                    };
+#pragma unroll
+                    for (int s = 0; s < ROWS / 32; ++s) {
+                        u32x4 xh[MT], xm[MT], xl[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) tile_planes(bx + mt * 16, px, s, xh[mt], xm[mt], xl[mt]);
+                        // dY tile nt+1 is read and split while the 6 MT MFMAs of tile nt issue: no fence between the two, the
+                        // scheduler interleaves the vector instructions with the (long-latency) MFMAs; one fence per tile
+                        u32x4 yh, ym, yl, zh, zm, zl;
+                        tile_planes(by + ycol(0), py, s, yh, ym, yl);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (nt + 1 < NT) tile_planes(by + ycol(nt + 1), py, s, zh, zm, zl);
+                            // six products per tile pair, product-major over the X tiles (consecutive MFMAs hit different accumulators)
+#define GGNN_XS(XP, YP) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(XP[mt], YP, acc[mt][nt]);
+                            GGNN_XS(xl, yh) GGNN_XS(xm, ym) GGNN_XS(xm, yh) GGNN_XS(xh, yl) GGNN_XS(xh, ym) GGNN_XS(xh, yh)
+#undef GGNN_XS
+                            yh = zh; ym = zm; yl = zl;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                dma_wait();
+                __syncthreads();                                          // slab[buf] consumed by all waves, slab[buf^1] landed
+                buf ^= 1;
+            }
+        }
+        if constexpr (ON) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int k0 = kcol0 + (kt0 + mt) * 16;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = ycol(nt) + li;
+                    if (n < a.N) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = k0 + 4 * kq + e;
+                            if (k < a.Kout) out[(size_t)k * a.N + n] = acc[mt][nt][e];
+                        }
+                    }
+                }
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IM = std::integral_constant<int, MTM>; using IM1 = std::integral_constant<int, MTM - 1>;
+    using IN = std::integral_constant<int, 2 * NTM>; using IN1 = std::integral_constant<int, 2 * NTM - 1>;
+    using IN2 = std::integral_constant<int, 2 * NTM - 2>;
+    if (my_mt == MTM && my_nt == 2 * NTM) run(IM{}, IN{});
+    else if (my_mt == MTM && my_nt == 2 * NTM - 1) run(IM{}, IN1{});
+    else if (my_mt == MTM && my_nt == 2 * NTM - 2) run(IM{}, IN2{});
+    else if (my_mt == MTM - 1 && my_nt == 2 * NTM) run(IM1{}, IN{});
+    else if (my_mt == MTM - 1 && my_nt == 2 * NTM - 1) run(IM1{}, IN1{});
+    else if (my_mt == MTM - 1 && my_nt == 2 * NTM - 2) run(IM1{}, IN2{});
+    else run(I0{}, I0{});
+}
+
 // C[b][i] = sum over the workgroup rows of batch b of part[row][i], in row order.  With a separate bias destination the K weight rows
 // go to C [nbatch][K][N] and the ones row to Cb [nbatch][N]; accumulate: the sums are ADDED to what the destinations hold (the
 // gradient buffers of the training step: one launch less per product, and no torch add on the side stream).
@@ -358,6 +569,23 @@ static int launch_xty(const XtyArgs& a, const XtyPlan& p, float* C, float* Cb, i
     if (p.wg_rows > 0) {
         if (p.lds > 64 * 1024) GGNN_CHECK_HIP((allow_dynamic_lds(&xty_kernel<GATHER, ROWS, MTM, NTM>, p.lds, lds_ok)));
         hipLaunchKernelGGL((xty_kernel<GATHER, ROWS, MTM, NTM>), dim3(p.kblocks, p.wg_rows), dim3(kXtyWaves * 64), p.lds, st, a);
+        GGNN_CHECK_HIP(hipGetLastError());
+    }
+    XtyReduceArgs ra;
+    for (int b = 0; b <= kXtyMaxBatch; ++b) ra.wg_off[b] = a.wg_off[b <= a.nbatch ? b : a.nbatch];
+    const long long total = (long long)a.Kout * a.N * a.nbatch;
+    hipLaunchKernelGGL(xty_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, (const float*)a.part, C, Cb, a.Kout * a.N,
+                       a.K * a.N, a.nbatch, accumulate, ra);
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+template <bool GATHER, int ROWS, int MTM, int NTM>
+static int launch_xty_split(const XtyArgs& a, const XtyPlan& p, float* C, float* Cb, int accumulate, hipStream_t st) {
+    static std::atomic<unsigned long long> lds_ok{0};
+    if (p.wg_rows > 0) {
+        if (p.lds > 64 * 1024) GGNN_CHECK_HIP((allow_dynamic_lds(&xty_split_kernel<GATHER, ROWS, MTM, NTM>, p.lds, lds_ok)));
+        hipLaunchKernelGGL((xty_split_kernel<GATHER, ROWS, MTM, NTM>), dim3(p.kblocks, p.wg_rows), dim3(kXtySplitWaves * 64), p.lds, st, a);
         GGNN_CHECK_HIP(hipGetLastError());
     }
     XtyReduceArgs ra;
@@ -462,6 +690,17 @@ extern "C" int ggnn_xty_acc_f32(const float* const* x_segs, int nseg, int Dseg, 
         return fail(GGNN_E_UNSUPPORTED, "xty: slab too wide (K=%d N=%d)", K, N);
     const int mtm = (p.kb_tiles + 3) / 4, ntm = (p.n_tiles + 3) / 4;
     const bool g = x_rows != nullptr;
+    // split form (K0): the shapes of the training step at D = 100 (the others stay on the f32 kernel); the tile groups of a
+    // wave must come out as (MTM or MTM-1) x (2 NTM .. 2 NTM - 2) tiles: true whenever no group is empty
+    static const bool xty_split = [] { const char* e = getenv("GGNN_XTY_SPLIT"); return !e || atoi(e) != 0; }();
+    if (split_matrix_path() && xty_split && p.kb_tiles >= 4 && p.n_tiles >= 4 && (p.rows * p.px / 256 + kXtySplitWaves - 1) / kXtySplitWaves <= kXtySplitMaxI &&
+        (p.rows * p.py / 256 + kXtySplitWaves - 1) / kXtySplitWaves <= kXtySplitMaxI) {
+#define GGNN_XTYS_CASE(G, R, M, Nn) if (g == G && p.rows == R && mtm == M && ntm == Nn) return launch_xty_split<G, R, M, Nn>(a, p, C, Cb, accumulate, st);
+        GGNN_XTYS_CASE(false, 32, 4, 4) GGNN_XTYS_CASE(false, 32, 3, 4) GGNN_XTYS_CASE(false, 64, 4, 2) GGNN_XTYS_CASE(false, 64, 3, 2)
+        // (the row-gathered edge-weight products, 2 x 2 tile groups per wave, measure slower in split form -- 52 vs 48 us: with so
+        //  few tile pairs per operand tile the split work is not amortised -- and stay on the f32 kernel)
+#undef GGNN_XTYS_CASE
+    }
 #define GGNN_XTY_CASE(G, R, M, Nn) if (g == G && p.rows == R && mtm == M && ntm == Nn) return launch_xty<G, R, M, Nn>(a, p, C, Cb, accumulate, st);
 #define GGNN_XTY_ROW32(M) GGNN_XTY_CASE(false, 32, M, 1) GGNN_XTY_CASE(false, 32, M, 2) GGNN_XTY_CASE(false, 32, M, 3) GGNN_XTY_CASE(false, 32, M, 4)
     GGNN_XTY_ROW32(1) GGNN_XTY_ROW32(2) GGNN_XTY_ROW32(3) GGNN_XTY_ROW32(4)
