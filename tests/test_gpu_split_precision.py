@@ -45,3 +45,27 @@ def test_split_products_are_as_accurate_as_f32_mfma(cuda):
         assert f32[key]["max_rel_to_sum_abs"] < 4e-7, (key, f32[key])
     for key in ("D100_nx1", "D100_nx3", "D64_nx2", "D32_nx1"):
         assert split[key]["h_max"] < 3e-6 and split[key]["c_max"] < 4e-6, (key, split[key])
+
+
+def test_power_of_two_scaling_commutes_bitwise(pkg, cuda):
+    """A power-of-two rescaling of the operands moves exponents only: h 2^k and W 2^-k must give bit-identical products in either
+    matrix path -- on the split path this pins the exponent handling of the bf16 pieces (truncation split, exact residuals, bf16's
+    f32 exponent range) on the hardware, far from the magnitudes the model's states live at."""
+    import numpy as np
+    import torch
+    ops = pkg.ops
+    V, D, T = 4000, 100, 4
+    g = torch.Generator(device="cpu").manual_seed(3)
+    h = torch.rand(V, D, generator=g) * 2 - 1
+    W = (torch.rand(T, D, D, generator=g) * 2 - 1) * 0.3
+    src = torch.randint(0, V, (3 * V,), generator=g); tgt = torch.randint(0, V, (3 * V,), generator=g)
+    adj = [torch.stack([src[t::T], tgt[t::T]], 1).to(torch.int32).to(cuda) for t in range(T)]
+    comp = ops.build_compact_sources(ops.build_message_index(adj, V))
+    base = ops.msg_transform_compact(h.to(cuda), W.to(cuda), comp)[:comp.num_rows].clone()
+    for k in (40, -40, 90):
+        got = ops.msg_transform_compact((h * 2.0 ** k).to(cuda), (W * 2.0 ** -k).to(cuda), comp)[:comp.num_rows]
+        assert torch.equal(got, base), k
+    # and linearity in the rows: a row scaled by 2^k scales its product by 2^k
+    got = ops.msg_transform_compact((h * 2.0 ** 20).to(cuda), W.to(cuda), comp)[:comp.num_rows]
+    assert torch.equal(got, base * 2.0 ** 20)
+    assert np.isfinite(base.cpu().numpy()).all()
