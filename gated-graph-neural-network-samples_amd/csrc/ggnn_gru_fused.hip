@@ -31,6 +31,16 @@
 #ifndef GGNN_COOP_DEPTH
 #define GGNN_COOP_DEPTH 1
 #endif
+// The s_memtime stamps behind GGNN_GRU_TPTR (tools/gru_timeline.py) cost scalar registers and branches in the hot loop -- 20 B of
+// the split R >= 1 kernels' scratch: compiled in only with -DGGNN_GRU_STAMPS=1 (tools/variant_lib.sh builds such a library).
+#ifndef GGNN_GRU_STAMPS
+#define GGNN_GRU_STAMPS 0
+#endif
+#if GGNN_GRU_STAMPS
+#define GGNN_TDBG(a) (a).tdbg
+#else
+#define GGNN_TDBG(a) ((unsigned long long*)nullptr)
+#endif
 
 namespace ggnn {
 
@@ -110,7 +120,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
-    if (a.tdbg && tid == 0) {   // debug: per-workgroup [start, end] in shader-clock and 100 MHz real-time ticks
+    if (GGNN_TDBG(a) && tid == 0) {   // debug: per-workgroup [start, end] in shader-clock and 100 MHz real-time ticks
         a.tdbg[4096 + blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
         a.tdbg[4096 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
@@ -327,7 +337,11 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             if constexpr (POS == NSTAGE - 1 && !(GATHER && GSEG == 0)) load_frag<D>(xf[0], a.x[0], rown, kq);
         };
 
+#if GGNN_GRU_STAMPS
 #define GGNN_T(CI, K) if (a.tdbg && blockIdx.x == 0 && lane == 0) a.tdbg[((p * NSTAGE + (CI)) * NW + wave) * 4 + (K)] = __builtin_amdgcn_s_memtime();
+#else
+#define GGNN_T(CI, K)
+#endif
         // one stage: prefetches, start the DMA of the next image, MFMAs on the current one, publish
         // Cooperative tail pass: no ring, no per-stage barrier.  Wave w multiplies by column tile w only, whose weights
         // (1/NT of the image) it reads from the image in global memory into registers TWD stages ahead.
@@ -574,7 +588,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     int p = 0;
     for (; tk < n_main; ++p) run_pass(std::false_type{}, p);
     for (; tk < n_tk; ++p) run_pass(std::true_type{}, p);
-    if (a.tdbg && tid == 0) {
+    if (GGNN_TDBG(a) && tid == 0) {
         a.tdbg[4096 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
         a.tdbg[4096 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }

@@ -1,5 +1,7 @@
 """Per-stage s_memtime timeline of workgroup 0 of the fused GRU + per-workgroup start/end stamps (debug
-instrumentation behind GGNN_GRU_TPTR; not part of the product path).   python tools/gru_timeline.py [nx]"""
+instrumentation behind GGNN_GRU_TPTR; not part of the product path: the stamps are compiled in only with -DGGNN_GRU_STAMPS=1).
+    bash tools/variant_lib.sh tl ggnn_gru_fused.hip,ggnn_gru_fused_split.hip -DGGNN_GRU_STAMPS=1
+    GGNN_LIB_VARIANT=tl python tools/gru_timeline.py [nx]"""
 import importlib, os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("gated-graph-neural-network-samples_amd")
