@@ -44,7 +44,9 @@ def _headers():
 # Kernels on the bf16 matrix pipe are compiled WITHOUT packed-f32 vector instructions (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32):
 # next to bf16 MFMAs of the partner wave a packed-f32 instruction stalls the SIMD for the length of the MFMA stream, a plain
 # v_fma_f32 does not (tools/mfma_overlap.hip -DBF16: 6400 FMAs beside 1600 MFMAs take 59.6k clocks unpacked, 71.7k = the sum packed).
-NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+# ... and with the AMDGPU register-pressure trackers in the machine scheduler: at the 256-register limit these kernels sit at, the
+# default scheduler's pressure estimate costs 8-70 B of scratch per lane more (split fused GRU R = 1: 8 -> 0 B; panel GRU 228 -> 156 B).
+NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
 PER_SOURCE_FLAGS = {"ggnn_gru_fused_split.hip": NO_PACKED_F32, "ggnn_gru_bwd_fused_split.hip": NO_PACKED_F32, "ggnn_msg_compact.hip": NO_PACKED_F32, "ggnn_panel.hip": NO_PACKED_F32, "ggnn_bwd_gemm.hip": NO_PACKED_F32}
 
 

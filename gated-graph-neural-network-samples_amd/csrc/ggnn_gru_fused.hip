@@ -109,7 +109,10 @@ __device__ __forceinline__ void frag_add(Frag<D>& f, const Frag<D>& t) {
 // for it (only slots beyond the pipelined depth, 4 per row = the largest valence in QM9, are fetched synchronously).
 // SPLIT: the products run on the bf16 matrix pipe in 3-way split form (ggnn_split.hpp) -- same stages, same fragments, same
 // accumulators; the stage images are the split ones and every activation fragment is split in registers before its first stage.
-template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT>
+// SAVEX: the gathered segment is stored too (save_x; training).  The split-form inference dispatch runs <SAVE = true, SAVEX =
+// false>: the instantiation with the r / u / c stores (skipped at run time) but without the save_x path comes out of the register
+// allocator with the least scratch (R = 1 / 2: 8 / 36 B; with it 28 / 40 B; SAVE = false: 164 / 196 B).
+template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE>
 __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a, const float* __restrict__ packed) {
     using C = StageCfg<D>;
     using I = ImgCfg<D, SPLIT>;
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             if constexpr (G_NEXT) {
                 g_ptrs(r0c, on);
                 if (on) { g_index(); g_rows0(xf[0]); g_rows(xf[0], 2); g_rows(xf[0], 3); g_finish(xf[0]); }
-                if constexpr (SAVE) { if (on && r0 < a.V && a.save_x) store_x(xf[0], r0); }
+                if constexpr (SAVEX) { if (on && r0 < a.V && a.save_x) store_x(xf[0], r0); }
             } else {
                 if constexpr (G_U - 5 < 0) g_ptrs(r0c, on);
                 if constexpr (G_U - 4 < 0) g_index();         // (also for a wave without a tile: its slots -> row 0)
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         {                                                                                                \
             GGNN_T(POS, 0)                                                                               \
             if constexpr (GATHER && (POS) == G_U % NSTAGE) {                                             \
-                if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVE) { if (row < a.V && a.save_x) store_x(xf[GBUF], row); } } \
+                if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVEX) { if (row < a.V && a.save_x) store_x(xf[GBUF], row); } } \
             }                                                                                            \
             if constexpr ((POS) + TWD < NSTAGE) {                                                        \
                 if (wave < NT) load_tile_weights<D>(tw[((POS) + TWD) % (TWD + 1)],                       \
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             float* ndst_ = ring + (cur ^ 1) * I::IMG;                                                    \
             GGNN_T(POS, 0)                                                                               \
             if constexpr (GATHER && (POS) == G_U % NSTAGE) {   /* the fragment this stage multiplies */  \
-                if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVE) { if (row < a.V && a.save_x) store_x(xf[GBUF], row); } } \
+                if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVEX) { if (row < a.V && a.save_x) store_x(xf[GBUF], row); } } \
             }                                                                                            \
             /* Side work of the stage (prefetches, the DMA of the whole next image): the LATE waves do it  \
                before their MFMA burst, the EARLY waves after theirs, so its memory instructions issue      \
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     }
 }
 
-template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT>
+template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE>
 static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream_t st) {
     using C = StageCfg<D>;
     using I = ImgCfg<D, SPLIT>;
@@ -623,8 +626,8 @@ static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream
     static const int coop_small = [] { const char* e = getenv("GGNN_GRU_COOP_SMALL"); return e ? atoi(e) : 1; }();
     if (coop_small && wt_total > nb && wt_total <= 2 * nb && StageCfg<D>::NT <= NW) nb = wt_total;
     static std::atomic<unsigned long long> lds_ok{0};        // (one per template instantiation)
-    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT>, lds, lds_ok));
-    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
+    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX>, lds, lds_ok));
+    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
@@ -637,9 +640,11 @@ static int split_launch_d(int nx, bool gather, const GruFusedArgs& a, float* pac
     if constexpr (SplitCfg<D>::OK) {
         if (gather) {
             switch (nx) {
-                case 1: return launch_gru_fused_m<D, 1, 8, true, true, true>(a, packed, st);
-                case 2: return launch_gru_fused_m<D, 2, 8, true, true, true>(a, packed, st);
-                case 3: return launch_gru_fused_m<D, 3, 8, true, true, true>(a, packed, st);
+                case 1: return launch_gru_fused_m<D, 1, 8, true, true, true>(a, packed, st);        // (R = 0: no scratch either way)
+                case 2: return a.save_x ? launch_gru_fused_m<D, 2, 8, true, true, true, true>(a, packed, st)
+                                        : launch_gru_fused_m<D, 2, 8, true, true, true, false>(a, packed, st);
+                case 3: return a.save_x ? launch_gru_fused_m<D, 3, 8, true, true, true, true>(a, packed, st)
+                                        : launch_gru_fused_m<D, 3, 8, true, true, true, false>(a, packed, st);
             }
         } else {
             switch (nx) {
@@ -657,7 +662,10 @@ int gru_split_launch(int D, int nx, bool save, bool gather, const GruFusedArgs& 
 #ifndef GGNN_PROBE_SAVE
 #define GGNN_PROBE_SAVE true
 #endif
-    return launch_gru_fused_m<100, GGNN_PROBE_NX, 8, GGNN_PROBE_SAVE, true, true>(a, packed, st);
+#ifndef GGNN_PROBE_SAVEX
+#define GGNN_PROBE_SAVEX GGNN_PROBE_SAVE
+#endif
+    return launch_gru_fused_m<100, GGNN_PROBE_NX, 8, GGNN_PROBE_SAVE, true, true, GGNN_PROBE_SAVEX>(a, packed, st);
 #else
     switch (D) {
         case 100: return split_launch_d<100>(nx, gather, a, packed, st);
