@@ -13,7 +13,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GGNN_LIB_VARIANT=<tag>: load libggnn_hip_<tag>.so (kernel experiments built by tools/variant_lib.sh; never set in production)
 LIB_PATH = os.path.join(_HERE, "libggnn_hip%s.so" % ("_" + os.environ["GGNN_LIB_VARIANT"] if os.environ.get("GGNN_LIB_VARIANT") else ""))
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/ggnn_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {

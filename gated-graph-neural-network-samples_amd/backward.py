@@ -80,10 +80,29 @@ class _WeightGradSink:
         """After the side stream's products have been ordered before the current stream: gradients that were accumulated in
         front of a weight-dropout mask (chem_tensorflow_sparse.py:91: d variable = mask/keep * d masked weights, one mask per layer
         and step) are masked in place, once per variable instead of once per timestep."""
-        for ptr, (keep, seed) in self.masks.items():
-            t = self.targets[ptr]
-            ops.dropout(t, keep, seed, out=t)
+        for ptr, mask in self.masks.items():
+            if mask is not None:                       # (None: the variable's contributions were masked one by one, see defer_mask)
+                t = self.targets[ptr]
+                ops.dropout(t, mask[0], mask[1], out=t)
         self.masks = {}
+
+    def defer_mask(self, ptr, keep, seed) -> bool:
+        """May the contribution about to be added to the buffer of `ptr` stay unmasked until finish()?  Only while every
+        contribution of the step shares ONE (keep, seed): the sparse model draws one mask per layer and step
+        (chem_tensorflow_sparse.py:91), the dense model one per TIMESTEP on the same shared variable
+        (chem_tensorflow_dense.py:104) -- sum_i mask_i * dW_i is not mask * sum_i dW_i.  On the first different mask the pending
+        one is applied to what has accumulated so far (on the side stream, behind the products that wrote it) and the variable
+        switches to per-contribution masking for the rest of the step."""
+        state = self.masks.get(ptr, "unset")
+        mask = (float(keep), int(seed))
+        if state == "unset" or state == mask:
+            self.masks[ptr] = mask
+            return True
+        if state is not None:
+            t = self.targets[ptr]
+            _on_side_stream([], lambda: ops.dropout(t, state[0], state[1], out=t))
+            self.masks[ptr] = None
+        return False
 
     def add(self, ptr, target, value):
         target.add_(value.view_as(target))
@@ -116,10 +135,14 @@ def weight_gradient_sink(targets):
     _SINK.targets, _SINK.used, _SINK.masks = dict(targets), set(), {}
     try:
         yield _SINK
-    finally:
-        if _SINK.masks:
+    except BaseException:
+        _SINK.targets, _SINK.masks = None, {}          # the body's own error is the one to report
+        raise
+    else:
+        pending = any(m is not None for m in _SINK.masks.values())
+        _SINK.targets, _SINK.masks = None, {}
+        if pending:
             raise RuntimeError("weight_gradient_sink left without sink.finish(): masked gradients pending")
-        _SINK.targets = None
 
 
 def _on_side_stream(tensors, fn):
@@ -288,12 +311,15 @@ class PropagationStepFn(torch.autograd.Function):
 
         # ---- 6.-8. segment sum and compacted transform  Hc[r] = h[node(r)] W_type(r)  on the same R rows
         tW = _SINK.target(ctx.var_ptrs[0], ctx.var_shapes[0])
-        dW = transform_backward(ctx.index, ctx.comp, h, W, dinc, dh, sink=None if tW is None else (ctx.var_ptrs[0], tW))
-        if ctx.ew_mask is not None:
-            if tW is not None:
-                _SINK.masks[ctx.var_ptrs[0]] = (float(ctx.ew_mask[0]), int(ctx.ew_mask[1]))      # masked once, in sink.finish()
-            else:
-                dW = ops.dropout(dW.contiguous(), float(ctx.ew_mask[0]), int(ctx.ew_mask[1]))
+        # the raw product may go straight into the sink's buffer when no mask applies, or when the mask can wait for sink.finish()
+        direct = tW is not None and (ctx.ew_mask is None or _SINK.defer_mask(ctx.var_ptrs[0], ctx.ew_mask[0], ctx.ew_mask[1]))
+        dW = transform_backward(ctx.index, ctx.comp, h, W, dinc, dh, sink=(ctx.var_ptrs[0], tW) if direct else None)
+        if ctx.ew_mask is not None and not direct:
+            dW = ops.dropout(dW.contiguous(), float(ctx.ew_mask[0]), int(ctx.ew_mask[1]))
+            if tW is not None:                          # this timestep's own mask (dense model), then into the buffer
+                masked, ptr0 = dW, ctx.var_ptrs[0]
+                _on_side_stream([masked], lambda: _SINK.add(ptr0, tW, masked))
+                dW = None
         return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, None, *d_res)
 
 

@@ -103,7 +103,7 @@ class DeviceMoleculeSet:
         if G == self.host.num_graphs and G and order[0] == 0 and order[-1] == G - 1 and bool((np.diff(order) == 1).all()):
             ident = getattr(self, "_identity_order", None)
             if ident is None:
-                ident = self._identity_order = torch.arange(G, dtype=torch.int64, device=self.device)
+                ident = self._identity_order = self._complete(torch.arange(G, dtype=torch.int64, device=self.device))
             return ident
         if self.device.type != "cuda":
             return torch.from_numpy(order).to(self.device)
@@ -111,26 +111,37 @@ class DeviceMoleculeSet:
         if stage is None or stage[0].numel() < G:
             stage = self._order_stage = (torch.empty(max(G, 1), dtype=torch.int64, pin_memory=True), torch.cuda.Stream(self.device))
         pinned, up = stage
+        up.synchronize()                                 # (the previous epoch's copy out of the staging buffer is long done; cheap)
         pinned[:G].copy_(torch.from_numpy(order))
-        dev_order = torch.empty(G, dtype=torch.int64, device=self.device)
-        # on a stream of its own, so that waiting for the copy waits for nothing else; complete on return (any stream may read it)
+        # On a stream of its own, so that waiting for the copy waits for nothing else; complete on return (any stream may read it).
+        # The block is ALLOCATED under that stream too: the caching allocator then hands out a block of that stream's pool -- one
+        # whose earlier uses were on `up` or were recorded -- never one that kernels still queued on the packing stream read
+        # (round-3 advisor finding).  Readers on other streams record their use (pack_batches_device).
         with torch.cuda.stream(up):
+            dev_order = torch.empty(G, dtype=torch.int64, device=self.device)
             dev_order.copy_(pinned[:G], non_blocking=True)
         up.synchronize()
         return dev_order
+
+    def _complete(self, t: torch.Tensor) -> torch.Tensor:
+        """A cached, never-freed device tensor that ANY stream may read without an event: the stream that fills it is drained once,
+        when the tensor is created (the packing streams read these caches with no ordering behind the creating stream)."""
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+        return t
 
     def arange_i32(self, n: int) -> torch.Tensor:
         """arange(n) int32 on the device, cut from one cached ramp (the identity row list of the backward's compacted transform:
         one launch less per training batch)."""
         ramp = getattr(self, "_ramp", None)
         if ramp is None or ramp.numel() < n:
-            ramp = self._ramp = torch.arange(max(n, 1 << 18), dtype=torch.int32, device=self.device)
+            ramp = self._ramp = self._complete(torch.arange(max(n, 1 << 18), dtype=torch.int32, device=self.device))
         return ramp[:n]
 
     def task_ids_dev(self, task_ids) -> torch.Tensor:
         key = tuple(int(t) for t in task_ids)
         if getattr(self, "_tids", (None, None))[0] != key:
-            self._tids = (key, torch.as_tensor(list(key), dtype=torch.int64, device=self.device))
+            self._tids = (key, self._complete(torch.as_tensor(list(key), dtype=torch.int64, device=self.device)))
         return self._tids[1]
 
     def static_backward_tables(self, num_edge_types: int, tie_fwd_bkwd: bool):
@@ -410,5 +421,7 @@ def pack_batches_device(dms: DeviceMoleculeSet, params: dict, num_edge_types: in
         i = s * world_size + rank
         ids = order[bounds[i]:bounds[i + 1]] if i < nb else np.zeros(0, np.int64)
         ids_dev = order_dev[bounds[i]:bounds[i + 1]] if i < nb else order_dev[:0]
+        if order_dev.is_cuda:
+            order_dev.record_stream(torch.cuda.current_stream(order_dev.device))    # (allocated on the upload stream, read on this one)
         yield pack_batch_device(dms, ids, num_edge_types, params["hidden_size"], params.get("tie_fwd_bkwd", True),
                                 params.get("task_ids", [0]), compact, training, graph_ids_dev=ids_dev)

@@ -551,13 +551,15 @@ class SparseGGNNChemModel(ChemModel):
         cur = torch.cuda.current_stream(self.device)
         for st in pipe[0]:
             st.wait_stream(cur)
-        with torch.no_grad():
-            for feed, st in StreamPrefetcher(gen, self.device, consumer_streams=pipe[0], pack_streams=pipe[1]):
-                with torch.cuda.stream(st):
-                    if feed_hook is not None:
-                        feed_hook(feed)
-                    self.feed(feed)
-                    yield feed, self.compute_final_node_representations(), st
+        # (the generator computes inside no_grad / the consumer stream's context but YIELDS outside them: a suspended generator must not
+        # leave its caller with grad mode off and another stream current -- round-3 advisor finding)
+        for feed, st in StreamPrefetcher(gen, self.device, consumer_streams=pipe[0], pack_streams=pipe[1]):
+            with torch.no_grad(), torch.cuda.stream(st):
+                if feed_hook is not None:
+                    feed_hook(feed)
+                self.feed(feed)
+                states = self.compute_final_node_representations()
+            yield feed, states, st
 
     def evaluate_one_batch(self, data):
         """chem_tensorflow_sparse.py:352-362."""

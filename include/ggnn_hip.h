@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define GGNN_ABI_VERSION 1
+/* Bumped whenever the argument contract of an EXISTING entry point changes (not when symbols are added).
+ *   2: ggnn_assemble_batch takes 11 output pointers (slot heads), ggnn_sparse_propagate_f32 / ggnn_gru_packed_gather_f32 take the
+ *      slot-head table (round 3 changed these while the version still said 1; a caller built against that header must rebuild). */
+#define GGNN_ABI_VERSION 2
 
 #define GGNN_OK 0
 #define GGNN_E_INVALID (-1)      /* bad argument (null pointer, negative size, misalignment) */

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for s in syms:
         assert hasattr(lib, s), "libggnn_hip.so lacks %s" % s
     assert set(syms) == set(pkg._lib.SYMBOLS), "ctypes table and header disagree"
-    assert lib.ggnn_abi_version() == 1
+    assert lib.ggnn_abi_version() == pkg._lib.ABI_VERSION == 2
 
 
 def test_argument_validation_without_gpu(pkg):

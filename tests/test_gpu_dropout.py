@@ -143,3 +143,37 @@ def test_masks_follow_step_and_node_identity(pkg, oracle, cuda):
         model.feed(feed)
         h2 = model.compute_final_node_representations().cpu().numpy()
     assert not np.array_equal(h2 == 0, h == 0)
+
+
+def test_dense_model_weight_dropout_masks_each_timestep(pkg, oracle, cuda, monkeypatch):
+    """Advisor finding (round 3): the dense model trains ONE shared edge-weight variable under a different mask per timestep
+    (chem_tensorflow_dense.py:104).  The gradient sink used to keep a single pending mask per variable and apply the last one
+    registered to the SUM of all timesteps' raw products -- mask_0 * sum_i dW_i instead of sum_i mask_i * dW_i.  Now a second,
+    different mask settles the pending one and the variable's later contributions are masked one by one: the sink's gradient
+    must equal plain autograd's (every product masked where it is formed) to rounding, and the trained weights with it."""
+    ms = pkg.synthetic_qm9(120, mean_nodes=9, seed=3)
+    grads, weights = [], []
+    for side in (True, False):
+        monkeypatch.setattr(pkg.backward, "USE_WGRAD_STREAM", side)
+        model = pkg.DenseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms,
+                                        "--config": {"batch_size": 8, "graph_state_dropout_keep_prob": 0.8}})
+        feed = dict(next(iter(model.make_minibatch_iterator(model.train_data, is_training=True))))
+        assert feed["edge_weight_dropout_keep_prob"] == 0.8            # (:222-223: fed from graph_state_dropout_keep_prob)
+        feed["graph_state_keep_prob"] = 1.0                            # isolate the weight masks
+        feed["out_layer_dropout_keep_prob"] = 1.0
+        seeds = {model.dropout_seed("edge_weights", i) for i in range(model.params["num_timesteps"])}
+        assert len(seeds) == model.params["num_timesteps"]             # one mask per timestep
+        W0 = model.weights["edge_weights"].detach().clone()
+        model.train_batch(feed)
+        torch.cuda.synchronize()
+        # Adam's first step is lr * sign-like in g / (|g| + eps): compare the recorded gradient itself where the model keeps it,
+        # else the weight update
+        weights.append((model.weights["edge_weights"].detach() - W0).cpu().numpy())
+        if side:
+            assert not any(m is not None for m in pkg.backward._SINK.masks.values())
+    upd_sink, upd_auto = weights
+    # first Adam step: update = -lr * g / (|g| + 1e-8) -> +-lr where g != 0, 0 where the entry was dropped at EVERY timestep.
+    # The old behaviour zeroes every entry the LAST mask drops (20 % of them), this one only those all four masks drop (0.2^4).
+    assert np.array_equal(upd_sink == 0, upd_auto == 0)
+    assert (upd_auto == 0).mean() < 0.02
+    np.testing.assert_allclose(upd_sink, upd_auto, atol=2e-6, rtol=0)

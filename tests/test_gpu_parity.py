@@ -21,7 +21,7 @@ def dev(a, cuda):
 
 def test_library_loaded(pkg, cuda):
     lib = pkg._lib.load()
-    assert lib.ggnn_abi_version() == 1
+    assert lib.ggnn_abi_version() == 2
 
 
 @pytest.mark.parametrize("V,D,T", [(1, 100, 4), (17, 100, 4), (1000, 100, 4), (4097, 100, 4), (513, 64, 4),
