@@ -374,7 +374,9 @@ def dry_run(args, pkg, dist_ctx):
         dist_ctx.broadcast_(list(model.named_variables().values()))
     batches = pkg.data.pack_batches(ms, model.params, model.num_edge_types, None, None, rank, world)
     tot = torch.tensor([sum(b.num_nodes for b in batches), sum(b.num_graphs for b in batches), len(batches)], dtype=torch.float64)
+    per_rank = torch.zeros(world, dtype=torch.float64); per_rank[rank] = tot[0]
     dist_ctx.all_reduce_sum_(tot)
+    dist_ctx.all_reduce_sum_(per_rank)
     variables = list(model.trainable_variables.values())
     grads = [torch.full_like(v, float(rank + 1)) for v in variables]
     ar = []
@@ -396,15 +398,33 @@ def dry_run(args, pkg, dist_ctx):
                           "allreduce_us": float(np.min(ar)) if world > 1 else None,
                           "allreduce_bytes": int(sum(v.numel() for v in variables) * 4),
                           "sharded_nodes_total": float(tot[0]), "sharded_graphs_total": float(tot[1]), "dataset_graphs": ms.num_graphs,
-                          "batches_total_incl_padding": float(tot[2]), "bracket_seconds": float(el.item())}))
+                          "batches_total_incl_padding": float(tot[2]), "bracket_seconds": float(el.item()),
+                          "rank_nodes_max_over_min": float(per_rank.max() / per_rank.min().clamp(min=1.0)),
+                          "cpu_affinity_rank0": sorted(os.sched_getaffinity(0))[:4] + ["...", len(os.sched_getaffinity(0))]}))
     if world > 1:
         dist_ctx.barrier()
         torch.distributed.destroy_process_group()
 
 
+def pin_rank_cpus():
+    """One process per GPU: each rank keeps to its own slice of the host's CPUs (LOCAL_RANK-th of LOCAL_WORLD_SIZE equal slices of
+    the CPUs this process may run on), so that eight ranks' launch threads, packer threads and OpenMP pools do not migrate over
+    each other.  GGNN_PIN_CPUS=0 leaves the affinity alone."""
+    if os.environ.get("GGNN_PIN_CPUS", "1") == "0" or "LOCAL_RANK" not in os.environ or not hasattr(os, "sched_setaffinity"):
+        return
+    local, lworld = int(os.environ["LOCAL_RANK"]), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // max(lworld, 1)
+    if lworld > 1 and per >= 1:
+        mine = cpus[local * per:(local + 1) * per]
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(mine))))
+
+
 def main():
     args = parse_args()
     respawn_as_ranks(args)
+    pin_rank_cpus()
     pkg = importlib.import_module(PKG)
     dist_ctx = pkg.parallel.DataParallelContext.from_env()
     rank, world = dist_ctx.rank, dist_ctx.world_size

@@ -264,6 +264,44 @@ def batch_boundaries(nodes_per_graph: np.ndarray, batch_size: int) -> List[int]:
     return bounds
 
 
+def epoch_boundaries(nodes_per_graph: np.ndarray, batch_size: int, world_size: int = 1, balance: bool = True) -> List[int]:
+    """Batch boundaries of one epoch for `world_size` data-parallel ranks (batch i goes to rank i % world_size).
+
+    One rank, or an epoch whose greedy batch count B (batch_boundaries: the reference's packing) already divides by the rank
+    count: the reference's batches.  Otherwise sharding whole greedy batches pads the last step with EMPTY batches -- full
+    QM9 (~25 batches of < 100,000 nodes) on 8 ranks runs 4 steps of which the last is 1/8 occupied: 25/32 = 0.78 of the
+    ranks' time does work.  With `balance` the epoch is re-cut into ceil(B / N) * N batches of EQUAL node count (each still
+    below batch_size, the reference's bound, chem_tensorflow_sparse.py:297): every rank carries the same work in every step
+    and no step is padded.  A step of the data-parallel job is the union of its N batches under ONE global loss
+    normalisation (parallel.py), so re-cutting changes which graphs share a step -- like any other batch_size -- not what a
+    step computes.  Falls back to the greedy boundaries when an equal cut would overflow a batch or leave one empty."""
+    bounds = batch_boundaries(nodes_per_graph, batch_size)
+    nb = len(bounds) - 1
+    if world_size <= 1 or not balance or nb == 0 or nb % world_size == 0:
+        return bounds
+    target = (nb + world_size - 1) // world_size * world_size
+    G = len(nodes_per_graph)
+    if target > G:
+        return bounds
+    csum = np.concatenate([[0], np.cumsum(nodes_per_graph)]).astype(np.int64)
+    total = int(csum[-1])
+    cuts = [0]
+    for k in range(1, target):
+        want = total * k / target
+        e = int(np.searchsorted(csum, want, side="left"))                 # first boundary at or past the target
+        if e > 0 and abs(csum[e - 1] - want) <= abs(csum[min(e, G)] - want):
+            e -= 1                                                        # ... or the one before it, whichever is nearer
+        e = min(max(e, cuts[-1] + 1), G - (target - k))                   # at least one graph per batch, also for those to come
+        while e > cuts[-1] + 1 and csum[e] - csum[cuts[-1]] >= batch_size:
+            e -= 1
+        cuts.append(e)
+    cuts.append(G)
+    sizes = np.diff(csum[cuts])
+    if (sizes >= batch_size).any() or (np.diff(cuts) <= 0).any():
+        return bounds
+    return [int(c) for c in cuts]
+
+
 def pack_batch(ms: MoleculeSet, graph_ids: np.ndarray, num_edge_types: int, hidden_size: int,
                tie_fwd_bkwd: bool = True, task_ids: Sequence[int] = (0,),
                label_mask: Optional[np.ndarray] = None) -> SparseBatch:
@@ -319,12 +357,13 @@ def pack_batches(ms: MoleculeSet, params: dict, num_edge_types: int, order: Opti
                  label_mask: Optional[np.ndarray] = None, rank: int = 0, world_size: int = 1) -> List[SparseBatch]:
     """All minibatches of one epoch (chem_tensorflow_sparse.py:278-350) for graph order `order`.
 
-    Data parallel (world_size > 1): the epoch's batches are formed exactly as on one device and batch i
-    goes to rank i % world_size; every rank gets the same number of batches (ceil(B/world_size)), the
-    tail is padded with EMPTY batches (no graphs) so the per-step gradient all-reduce stays matched."""
+    Data parallel (world_size > 1): batch i goes to rank i % world_size and every rank gets the same number of batches.
+    The epoch is cut by epoch_boundaries: into equal-node batches whose count divides by the rank count
+    (params['dp_balance_nodes'], default on), or -- switched off -- exactly as on one device, the tail padded with EMPTY
+    batches (no graphs) so that the per-step gradient all-reduce stays matched."""
     G = ms.num_graphs
     order = np.arange(G, dtype=np.int64) if order is None else np.asarray(order, np.int64)
-    bounds = batch_boundaries(np.diff(ms.node_ptr)[order], params["batch_size"])
+    bounds = epoch_boundaries(np.diff(ms.node_ptr)[order], params["batch_size"], world_size, bool(params.get("dp_balance_nodes", True)))
     nb = len(bounds) - 1
     steps = (nb + world_size - 1) // world_size
     out = []

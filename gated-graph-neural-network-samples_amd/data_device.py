@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from .data import MoleculeSet, batch_boundaries
+from .data import MoleculeSet, batch_boundaries, epoch_boundaries
 
 # Batches gathered from dataset-level tables (ggnn_assemble_batch) instead of being sorted and scanned one by one;
 # GGNN_PACK_STATIC=0 keeps the general per-batch builders (same outputs, bit for bit: tests/test_gpu_parity.py).
@@ -405,15 +405,17 @@ def pack_batches_device(dms: DeviceMoleculeSet, params: dict, num_edge_types: in
     G = ms.num_graphs
     if order is None:
         # dataset order (validation, inference): order, batch boundaries and the device copy of the order are the same every epoch
-        cached = dms._identity_epoch.get(int(params["batch_size"]))
+        balance = bool(params.get("dp_balance_nodes", True))
+        key = (int(params["batch_size"]), int(world_size), balance)
+        cached = dms._identity_epoch.get(key)
         if cached is None:
             ident = np.arange(G, dtype=np.int64)
-            cached = dms._identity_epoch[int(params["batch_size"])] = (ident, batch_boundaries(dms.nodes_per_graph, params["batch_size"]),
-                                                                      dms.upload_order(ident))
+            cached = dms._identity_epoch[key] = (ident, epoch_boundaries(dms.nodes_per_graph, params["batch_size"], world_size, balance),
+                                                 dms.upload_order(ident))
         order, bounds, order_dev = cached
     else:
         order = np.asarray(order, np.int64)
-        bounds = batch_boundaries(dms.nodes_per_graph[order], params["batch_size"])
+        bounds = epoch_boundaries(dms.nodes_per_graph[order], params["batch_size"], world_size, bool(params.get("dp_balance_nodes", True)))
         order_dev = dms.upload_order(order)                     # ONE upload per epoch: the batches slice it on the device
     nb = len(bounds) - 1
     steps = (nb + world_size - 1) // world_size

@@ -18,8 +18,11 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 PKG = "gated-graph-neural-network-samples_amd"
+# dp_balance_nodes off: the epoch is cut as on one device and whole batches are dealt to the ranks -- the case with an EMPTY
+# padding batch on one rank; CFG_BALANCED: the default, equal-node re-cut (data.epoch_boundaries)
 CFG = {"batch_size": 700, "edge_weight_dropout_keep_prob": 1.0, "graph_state_dropout_keep_prob": 1.0,
-       "task_sample_ratios": {}}
+       "task_sample_ratios": {}, "dp_balance_nodes": False}
+CFG_BALANCED = dict(CFG, dp_balance_nodes=True)
 # the reference's training recipe (chem_tensorflow_sparse.py:59,91,113-114,285): weight dropout 0.8, plus state and readout
 # dropout -- every mask is counter-based (ggnn_dropout_f32), so the ranks' weight masks agree by construction and a node keeps
 # its state mask whichever shard it lands in
@@ -44,7 +47,7 @@ def _rank_worker(rank, world, port, backend, ret, cfg=None):
     model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_data": ms, "valid_data": ms,
                                      "--config": dict(cfg), "dist": ctx})
     ctx.broadcast_(list(model.named_variables().values()))
-    if rank == 1 and cfg is not CFG:
+    if rank == 1 and cfg is CFG_DROPOUT:
         torch.rand(977, device="cuda:0"); np.random.rand(3)    # a rank that drew something else: the masks must not care
     np.random.seed(123)                                        # the epoch shuffle: same order on every rank
     loss, accs, errs, speed, steps = model.run_epoch("epoch 1 (training)", model.train_data, True)
@@ -62,9 +65,11 @@ def _single_process_reference(pkg, world, cfg=CFG):
     data = model.train_data
     msd = data["molecules"]
     perm = np.random.permutation(msd.num_graphs)               # what make_minibatch_iterator draws (sparse:281-282)
-    bounds = pkg.data.batch_boundaries(np.diff(msd.node_ptr)[perm], CFG["batch_size"])
+    bounds = pkg.data.epoch_boundaries(np.diff(msd.node_ptr)[perm], CFG["batch_size"], world, cfg["dp_balance_nodes"])
     nb = len(bounds) - 1
-    assert nb >= 3 and nb % world != 0, "want unequal work: the last step has an empty padding batch on one rank"
+    greedy = len(pkg.data.batch_boundaries(np.diff(msd.node_ptr)[perm], CFG["batch_size"])) - 1
+    assert greedy >= 3 and greedy % world != 0, "want unequal work: cut as on one device, the last step has an empty padding batch on one rank"
+    assert (nb % world == 0) == bool(cfg["dp_balance_nodes"])
     losses, graphs, accs = [], [], []
     for s in range((nb + world - 1) // world):
         lo, hi = bounds[s * world], bounds[min((s + 1) * world, nb)]
@@ -81,7 +86,7 @@ def _single_process_reference(pkg, world, cfg=CFG):
             float((np.asarray(losses) * g).sum() / g.sum()), float((np.asarray(accs) * g).sum() / g.sum()), len(losses))
 
 
-@pytest.mark.parametrize("cfg", [CFG, CFG_DROPOUT], ids=["keep1", "reference-dropout"])
+@pytest.mark.parametrize("cfg", [CFG, CFG_DROPOUT, CFG_BALANCED], ids=["keep1", "reference-dropout", "balanced-shards"])
 def test_two_ranks_on_one_gpu_equal_single_process_union_batches(pkg, cuda, cfg):
     world = 2
     mgr = mp.Manager(); ret = mgr.dict()
