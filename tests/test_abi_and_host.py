@@ -89,11 +89,17 @@ def test_batch_boundaries_follow_strict_less_than(pkg):
     batches = pkg.pack_batches(ms, p, 4)
     assert sum(b.num_graphs for b in batches) == 300
     assert all(b.num_nodes < 500 for b in batches)
-    # data-parallel sharding: same global batches, dealt round-robin, equal step counts, empty padding
+    # data-parallel sharding with dp_balance_nodes off: same global batches, dealt round-robin, equal step counts, empty padding
+    p["dp_balance_nodes"] = False
     shards = [pkg.pack_batches(ms, p, 4, rank=r, world_size=4) for r in range(4)]
     assert len({len(s) for s in shards}) == 1
     dealt = [b for i in range(len(shards[0])) for s in shards for b in [s[i]] if b.num_graphs]
     assert [b.num_nodes for b in dealt] == [b.num_nodes for b in batches]
+    # default (balanced): the epoch re-cut into a multiple of 4 equal-node batches, still every graph once and below batch_size
+    p["dp_balance_nodes"] = True
+    shards = [pkg.pack_batches(ms, p, 4, rank=r, world_size=4) for r in range(4)]
+    assert len({len(s) for s in shards}) == 1 and all(b.num_graphs > 0 and b.num_nodes < 500 for s in shards for b in s)
+    assert sum(b.num_graphs for s in shards for b in s) == 300
 
 
 def test_synthetic_molecules_are_qm9_shaped(pkg):
