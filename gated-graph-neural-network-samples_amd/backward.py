@@ -29,15 +29,13 @@ import torch
 
 from . import _lib, ops
 from ._lib import check
-from .utils import SMALL_NUMBER, tn_matmul
+from .utils import SMALL_NUMBER
 
 # Training forward/backward on the compacted message transform (default wherever the hidden size has one) or on the dense
 # [V, T*D] form (GGNN_TRAIN_COMPACT=0; always for other hidden sizes).
 USE_COMPACT_TRANSFORM = os.environ.get("GGNN_TRAIN_COMPACT", "1") != "0"
 
-# Dense-form fallback only: weight gradients X^T dY on the vendor BLAS batched along the rows (utils.tn_matmul) or on the
-# package's first row-split kernel ggnn_gemm_tn_f32 (GGNN_TN_KERNEL=1).
-USE_TN_KERNEL = os.environ.get("GGNN_TN_KERNEL", "0") != "0"
+# (dense-form fallback: weight gradients X^T dY on the row-split kernel ggnn_gemm_tn_f32 -- no vendor BLAS anywhere in the package)
 
 
 # ---- weight gradients on a side stream -----------------------------------------------------------------------------------
@@ -159,9 +157,25 @@ def _on_side_stream(tensors, fn):
 
 
 def _tn(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
-    if USE_TN_KERNEL and dy.shape[1] % 4 == 0 and dy.shape[1] <= 512:
+    """x^T @ dy over ~1e5 rows on ggnn_gemm_tn_f32 (rows split over the whole GPU, deterministic reduction); dy wider than the
+    kernel's 512 columns goes through in column blocks (views: the kernel takes any row stride)."""
+    N = dy.shape[1]
+    if N <= 512:
         return ops.gemm_tn(x, dy)
-    return tn_matmul(x, dy)
+    step = 512
+    return torch.cat([ops.gemm_tn(x, dy[:, c:min(c + step, N)]) for c in range(0, N, step)], dim=1)
+
+
+def weight_grad(x_segs, dy: torch.Tensor):
+    """(dW [K, N], db [N]) = (concat(x_segs, dim=1)^T dy, column sums of dy) for a weight matrix applied to [x_0 | x_1 | ..].
+    Shapes of the fused kernels' hidden sizes: ONE ggnn_xty_f32 launch, the bias gradient as its ones row.  Wider ones (hidden
+    128 / 192 / 256): per segment on the row-split kernel ggnn_gemm_tn_f32, the bias gradient by ggnn_colsum_f32."""
+    D, N = x_segs[0].shape[1], dy.shape[1]
+    if D <= 104 and N <= 208:
+        K = len(x_segs) * D
+        w = ops.xty(list(x_segs), dy, ones_row=True)
+        return w[:K], w[K]
+    return torch.cat([_tn(x, dy) for x in x_segs], dim=0), ops.colsum(dy)
 
 
 def _source_index(index: "ops.MessageIndex", num_nodes: int) -> "ops.MessageIndex":
@@ -369,14 +383,14 @@ def _gru_backward_unfused(lib, g, h, r, u, c, Wg, Wc, nin, xs, nx, T, act, use_a
         dh.data_ptr(), rh.data_ptr(), D, 0, V, D, st))
     # ---- 2. candidate weights (+ bias: the ones row of the same product)
     Kx = (nx + 1) * D
-    wc = ops.xty(xs + [rh], dpc, ones_row=True); dWc, dbc = wc[:Kx], wc[Kx]
+    dWc, dbc = weight_grad(xs + [rh], dpc)
     # ---- 3. dpc Wc^T; gates pre-activation gradients ([r|u] = sigmoid([x | h] Wg + bg))
     dx = torch.empty((V, nx * D), dtype=torch.float32, device=dev)
     ops._launch("gru_bwd_dx_cand[nx=%d]" % nx, lambda: lib.ggnn_gru_bwd_dx_cand_f32(
         dpc.data_ptr(), _TRANSPOSED.get(Wc).data_ptr(), h.data_ptr(), r.data_ptr(), dx.data_ptr(), dh.data_ptr(), dpg.data_ptr(),
         nx, V, D, st))
     # ---- 4. gate weights
-    wg = ops.xty(xs + [h], dpg, ones_row=True); dWg, dbg = wg[:Kx], wg[Kx]
+    dWg, dbg = weight_grad(xs + [h], dpg)
     # ---- 5. dpg Wg^T; mean aggregation (chem_tensorflow_sparse.py:206-209)
     dinc = torch.empty_like(h)
     ops._launch("gru_bwd_dx_gates[nx=%d]" % nx, lambda: lib.ggnn_gru_bwd_dx_gates_f32(
@@ -388,7 +402,7 @@ def _gru_backward_unfused(lib, g, h, r, u, c, Wg, Wc, nin, xs, nx, T, act, use_a
 
 def _backward_dense_form(ctx, g):
     """Hidden sizes without a compacted transform (or GGNN_TRAIN_COMPACT=0): the dense [V, T*D] message transform; its
-    weight gradients are plain tall-skinny products on the vendor BLAS (utils.tn_matmul)."""
+    weight gradients are plain tall-skinny products on ggnn_gemm_tn_f32, the bias gradients column sums (ggnn_colsum_f32)."""
     lib = _lib.load()
     h, nin, W, Wg, Wc, incoming, r, u, c, *residuals = ctx.saved_tensors
     V, D = h.shape
@@ -408,14 +422,14 @@ def _backward_dense_form(ctx, g):
     check(lib.ggnn_gru_bwd_stage1_f32(g.data_ptr(), h.data_ptr(), r.data_ptr(), u.data_ptr(), c.data_ptr(), act,
                                       dpc.data_ptr(), dpg.data_ptr(), dh.data_ptr(), a_c.data_ptr(), K, nx * D, V, D, st))
     dWc = _tn(a_c, dpc)
-    dbc = dpc.sum(0)
-    dxrh = ops.gemm([dpc], Wc.t().contiguous())                            # [V, (nx+1)D] = dpc Wc^T
+    dbc = ops.colsum(dpc)
+    dxrh = ops.gemm([dpc], _TRANSPOSED.get(Wc))                            # [V, (nx+1)D] = dpc Wc^T
     drh = dxrh[:, nx * D:]
     check(lib.ggnn_gru_bwd_stage2_f32(drh.data_ptr(), K, h.data_ptr(), r.data_ptr(), dh.data_ptr(), dpg.data_ptr(), V, D, st))
     a_c[:, nx * D:] = h                                                    # reuse the buffer as [x | h]
     dWg = _tn(a_c, dpg)
-    dbg = dpg.sum(0)
-    dxh = ops.gemm([dpg[:, :D], dpg[:, D:]], Wg.t().contiguous())           # [V, (nx+1)D] = dpg Wg^T
+    dbg = ops.colsum(dpg)
+    dxh = ops.gemm([dpg[:, :D], dpg[:, D:]], _TRANSPOSED.get(Wg))          # [V, (nx+1)D] = dpg Wg^T
     dh += dxh[:, nx * D:]
     dx = dxrh[:, :nx * D] + dxh[:, :nx * D]
     d_res = [dx[:, i * D:(i + 1) * D] for i in range(nx - 1)]
@@ -423,7 +437,7 @@ def _backward_dense_form(ctx, g):
     if ctx.use_avg:
         dinc = dinc / (nin.sum(dim=-1, keepdim=True) + SMALL_NUMBER)
     dinc = dinc.contiguous()
-    dbias = nin.t().matmul(dinc) if ctx.has_bias else None
+    dbias = ops.gemm_tn(nin, dinc) if ctx.has_bias else None              # nin^T dinc   [T, D]
     dH = ops.segment_sum_rows_by_index(dinc, _source_index(ctx.index, V)).view(V, T * D)
     WT = W.transpose(1, 2).reshape(T * D, D).contiguous()                  # rows t*D..: W_t^T
     for t0 in range(0, T, 4):                                              # (the GEMM takes <= 4 K segments)

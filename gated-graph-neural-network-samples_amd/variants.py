@@ -9,61 +9,22 @@ ops.gru), exactly what inference runs.  The backward is hand-written on the same
   attention ggnn_attn_bwd_target_f32 (softmax backward per target node, no [M,D] tensor), ggnn_weighted_segment_sum_f32
             (transpose gathers with the per-message coefficients), ggnn_range_sum_f32 (d attention factor per type)
   transform backward.transform_backward (compact rows; the compacted transform kernel on W^T)
-`_step_torch` -- the timestep in differentiable torch ops -- is kept as a TEST ORACLE (GGNN_VARIANT_TORCH_BWD=1 routes the
-backward through it; tests compare both) and for hidden sizes the HIP backward does not cover.
+Hidden sizes beyond the fused kernels' (128 / 192 / 256 and what pads to them) run the same backward on the generic kernels:
+the un-fused GRU backward, ggnn_gemm_tn_f32 / ggnn_colsum_f32 for the weight and bias gradients.  The timestep restated in
+differentiable torch ops lives in tests/variant_oracle.py (a test oracle; BACKWARD_ORACLE below is its hook).
 """
 from __future__ import annotations
 
 from typing import Optional, Sequence
-
-import os
 
 import torch
 
 from . import ops
 from .utils import SMALL_NUMBER
 
-TORCH_BACKWARD = os.environ.get("GGNN_VARIANT_TORCH_BWD", "0") != "0"      # derive the backward with torch autograd (test oracle)
-
-
-def _activation(name: str):
-    return torch.tanh if name.lower() == "tanh" else torch.relu
-
-
-def _step_torch(h, index: "ops.MessageIndex", nin, edge_weights, edge_biases, attention_weights, use_avg: bool,
-                residuals: Sequence[torch.Tensor], cell_type: str, cell: Sequence[torch.Tensor], activation: str):
-    """One timestep of chem_tensorflow_sparse.py:153-216 in differentiable torch ops (reference op order)."""
-    V, D = h.shape
-    T = edge_weights.shape[0]
-    src, dst = index.adj[:, 0].long(), index.adj[:, 1].long()
-    off = index.type_off
-    etype = torch.cat([torch.full((off[t + 1] - off[t],), t, dtype=torch.long, device=h.device) for t in range(T)]) \
-        if index.num_messages else torch.zeros(0, dtype=torch.long, device=h.device)
-    H = torch.einsum('vd,tde->vte', h, edge_weights)                      # :160-164 for every type at once
-    messages = H[src, etype]                                              # [M, D], type-major like :168
-    if attention_weights is not None:                                     # :147-149, 170-196
-        scores = (h[src] * h[dst]).sum(-1) * attention_weights[etype]
-        smax = torch.full((V,), torch.finfo(h.dtype).min, dtype=h.dtype, device=h.device)
-        smax = smax.scatter_reduce(0, dst, scores, reduce="amax", include_self=True)
-        exped = torch.exp(scores - smax[dst])
-        ssum = torch.zeros(V, dtype=h.dtype, device=h.device).index_add(0, dst, exped)
-        messages = messages * (exped / (ssum[dst] + SMALL_NUMBER)).unsqueeze(-1)
-    incoming = torch.zeros_like(h).index_add(0, dst, messages)            # :198-200
-    if edge_biases is not None:
-        incoming = incoming + nin.matmul(edge_biases)                     # :202-204
-    if use_avg:
-        incoming = incoming / (nin.sum(dim=-1, keepdim=True) + SMALL_NUMBER)   # :206-209
-    x = torch.cat(list(residuals) + [incoming], dim=-1)                   # :211-212
-    if cell_type == 'rnn':                                                # BasicRNNCell: act([x,h] W + b)
-        kernel, bias = cell
-        return _activation(activation)(torch.cat([x, h], dim=1).matmul(kernel) + bias)
-    gates = torch.sigmoid(torch.cat([x, h], dim=1).matmul(cell[0]) + cell[1])
-    r, u = gates[:, :D], gates[:, D:]                                     # r first, then u
-    if cell_type == 'gru':
-        c = _activation(activation)(torch.cat([x, r * h], dim=1).matmul(cell[2]) + cell[3])
-    else:                                                                 # CudnnCompatibleGRUCell
-        c = torch.tanh(x.matmul(cell[2]) + cell[3] + r * (h.matmul(cell[4]) + cell[5]))
-    return u * h + (1 - u) * c
+# Test hook: tests/variant_oracle.py installs `autograd_backward` here -- the timestep restated in differentiable torch ops and
+# differentiated by torch autograd -- to hold the hand-written backward against it.  The product never sets it.
+BACKWARD_ORACLE = None
 
 
 class VariantStepFn(torch.autograd.Function):
@@ -83,7 +44,10 @@ class VariantStepFn(torch.autograd.Function):
             incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
         xs = list(residuals) + [incoming]
         D = h.shape[1]
-        ctx.hip_backward = (not TORCH_BACKWARD) and ops.compact_supported(D) and 2 * D <= 208 and index.num_messages > 0
+        if not ops.compact_supported(D):
+            raise NotImplementedError("training of the attention / RNN / CudnnGRU variants needs a hidden size with a compacted "
+                                      "transform kernel (32, 64, 100, 128, 192, 256 or a size that pads to one): got %d" % D)
+        ctx.hip_backward = BACKWARD_ORACLE is None
         extra = []                                              # what the hand-written backward needs beyond the inputs
         if cell_type == 'gru':
             save = {} if ctx.hip_backward else None
@@ -123,30 +87,13 @@ class VariantStepFn(torch.autograd.Function):
         if ctx.hip_backward:
             extra = saved[k + ctx.num_cell + ctx.num_res:]
             return _hip_backward(ctx, g.contiguous(), h, nin, W, bias, attn, cell, residuals, extra)
-        leaves = [t.detach().requires_grad_(True) for t in [h, W] + ([bias] if bias is not None else []) +
-                  ([attn] if attn is not None else []) + list(cell) + list(residuals)]
-        it = iter(leaves)
-        h_, W_ = next(it), next(it)
-        bias_ = next(it) if bias is not None else None
-        attn_ = next(it) if attn is not None else None
-        cell_ = [next(it) for _ in range(ctx.num_cell)]
-        res_ = [next(it) for _ in range(ctx.num_res)]
-        with torch.enable_grad():
-            out = _step_torch(h_, ctx.index, nin, W_, bias_, attn_, ctx.use_avg, res_, ctx.cell_type, cell_, ctx.activation)
-        grads = list(torch.autograd.grad(out, leaves, g.contiguous(), allow_unused=True))
-        it = iter(grads)
-        dh, dW = next(it), next(it)
-        dbias = next(it) if bias is not None else None
-        dattn = next(it) if attn is not None else None
-        dcell = [next(it) for _ in range(ctx.num_cell)]
-        dres = [next(it) for _ in range(ctx.num_res)]
-        return (dh, None, None, None, None, None, None, None, dW, dbias, dattn, *dcell, *dres)
+        return BACKWARD_ORACLE(ctx, g.contiguous(), h, nin, W, bias, attn, cell, residuals)
 
 
 def _hip_backward(ctx, g, h, nin, W, bias, attn, cell, residuals, extra):
     """The timestep's backward on HIP kernels only (see the module docstring)."""
     from .autograd import _PACKED
-    from .backward import _TRANSPOSED, transform_backward
+    from .backward import _TRANSPOSED, transform_backward, weight_grad
     index = ctx.index
     V, D = h.shape
     T = W.shape[0]
@@ -176,8 +123,7 @@ def _hip_backward(ctx, g, h, nin, W, bias, attn, cell, residuals, extra):
     elif ctx.cell_type == 'rnn':                                       # h' = act([x|h] W + b)
         out = extra[1]
         dP = ops.act_bwd(g, out, ctx.activation)
-        wk = ops.xty(xs + [h], dP, ones_row=True)
-        dcell = [wk[:Kx], wk[Kx]]
+        dcell = list(weight_grad(xs + [h], dP))
         dx = torch.empty((V, nx * D), dtype=torch.float32, device=dev)
         dinc = torch.empty_like(h); dh = torch.empty_like(h)
         ops.bwd_dx(dP, 1, _TRANSPOSED.get(cell[0]), nx * D, True, dx, dinc, nin, ctx.use_avg, dh, False, False, D)
@@ -186,10 +132,7 @@ def _hip_backward(ctx, g, h, nin, W, bias, attn, cell, residuals, extra):
         r, u, c, hc = extra[1:5]
         Wg, _, Wcx, _, Wch, _ = cell
         dpc, dpg, dh, dhc = ops.cudnn_gru_bwd_stage(g, h, r, u, c, hc)
-        wg = ops.xty(xs + [h], dpg, ones_row=True)
-        wcx = ops.xty(xs, dpc, ones_row=True)
-        wch = ops.xty([h], dhc, ones_row=True)
-        dcell = [wg[:Kx], wg[Kx], wcx[:nx * D], wcx[nx * D], wch[:D], wch[D]]
+        dcell = [*weight_grad(xs + [h], dpg), *weight_grad(xs, dpc), *weight_grad([h], dhc)]
         dx = torch.empty((V, nx * D), dtype=torch.float32, device=dev)
         dinc = torch.empty_like(h)
         ops.bwd_dx(dpc, 1, _TRANSPOSED.get(Wcx), nx * D, False, dx, None, None, False, None, False, False, D)       # dx = dpc Wcx^T
@@ -198,13 +141,15 @@ def _hip_backward(ctx, g, h, nin, W, bias, attn, cell, residuals, extra):
         d_res = [dx[:, i * D:(i + 1) * D] for i in range(nx - 1)]
 
     # ---- aggregation: dinc is dL/d(sum of (attention-weighted) messages + nin @ bias) --------------------------------------------
-    dbias = ops.xty([dinc], nin).t().contiguous() if bias is not None else None                  # :202-204
+    dbias = ops.gemm_tn(nin, dinc) if bias is not None else None                                 # :202-204  nin^T dinc  [T, D]
     comp = getattr(index, "_compact", None)
     if comp is None:
         comp = index._compact = ops.build_compact_sources(index)
     dattn = None
     weights = None
-    if attn is not None:                                                # :170-196
+    if attn is not None and not index.num_messages:                     # no message: nothing attends, no gradient
+        dattn = torch.zeros_like(attn)
+    elif attn is not None:                                              # :170-196
         H = ops.msg_transform(h, W)                                     # the messages' values, recomputed (dense form)
         weights, coef_s, dfac = ops.attn_backward_target(H.view(-1, D), h, dinc, index, attn, dh)
         del H

@@ -175,5 +175,8 @@ def test_dense_model_weight_dropout_masks_each_timestep(pkg, oracle, cuda, monke
     # first Adam step: update = -lr * g / (|g| + 1e-8) -> +-lr where g != 0, 0 where the entry was dropped at EVERY timestep.
     # The old behaviour zeroes every entry the LAST mask drops (20 % of them), this one only those all four masks drop (0.2^4).
     assert np.array_equal(upd_sink == 0, upd_auto == 0)
-    assert (upd_auto == 0).mean() < 0.02
+    T = upd_auto.size // (upd_auto.shape[-1] ** 2)
+    blocks = upd_auto.reshape(T, -1)
+    present = [t for t in range(T) if (blocks[t] != 0).any()]           # (an edge type without a bond in this batch: zero gradient)
+    assert len(present) >= 2 and all((blocks[t] == 0).mean() < 0.02 for t in present)
     np.testing.assert_allclose(upd_sink, upd_auto, atol=2e-6, rtol=0)

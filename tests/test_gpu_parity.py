@@ -261,7 +261,9 @@ def test_device_packer_equals_host_packer(pkg, cuda, tie):
     ms = pkg.synthetic_qm9(700, mean_nodes=12, seed=33)
     rng = np.random.default_rng(5)
     T = 4 if tie else 8
-    params = {"batch_size": 2500, "hidden_size": 32, "tie_fwd_bkwd": tie, "task_ids": [0]}
+    # dp_balance_nodes off: whole greedy batches dealt to the ranks (the case with an empty padding batch); on (the default,
+    # data.epoch_boundaries: the epoch re-cut into equal-node batches) at the end
+    params = {"batch_size": 2500, "hidden_size": 32, "tie_fwd_bkwd": tie, "task_ids": [0], "dp_balance_nodes": False}
     label_mask = (rng.random((ms.num_graphs, ms.targets.shape[1])) < 0.7).astype(np.float32)
     order = rng.permutation(ms.num_graphs)
     dms = pkg.data_device.DeviceMoleculeSet(ms, cuda, label_mask)
@@ -283,6 +285,17 @@ def test_device_packer_equals_host_packer(pkg, cuda, tie):
             assert np.array_equal(db["target_mask"].cpu().numpy(), hb.target_mask)
             assert db["message_index"].num_messages == hb.num_messages
     assert devb[-1]["num_graphs"] == 0 and devb[-1]["initial_node_representation"].shape[0] == 0
+    balanced = dict(params, dp_balance_nodes=True)
+    seen = 0
+    for rank in range(nb + 1):
+        host = pkg.data.pack_batches(ms, balanced, T, order, label_mask, rank, nb + 1)
+        devb = list(pkg.data_device.pack_batches_device(dms, balanced, T, order, rank, nb + 1))
+        assert len(host) == len(devb) == 1 and host[0].num_graphs > 0
+        assert devb[0]["num_graphs"] == host[0].num_graphs
+        assert np.array_equal(devb[0]["initial_node_representation"].cpu().numpy(), host[0].initial_node_representation)
+        assert np.array_equal(devb[0]["target_values"].cpu().numpy(), host[0].target_values)
+        seen += host[0].num_graphs
+    assert seen == ms.num_graphs
 
 
 def test_sparse_model_graph_disjointness(pkg, oracle, cuda):

@@ -199,15 +199,20 @@ def test_training_reduces_loss(pkg, oracle, cuda):
     {"graph_rnn_cell": "CudnnCompatibleGRUCell"},
     {"graph_rnn_cell": "CudnnCompatibleGRUCell", "use_propagation_attention": True, "layer_timesteps": [1, 2],
      "residual_connections": {"1": [0]}},
-], ids=["attention", "attention-bias-sum-h64", "rnn-relu", "rnn-bias-residual", "cudnn-gru", "cudnn-gru-attention-residual"])
+    {"use_propagation_attention": True, "hidden_size": 128, "layer_timesteps": [2, 1], "residual_connections": {"1": [0]}},
+    {"graph_rnn_cell": "RNN", "hidden_size": 192, "layer_timesteps": [1, 1], "residual_connections": {"1": [0]}},
+    {"graph_rnn_cell": "CudnnCompatibleGRUCell", "hidden_size": 256, "use_edge_bias": True, "layer_timesteps": [2]},
+], ids=["attention", "attention-bias-sum-h64", "rnn-relu", "rnn-bias-residual", "cudnn-gru", "cudnn-gru-attention-residual",
+        "attention-h128", "rnn-h192", "cudnn-gru-h256"])
 def test_variant_hip_backward_equals_autograd_of_torch_restatement(pkg, oracle, cuda, config, monkeypatch):
     """The non-default switches (attention, BasicRNNCell, CudnnCompatibleGRUCell): the hand-written HIP backward against torch
-    autograd of the timestep restated in differentiable torch ops (variants._step_torch, the test oracle)."""
+    autograd of the timestep restated in differentiable torch ops (tests/variant_oracle.py)."""
     from importlib import import_module
+    import variant_oracle
     variants = import_module(pkg.__name__ + ".variants")
     grads = {}
     for mode in (False, True):
-        monkeypatch.setattr(variants, "TORCH_BACKWARD", mode)
+        monkeypatch.setattr(variants, "BACKWARD_ORACLE", variant_oracle.autograd_backward if mode else None)
         model, layers, feed = _setup(pkg, oracle, config, n=80, seed=4)
         variables = model.trainable_variables
         for v in variables.values():

@@ -41,12 +41,12 @@ __device__ __forceinline__ void filler(Ctx& c, int i) {
         f32x2& p = *reinterpret_cast<f32x2*>(&c.f[(i & 3) * 2]);
         asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p) : "v"(p));
     } else if constexpr (KIND == DSREAD) {
-        asm volatile("ds_read_b128 %0, %1" : "=v"(c.ld[i & 3]) : "v"(c.lds_off + (unsigned)(i & 15) * 1024u));
+        asm volatile("ds_read_b128 %0, %1" : "+v"(c.ld[i & 3]) : "v"(c.lds_off + (unsigned)(i & 15) * 1024u));
     } else if constexpr (KIND == DMA) {
         const unsigned l = __builtin_amdgcn_readfirstlane(c.lds_base + (unsigned)(i & 15) * 1024u);
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(l), "v"(c.voff), "s"(c.gsrc + (size_t)(i & 63) * 256) : "memory");
     } else if constexpr (KIND == GLOAD) {
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(c.ld[i & 3]) : "v"(c.voff + (unsigned)(i & 63) * 1024u), "s"(c.gsrc) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(c.ld[i & 3]) : "v"(c.voff + (unsigned)(i & 63) * 1024u), "s"(c.gsrc) : "memory");
     } else if constexpr (KIND == GSTORE) {
         asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(c.voff + (unsigned)(i & 63) * 1024u), "v"(c.ld[i & 3]), "s"(c.gdst) : "memory");
     }
@@ -131,18 +131,21 @@ void run(const Bufs& b, const char* what, int role_a, int role_b, int n_outer) {
     auto k = probe<NWAVES, SHAPE, NACC, DEP, KIND, NFILL, EVERY>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     std::vector<unsigned long long> h(16);
+    printf("%-58s ", what); fflush(stdout);
     for (int rep = 0; rep < 3; ++rep) {
         hipLaunchKernelGGL(k, dim3(256), dim3(NWAVES * 64), 128 * 1024, 0, role_a, role_b, n_outer, b.gsrc, b.gdst, b.out, b.t);
-        hipDeviceSynchronize();
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) { printf("HIP error %s\n", hipGetErrorString(e)); fflush(stdout); return; }
     }
     hipMemcpy(h.data(), b.t, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     const int n_mfma = n_outer * NACC * DEP;
     const int wb = NWAVES == 8 ? 4 : 0;
-    printf("%-58s waves=%d roles=%d|%d  mfma/wave=%5d fill/wave=%5d : waveA %7llu clk (%.1f/mfma)  waveB %7llu  until-barrier %7llu (%.1f/mfma)\n", what,
+    printf("waves=%d roles=%d|%d  mfma/wave=%5d fill/wave=%5d : waveA %7llu clk (%.1f/mfma)  waveB %7llu  until-barrier %7llu (%.1f/mfma)\n",
            NWAVES, role_a, role_b, n_mfma, n_mfma / EVERY * NFILL, h[0], (double)h[0] / n_mfma, h[wb * 2], h[1], (double)h[1] / n_mfma);
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     Bufs b;
     hipMalloc(&b.gsrc, 256 * 65536 * sizeof(float) + (1 << 20)); hipMalloc(&b.gdst, 256 * 65536 * sizeof(float) + (1 << 20));
     hipMalloc(&b.out, 256 * 512 * sizeof(float)); hipMalloc(&b.t, 16 * sizeof(unsigned long long));
