@@ -360,6 +360,18 @@ def transform_backward(index, comp, h, W, dinc, dh, message_weights=None, sink=N
         dHc = ops.weighted_segment_sum(dinc, bwd.rows_index, bwd.rows_index.msg, message_weights)
     Z = ops.msg_transform_compact_packed(dHc, _PACKED.edge(_TRANSPOSED.get(W, (1, 2))), T, bwd.identity)       # dHc W_t^T
     ops.segment_sum_rows_acc(Z[:R], bwd.node_index, dh)                                      # sum over a node's types
+    D = h.shape[1]
+    if D > 128:
+        # the row-gathered product kernel takes <= 128 columns of each operand: wider blocks go through in 128-column views
+        dW = torch.empty((T, D, D), dtype=torch.float32, device=h.device)
+        for k0 in range(0, D, 128):
+            for n0 in range(0, D, 128):
+                dW[:, k0:k0 + 128, n0:n0 + 128] = ops.xty([h[:, k0:k0 + 128]], dHc[:, n0:n0 + 128], x_rows=comp.pair_node,
+                                                          row_off=comp.type_row_off)
+        if sink is not None:
+            _on_side_stream([dW], lambda: _SINK.add(sink[0], sink[1], dW))
+            return None
+        return dW
     if sink is not None:
         def edge_weight_products():
             ops.xty([h], dHc, x_rows=comp.pair_node, row_off=comp.type_row_off, add_to=sink[1])

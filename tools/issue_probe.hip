@@ -15,7 +15,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
-enum Fill { NONE = 0, FMA = 1, TRANS = 2, DSREAD = 3, DMA = 4, GLOAD = 5, PERM = 6, PKFMA = 7, GSTORE = 8 };
+enum Fill { NONE = 0, FMA = 1, TRANS = 2, DSREAD = 3, DMA = 4, GLOAD = 5, PERM = 6, PKFMA = 7, GSTORE = 8, MIX = 9, MIXDMA = 10, MIXALL = 11 };
 
 struct Ctx {
     float f[8];
@@ -47,6 +47,14 @@ __device__ __forceinline__ void filler(Ctx& c, int i) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(l), "v"(c.voff), "s"(c.gsrc + (size_t)(i & 63) * 256) : "memory");
     } else if constexpr (KIND == GLOAD) {
         asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(c.ld[i & 3]) : "v"(c.voff + (unsigned)(i & 63) * 1024u), "s"(c.gsrc) : "memory");
+    } else if constexpr (KIND == MIX || KIND == MIXDMA || KIND == MIXALL) {
+        // the fused GRU's side work per 32x32x16 MFMA, roughly: 3 plain VALU; every 2nd MFMA a weight-fragment ds_read_b128 and a
+        // transcendental; MIXDMA: every 8th an LDS-DMA KiB; MIXALL: also every 16th a global load and every 32nd a store
+        filler<FMA>(c, i); filler<PERM>(c, i + 1); filler<FMA>(c, i + 2);
+        if (i % 2 == 1) { filler<DSREAD>(c, i); filler<TRANS>(c, i); }
+        if (KIND != MIX && i % 8 == 7) filler<DMA>(c, i);
+        if (KIND == MIXALL && i % 16 == 11) filler<GLOAD>(c, i);
+        if (KIND == MIXALL && i % 32 == 19) filler<GSTORE>(c, i);
     } else if constexpr (KIND == GSTORE) {
         asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(c.voff + (unsigned)(i & 63) * 1024u), "v"(c.ld[i & 3]), "s"(c.gdst) : "memory");
     }
@@ -80,7 +88,7 @@ __device__ __forceinline__ void mfma_stream(int n_outer, Ctx& c, float& sink) {
             }
             SB();
         }
-        if constexpr (KIND == DSREAD || KIND == GLOAD) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+        if constexpr (KIND == DSREAD || KIND == GLOAD || KIND >= MIX) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -102,7 +110,8 @@ __global__ __launch_bounds__(NWAVES * 64) void probe(int role_a, int role_b, int
     for (int i = 0; i < 4; ++i) { c.u[i] = threadIdx.x * 77u + i; c.ld[i] = f32x4{0, 0, 0, 0}; }
     auto uni = [](const float* p) {
         const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-        return reinterpret_cast<const float*>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v));
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));   // (the builtin returns int)
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
     };
     c.gsrc = uni(gsrc + (size_t)blockIdx.x * 65536);
     c.gdst = const_cast<float*>(uni(gdst + (size_t)blockIdx.x * 65536 + wave * 16384 / 4));
@@ -170,6 +179,9 @@ int main() {
     run<4, 32, 4, 6, GLOAD, 1, 8>(b, "+1 global_load_dwordx4 per 8 MFMA", 3, 0, N);
     run<4, 32, 4, 6, GLOAD, 1, 4>(b, "+1 global_load_dwordx4 per 4 MFMA", 3, 0, N);
     run<4, 32, 4, 6, GSTORE, 1, 8>(b, "+1 global_store_dwordx4 per 8 MFMA", 3, 0, N);
+    run<4, 32, 4, 6, MIX, 1, 1>(b, "GRU-like mix (3 VALU; /2: ds_read + exp)", 3, 0, N);
+    run<4, 32, 4, 6, MIXDMA, 1, 1>(b, "GRU-like mix + LDS-DMA KiB per 8", 3, 0, N);
+    run<4, 32, 4, 6, MIXALL, 1, 1>(b, "GRU-like mix + DMA/8 + gload/16 + gstore/32", 3, 0, N);
     run<4, 32, 4, 6, FMA, 4, 1>(b, "fillers alone: 4 v_fma x n", 2, 0, N);
     run<4, 32, 4, 6, TRANS, 1, 1>(b, "fillers alone: 1 v_exp x n", 2, 0, N);
     run<4, 32, 4, 6, DMA, 1, 8>(b, "fillers alone: LDS-DMA KiB x n/8", 2, 0, N);
@@ -193,6 +205,7 @@ int main() {
     run<8, 16, 7, 6, DMA, 1, 16>(b, "16x16x32: A mfma | B LDS-DMA per 16", 1, 2, N);
     run<8, 16, 7, 6, DSREAD, 1, 2>(b, "16x16x32: A mfma | B ds_read per 2", 1, 2, N);
     run<8, 16, 7, 6, FMA, 2, 1>(b, "16x16x32: A mfma+2fma | B mfma+2fma", 3, 3, N);
+    run<8, 16, 7, 6, MIXDMA, 1, 2>(b, "16x16x32: A,B both mfma + mix/2 (+DMA)", 3, 3, N);
     run<8, 32, 4, 6, NONE, 0, 1>(b, "32x32x16: A mfma | B idle", 1, 0, N);
     run<8, 32, 4, 6, FMA, 4, 1>(b, "32x32x16: A mfma | B 4 v_fma per MFMA", 1, 2, N);
     run<8, 32, 4, 6, FMA, 4, 1>(b, "32x32x16: A idle | B 4 v_fma x n", 0, 2, N);
