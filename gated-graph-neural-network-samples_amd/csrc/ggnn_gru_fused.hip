@@ -112,12 +112,22 @@ __device__ __forceinline__ void frag_add(Frag<D>& f, const Frag<D>& t) {
 // SAVEX: the gathered segment is stored too (save_x; training).  The split-form inference dispatch runs <SAVE = true, SAVEX =
 // false>: the instantiation with the r / u / c stores (skipped at run time) but without the save_x path comes out of the register
 // allocator with the least scratch (R = 1 / 2: 8 / 36 B; with it 28 / 40 B; SAVE = false: 164 / 196 B).
-template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE>
-__global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a, const float* __restrict__ packed) {
+// HALF (split form, NW = 4): TWO workgroups of four waves per CU instead of one of eight.  The two waves of a SIMD then belong
+// to different workgroups and meet at no barrier: while one sits in an epilogue, a fragment split, a DMA wait or at its own
+// workgroup's stage barrier, the other issues MFMAs (tools/issue_probe.hip: vector, transcendental and LDS-DMA instructions of one
+// wave overlap the bf16 MFMAs of its SIMD partner completely -- what the 8-wave form loses is that its barriers put both waves
+// of a SIMD into the same phase at the same time).  Two rings must fit the LDS: a stage image goes through its workgroup's ring
+// in its two column halves (ggnn_split.hpp: half A = tiles [0, TA), half B the rest), a stage is two sub-stages with a barrier
+// each, ring slot = half A (37 KiB at D = 100).  Same products in the same order per accumulator: bit-identical to the 8-wave form.
+template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE, bool HALF = false>
+__global__ __launch_bounds__(NW * 64, HALF ? 2 : 1) void ggnn_gru_fused_kernel(GruFusedArgs a, const float* __restrict__ packed) {
     using C = StageCfg<D>;
     using I = ImgCfg<D, SPLIT>;
+    using SC = SplitCfg<D>;
+    static_assert(!HALF || (SPLIT && NW == 4), "the half-stage form is a split-form, four-wave kernel");
     constexpr int NT = C::NT, NC = C::NC, NR = C::NR;
     constexpr int NSTAGE = 3 * (NX + 1);
+    constexpr int SLOT = HALF ? SC::HA : I::IMG;                     // floats per ring slot
     extern __shared__ __attribute__((aligned(16))) float lds_[];    // [biases | ring [2][IMG]]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     // One-tile tail tickets (tail_w == 1, the usual case) are worked COOPERATIVELY: all waves take the same 16 rows and
     // wave w computes output column tile w of every gate (25 MFMAs per stage instead of 175 on one wave while seven
     // idle); the r*h fragment, which the candidate stage needs whole, is exchanged through LDS.
-    const bool coop_tail = (tail_w == 1) && (NT <= NW);
+    const bool coop_tail = (tail_w == 1) && (NT <= NW) && !HALF;
     auto is_coop = [&](int t) -> bool { return coop_tail && t >= full_tk && t < n_tk; };
     auto tile_of = [&](int t) -> int {                              // this wave's tile of ticket t, or -1
         if (t < full_tk) return t * NW + wave;
@@ -163,13 +173,14 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     float* ring = lds_ + BIAS_FLOATS;
     int* tk_slot = reinterpret_cast<int*>(bias_s + 4 * D);
     constexpr int RHP = C::BN + 4;                     // row pitch of the r*h exchange block (cooperative tail pass)
-    float* rh_x = ring + 2 * I::IMG;                   // [16][RHP], behind the ring
+    float* rh_x = ring + 2 * SLOT;                     // [16][RHP], behind the ring (cooperative tail passes only: not HALF)
     for (int i = tid; i < 4 * D; i += NW * 64)
         bias_s[i] = i < 2 * D ? -kLog2e * a.bg[i] : (i < 3 * D ? 2.0f * kLog2e * a.bc[i - 2 * D] : a.bc[i - 3 * D]);
     // The two waves of a SIMD (w and w + NW/2) do not interleave on the matrix pipe: the older one issues its whole
     // MFMA burst first.  The stage loop leans on that: the waves of the first half ("early") burst first and do
     // their side work afterwards, the second half ("late") the other way round.
-    const bool late = wave >= NW / 2;
+    // (HALF: the SIMD partner is another workgroup's wave at a phase of its own: every wave issues its side work first)
+    const bool late = HALF || wave >= NW / 2;
     int tk = blockIdx.x, tk_next = blockIdx.x + nb;                 // current / next pass's ticket (workgroup-uniform)
     if (a.tickets && tid == 0) *tk_slot = nb + atomicAdd(a.tickets, 1);
 
@@ -180,7 +191,9 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         else dma_image<I::IMG_BYTES, NW>(src, dst, wave, lane);
     };
     auto publish = [&]() { if constexpr (SPLIT) dma_wait(); __syncthreads(); };
-    dma(packed, ring);
+    auto dma_ha = [&](const float* src, float* dst) { dma_kib_asm<SC::HA_BYTES / 1024, NW>(src, dst, wave, lane); };
+    auto dma_hb = [&](const float* src, float* dst) { dma_kib_asm<SC::HB_BYTES / 1024, NW>(src, dst, wave, lane); };
+    if constexpr (HALF) dma_ha(packed, ring); else dma(packed, ring);
 
     // ---- the pipelined gather of the aggregated-messages segment (GATHER) --------------------------------------
     // Phases, each issued at a stage start and landed by that stage's closing barrier (U = the stage that consumes
@@ -375,7 +388,43 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
             if constexpr ((POS) == NSTAGE - 1) __syncthreads();   /* (the ticket slot written before this stage) */ \
             GGNN_T(POS, 3)                                                                               \
         }
+        // HALF: the stage in two sub-stages.  Entering, slot `cur` holds half A of this stage's image (published).
+#define GGNN_HALF_STAGE(POS, ACC, FRAG)                                                                  \
+        {                                                                                                \
+            constexpr int npos_ = (POS) + 1;                                                             \
+            const bool more_ = (npos_ < NSTAGE) || tk_next < n_dma;                                      \
+            const float* csrc_ = packed + (size_t)gru_stage_image<NX>(POS) * I::IMG;                     \
+            const float* nsrc_ = packed + (size_t)gru_stage_image<NX>(npos_ < NSTAGE ? npos_ : 0) * I::IMG; \
+            GGNN_T(POS, 0)                                                                               \
+            if constexpr (GATHER && (POS) == G_U % NSTAGE) {   /* the fragment this stage multiplies */  \
+                if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVEX) { if (row < a.V && a.save_x) store_x(xf[GBUF], row); } } \
+            }                                                                                            \
+            /* sub-stage A: half B of this image on its way into the other slot, the stage's fetches, tiles [0, TA) */ \
+            if (!(a.dbg & 8)) dma_hb(csrc_ + SC::HA, ring + (cur ^ 1) * SLOT);                           \
+            prefetch(std::integral_constant<int, (POS)>{});                                              \
+            GGNN_T(POS, 1)                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            constexpr int ntl_ = ((C::TAILPACK && (POS) % 3 == 1) ||                                     \
+                                  (C::TAILPACK3 && (POS) % 3 == 2 && (POS) < 3 * NX)) ? NT - 1 : NT;     \
+            if constexpr ((POS) % 3 == 0 || (POS) == NSTAGE - 1) { if (active && !(a.dbg & 16)) split_frag<D>(sf, FRAG); } \
+            if (active && !(a.dbg & 1))                                                                  \
+                stage_mma_split_at<D, (ntl_ < SC::TA ? ntl_ : SC::TA), ((POS) < 3), 0>(ACC, sf, FRAG, ring + cur * SLOT, ring + cur * SLOT, li, kq); \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            publish();                                                                                   \
+            cur ^= 1;                                                                                    \
+            /* sub-stage B: half A of the NEXT stage's image on its way, tiles [TA, ntl) from the slot that just landed */ \
+            if (more_ && !(a.dbg & 8)) dma_ha(nsrc_, ring + (cur ^ 1) * SLOT);                           \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            if (active && !(a.dbg & 1))                                                                  \
+                stage_mma_split_at<D, ntl_, ((POS) < 3), SC::TA>(ACC, sf, FRAG, ring + cur * SLOT, ring + cur * SLOT, li, kq); \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            GGNN_T(POS, 2)                                                                               \
+            publish();                                                                                   \
+            GGNN_T(POS, 3)                                                                               \
+            cur ^= 1;                                                                                    \
+        }
 #define GGNN_STAGE(POS, ACC, FRAG)                                                                       \
+        if constexpr (HALF) GGNN_HALF_STAGE(POS, ACC, FRAG) else                                         \
         if constexpr (coop && COOP_REGS) GGNN_COOP_STAGE(POS, ACC, FRAG) else                            \
         {                                                                                                \
             constexpr int npos_ = (POS) + 1;                                                             \
@@ -523,6 +572,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
         if (a.tickets && tid == 0) tk_slot[(p + 1) & 1] = nb + tk_fetch;
         GGNN_STAGE(3 * NX + 2, acc_c, rh)
 #undef GGNN_STAGE
+#undef GGNN_HALF_STAGE
 #undef GGNN_COOP_STAGE
         tk = tk_next;
         tk_next = a.tickets ? __builtin_amdgcn_readfirstlane(tk_slot[(p + 1) & 1]) : tk_next + nb;
@@ -597,7 +647,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_fused_kernel(GruFusedArgs a,
     }
 }
 
-template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE>
+template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE, bool HALF = false>
 static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream_t st) {
     using C = StageCfg<D>;
     using I = ImgCfg<D, SPLIT>;
@@ -612,22 +662,23 @@ static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream
     if ((unsigned long long)a.V * D >= (1ULL << 30) || (a.g_H && (unsigned long long)a.V * a.g_T * D >= (1ULL << 30)))
         return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit byte offsets: V*D (and V*T*D for the gathered rows) "
                                         "must be < 2^30 (V=%d, D=%d)", a.V, D);
-    const size_t lds = (size_t)2 * I::IMG_BYTES + (size_t)((4 * D + 4 + 63) / 64 * 64) * sizeof(float)    // biases, ticket slots + ring
-                     + (size_t)16 * (C::BN + 4) * sizeof(float);                                          // + r*h exchange block
+    const size_t lds = HALF ? (size_t)2 * SplitCfg<D>::HA_BYTES + (size_t)((4 * D + 4 + 63) / 64 * 64) * sizeof(float)   // two per CU
+                            : (size_t)2 * I::IMG_BYTES + (size_t)((4 * D + 4 + 63) / 64 * 64) * sizeof(float)    // biases, ticket slots + ring
+                              + (size_t)16 * (C::BN + 4) * sizeof(float);                                          // + r*h exchange block
     const int wt_total = (a.V + 15) / 16;
     // one workgroup per CU; with fewer than NW tiles per CU the tiles are spread over ALL CUs as thin tickets (the
     // kernel's tail rule: ceil(tiles / nb) waves busy per workgroup) rather than packed 8 to a workgroup on a few CUs --
     // a pass with one or two busy waves takes less than half the time of a full one
-    int nb = num_cus();
+    int nb = HALF ? 2 * num_cus() : num_cus();
     if (nb > wt_total) nb = wt_total;
     // Few tiles (the dense model's b = 256 x v = 29: 464): one tile per workgroup, worked cooperatively by its 8 waves (25 MFMAs
     // per stage and wave, weights straight from L2), the workgroups beyond the CU count following as the first ones retire --
     // instead of two-tile tickets on which two waves of a workgroup run the full 175-MFMA stages while six idle.
     static const int coop_small = [] { const char* e = getenv("GGNN_GRU_COOP_SMALL"); return e ? atoi(e) : 1; }();
-    if (coop_small && wt_total > nb && wt_total <= 2 * nb && StageCfg<D>::NT <= NW) nb = wt_total;
+    if (!HALF && coop_small && wt_total > nb && wt_total <= 2 * nb && StageCfg<D>::NT <= NW) nb = wt_total;
     static std::atomic<unsigned long long> lds_ok{0};        // (one per template instantiation)
-    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX>, lds, lds_ok));
-    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
+    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX, HALF>, lds, lds_ok));
+    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX, HALF>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
@@ -635,9 +686,25 @@ static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream
 #ifdef GGNN_GRU_TU_SPLIT
 // SAVE is a run-time matter in the kernel's epilogues (uniform branches on the save pointers): the training instantiation
 // serves inference too (it is also the one that comes out of the register allocator with less scratch).
+// GGNN_GRU_WG=1: the gather-fused launches as one 8-wave workgroup per CU (the form before round 4); default 2: two 4-wave
+// workgroups per CU on half-stage rings (HALF above)
+static int gru_wg_per_cu() {
+    static const int v = [] { const char* e = getenv("GGNN_GRU_WG"); return e ? atoi(e) : 2; }();
+    return v;
+}
+
 template <int D>
 static int split_launch_d(int nx, bool gather, const GruFusedArgs& a, float* packed, hipStream_t st) {
     if constexpr (SplitCfg<D>::OK) {
+        if (gather && gru_wg_per_cu() == 2) {
+            switch (nx) {
+                case 1: return launch_gru_fused_m<D, 1, 4, true, true, true, true, true>(a, packed, st);
+                case 2: return a.save_x ? launch_gru_fused_m<D, 2, 4, true, true, true, true, true>(a, packed, st)
+                                        : launch_gru_fused_m<D, 2, 4, true, true, true, false, true>(a, packed, st);
+                case 3: return a.save_x ? launch_gru_fused_m<D, 3, 4, true, true, true, true, true>(a, packed, st)
+                                        : launch_gru_fused_m<D, 3, 4, true, true, true, false, true>(a, packed, st);
+            }
+        }
         if (gather) {
             switch (nx) {
                 case 1: return launch_gru_fused_m<D, 1, 8, true, true, true>(a, packed, st);        // (R = 0: no scratch either way)

@@ -20,11 +20,16 @@
 // chained (output tile nt == activation chunk nt) exactly as in the f32 kernels, and split in registers.  The D % 16
 // remainder k indices (4 at D = 100) stay on the f32 MFMA.
 //
-// Stage image (one D x D block; BN = 16 ceil(D/16) columns):
+// Stage image (one D x D block; BN = 16 ceil(D/16) columns), stored as TWO column halves that are each a complete image of
+// their own (round 4: the two-workgroups-per-CU fused GRU streams a stage through its LDS ring half by half; every other
+// kernel brings the whole image in at once and never notices -- the (unit -> address) map below is resolved at compile time):
+//     half A = output tiles [0, TA), half B = tiles [TA, NT);  inside a half of BNH columns:
 //     plane p in {hi, mid, lo}:  [c2][g][n][8 x bf16]   one ds_read_b128 = the weight operand of (c2, tile of n)
 //     rem (f32): [q][g][n] = W[16 NC + 4q + g][n]       as in the f32 image
+// half A is padded to whole KiB (the half-stage DMA moves KiB pieces), the image to 8 KiB.
 #pragma once
 #include "ggnn_stage.hpp"
+#include <type_traits>
 
 namespace ggnn {
 
@@ -39,11 +44,21 @@ struct SplitCfg {
     using S = StageCfg<D>;
     static constexpr bool OK = (S::NC % 2 == 0) && S::NC > 0;
     static constexpr int NC2 = S::NC / 2;
-    static constexpr int PLANE_BYTES = NC2 * 4 * S::BN * 16;
-    static constexpr int MAIN_BYTES = 3 * PLANE_BYTES;
-    static constexpr int REM_BYTES = S::NR * 4 * S::BN * 4;
-    static constexpr int IMG_BYTES = (MAIN_BYTES + REM_BYTES + 8191) / 8192 * 8192;
+    static constexpr int TA = (S::NT + 1) / 2;                       // tiles in half A (D = 100: 4 of 7)
+    // geometry of a half holding NTH tiles
+    static constexpr int plane_bytes(int nth) { return NC2 * 4 * nth * 16 * 16; }
+    static constexpr int main_bytes(int nth) { return 3 * plane_bytes(nth); }
+    static constexpr int rem_bytes(int nth) { return S::NR * 4 * nth * 16 * 4; }
+    static constexpr int half_bytes(int nth) { return (main_bytes(nth) + rem_bytes(nth) + 1023) / 1024 * 1024; }
+    static constexpr int HA_BYTES = half_bytes(TA);                  // half A, whole KiB (D = 100: 37 KiB)
+    static constexpr int HB_BYTES = half_bytes(S::NT - TA);          // half B, whole KiB (28 KiB)
+    static constexpr int HA = HA_BYTES / 4;                          // float offset of half B inside the image
+    static constexpr int IMG_BYTES = (HA_BYTES + HB_BYTES + 8191) / 8192 * 8192;
     static constexpr int IMG = IMG_BYTES / 4;
+    // (unit-independent parts of the address of tile nt's operand: which half, its column count, the tile's index inside it)
+    static constexpr int half_of(int nt) { return nt < TA ? 0 : 1; }
+    static constexpr int nth_of(int nt) { return nt < TA ? TA : S::NT - TA; }
+    static constexpr int tile_in_half(int nt) { return nt < TA ? nt : nt - TA; }
 };
 
 // image geometry of a fused kernel: the f32 stage image or the split one
@@ -91,19 +106,22 @@ template <int D, class Value>
 __device__ __forceinline__ void pack_split_image(const Value& value, float* __restrict__ img, int first, int stride) {
     using C = SplitCfg<D>;
     using S = StageCfg<D>;
-    constexpr int PW = C::PLANE_BYTES / 4, MW = C::MAIN_BYTES / 4, RW = C::REM_BYTES / 4;
     for (int i = first; i < C::IMG; i += stride) {
         unsigned out = 0u;
-        if (i < MW) {
-            const int plane = i / PW, w = i % PW;
+        const int half = i < C::HA ? 0 : 1;
+        const int nth = half ? S::NT - C::TA : C::TA, bnh = nth * 16, n0 = half ? C::TA * 16 : 0;
+        const int w_ = i - (half ? C::HA : 0);                       // word inside the half
+        const int PW = C::plane_bytes(nth) / 4, MW = C::main_bytes(nth) / 4, RW = C::rem_bytes(nth) / 4;
+        if (w_ < MW) {
+            const int plane = w_ / PW, w = w_ % PW;
             const int slot = w >> 2, pr = w & 3;                 // 16-byte slot (c2, g, n); bf16 pair (j = 2 pr, 2 pr + 1)
-            const int n = slot % S::BN, cg = slot / S::BN, c2 = cg >> 2, g = cg & 3;
+            const int n = n0 + slot % bnh, cg = slot / bnh, c2 = cg >> 2, g = cg & 3;
             const int j0 = 2 * pr;
             const int k0 = 32 * c2 + 16 * (j0 >> 2) + 4 * g + (j0 & 3);
             out = split_piece_bits(value(k0, n), plane) | (split_piece_bits(value(k0 + 1, n), plane) << 16);
-        } else if (i < MW + RW) {
-            const int j = i - MW;
-            out = __float_as_uint(value(16 * S::NC + j / S::BN, j % S::BN));       // j / BN = q*4 + g
+        } else if (w_ < MW + RW) {
+            const int j = w_ - MW;
+            out = __float_as_uint(value(16 * S::NC + j / bnh, n0 + j % bnh));       // j / bnh = q*4 + g
         }
         img[i] = __uint_as_float(out);
     }
@@ -187,43 +205,60 @@ __device__ __forceinline__ f32x4 split_products(f32x4 acc, u32x4 wh, u32x4 wm, u
 // consumed in the order lo (1 product), mid (2), hi (3) and each plane's registers are refilled with the NEXT unit's fragment as
 // soon as its last product has issued: 12 weight registers in flight instead of 24 for a double buffer, the lo and mid fragments
 // of the next unit a full unit ahead, the hi fragment three MFMAs ahead (the partner wave's MFMAs cover what that leaves).
-template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false>
-__device__ __forceinline__ void stage_mma_split(f32x4 (&acc)[StageCfg<D>::NT], const SFrag<D>& a, const Frag<D>& af,
-                                                const float* img, int li, int kq) {
+// T0: first tile (the half-stage kernels multiply a stage in two calls, tiles [0, TA) from half A and [TA, NTILES) from half B,
+// each half at `img` / `img_b`; everyone else passes the whole image: img_b = img + HA).  Per accumulator the chain is the same
+// in both forms: chunks in order, then the remainder.
+template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false, int T0 = 0>
+__device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT], const SFrag<D>& a, const Frag<D>& af,
+                                                   const float* img, const float* img_b, int li, int kq) {
     using S = StageCfg<D>;
     using C = SplitCfg<D>;
-    constexpr int NU = C::NC2 * NTILES;                               // units, chunk-major
-    constexpr int PL = C::PLANE_BYTES / 16;                           // plane pitch in 16-byte slots
-    const u32x4* base = reinterpret_cast<const u32x4*>(img) + kq * S::BN + li;
-    auto slot = [&](int u, int p) { return base[p * PL + (u / NTILES) * 4 * S::BN + (u % NTILES) * 16]; };
-    u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
+    constexpr int NTW = NTILES - T0;                                  // tiles walked
+    constexpr int NU = C::NC2 * NTW;                                  // units, chunk-major
+    if constexpr (NU > 0) {
+        // lane part of the address, per half (the halves differ in their column count)
+        const u32x4* base_a = reinterpret_cast<const u32x4*>(img) + kq * (C::TA * 16) + li;
+        const u32x4* base_b = reinterpret_cast<const u32x4*>(img_b) + kq * ((S::NT - C::TA) * 16) + li;
+        auto slot = [&](int u, int p) {
+            const int nt = T0 + u % NTW, c2 = u / NTW;
+            const int nth = C::nth_of(nt);
+            const u32x4* b = C::half_of(nt) ? base_b : base_a;
+            return b[p * (C::plane_bytes(nth) / 16) + c2 * 4 * nth * 16 + C::tile_in_half(nt) * 16];
+        };
+        u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int c2 = u / NTILES, nt = u % NTILES;
-        const bool more = u + 1 < NU;
-        f32x4 c = (ZERO && c2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt];
-        c = mfma_bf16(wl, a.hi[c2], c);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) wl = slot(u + 1, 2);
-        c = mfma_bf16(wm, a.mid[c2], c);
-        c = mfma_bf16(wm, a.hi[c2], c);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) wm = slot(u + 1, 1);
-        c = mfma_bf16(wh, a.lo[c2], c);
-        c = mfma_bf16(wh, a.mid[c2], c);
-        c = mfma_bf16(wh, a.hi[c2], c);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) wh = slot(u + 1, 0);
-        acc[nt] = c;
+        for (int u = 0; u < NU; ++u) {
+            const int c2 = u / NTW, nt = T0 + u % NTW;
+            const bool more = u + 1 < NU;
+            f32x4 c = (ZERO && c2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt];
+            c = mfma_bf16(wl, a.hi[c2], c);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) wl = slot(u + 1, 2);
+            c = mfma_bf16(wm, a.mid[c2], c);
+            c = mfma_bf16(wm, a.hi[c2], c);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) wm = slot(u + 1, 1);
+            c = mfma_bf16(wh, a.lo[c2], c);
+            c = mfma_bf16(wh, a.mid[c2], c);
+            c = mfma_bf16(wh, a.hi[c2], c);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) wh = slot(u + 1, 0);
+            acc[nt] = c;
+        }
     }
     // the D % 16 remainder k values on the f32 MFMA, their weights two tiles ahead (2 registers in flight)
-    if constexpr (S::NR > 0) {
-        constexpr int NRM = S::NR * NTILES;
-        auto rw = [&](int i) { return img[C::MAIN_BYTES / 4 + ((i / NTILES) * 4 + kq) * S::BN + li + (i % NTILES) * 16]; };
+    if constexpr (S::NR > 0 && NTW > 0) {
+        constexpr int NRM = S::NR * NTW;
+        auto rw = [&](int i) {
+            const int nt = T0 + i % NTW, q = i / NTW;
+            const int nth = C::nth_of(nt);
+            const float* b = C::half_of(nt) ? img_b : img;
+            return b[C::main_bytes(nth) / 4 + (q * 4 + kq) * nth * 16 + li + C::tile_in_half(nt) * 16];
+        };
         float w0 = rw(0), w1 = NRM > 1 ? rw(1) : 0.f;
 #pragma unroll
         for (int i = 0; i < NRM; ++i) {
-            const int q = i / NTILES, nt = i % NTILES;
+            const int q = i / NTW, nt = T0 + i % NTW;
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, af.r[q], acc[nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             w0 = w1;
@@ -232,27 +267,38 @@ __device__ __forceinline__ void stage_mma_split(f32x4 (&acc)[StageCfg<D>::NT], c
     }
 }
 
+template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false>
+__device__ __forceinline__ void stage_mma_split(f32x4 (&acc)[StageCfg<D>::NT], const SFrag<D>& a, const Frag<D>& af,
+                                                const float* img, int li, int kq) {
+    stage_mma_split_at<D, NTILES, ZERO, 0>(acc, a, af, img, img + SplitCfg<D>::HA, li, kq);
+}
+
 // ONE output tile (wave-uniform, run time) of the same product: the cooperative tail pass
+#define NC2_PLANE_SLOTS(NC2_, NTH_) ((NC2_) * 4 * (NTH_) * 16)
 template <int D, bool ZERO>
 __device__ __forceinline__ void stage_mma_one_split(f32x4& acc, const SFrag<D>& a, const Frag<D>& af, const float* img, int li,
                                                     int kq, int tile) {
     using S = StageCfg<D>;
     using C = SplitCfg<D>;
-    constexpr int PL = C::PLANE_BYTES / 16;
-    const u32x4* base = reinterpret_cast<const u32x4*>(img) + kq * S::BN + li + tile * 16;
+    const bool hb = tile >= C::TA;                                    // (wave-uniform)
+    const int nth = hb ? S::NT - C::TA : C::TA, til = hb ? tile - C::TA : tile;
+    const float* him = hb ? img + C::HA : img;
+    const int PL = NC2_PLANE_SLOTS(C::NC2, nth);                      // plane pitch in 16-byte slots
+    const int CP = 4 * nth * 16;                                      // chunk pitch in slots
+    const u32x4* base = reinterpret_cast<const u32x4*>(him) + kq * nth * 16 + li + til * 16;
     f32x4 cin = acc;
     if constexpr (ZERO) cin = f32x4{0.f, 0.f, 0.f, 0.f};
     u32x4 w0 = base[0], w1 = base[PL], w2 = base[2 * PL];
 #pragma unroll
     for (int c2 = 0; c2 < C::NC2; ++c2) {
         const int cn = c2 + 1 < C::NC2 ? c2 + 1 : c2;
-        const u32x4 n0 = base[cn * 4 * S::BN], n1 = base[PL + cn * 4 * S::BN], n2 = base[2 * PL + cn * 4 * S::BN];
+        const u32x4 n0 = base[cn * CP], n1 = base[PL + cn * CP], n2 = base[2 * PL + cn * CP];
         cin = split_products<false>(cin, w0, w1, w2, a.hi[c2], a.mid[c2], a.lo[c2]);
         w0 = n0; w1 = n1; w2 = n2;
     }
 #pragma unroll
     for (int q = 0; q < S::NR; ++q) {
-        const float wr = img[C::MAIN_BYTES / 4 + (q * 4 + kq) * S::BN + li + tile * 16];
+        const float wr = him[3 * PL * 4 + (q * 4 + kq) * nth * 16 + li + til * 16];
         cin = __builtin_amdgcn_mfma_f32_16x16x4f32(wr, af.r[q], cin, 0, 0, 0);
     }
     acc = cin;
@@ -311,6 +357,45 @@ __device__ __forceinline__ void dma_image_asm(const float* src, float* dst, int 
                          :: "s"(l), "v"(voff), "s"(s) : "memory");
         else
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(l), "v"(voff), "s"(s) : "memory");
+    }
+}
+// KIB pieces of 1 KiB (any count) from src into LDS at dst by an NW-wave workgroup, issued like dma_image_asm: wave w moves the
+// pieces [w Q, (w + 1) Q) with Q = KIB / NW, and the KIB % NW pieces behind them go one each to the first waves.
+template <int KIB, int NW>
+__device__ __forceinline__ void dma_kib_asm(const float* src, float* dst, int wave, int lane) {
+    constexpr int Q = KIB / NW, R = KIB % NW;
+    const unsigned voff = (unsigned)lane * 16u;
+    const unsigned lds0 = (unsigned)(unsigned long)(lds_void*)dst;
+    const unsigned long long src0 = reinterpret_cast<unsigned long long>(src);
+    auto group = [&](unsigned byte_off, auto nc) {                    // <= 4 consecutive KiB at byte_off (wave-uniform)
+        constexpr int n = decltype(nc)::value;
+        const unsigned long long sb = src0 + byte_off;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+        const unsigned long long s = ((unsigned long long)hi << 32) | lo;
+        const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + byte_off);
+        if constexpr (n == 4)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072" :: "s"(l), "v"(voff), "s"(s) : "memory");
+        else if constexpr (n == 3)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:2048" :: "s"(l), "v"(voff), "s"(s) : "memory");
+        else if constexpr (n == 2)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
+                         :: "s"(l), "v"(voff), "s"(s) : "memory");
+        else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(l), "v"(voff), "s"(s) : "memory");
+    };
+#pragma unroll
+    for (int i0 = 0; i0 < Q; i0 += 4) {
+        const unsigned off = ((unsigned)wave * Q + (unsigned)i0) * 1024u;
+        if (Q - i0 >= 4) group(off, std::integral_constant<int, 4>{});
+        else if (Q - i0 == 3) group(off, std::integral_constant<int, 3>{});
+        else if (Q - i0 == 2) group(off, std::integral_constant<int, 2>{});
+        else group(off, std::integral_constant<int, 1>{});
+    }
+    if constexpr (R > 0) {
+        if (wave < R) group(((unsigned)(NW * Q) + (unsigned)wave) * 1024u, std::integral_constant<int, 1>{});
     }
 }
 // every load this wave has issued (DMA pieces included) has landed
