@@ -112,19 +112,30 @@ __device__ __forceinline__ void frag_add(Frag<D>& f, const Frag<D>& t) {
 // SAVEX: the gathered segment is stored too (save_x; training).  The split-form inference dispatch runs <SAVE = true, SAVEX =
 // false>: the instantiation with the r / u / c stores (skipped at run time) but without the save_x path comes out of the register
 // allocator with the least scratch (R = 1 / 2: 8 / 36 B; with it 28 / 40 B; SAVE = false: 164 / 196 B).
-// HALF (split form, NW = 4): TWO workgroups of four waves per CU instead of one of eight.  The two waves of a SIMD then belong
-// to different workgroups and meet at no barrier: while one sits in an epilogue, a fragment split, a DMA wait or at its own
-// workgroup's stage barrier, the other issues MFMAs (tools/issue_probe.hip: vector, transcendental and LDS-DMA instructions of one
-// wave overlap the bf16 MFMAs of its SIMD partner completely -- what the 8-wave form loses is that its barriers put both waves
-// of a SIMD into the same phase at the same time).  Two rings must fit the LDS: a stage image goes through its workgroup's ring
-// in its two column halves (ggnn_split.hpp: half A = tiles [0, TA), half B the rest), a stage is two sub-stages with a barrier
-// each, ring slot = half A (37 KiB at D = 100).  Same products in the same order per accumulator: bit-identical to the 8-wave form.
-template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE, bool HALF = false>
-__global__ __launch_bounds__(NW * 64, HALF ? 2 : 1) void ggnn_gru_fused_kernel(GruFusedArgs a, const float* __restrict__ packed) {
+// FORM: how a pass's stage images come through the LDS ring.
+//   0  one 8-wave workgroup per CU, whole images, 2 slots; the barrier that closes a stage waits for EVERY load the wave has
+//      issued (vmcnt(0): the next image's DMA, but also the stage's gather / fragment fetches).
+//   1  (HALF) two 4-wave workgroups per CU, each with a 2-slot ring of HALF images (ggnn_split.hpp: half A = tiles [0, TA), half
+//      B the rest; a stage = two sub-stages with a barrier each): the two waves of a SIMD belong to different workgroups and
+//      meet at no barrier.  Measured (round 4): no faster than form 0 at R = 0, 5-12 % faster with residual inputs.
+//   2  (DEEP) one 8-wave workgroup, half images, THREE slots: the DMA of sub-stage k + 2 is issued in sub-stage k, so the barrier
+//      that closes sub-stage k only has to know that DMA k + 1 -- a whole sub-stage old -- has landed.  The load counter retires
+//      in order; waiting until no more than this sub-stage's own DMA pieces are outstanding (they were issued BEFORE the
+//      sub-stage's fetches: "vmcnt(pieces)") proves it, and leaves every gather / fragment fetch of the sub-stage in flight.
+//      Ablation that led here (tools/fwd_kernels.py, GGNN_GRU_DBG): the R = 0 launch takes 34 us with the MFMAs, epilogues,
+//      splits and DMA all switched off -- 18 stage barriers each waiting out one HBM round trip -- 63 us with only the MFMAs
+//      added, 63 us with only the side work added, 88 us with both: the three parts ran one after the other.
+// Same products in the same order per accumulator in every form: bit-identical results.
+template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE, int FORM = 0>
+__global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_kernel(GruFusedArgs a, const float* __restrict__ packed) {
     using C = StageCfg<D>;
     using I = ImgCfg<D, SPLIT>;
     using SC = SplitCfg<D>;
-    static_assert(!HALF || (SPLIT && NW == 4), "the half-stage form is a split-form, four-wave kernel");
+    constexpr bool HALF = FORM != 0;                                  // stage images travel as halves
+    constexpr bool DEEP = FORM == 2;
+    constexpr int NSLOT = DEEP ? 3 : 2;
+    static_assert(!HALF || SPLIT, "the half-stage forms are split-form kernels");
+    static_assert(FORM != 1 || NW == 4, "form 1 is the four-wave kernel");
     constexpr int NT = C::NT, NC = C::NC, NR = C::NR;
     constexpr int NSTAGE = 3 * (NX + 1);
     constexpr int SLOT = HALF ? SC::HA : I::IMG;                     // floats per ring slot
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : 1) void ggnn_gru_fused_kernel(G
     // One-tile tail tickets (tail_w == 1, the usual case) are worked COOPERATIVELY: all waves take the same 16 rows and
     // wave w computes output column tile w of every gate (25 MFMAs per stage instead of 175 on one wave while seven
     // idle); the r*h fragment, which the candidate stage needs whole, is exchanged through LDS.
-    const bool coop_tail = (tail_w == 1) && (NT <= NW) && !HALF;
+    const bool coop_tail = (tail_w == 1) && (NT <= NW) && !HALF;   // (the half-stage forms run thin tail tickets on single waves)
     auto is_coop = [&](int t) -> bool { return coop_tail && t >= full_tk && t < n_tk; };
     auto tile_of = [&](int t) -> int {                              // this wave's tile of ticket t, or -1
         if (t < full_tk) return t * NW + wave;
@@ -173,14 +184,14 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : 1) void ggnn_gru_fused_kernel(G
     float* ring = lds_ + BIAS_FLOATS;
     int* tk_slot = reinterpret_cast<int*>(bias_s + 4 * D);
     constexpr int RHP = C::BN + 4;                     // row pitch of the r*h exchange block (cooperative tail pass)
-    float* rh_x = ring + 2 * SLOT;                     // [16][RHP], behind the ring (cooperative tail passes only: not HALF)
+    float* rh_x = ring + NSLOT * SLOT;                     // [16][RHP], behind the ring (cooperative tail passes only: not HALF)
     for (int i = tid; i < 4 * D; i += NW * 64)
         bias_s[i] = i < 2 * D ? -kLog2e * a.bg[i] : (i < 3 * D ? 2.0f * kLog2e * a.bc[i - 2 * D] : a.bc[i - 3 * D]);
     // The two waves of a SIMD (w and w + NW/2) do not interleave on the matrix pipe: the older one issues its whole
     // MFMA burst first.  The stage loop leans on that: the waves of the first half ("early") burst first and do
     // their side work afterwards, the second half ("late") the other way round.
-    // (HALF: the SIMD partner is another workgroup's wave at a phase of its own: every wave issues its side work first)
-    const bool late = HALF || wave >= NW / 2;
+    // (form 1: the SIMD partner is another workgroup's wave at a phase of its own: every wave issues its side work first)
+    const bool late = FORM == 1 || wave >= NW / 2;
     int tk = blockIdx.x, tk_next = blockIdx.x + nb;                 // current / next pass's ticket (workgroup-uniform)
     if (a.tickets && tid == 0) *tk_slot = nb + atomicAdd(a.tickets, 1);
 
@@ -193,7 +204,32 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : 1) void ggnn_gru_fused_kernel(G
     auto publish = [&]() { if constexpr (SPLIT) dma_wait(); __syncthreads(); };
     auto dma_ha = [&](const float* src, float* dst) { dma_kib_asm<SC::HA_BYTES / 1024, NW>(src, dst, wave, lane); };
     auto dma_hb = [&](const float* src, float* dst) { dma_kib_asm<SC::HB_BYTES / 1024, NW>(src, dst, wave, lane); };
-    if constexpr (HALF) dma_ha(packed, ring); else dma(packed, ring);
+    // own pieces of a half-image DMA (dma_kib_asm's split): what the DEEP barrier may leave outstanding
+    constexpr int KA = SC::HA_BYTES / 1024, KB = SC::HB_BYTES / 1024;
+    const int own_a = KA / NW + (wave < KA % NW ? 1 : 0), own_b = KB / NW + (wave < KB % NW ? 1 : 0);
+    // barrier of a DEEP sub-stage: `own` = this wave's pieces of the DMA issued in the sub-stage (0: none was issued)
+    auto publish_deep = [&](int own) {
+        switch (own) {                                               // (wave-uniform; s_waitcnt takes an immediate)
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    static_assert(!DEEP || (SC::HA_BYTES / 1024 + NW - 1) / NW <= 10, "publish_deep covers <= 10 pieces per wave");
+    if constexpr (DEEP) {                                            // sub-stages 0 and 1 of the first pass
+        dma_ha(packed, ring);
+        dma_hb(packed + SC::HA, ring + SLOT);
+    } else if constexpr (HALF) dma_ha(packed, ring);
+    else dma(packed, ring);
 
     // ---- the pipelined gather of the aggregated-messages segment (GATHER) --------------------------------------
     // Phases, each issued at a stage start and landed by that stage's closing barrier (U = the stage that consumes
@@ -224,25 +260,38 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : 1) void ggnn_gru_fused_kernel(G
             }
         }
     };
-    auto g_index = [&]() {                            // level 2: the first KI source rows
+    // Every phase below has a CONSUME half (it needs values an earlier stage fetched: the compiler puts its load-counter wait in
+    // front of the first use) and an ISSUE half (new loads).  The DEEP form runs all consume halves of a stage, then its DMA, then
+    // all issue halves -- a wait placed behind the DMA would count its pieces among the "younger" loads and stall on them; the
+    // other forms run them back to back (part 0).
+    auto touch = [](auto v) { asm volatile("" :: "v"(v)); };         // "this value is needed HERE"
+    auto g_index = [&](int part) {                    // level 2: the first KI source rows
         // a slot beyond the row's degree points at row 0 of Hrows: the row loads below are then UNCONDITIONAL (no
         // zero-fills, no exec-mask juggling around 7 loads -- vector-ALU instructions cost matrix-pipe time) and only
         // the adds are predicated; Hrows always has at least one row
-#pragma unroll
-        for (int j = 0; j < KI; ++j) {
-            g_i[j] = 0;
-            if (g_beg + j < g_end) g_i[j] = ldi_b(a.g_idx, (unsigned)(g_beg + j) * 4u);
+        if (part != 2) {
+            touch(g_beg); touch(g_end);
+            g_den = (((g_n.x + g_n.y) + g_n.z) + g_n.w) + 1e-7f;
+            if constexpr (NX == 1) g_rcp = 1.0f / g_den;    // the in-degrees landed with the slot range
         }
-        g_den = (((g_n.x + g_n.y) + g_n.z) + g_n.w) + 1e-7f;
-        if constexpr (NX == 1) g_rcp = 1.0f / g_den;    // the in-degrees landed with the slot range
+        if (part != 1) {
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                g_i[j] = 0;
+                if (g_beg + j < g_end) g_i[j] = ldi_b(a.g_idx, (unsigned)(g_beg + j) * 4u);
+            }
+        }
     };
-    auto g_rows0 = [&](Frag<D>& f) {                  // level 3: slot 0 straight into f, slot 1 into the temporary
-        load_frag<D>(f, a.g_H, g_i[0], kq);           // (0 + slot 0 of the segment-sum kernel: same value, up to -0)
-        load_frag<D>(gt, a.g_H, g_i[1], kq);
+    auto g_rows0 = [&](Frag<D>& f, int part) {        // level 3: slot 0 straight into f, slot 1 into the temporary
+        if (part != 2) { touch(g_i[0]); touch(g_i[1]); touch(g_i[2]); touch(g_i[3]); }
+        if (part != 1) {
+            load_frag<D>(f, a.g_H, g_i[0], kq);       // (0 + slot 0 of the segment-sum kernel: same value, up to -0)
+            load_frag<D>(gt, a.g_H, g_i[1], kq);
+        }
     };
-    auto g_rows = [&](Frag<D>& f, int k) {            // add slot k-1 (landed), fetch slot k
-        if (g_beg + k - 1 < g_end) frag_add<D>(f, gt);
-        load_frag<D>(gt, a.g_H, g_i[k], kq);
+    auto g_rows = [&](Frag<D>& f, int k, int part) {  // add slot k-1 (landed), fetch slot k
+        if (part != 2) { if (g_beg + k - 1 < g_end) frag_add<D>(f, gt); }
+        if (part != 1) load_frag<D>(gt, a.g_H, g_i[k], kq);
     };
     auto g_finish = [&](Frag<D>& f) {                 // slot 3, any further slots (synchronously), mean
         if (g_beg + KI - 1 < g_end) frag_add<D>(f, gt);
@@ -287,11 +336,11 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : 1) void ggnn_gru_fused_kernel(G
         if constexpr (GATHER) {                       // first tile: the phases of the previous pass, synchronously
             if constexpr (G_NEXT) {
                 g_ptrs(r0c, on);
-                if (on) { g_index(); g_rows0(xf[0]); g_rows(xf[0], 2); g_rows(xf[0], 3); g_finish(xf[0]); }
+                if (on) { g_index(0); g_rows0(xf[0], 0); g_rows(xf[0], 2, 0); g_rows(xf[0], 3, 0); g_finish(xf[0]); }
                 if constexpr (SAVEX) { if (on && r0 < a.V && a.save_x) store_x(xf[0], r0); }
             } else {
                 if constexpr (G_U - 5 < 0) g_ptrs(r0c, on);
-                if constexpr (G_U - 4 < 0) g_index();         // (also for a wave without a tile: its slots -> row 0)
+                if constexpr (G_U - 4 < 0) g_index(0);        // (also for a wave without a tile: its slots -> row 0)
                 load_frag<D>(xf[0], a.x[0], r0c, kq);
             }
         } else {
@@ -330,27 +379,32 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : 1) void ggnn_gru_fused_kernel(G
 
         // what is fetched at the START of stage POS (it lands in the shadow of that stage's MFMAs and is drained
         // by its closing barrier)
-        auto prefetch = [&](auto posc) {
+        // part 0: everything; 1: the consume halves of the stage's phases; 2: their issue halves (see g_index)
+        auto prefetch = [&](auto posc, int part = 0) {
             constexpr int POS = decltype(posc)::value;
             constexpr int s = POS / 3, j = POS % 3;
             if constexpr (GATHER) {
                 // a phase at position v < 0 (or any phase when G_NEXT) runs one pass ahead, for the next tile's row
                 constexpr int P_PTR = G_U - 5, P_IDX = G_U - 4, P_R0 = G_U - 3, P_R1 = G_U - 2, P_R2 = G_U - 1;
                 if constexpr (POS == (P_PTR + NSTAGE) % NSTAGE) {
-                    if constexpr (G_NEXT || P_PTR < 0) g_ptrs(rown, has_next);
-                    else g_ptrs(rowc, active);
+                    if (part != 1) {
+                        if constexpr (G_NEXT || P_PTR < 0) g_ptrs(rown, has_next);
+                        else g_ptrs(rowc, active);
+                    }
                 }
-                if constexpr (POS == (P_IDX + NSTAGE) % NSTAGE) g_index();
-                if constexpr (POS == (P_R0 + NSTAGE) % NSTAGE) g_rows0(xf[GBUF]);
-                if constexpr (POS == (P_R1 + NSTAGE) % NSTAGE) g_rows(xf[GBUF], 2);
-                if constexpr (POS == (P_R2 + NSTAGE) % NSTAGE) g_rows(xf[GBUF], 3);
+                if constexpr (POS == (P_IDX + NSTAGE) % NSTAGE) g_index(part);
+                if constexpr (POS == (P_R0 + NSTAGE) % NSTAGE) g_rows0(xf[GBUF], part);
+                if constexpr (POS == (P_R1 + NSTAGE) % NSTAGE) g_rows(xf[GBUF], 2, part);
+                if constexpr (POS == (P_R2 + NSTAGE) % NSTAGE) g_rows(xf[GBUF], 3, part);
             }
-            // h: one stage before its first use (kept out of the registers until then)
-            if constexpr (POS == 3 * NX - 1) load_frag<D>(hf, a.h, rowc, kq);
-            // the next plain segment, one stage before its first use
-            if constexpr (j == 2 && s + 1 < NX && !(GATHER && s + 1 == GSEG)) load_frag<D>(xf[(s + 1) & 1], a.x[s + 1], rowc, kq);
-            // the next pass's first segment (xf[0] is dead by the last stage)
-            if constexpr (POS == NSTAGE - 1 && !(GATHER && GSEG == 0)) load_frag<D>(xf[0], a.x[0], rown, kq);
+            if (part != 1) {
+                // h: one stage before its first use (kept out of the registers until then)
+                if constexpr (POS == 3 * NX - 1) load_frag<D>(hf, a.h, rowc, kq);
+                // the next plain segment, one stage before its first use
+                if constexpr (j == 2 && s + 1 < NX && !(GATHER && s + 1 == GSEG)) load_frag<D>(xf[(s + 1) & 1], a.x[s + 1], rowc, kq);
+                // the next pass's first segment (xf[0] is dead by the last stage)
+                if constexpr (POS == NSTAGE - 1 && !(GATHER && GSEG == 0)) load_frag<D>(xf[0], a.x[0], rown, kq);
+            }
         };
 
 #if GGNN_GRU_STAMPS
@@ -388,40 +442,72 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : 1) void ggnn_gru_fused_kernel(G
             if constexpr ((POS) == NSTAGE - 1) __syncthreads();   /* (the ticket slot written before this stage) */ \
             GGNN_T(POS, 3)                                                                               \
         }
-        // HALF: the stage in two sub-stages.  Entering, slot `cur` holds half A of this stage's image (published).
+        // Forms 1 and 2: the stage in two sub-stages.  Entering, slot `cur` holds half A of this stage's image (published).
+        //   form 1: half B of this image is fetched during sub-stage A, half A of the next stage's during sub-stage B; the barriers
+        //           wait for everything (vmcnt(0)).
+        //   form 2: the DMA runs TWO sub-stages ahead (3 slots): sub-stage A fetches the NEXT stage's half A, sub-stage B its half
+        //           B; a sub-stage is  consume | DMA | issue | MFMAs | vmcnt(own pieces) + barrier  (early waves: MFMAs first).
 #define GGNN_HALF_STAGE(POS, ACC, FRAG)                                                                  \
         {                                                                                                \
             constexpr int npos_ = (POS) + 1;                                                             \
             const bool more_ = (npos_ < NSTAGE) || tk_next < n_dma;                                      \
             const float* csrc_ = packed + (size_t)gru_stage_image<NX>(POS) * I::IMG;                     \
             const float* nsrc_ = packed + (size_t)gru_stage_image<NX>(npos_ < NSTAGE ? npos_ : 0) * I::IMG; \
+            constexpr int ntl_ = ((C::TAILPACK && (POS) % 3 == 1) ||                                     \
+                                  (C::TAILPACK3 && (POS) % 3 == 2 && (POS) < 3 * NX)) ? NT - 1 : NT;     \
+            const int nxt_ = cur + 1 < NSLOT ? cur + 1 : 0, nx2_ = nxt_ + 1 < NSLOT ? nxt_ + 1 : 0;      \
             GGNN_T(POS, 0)                                                                               \
             if constexpr (GATHER && (POS) == G_U % NSTAGE) {   /* the fragment this stage multiplies */  \
                 if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVEX) { if (row < a.V && a.save_x) store_x(xf[GBUF], row); } } \
             }                                                                                            \
-            /* sub-stage A: half B of this image on its way into the other slot, the stage's fetches, tiles [0, TA) */ \
-            if (!(a.dbg & 8)) dma_hb(csrc_ + SC::HA, ring + (cur ^ 1) * SLOT);                           \
-            prefetch(std::integral_constant<int, (POS)>{});                                              \
+            if constexpr ((POS) % 3 == 0 || (POS) == NSTAGE - 1) { if (active && !(a.dbg & 16)) split_frag<D>(sf, FRAG); } \
+            /* ---- sub-stage A: tiles [0, TA) from slot cur */                                          \
+            bool dma_a_ = false;                                                                         \
+            if constexpr (DEEP) {                                                                        \
+                if (late) {                                                                              \
+                    prefetch(std::integral_constant<int, (POS)>{}, 1);                                   \
+                    if (more_ && !(a.dbg & 8)) { dma_ha(nsrc_, ring + nx2_ * SLOT); dma_a_ = true; }     \
+                    prefetch(std::integral_constant<int, (POS)>{}, 2);                                   \
+                }                                                                                        \
+            } else {                                                                                     \
+                if (!(a.dbg & 8)) dma_hb(csrc_ + SC::HA, ring + nxt_ * SLOT);                            \
+                prefetch(std::integral_constant<int, (POS)>{});                                          \
+            }                                                                                            \
             GGNN_T(POS, 1)                                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                           \
-            constexpr int ntl_ = ((C::TAILPACK && (POS) % 3 == 1) ||                                     \
-                                  (C::TAILPACK3 && (POS) % 3 == 2 && (POS) < 3 * NX)) ? NT - 1 : NT;     \
-            if constexpr ((POS) % 3 == 0 || (POS) == NSTAGE - 1) { if (active && !(a.dbg & 16)) split_frag<D>(sf, FRAG); } \
             if (active && !(a.dbg & 1))                                                                  \
                 stage_mma_split_at<D, (ntl_ < SC::TA ? ntl_ : SC::TA), ((POS) < 3), 0>(ACC, sf, FRAG, ring + cur * SLOT, ring + cur * SLOT, li, kq); \
             __builtin_amdgcn_sched_barrier(0);                                                           \
-            publish();                                                                                   \
-            cur ^= 1;                                                                                    \
-            /* sub-stage B: half A of the NEXT stage's image on its way, tiles [TA, ntl) from the slot that just landed */ \
-            if (more_ && !(a.dbg & 8)) dma_ha(nsrc_, ring + (cur ^ 1) * SLOT);                           \
-            __builtin_amdgcn_sched_barrier(0);                                                           \
-            if (active && !(a.dbg & 1))                                                                  \
-                stage_mma_split_at<D, ntl_, ((POS) < 3), SC::TA>(ACC, sf, FRAG, ring + cur * SLOT, ring + cur * SLOT, li, kq); \
-            __builtin_amdgcn_sched_barrier(0);                                                           \
-            GGNN_T(POS, 2)                                                                               \
-            publish();                                                                                   \
-            GGNN_T(POS, 3)                                                                               \
-            cur ^= 1;                                                                                    \
+            if constexpr (DEEP) {                                                                        \
+                if (!late) {                                                                             \
+                    prefetch(std::integral_constant<int, (POS)>{}, 1);                                   \
+                    if (more_ && !(a.dbg & 8)) { dma_ha(nsrc_, ring + nx2_ * SLOT); dma_a_ = true; }     \
+                    prefetch(std::integral_constant<int, (POS)>{}, 2);                                   \
+                }                                                                                        \
+                publish_deep(dma_a_ ? own_a : 0);                                                        \
+            } else publish();                                                                            \
+            cur = nxt_;                                                                                  \
+            /* ---- sub-stage B: tiles [TA, ntl) from the slot that has just been published */           \
+            {                                                                                            \
+                const int nb1_ = cur + 1 < NSLOT ? cur + 1 : 0, nb2_ = nb1_ + 1 < NSLOT ? nb1_ + 1 : 0;  \
+                bool dma_b_ = false;                                                                     \
+                if constexpr (DEEP) {                                                                    \
+                    if (late && more_ && !(a.dbg & 8)) { dma_hb(nsrc_ + SC::HA, ring + nb2_ * SLOT); dma_b_ = true; } \
+                } else {                                                                                 \
+                    if (more_ && !(a.dbg & 8)) dma_ha(nsrc_, ring + nb1_ * SLOT);                        \
+                }                                                                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                if (active && !(a.dbg & 1))                                                              \
+                    stage_mma_split_at<D, ntl_, ((POS) < 3), SC::TA>(ACC, sf, FRAG, ring + cur * SLOT, ring + cur * SLOT, li, kq); \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+                GGNN_T(POS, 2)                                                                           \
+                if constexpr (DEEP) {                                                                    \
+                    if (!late && more_ && !(a.dbg & 8)) { dma_hb(nsrc_ + SC::HA, ring + nb2_ * SLOT); dma_b_ = true; } \
+                    publish_deep(dma_b_ ? own_b : 0);                                                    \
+                } else publish();                                                                        \
+                GGNN_T(POS, 3)                                                                           \
+                cur = nb1_;                                                                              \
+            }                                                                                            \
         }
 #define GGNN_STAGE(POS, ACC, FRAG)                                                                       \
         if constexpr (HALF) GGNN_HALF_STAGE(POS, ACC, FRAG) else                                         \
@@ -640,14 +726,14 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : 1) void ggnn_gru_fused_kernel(G
     // tickets come to a workgroup in increasing order: its ordinary passes first, then (at most a few) tail passes
     int p = 0;
     for (; tk < n_main; ++p) run_pass(std::false_type{}, p);
-    for (; tk < n_tk; ++p) run_pass(std::true_type{}, p);
+    if constexpr (!HALF) { for (; tk < n_tk; ++p) run_pass(std::true_type{}, p); }   // (cooperative tail passes: form 0 only)
     if (GGNN_TDBG(a) && tid == 0) {
         a.tdbg[4096 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
         a.tdbg[4096 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
-template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE, bool HALF = false>
+template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE, int FORM = 0>
 static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream_t st) {
     using C = StageCfg<D>;
     using I = ImgCfg<D, SPLIT>;
@@ -662,23 +748,24 @@ static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream
     if ((unsigned long long)a.V * D >= (1ULL << 30) || (a.g_H && (unsigned long long)a.V * a.g_T * D >= (1ULL << 30)))
         return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit byte offsets: V*D (and V*T*D for the gathered rows) "
                                         "must be < 2^30 (V=%d, D=%d)", a.V, D);
-    const size_t lds = HALF ? (size_t)2 * SplitCfg<D>::HA_BYTES + (size_t)((4 * D + 4 + 63) / 64 * 64) * sizeof(float)   // two per CU
-                            : (size_t)2 * I::IMG_BYTES + (size_t)((4 * D + 4 + 63) / 64 * 64) * sizeof(float)    // biases, ticket slots + ring
-                              + (size_t)16 * (C::BN + 4) * sizeof(float);                                          // + r*h exchange block
+    constexpr size_t bias_b = (size_t)((4 * D + 4 + 63) / 64 * 64) * sizeof(float);                       // biases, ticket slots
+    const size_t lds = FORM == 1 ? (size_t)2 * SplitCfg<D>::HA_BYTES + bias_b                                   // two workgroups per CU
+                     : FORM == 2 ? (size_t)3 * SplitCfg<D>::HA_BYTES + bias_b
+                                 : (size_t)2 * I::IMG_BYTES + bias_b + (size_t)16 * (C::BN + 4) * sizeof(float);  // + r*h exchange block
     const int wt_total = (a.V + 15) / 16;
     // one workgroup per CU; with fewer than NW tiles per CU the tiles are spread over ALL CUs as thin tickets (the
     // kernel's tail rule: ceil(tiles / nb) waves busy per workgroup) rather than packed 8 to a workgroup on a few CUs --
     // a pass with one or two busy waves takes less than half the time of a full one
-    int nb = HALF ? 2 * num_cus() : num_cus();
+    int nb = FORM == 1 ? 2 * num_cus() : num_cus();
     if (nb > wt_total) nb = wt_total;
     // Few tiles (the dense model's b = 256 x v = 29: 464): one tile per workgroup, worked cooperatively by its 8 waves (25 MFMAs
     // per stage and wave, weights straight from L2), the workgroups beyond the CU count following as the first ones retire --
     // instead of two-tile tickets on which two waves of a workgroup run the full 175-MFMA stages while six idle.
     static const int coop_small = [] { const char* e = getenv("GGNN_GRU_COOP_SMALL"); return e ? atoi(e) : 1; }();
-    if (!HALF && coop_small && wt_total > nb && wt_total <= 2 * nb && StageCfg<D>::NT <= NW) nb = wt_total;
+    if (FORM == 0 && coop_small && wt_total > nb && wt_total <= 2 * nb && StageCfg<D>::NT <= NW) nb = wt_total;
     static std::atomic<unsigned long long> lds_ok{0};        // (one per template instantiation)
-    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX, HALF>, lds, lds_ok));
-    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX, HALF>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
+    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX, FORM>, lds, lds_ok));
+    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX, FORM>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
@@ -686,23 +773,32 @@ static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream
 #ifdef GGNN_GRU_TU_SPLIT
 // SAVE is a run-time matter in the kernel's epilogues (uniform branches on the save pointers): the training instantiation
 // serves inference too (it is also the one that comes out of the register allocator with less scratch).
-// GGNN_GRU_WG=1: the gather-fused launches as one 8-wave workgroup per CU (the form before round 4); default 2: two 4-wave
-// workgroups per CU on half-stage rings (HALF above)
-static int gru_wg_per_cu() {
-    static const int v = [] { const char* e = getenv("GGNN_GRU_WG"); return e ? atoi(e) : 2; }();
+// GGNN_GRU_FORM: ring form of the gather-fused launches (the kernel's FORM): 0 whole images / 8 waves (the form before round 4),
+// 1 two 4-wave workgroups per CU on half-image rings, 2 (default) 8 waves on a 3-slot half-image ring with partial waits
+static int gru_form() {
+    static const int v = [] { const char* e = getenv("GGNN_GRU_FORM"); return e ? atoi(e) : 2; }();
     return v;
 }
 
 template <int D>
 static int split_launch_d(int nx, bool gather, const GruFusedArgs& a, float* packed, hipStream_t st) {
     if constexpr (SplitCfg<D>::OK) {
-        if (gather && gru_wg_per_cu() == 2) {
+        if (gather && gru_form() == 2) {
             switch (nx) {
-                case 1: return launch_gru_fused_m<D, 1, 4, true, true, true, true, true>(a, packed, st);
-                case 2: return a.save_x ? launch_gru_fused_m<D, 2, 4, true, true, true, true, true>(a, packed, st)
-                                        : launch_gru_fused_m<D, 2, 4, true, true, true, false, true>(a, packed, st);
-                case 3: return a.save_x ? launch_gru_fused_m<D, 3, 4, true, true, true, true, true>(a, packed, st)
-                                        : launch_gru_fused_m<D, 3, 4, true, true, true, false, true>(a, packed, st);
+                case 1: return launch_gru_fused_m<D, 1, 8, true, true, true, true, 2>(a, packed, st);
+                case 2: return a.save_x ? launch_gru_fused_m<D, 2, 8, true, true, true, true, 2>(a, packed, st)
+                                        : launch_gru_fused_m<D, 2, 8, true, true, true, false, 2>(a, packed, st);
+                case 3: return a.save_x ? launch_gru_fused_m<D, 3, 8, true, true, true, true, 2>(a, packed, st)
+                                        : launch_gru_fused_m<D, 3, 8, true, true, true, false, 2>(a, packed, st);
+            }
+        }
+        if (gather && gru_form() == 1) {
+            switch (nx) {
+                case 1: return launch_gru_fused_m<D, 1, 4, true, true, true, true, 1>(a, packed, st);
+                case 2: return a.save_x ? launch_gru_fused_m<D, 2, 4, true, true, true, true, 1>(a, packed, st)
+                                        : launch_gru_fused_m<D, 2, 4, true, true, true, false, 1>(a, packed, st);
+                case 3: return a.save_x ? launch_gru_fused_m<D, 3, 4, true, true, true, true, 1>(a, packed, st)
+                                        : launch_gru_fused_m<D, 3, 4, true, true, true, false, 1>(a, packed, st);
             }
         }
         if (gather) {
