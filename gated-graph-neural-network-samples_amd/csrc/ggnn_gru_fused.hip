@@ -210,17 +210,17 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
     // barrier of a DEEP sub-stage: `own` = this wave's pieces of the DMA issued in the sub-stage (0: none was issued)
     auto publish_deep = [&](int own) {
         switch (own) {                                               // (wave-uniform; s_waitcnt takes an immediate)
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
         }
         __builtin_amdgcn_s_barrier();
     };
@@ -408,9 +408,11 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
         };
 
 #if GGNN_GRU_STAMPS
-#define GGNN_T(CI, K) if (a.tdbg && blockIdx.x == 0 && lane == 0) a.tdbg[((p * NSTAGE + (CI)) * NW + wave) * 4 + (K)] = __builtin_amdgcn_s_memtime();
+#define GGNN_T(CI, K) if (a.tdbg && blockIdx.x == 0 && lane == 0 && p < 4) a.tdbg[((p * NSTAGE + (CI)) * NW + wave) * 4 + (K)] = __builtin_amdgcn_s_memtime();
+#define GGNN_T2(CI, K) if (a.tdbg && blockIdx.x == 0 && lane == 0 && p < 4) a.tdbg[2048 + ((p * NSTAGE + (CI)) * NW + wave) * 4 + (K)] = __builtin_amdgcn_s_memtime();
 #else
 #define GGNN_T(CI, K)
+#define GGNN_T2(CI, K)
 #endif
         // one stage: prefetches, start the DMA of the next image, MFMAs on the current one, publish
         // Cooperative tail pass: no ring, no per-stage barrier.  Wave w multiplies by column tile w only, whose weights
@@ -475,9 +477,12 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
             }                                                                                            \
             GGNN_T(POS, 1)                                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                           \
+            if (a.dbg & 32) __builtin_amdgcn_s_setprio(3);                                               \
             if (active && !(a.dbg & 1))                                                                  \
                 stage_mma_split_at<D, (ntl_ < SC::TA ? ntl_ : SC::TA), ((POS) < 3), 0>(ACC, sf, FRAG, ring + cur * SLOT, ring + cur * SLOT, li, kq); \
+            if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);                                               \
             __builtin_amdgcn_sched_barrier(0);                                                           \
+            GGNN_T(POS, 2)                                                                               \
             if constexpr (DEEP) {                                                                        \
                 if (!late) {                                                                             \
                     prefetch(std::integral_constant<int, (POS)>{}, 1);                                   \
@@ -486,6 +491,7 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
                 }                                                                                        \
                 publish_deep(dma_a_ ? own_a : 0);                                                        \
             } else publish();                                                                            \
+            GGNN_T(POS, 3)                                                                               \
             cur = nxt_;                                                                                  \
             /* ---- sub-stage B: tiles [TA, ntl) from the slot that has just been published */           \
             {                                                                                            \
@@ -497,15 +503,19 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
                     if (more_ && !(a.dbg & 8)) dma_ha(nsrc_, ring + nb1_ * SLOT);                        \
                 }                                                                                        \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
+                GGNN_T2(POS, 0)                                                                          \
+                if (a.dbg & 32) __builtin_amdgcn_s_setprio(3);                                           \
                 if (active && !(a.dbg & 1))                                                              \
                     stage_mma_split_at<D, ntl_, ((POS) < 3), SC::TA>(ACC, sf, FRAG, ring + cur * SLOT, ring + cur * SLOT, li, kq); \
+                if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);                                           \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
-                GGNN_T(POS, 2)                                                                           \
+                GGNN_T2(POS, 1)                                                                          \
                 if constexpr (DEEP) {                                                                    \
                     if (!late && more_ && !(a.dbg & 8)) { dma_hb(nsrc_ + SC::HA, ring + nb2_ * SLOT); dma_b_ = true; } \
+                    GGNN_T2(POS, 2)                                                                      \
                     publish_deep(dma_b_ ? own_b : 0);                                                    \
                 } else publish();                                                                        \
-                GGNN_T(POS, 3)                                                                           \
+                GGNN_T2(POS, 3)                                                                          \
                 cur = nb1_;                                                                              \
             }                                                                                            \
         }
@@ -539,6 +549,7 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
             /* stages 0..2 open the three accumulator sets: they start from the constant 0 */            \
             /* SPLIT: a fragment is split into its bf16 planes before the first of its stages */         \
             if constexpr (SPLIT && ((POS) % 3 == 0 || (POS) == NSTAGE - 1)) { if (active && !(a.dbg & 16)) split_frag<D>(sf, FRAG); } \
+            if (a.dbg & 32) __builtin_amdgcn_s_setprio(3);                                               \
             if (active && !(a.dbg & 1)) {                                                                \
                 const float* img_ = ring + cur * I::IMG;                                                 \
                 if constexpr (!coop) {                                                                   \
@@ -554,6 +565,7 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
                     else stage_mma_one<D, ((POS) < 3)>(ACC[0], FRAG, img_, li, kq, wave);                \
                 }                                                                                        \
             }                                                                                            \
+            if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);                                               \
             __builtin_amdgcn_sched_barrier(0);                                                           \
             if (!late) {                                                                                 \
                 prefetch(std::integral_constant<int, (POS)>{});                                          \
@@ -774,7 +786,7 @@ static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream
 // SAVE is a run-time matter in the kernel's epilogues (uniform branches on the save pointers): the training instantiation
 // serves inference too (it is also the one that comes out of the register allocator with less scratch).
 // GGNN_GRU_FORM: ring form of the gather-fused launches (the kernel's FORM): 0 whole images / 8 waves (the form before round 4),
-// 1 two 4-wave workgroups per CU on half-image rings, 2 (default) 8 waves on a 3-slot half-image ring with partial waits
+// 1 two 4-wave workgroups per CU on half-image rings, 2 8 waves on a 3-slot half-image ring with partial waits
 static int gru_form() {
     static const int v = [] { const char* e = getenv("GGNN_GRU_FORM"); return e ? atoi(e) : 2; }();
     return v;

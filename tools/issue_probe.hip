@@ -104,7 +104,7 @@ __global__ __launch_bounds__(NWAVES * 64) void probe(int role_a, int role_b, int
     extern __shared__ __attribute__((aligned(16))) float lds[];            // 100 KiB+: one workgroup per CU
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool second = wave >= NWAVES / 2 && NWAVES == 8;
-    const int role = second ? role_b : role_a;
+    int role = second ? role_b : role_a;
     Ctx c;
     for (int i = 0; i < 8; ++i) c.f[i] = 0.001f * (threadIdx.x + i);
     for (int i = 0; i < 4; ++i) { c.u[i] = threadIdx.x * 77u + i; c.ld[i] = f32x4{0, 0, 0, 0}; }
@@ -121,6 +121,8 @@ __global__ __launch_bounds__(NWAVES * 64) void probe(int role_a, int role_b, int
     float sink = 0.f;
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (role & 4) __builtin_amdgcn_s_setprio(3);
+    role &= 3;
     if (role == 1) mfma_stream<SHAPE, NACC, DEP, KIND, NFILL, EVERY, true, false>(n_outer, c, sink);
     else if (role == 2) mfma_stream<SHAPE, NACC, DEP, KIND, NFILL, EVERY, false, true>(n_outer, c, sink);
     else if (role == 3) mfma_stream<SHAPE, NACC, DEP, KIND, NFILL, EVERY, true, true>(n_outer, c, sink);
@@ -206,6 +208,15 @@ int main() {
     run<8, 16, 7, 6, DSREAD, 1, 2>(b, "16x16x32: A mfma | B ds_read per 2", 1, 2, N);
     run<8, 16, 7, 6, FMA, 2, 1>(b, "16x16x32: A mfma+2fma | B mfma+2fma", 3, 3, N);
     run<8, 16, 7, 6, MIXDMA, 1, 2>(b, "16x16x32: A,B both mfma + mix/2 (+DMA)", 3, 3, N);
+    printf("-- who wins the issue port: waves 0-3 (A) are the OLDER waves of their SIMDs; role +4 = s_setprio 3 --\n");
+    run<8, 16, 7, 6, FMA, 4, 1>(b, "16x16x32: A 4 v_fma x n | B mfma", 2, 1, N);
+    run<8, 16, 7, 6, FMA, 4, 1>(b, "16x16x32: A 4 v_fma x n | B mfma PRIO", 2, 5, N);
+    run<8, 16, 7, 6, FMA, 4, 1>(b, "16x16x32: A mfma | B 4 v_fma x n", 1, 2, N);
+    run<8, 16, 7, 6, FMA, 4, 1>(b, "16x16x32: A mfma PRIO | B 4 v_fma x n", 5, 2, N);
+    run<8, 16, 7, 6, TRANS, 1, 1>(b, "16x16x32: A v_exp x n | B mfma", 2, 1, N);
+    run<8, 16, 7, 6, TRANS, 1, 1>(b, "16x16x32: A v_exp x n | B mfma PRIO", 2, 5, N);
+    run<8, 16, 7, 6, MIX, 1, 1>(b, "16x16x32: A mix x n (no mfma) | B mfma", 2, 1, N);
+    run<8, 16, 7, 6, MIX, 1, 1>(b, "16x16x32: A mix x n (no mfma) | B mfma PRIO", 2, 5, N);
     run<8, 32, 4, 6, NONE, 0, 1>(b, "32x32x16: A mfma | B idle", 1, 0, N);
     run<8, 32, 4, 6, FMA, 4, 1>(b, "32x32x16: A mfma | B 4 v_fma per MFMA", 1, 2, N);
     run<8, 32, 4, 6, FMA, 4, 1>(b, "32x32x16: A idle | B 4 v_fma x n", 0, 2, N);
