@@ -208,6 +208,9 @@ __device__ __forceinline__ f32x4 split_products(f32x4 acc, u32x4 wh, u32x4 wm, u
 // T0: first tile (the half-stage kernels multiply a stage in two calls, tiles [0, TA) from half A and [TA, NTILES) from half B,
 // each half at `img` / `img_b`; everyone else passes the whole image: img_b = img + HA).  Per accumulator the chain is the same
 // in both forms: chunks in order, then the remainder.
+#ifndef GGNN_SPLIT_WH2
+#define GGNN_SPLIT_WH2 0     // 1: the hi plane of the NEXT unit is fetched at the start of the current one into a second register
+#endif                       //    set (9 MFMAs ahead instead of 3; +4 registers) -- experiment, see DESIGN.md K3
 template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false, int T0 = 0>
 __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT], const SFrag<D>& a, const Frag<D>& af,
                                                    const float* img, const float* img_b, int li, int kq) {
@@ -226,11 +229,18 @@ __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT]
             return b[p * (C::plane_bytes(nth) / 16) + c2 * 4 * nth * 16 + C::tile_in_half(nt) * 16];
         };
         u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
+#if GGNN_SPLIT_WH2
+        u32x4 wh_n = wh;
+#endif
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int c2 = u / NTW, nt = T0 + u % NTW;
             const bool more = u + 1 < NU;
             f32x4 c = (ZERO && c2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt];
+#if GGNN_SPLIT_WH2
+            if (more) wh_n = slot(u + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             c = mfma_bf16(wl, a.hi[c2], c);
             __builtin_amdgcn_sched_barrier(0);
             if (more) wl = slot(u + 1, 2);
@@ -242,7 +252,11 @@ __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT]
             c = mfma_bf16(wh, a.mid[c2], c);
             c = mfma_bf16(wh, a.hi[c2], c);
             __builtin_amdgcn_sched_barrier(0);
+#if GGNN_SPLIT_WH2
+            wh = wh_n;
+#else
             if (more) wh = slot(u + 1, 0);
+#endif
             acc[nt] = c;
         }
     }

@@ -238,43 +238,58 @@ def tf_dropout(x: torch.Tensor, keep_prob: float, seed=None, row_key=None) -> to
     return _CounterDropout.apply(x, float(keep_prob), int(seed), row_key)
 
 
-def tn_matmul(x: torch.Tensor, dy: torch.Tensor, chunk: int = 2048) -> torch.Tensor:
-    """x^T @ dy for tall-skinny operands ([V,K]^T [V,N] -> [K,N], V ~ 1e5, K,N <= 400).
-
-    A single vendor-BLAS GEMM launches only ceil(K/64)*ceil(N/64) ~ 12 workgroups for this shape (no split along
-    the 1e5-long reduction) and took ~340 us; batching the reduction into V/chunk independent [K,chunk]x[chunk,N]
-    products fills the GPU, and the [V/chunk, K, N] partials are summed in one small reduction."""
-    V = x.shape[0]
-    nb = V // chunk
-    if nb < 8:
-        return x.t().matmul(dy)
-    main = nb * chunk
-    part = torch.bmm(x[:main].view(nb, chunk, x.shape[1]).transpose(1, 2), dy[:main].view(nb, chunk, dy.shape[1])).sum(0)
-    if main < V:
-        part = part + x[main:].t().matmul(dy[main:])
-    return part
-
-
 class _TallLinear(torch.autograd.Function):
-    """x @ W + b for tall x ([V,K], V ~ 1e5): same forward as torch, but the weight gradient x^T dy -- a reduction over
-    all V rows that the vendor BLAS runs on a dozen workgroups (~330 us for the [V,200]^T [V,1] of the readout) -- is
-    batched along V (tn_matmul)."""
+    """x @ W + b for tall x ([V,K], V ~ 1e5) on the package's own kernels -- the op-by-op readout of chem_tensorflow_sparse.py:220-231
+    / utils.py:64-70, used only where the fused readout + loss kernels do not apply (an unsorted graph_nodes_list, widths beyond
+    256): forward and d x on the tiled GEMM (ggnn_gemm_f32: the weight matrix padded to 4 output columns, x as column segments
+    of a width the kernel takes), the weight gradient x^T dy on the row-split kernel ggnn_gemm_tn_f32, the bias gradient by
+    ggnn_colsum_f32.  No vendor BLAS."""
+
+    @staticmethod
+    def _segments(x):
+        """x [V,K] as equal column segments of a width the GEMM kernel takes (a multiple of 100, 64 or 32)."""
+        K = x.shape[1]
+        for seg in (K, K // 2, K // 3, K // 4):
+            if seg and K % seg == 0 and K // seg <= 4 and (seg % 100 == 0 or seg % 32 == 0):
+                return [x[:, i * seg:(i + 1) * seg] for i in range(K // seg)]
+        raise NotImplementedError("the op-by-op readout needs an input width whose halves / thirds / quarters are multiples of "
+                                  "32 or 100 (got %d); the fused readout (sorted graph_nodes_list, width <= 256) has no such limit" % K)
+
+    @staticmethod
+    def _pad4(W):
+        n = W.shape[1]
+        if n % 4 == 0:
+            return W.contiguous(), n
+        Wp = W.new_zeros((W.shape[0], (n + 3) // 4 * 4))
+        Wp[:, :n] = W
+        return Wp, n
 
     @staticmethod
     def forward(ctx, x, W, b):
+        from . import ops
+        x = x.contiguous()
         ctx.save_for_backward(x, W)
-        return x.matmul(W) + b
+        Wp, n = _TallLinear._pad4(W)
+        return ops.gemm(_TallLinear._segments(x), Wp)[:, :n] + b
 
     @staticmethod
     def backward(ctx, dy):
+        from . import ops
         x, W = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = dy.matmul(W.t()) if ctx.needs_input_grad[0] else None
-        if W.shape[1] == 1:
-            dW = (x * dy).sum(0).unsqueeze(1)
-        else:
-            dW = tn_matmul(x, dy)
-        return dx, dW, dy.sum(0)
+        n = W.shape[1]
+        dyp = dy.new_zeros((dy.shape[0], (n + 3) // 4 * 4))
+        dyp[:, :n] = dy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            WTp = W.new_zeros((dyp.shape[1], (W.shape[0] + 3) // 4 * 4))          # W^T, rows and columns padded to the kernel's granules
+            WTp[:n, :W.shape[0]] = W.t()
+            if dyp.shape[1] % 32 == 0:
+                dx = ops.gemm([dyp], WTp)[:, :W.shape[0]]
+            else:                                                                    # n <= 4 columns: d x = sum_j dy[:, j] W[:, j]^T
+                dx = sum(dyp[:, j:j + 1] * WTp[j:j + 1, :W.shape[0]] for j in range(n))
+        dW = ops.gemm_tn(x, dyp)[:, :n]
+        db = ops.colsum(dyp)[:n]
+        return dx, dW, db
 
 
 class MLP(object):

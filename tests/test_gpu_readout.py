@@ -100,3 +100,24 @@ def test_model_readout_paths_agree(pkg, oracle, cuda):
         wl, wa = oracle.task_loss(pred, f(feed["target_values"])[0], f(feed["target_mask"])[0])
         assert abs(loss - wl) <= 1e-5 * max(1.0, abs(wl))
         assert abs(float(model.ops['accuracy_task0']) - wa) <= 1e-5 * max(1.0, abs(wa))
+
+
+@pytest.mark.parametrize("V,K,n", [(3000, 200, 1), (1500, 100, 1), (777, 128, 3), (500, 64, 4)])
+def test_op_by_op_readout_linear_on_package_kernels(pkg, cuda, V, K, n):
+    """utils.MLP's layer (the op-by-op readout of chem_tensorflow_sparse.py:220-231 / utils.py:64-70, used where the fused readout
+    does not apply) runs on the package's GEMM / X^T dY / column-sum kernels -- no vendor BLAS: forward and all three gradients
+    against torch autograd in float64."""
+    rng = np.random.default_rng(V + K + n)
+    x = torch.from_numpy(rng.uniform(-1, 1, (V, K)).astype(np.float32)).to(cuda).requires_grad_(True)
+    W = torch.from_numpy(rng.uniform(-0.3, 0.3, (K, n)).astype(np.float32)).to(cuda).requires_grad_(True)
+    b = torch.from_numpy(rng.uniform(-0.3, 0.3, (n,)).astype(np.float32)).to(cuda).requires_grad_(True)
+    g = torch.from_numpy(rng.uniform(-1, 1, (V, n)).astype(np.float32)).to(cuda)
+    y = pkg.utils._TallLinear.apply(x, W, b)
+    y.backward(g)
+    x64, W64, b64 = (t.detach().double().requires_grad_(True) for t in (x, W, b))
+    y64 = x64.matmul(W64) + b64
+    y64.backward(g.double())
+    assert float((y.detach().double() - y64).abs().max()) < 2e-5
+    for got, want in ((x.grad, x64.grad), (W.grad, W64.grad), (b.grad, b64.grad)):
+        scale = float(want.abs().max()) + 1e-12
+        assert float((got.double() - want).abs().max()) <= 3e-5 * scale + 1e-6

@@ -25,7 +25,7 @@ for (nseg, N) in ((2, 200), (2, 100)):
     dy = torch.rand(V, N, device=dev)
     t = timeit(lambda: pkg.ops.xty(xs, dy, ones_row=True))
     xc = torch.cat(xs, 1)
-    tb = timeit(lambda: pkg.utils.tn_matmul(xc, dy))
+    tb = timeit(lambda: torch.matmul(xc.t(), dy))   # (vendor BLAS, for comparison only)
     gf = 2.0 * V * nseg * 100 * N / 1e9
     print("K=%d N=%d: xty %.1f us (%.1f TF)   batched BLAS %.1f us (%.1f TF)" % (nseg * 100, N, t, gf / t * 1e-3 * 1e3 / 1e3 * 1e3 / 1e3 * 1e3 if False else gf / (t * 1e-6) / 1e3, tb, gf / (tb * 1e-6) / 1e3))
 R, T = 122638, 4
