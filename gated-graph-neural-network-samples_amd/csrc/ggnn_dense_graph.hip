@@ -18,21 +18,10 @@
 //   * GRU (TF-1.3 GRUCell, :115): r, u = sigmoid([acts|h] Wg + bg), c = tanh([acts | r*h] Wc + bc), h' = u h + (1-u) c; the r*h tile of
 //     a wave is r times chunk w of its h fragment (output tile nt == activation chunk nt, as in the fused GRU).
 #include "ggnn_stage.hpp"
+#include "ggnn_dense_graph.hpp"
+#include "ggnn_split.hpp"
 
 namespace ggnn {
-
-struct DenseGraphArgs {
-    const float* h0;        // [b, v, D]
-    const float* A;         // [b, E, v, v]  A[g,e,dst,src]
-    const float* eimg;      // E stage images of W_e            (ggnn_dense_edge_pack_f32)
-    const float* gimg;      // 6 stage images: Wg[x,r] Wg[h,r] Wg[x,u] Wg[h,u] Wc[x] Wc[h]   (dense_gru_pack_kernel)
-    const float* ebias;     // [E, D] or NULL
-    const float* bg;        // [2D]
-    const float* bc;        // [D]
-    float* out;             // [b, v, D]
-    int b, v, steps;
-    unsigned long long* tdbg;   // (debug) s_memtime stamps of workgroup 0, waves 0 and 6: [step][wave sel][8]   (GGNN_DG_TPTR)
-};
 
 template <int D>
 __global__ void dense_gru_pack_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, float* __restrict__ out) {
@@ -298,14 +287,19 @@ __global__ void dense_edge_pack_kernel(const float* __restrict__ W, float* __res
                         gridDim.x * blockDim.x);
 }
 
-extern "C" size_t ggnn_dense_edge_packed_bytes(int D, int T) {
-    if (T <= 0) return 0;
+static size_t dense_edge_f32_bytes(int D, int T) {
     switch (D) {
         case 100: return (size_t)T * StageCfg<100>::IMG * sizeof(float);
         case 64: return (size_t)T * StageCfg<64>::IMG * sizeof(float);
         case 32: return (size_t)T * StageCfg<32>::IMG * sizeof(float);
         default: return 0;
     }
+}
+// (the packed buffers hold the f32 stage images FOLLOWED by the split ones: which kernel runs is decided per launch -- matrix
+// path of the process, and whether the split kernel's LDS blocks fit the launch's number of edge types)
+extern "C" size_t ggnn_dense_edge_packed_bytes(int D, int T) {
+    if (T <= 0 || !dense_edge_f32_bytes(D, T)) return 0;
+    return dense_edge_f32_bytes(D, T) + dense_split_edge_bytes(D, T);
 }
 
 extern "C" int ggnn_dense_edge_pack_f32(const float* W, int T, int D, float* packed, ggnn_stream_t stream) {
@@ -318,16 +312,19 @@ extern "C" int ggnn_dense_edge_pack_f32(const float* W, int T, int D, float* pac
         default: return fail(GGNN_E_UNSUPPORTED, "no graph-resident dense kernel for hidden size %d", D);
     }
     GGNN_CHECK_HIP(hipGetLastError());
-    return GGNN_OK;
+    return dense_split_pack_edge(W, T, D, packed + dense_edge_f32_bytes(D, T) / sizeof(float), st);
 }
 
-extern "C" size_t ggnn_dense_gru_packed_bytes(int D) {
+static size_t dense_gru_f32_bytes(int D) {
     switch (D) {
         case 100: return (size_t)6 * StageCfg<100>::IMG * sizeof(float);
         case 64: return (size_t)6 * StageCfg<64>::IMG * sizeof(float);
         case 32: return (size_t)6 * StageCfg<32>::IMG * sizeof(float);
         default: return 0;
     }
+}
+extern "C" size_t ggnn_dense_gru_packed_bytes(int D) {
+    return dense_gru_f32_bytes(D) ? dense_gru_f32_bytes(D) + dense_split_gru_bytes(D) : 0;
 }
 
 extern "C" int ggnn_dense_gru_pack_f32(const float* Wg, const float* Wc, int D, float* packed, ggnn_stream_t stream) {
@@ -340,7 +337,7 @@ extern "C" int ggnn_dense_gru_pack_f32(const float* Wg, const float* Wc, int D, 
         default: return fail(GGNN_E_UNSUPPORTED, "no graph-resident dense kernel for hidden size %d", D);
     }
     GGNN_CHECK_HIP(hipGetLastError());
-    return GGNN_OK;
+    return dense_split_pack_gru(Wg, Wc, D, packed + dense_gru_f32_bytes(D) / sizeof(float), st);
 }
 
 extern "C" int ggnn_dense_propagate_f32(const float* h0, const float* A, const float* edge_packed, const float* gru_packed,
@@ -356,6 +353,14 @@ extern "C" int ggnn_dense_propagate_f32(const float* h0, const float* A, const f
     DenseGraphArgs a{h0, A, edge_packed, gru_packed, edge_bias, bg, bc, out, b, v, steps, nullptr};
     { const char* e = getenv("GGNN_DG_TPTR"); a.tdbg = e ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
     hipStream_t st = (hipStream_t)stream;
+    // split form (bf16 pipe, ggnn_dense_graph_split.hip) where it exists and fits; GGNN_DENSE_SPLIT=0 keeps the f32-MFMA kernel
+    static const bool want_split = [] { const char* e = getenv("GGNN_DENSE_SPLIT"); return !e || atoi(e) != 0; }();
+    if (want_split && split_matrix_path() && dense_split_supported(v, E, D)) {
+        DenseGraphArgs s = a;
+        s.eimg = edge_packed + dense_edge_f32_bytes(D, E) / sizeof(float);
+        s.gimg = gru_packed + dense_gru_f32_bytes(D) / sizeof(float);
+        return dense_split_launch(s, E, D, st);
+    }
 #define GGNN_DG_CASE(DD, EE) if (D == DD && E == EE) return launch_dense_graph<DD, EE>(a, st);
     GGNN_DG_CASE(100, 4) GGNN_DG_CASE(100, 8) GGNN_DG_CASE(100, 2) GGNN_DG_CASE(100, 6)
     GGNN_DG_CASE(64, 4) GGNN_DG_CASE(64, 8) GGNN_DG_CASE(64, 2) GGNN_DG_CASE(64, 6)
