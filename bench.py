@@ -66,6 +66,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 dense (2495 measu
 SPLIT_PRODUCTS = 6
 SPLIT_KERNELS = ("msg_transform_compact", "gru_fused")
 SPLIT_ACTIVE = False               # set from ggnn_matrix_path_is_split() in main()
+DENSE_SPLIT = False                # set from ggnn_dense_propagate_is_split() for the configs[2] shape in secondary_dense()
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 HBM_COPY_GBPS = 6290.0
 
@@ -175,7 +176,7 @@ def kernel_table(res, reps, V, M, D, T, R=None):
                          "max_us": float(np.max(times)) * 1e3, "launches_per_step": len(times) / reps,
                          "time_share": None, "traffic": None, "algorithmic_bytes": by,
                          "hbm_frac": by / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        if bound == "mfma" and SPLIT_ACTIVE and name.startswith(SPLIT_KERNELS):
+        if bound == "mfma" and SPLIT_ACTIVE and (name.startswith(SPLIT_KERNELS) or (name.startswith("dense_propagate") and DENSE_SPLIT)):
             # A split-form kernel (whole-block kernels at D = 32 / 64 / 100, column-panel kernels at 128 / 192 / 256) issues
             # v_mfma_f32_*_bf16: its ceiling is the bf16 pipe's dense peak / 6 products per f32 product, in f32-equivalent flops.
             # `peak` / `frac` are that pipe's; the ratio to the f32-MFMA peak (which such a kernel can exceed) is kept beside them.
@@ -345,6 +346,8 @@ def secondary_dense(pkg, dev):
             step(i)
     b, v = feeds[0]["initial_node_representation"].shape[:2]
     D, T = model.params["hidden_size"], model.num_edge_types
+    global DENSE_SPLIT
+    DENSE_SPLIT = bool(pkg._lib.load().ggnn_dense_propagate_is_split(int(v), int(T), int(D)))
     kernels, tot_ms = kernel_table(kt.results(), 6, b * v, b * T * v * v, D, T)
     err = attach_traffic(kernels, "dense", D)
     out = {"workload": "configs[2]: dense GGNN forward, padded batch %d x v=%d, h=%d, %d edge types, %d timesteps" % (

@@ -87,6 +87,7 @@ SYMBOLS = {
     "ggnn_xty_f32": (c_int, [POINTER(c_void_p), c_int, c_int, POINTER(c_int32), c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                              c_int, POINTER(c_int32), c_int, c_void_p, c_size_t, c_void_p]),
     "ggnn_dense_propagate_supported": (c_int, [c_int, c_int, c_int]),
+    "ggnn_dense_propagate_is_split": (c_int, [c_int, c_int, c_int]),
     "ggnn_dense_edge_packed_bytes": (c_size_t, [c_int, c_int]),
     "ggnn_dense_edge_pack_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_dense_gru_packed_bytes": (c_size_t, [c_int]),

@@ -340,6 +340,12 @@ extern "C" int ggnn_dense_gru_pack_f32(const float* Wg, const float* Wc, int D, 
     return dense_split_pack_gru(Wg, Wc, D, packed + dense_gru_f32_bytes(D) / sizeof(float), st);
 }
 
+// split form (bf16 pipe, ggnn_dense_graph_split.hip) where it exists and fits; GGNN_DENSE_SPLIT=0 keeps the f32-MFMA kernel
+extern "C" int ggnn_dense_propagate_is_split(int v, int E, int D) {
+    static const bool want_split = [] { const char* e = getenv("GGNN_DENSE_SPLIT"); return !e || atoi(e) != 0; }();
+    return (want_split && split_matrix_path() && ggnn_dense_propagate_supported(v, E, D) && dense_split_supported(v, E, D)) ? 1 : 0;
+}
+
 extern "C" int ggnn_dense_propagate_f32(const float* h0, const float* A, const float* edge_packed, const float* gru_packed,
                                         const float* edge_bias, const float* bg, const float* bc, float* out, int b, int v, int E,
                                         int D, int steps, ggnn_stream_t stream) {
@@ -353,9 +359,7 @@ extern "C" int ggnn_dense_propagate_f32(const float* h0, const float* A, const f
     DenseGraphArgs a{h0, A, edge_packed, gru_packed, edge_bias, bg, bc, out, b, v, steps, nullptr};
     { const char* e = getenv("GGNN_DG_TPTR"); a.tdbg = e ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
     hipStream_t st = (hipStream_t)stream;
-    // split form (bf16 pipe, ggnn_dense_graph_split.hip) where it exists and fits; GGNN_DENSE_SPLIT=0 keeps the f32-MFMA kernel
-    static const bool want_split = [] { const char* e = getenv("GGNN_DENSE_SPLIT"); return !e || atoi(e) != 0; }();
-    if (want_split && split_matrix_path() && dense_split_supported(v, E, D)) {
+    if (ggnn_dense_propagate_is_split(v, E, D)) {
         DenseGraphArgs s = a;
         s.eimg = edge_packed + dense_edge_f32_bytes(D, E) / sizeof(float);
         s.gimg = gru_packed + dense_gru_f32_bytes(D) / sizeof(float);

@@ -333,10 +333,13 @@ int ggnn_gru_bwd_stage2_f32(const float* drh, int ld_drh, const float* h, const 
 /* The WHOLE dense forward (chem_tensorflow_dense.py:93-117, `steps` timesteps of  h <- GRU(sum_e A_e (h W_e + b_e), h)) in one launch:
  * workgroup g keeps graph g's v <= 32 vertex states on its CU for all timesteps (a graph reads only its own vertices).
  *   ggnn_dense_propagate_supported(v, E, D): v <= 32, E in {2,4,6,8}, D in {32,64,100}.
- *   edge_packed: ggnn_dense_edge_pack_f32 of W [E,D,D] (ggnn_dense_edge_packed_bytes(D,E) bytes; always f32 stage images, whatever the
- *   process's matrix path);  gru_packed: ggnn_dense_gru_pack_f32 of Wg [2D,2D], Wc [2D,D]
- *   (ggnn_dense_gru_packed_bytes(D) bytes);  edge_bias [E,D] or NULL;  h0, out [b,v,D];  A [b,E,v,v] (A[g,e,dst,src]). */
+ *   edge_packed: ggnn_dense_edge_pack_f32 of W [E,D,D] (ggnn_dense_edge_packed_bytes(D,E) bytes: the f32 stage images followed by the
+ *   split ones);  gru_packed: ggnn_dense_gru_pack_f32 of Wg [2D,2D], Wc [2D,D] (ggnn_dense_gru_packed_bytes(D) bytes, likewise);
+ *   edge_bias [E,D] or NULL;  h0, out [b,v,D];  A [b,E,v,v] (A[g,e,dst,src]).
+ *   ggnn_dense_propagate_is_split(v, E, D): 1 when the launch runs the split-form kernel (bf16 matrix pipe, f32 arithmetic: the
+ *   process's default matrix path, and the kernel's LDS blocks fit E edge types), 0 for the f32-MFMA kernel. */
 int ggnn_dense_propagate_supported(int v, int E, int D);
+int ggnn_dense_propagate_is_split(int v, int E, int D);
 size_t ggnn_dense_edge_packed_bytes(int D, int T);
 int ggnn_dense_edge_pack_f32(const float* W, int T, int D, float* packed, ggnn_stream_t stream);
 size_t ggnn_dense_gru_packed_bytes(int D);

@@ -26,6 +26,7 @@ import bench                                                        # noqa: E402
 
 pkg = importlib.import_module("gated-graph-neural-network-samples_amd")
 DEV = torch.device("cuda:0")
+bench.SPLIT_ACTIVE = bool(pkg._lib.load().ggnn_matrix_path_is_split())     # (bench.main() sets it; these legs bypass main)
 
 
 def dense():
