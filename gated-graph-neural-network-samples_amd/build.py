@@ -33,12 +33,32 @@ def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(s) > t for s in _deps())
+    if any(os.path.getmtime(s) > t for s in _deps()):
+        return True
+    # ... or an object older than a source it #includes (a library linked from such an object is newer than every source)
+    for src in sources():
+        obj = os.path.join(HERE, "build", os.path.basename(src)[:-4] + ".o")
+        if os.path.exists(obj) and any(os.path.getmtime(i) > os.path.getmtime(obj) for i in _included_sources(src)):
+            return True
+    return False
 
 
 def _headers():
     root = os.path.dirname(HERE)
     return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(root, "include", "*.h"))
+
+
+def _included_sources(src: str) -> list:
+    """The csrc/*.hip files `src` pulls in with #include "x.hip" (the *_split.hip translation units are their base file compiled
+    a second time): an object is stale when one of THESE is newer too -- headers are covered by newest_header."""
+    import re
+    out = []
+    with open(src, "r", encoding="utf-8", errors="replace") as f:
+        for m in re.finditer(r'^\s*#\s*include\s+"([^"]+\.hip)"', f.read(), re.M):
+            inc = os.path.join(CSRC, m.group(1))
+            if os.path.exists(inc):
+                out += [inc] + _included_sources(inc)
+    return out
 
 
 # Kernels on the bf16 matrix pipe are compiled WITHOUT packed-f32 vector instructions (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32):
@@ -66,7 +86,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     jobs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header)
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
+            [os.path.getmtime(src), newest_header] + [os.path.getmtime(i) for i in _included_sources(src)])
         jobs.append((src, obj, stale))
 
     def compile_one(job):
