@@ -53,7 +53,6 @@ int gru_panel_dispatch(const GruFusedArgs& a, int D, float* packed, hipStream_t 
 // ggnn_gru_fused_split.hip (GGNN_GRU_TU_SPLIT), for the SPLIT instantiations -- that translation unit is built without
 // packed-f32 vector instructions (build.py: a v_pk_* instruction beside the partner wave's bf16 MFMAs stalls the SIMD).
 int gru_split_launch(int D, int nx, bool save, bool gather, const GruFusedArgs& a, float* packed, hipStream_t st);
-int gru_blk_launch(const GruFusedArgs& a, float* packed, hipStream_t st);        // form 4 (D = 100, one input segment), ggnn_gru_blk.hip
 
 #ifndef GGNN_GRU_TU_SPLIT
 int gru_pack_floats(int D, int nx) {
@@ -799,7 +798,6 @@ static int gru_form(int nx) {
 template <int D>
 static int split_launch_d(int nx, bool gather, const GruFusedArgs& a, float* packed, hipStream_t st) {
     if constexpr (SplitCfg<D>::OK) {
-        if constexpr (D == 100) { if (gather && nx == 1 && gru_form(nx) == 4) return gru_blk_launch(a, packed, st); }
         if (gather && gru_form(nx) == 2) {
             switch (nx) {
                 case 1: return launch_gru_fused_m<D, 1, 8, true, true, true, true, 2>(a, packed, st);
