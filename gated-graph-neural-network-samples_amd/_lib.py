@@ -114,6 +114,7 @@ SYMBOLS = {
     "ggnn_gru_bwd_is_fused": (c_int, [c_int]),
     "ggnn_gru_bwd_packed_bytes": (c_size_t, [c_int, c_int]),
     "ggnn_gru_bwd_fused_f32": (c_int, [c_void_p] * 12 + [POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ggnn_gru_bwd_fused_gather_f32": (c_int, [c_void_p] * 12 + [POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ggnn_optim_block_floats": (c_int, []),
     "ggnn_clip_adam_f32": (c_int, [c_void_p] * 9 + [c_int, c_float, c_float, c_float, c_float, c_float, c_void_p]),
     "ggnn_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -30,6 +30,9 @@ struct GruBwdArgs {
     float* dx[3];                       // nx outputs [V,D]; the last one is d_incoming (scaled when use_avg)
     const float* nin; int T; int use_avg;
     int nx; int V; int act;
+    // optional: g_eff[v] = g[v] + sum over the (up to four) rows gz_heads[v] names of gz -- the per-node sum that closes the
+    // PREVIOUS timestep's transform backward (dh[v] += sum_t Z[row(v,t)]), taken on load here instead of by a launch of its own
+    const float* gz; const int* gz_heads;
     unsigned long long* tdbg;           // debug: s_memtime stamps of workgroup 0 (GGNN_BWD_TPTR; tools/gru_bwd_timeline.py)
 };
 
@@ -71,10 +74,9 @@ __device__ __forceinline__ void store_frag(float* base, int row, int kq, const F
 // SPLIT: the products on the bf16 matrix pipe in 3-way split form (ggnn_split.hpp); dpc, dpr, dpu are split once, when complete,
 // and their planes serve all 1 + NX stages that multiply them.
 template <int D, int NX, int NW, int PREFETCH, int RING, bool SPLIT>
-__global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs a, const float* __restrict__ packed) {
+__global__ __launch_bounds__(NW * 64, (RING == 1 && NW == 4) ? 2 : 1) void ggnn_gru_bwd_fused_kernel(GruBwdArgs a, const float* __restrict__ packed) {
     using C = StageCfg<D>;
     using I = ImgCfg<D, SPLIT>;
-    static_assert(!SPLIT || RING == 2, "the split form runs the two-image ring");
     constexpr int NT = C::NT, NC = C::NC, NR = C::NR;
     constexpr int NSTAGE = 3 * (NX + 1);
     extern __shared__ __attribute__((aligned(16))) float ring[];    // [2][IMG]
@@ -170,7 +172,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
                     // one image in LDS (two of these 4-wave workgroups share a CU and run out of phase: the DMA wait and the
                     // load / epilogue phases of one are covered by the MFMAs of the other)
                     __syncthreads();                                   // the previous stage's image has been consumed
-                    dma_stage_image<D, NW>(packed + (size_t)img_idx * I::IMG, ring, wave, lane);
+                    if constexpr (SPLIT) { dma_image_asm<I::IMG_BYTES, NW>(packed + (size_t)img_idx * I::IMG, ring, wave, lane); dma_wait(); }
+                    else dma_stage_image<D, NW>(packed + (size_t)img_idx * I::IMG, ring, wave, lane);
                     __syncthreads();                                   // (vmcnt(0) + barrier: landed)
                     if constexpr (ACT) mma(zero_c, acc, A, S, ring);
                     after();
@@ -191,7 +194,41 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_bwd_fused_kernel(GruBwdArgs 
             Frag<D> dpc, dpu, gu, rf, hrr, dpr;
             SFrag<D> sdpc, sdpr, sdpu;                              // (SPLIT) their bf16 planes
             if constexpr (ACT) {
+                // (gathered g) the head record first: it is the start of a dependent chain record -> rows
+                int hz0 = -1, hz1 = -1, hz2 = -1, hz3 = -1;
+                if (a.gz) {
+                    const int rc = row < a.V ? row : a.V - 1;
+                    const int4 hd = *reinterpret_cast<const int4*>(a.gz_heads + 4 * (size_t)rc);
+                    hz0 = hd.x; hz1 = hd.y; hz2 = hd.z; hz3 = hd.w;
+                }
                 if constexpr (!PREFETCH) { fetch_raw(raw, tk, 0); fetch_raw(raw, tk, 1); }
+                if (a.gz) {
+                    // the sums of ggnn_gather_segment_sum_heads_f32(accumulate = 1), in its order: ((0 + z0) + z1 + z2 + z3) + g; slots 2, 3
+                    // exist for few nodes (a node with three or more edge types): a second round that most tiles skip as a wave
+                    Frag<D> z0, z1, zs;
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) { z0.v[cc] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) z0.r[q] = 0.f;
+                    if (hz0 >= 0) load_frag<D>(z0, a.gz, hz0, kq);
+                    if (hz1 >= 0) load_frag<D>(z1, a.gz, hz1, kq);
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) { zs.v[cc] = 0.f + z0.v[cc]; if (hz1 >= 0) zs.v[cc] = zs.v[cc] + z1.v[cc]; }
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) { zs.r[q] = 0.f + z0.r[q]; if (hz1 >= 0) zs.r[q] = zs.r[q] + z1.r[q]; }
+                    if (hz2 >= 0) {
+                        load_frag<D>(z0, a.gz, hz2, kq);
+                        if (hz3 >= 0) load_frag<D>(z1, a.gz, hz3, kq);
+#pragma unroll
+                        for (int cc = 0; cc < NC; ++cc) { zs.v[cc] = zs.v[cc] + z0.v[cc]; if (hz3 >= 0) zs.v[cc] = zs.v[cc] + z1.v[cc]; }
+#pragma unroll
+                        for (int q = 0; q < NR; ++q) { zs.r[q] = zs.r[q] + z0.r[q]; if (hz3 >= 0) zs.r[q] = zs.r[q] + z1.r[q]; }
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) raw.g.v[cc] = zs.v[cc] + raw.g.v[cc];
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) raw.g.r[q] = zs.r[q] + raw.g.r[q];
+                }
                 auto dact = [&](float cv) { return a.act == GGNN_ACT_TANH ? 1.0f - cv * cv : (cv > 0.f ? 1.0f : 0.f); };
                 const unsigned os = ((unsigned)row * (unsigned)D + 4u * (unsigned)kq) * 4u;
 #pragma unroll
@@ -379,9 +416,13 @@ template <int D, int NX>
 static int launch_gru_bwd_split(const GruBwdArgs& a, const float* Wg, const float* Wc, float* packed, hipStream_t st) {
     bool done;
     if (int rc = gru_bwd_prepare<D, NX, true>(a, Wg, Wc, packed, st, &done); rc != GGNN_OK || done) return rc;
-    // GGNN_BWD_FORM=1: the next tile's inputs prefetched under the last stage
+    // GGNN_BWD_FORM=1: the next tile's inputs prefetched under the last stage; 2: two 4-wave workgroups per CU with one image each
+    // (round 4, MI355X, V = 100k: 164.7 us form 0, 163.8 form 2, 189.5 form 1; starting every other workgroup 5-25 us late moves
+    // the launch time by -2 .. +4 us: with half the chip idle the rest clocks higher -- the launch is paced by the chip's power
+    // budget, not by how its phases line up; profiles/r04_experiments/gru_bwd_forms_stagger.txt)
     const int form = [] { const char* e = getenv("GGNN_BWD_FORM"); return e ? atoi(e) : 0; }();
     if (form == 1) return launch_gru_bwd_variant<D, NX, 8, 1, 2, true>(a, packed, st);
+    if (form == 2) return launch_gru_bwd_variant<D, NX, 4, 0, 1, true>(a, packed, st);     // two 4-wave workgroups per CU, one image each
     return launch_gru_bwd_variant<D, NX, 8, 0, 2, true>(a, packed, st);
 }
 template <int D>
@@ -456,8 +497,30 @@ extern "C" size_t ggnn_gru_bwd_packed_bytes(int D, int nx) {
     return (size_t)3 * (nx + 1) * img * sizeof(float);
 }
 
+static int gru_bwd_fused_impl(const float* g, const float* gz, const int32_t* gz_heads, const float* h, const float* r, const float* u,
+                              const float* c, const float* Wg, const float* Wc, float* packed, float* dpc, float* dpg, float* rh, float* dh,
+                              float* const* dx, const float* nin, int T, int use_avg, int nx, int V, int D, int act, ggnn_stream_t stream);
+
 // Wg / Wc given: (re)build the packed transposed-block images into `packed` first; g == NULL: pack only.
 extern "C" int ggnn_gru_bwd_fused_f32(const float* g, const float* h, const float* r, const float* u, const float* c, const float* Wg,
+                                      const float* Wc, float* packed, float* dpc, float* dpg, float* rh, float* dh,
+                                      float* const* dx, const float* nin, int T, int use_avg, int nx, int V, int D, int act,
+                                      ggnn_stream_t stream) {
+    return gru_bwd_fused_impl(g, nullptr, nullptr, h, r, u, c, Wg, Wc, packed, dpc, dpg, rh, dh, dx, nin, T, use_avg, nx, V, D, act, stream);
+}
+
+// ... with g[v] + sum of the rows gz_heads[v] (an int4 slot-head record per node, -1 = no such slot) names of gz as the incoming
+// gradient: ggnn_gather_segment_sum_heads_f32(gz, .., heads, accumulate = 1) into g followed by ggnn_gru_bwd_fused_f32, bit for bit,
+// for nodes with at most four rows (more: the caller runs the stand-alone sum).  Pre-packed weights only.
+extern "C" int ggnn_gru_bwd_fused_gather_f32(const float* g, const float* gz, const int32_t* gz_heads, const float* h, const float* r,
+                                             const float* u, const float* c, float* packed, float* dpc, float* dpg, float* rh, float* dh,
+                                             float* const* dx, const float* nin, int T, int use_avg, int nx, int V, int D, int act,
+                                             ggnn_stream_t stream) {
+    GGNN_CHECK_ARG(g && gz && gz_heads && aligned16(gz) && aligned16(gz_heads), "gathered gradient: null or misaligned pointer");
+    return gru_bwd_fused_impl(g, gz, gz_heads, h, r, u, c, nullptr, nullptr, packed, dpc, dpg, rh, dh, dx, nin, T, use_avg, nx, V, D, act, stream);
+}
+
+static int gru_bwd_fused_impl(const float* g, const float* gz, const int32_t* gz_heads, const float* h, const float* r, const float* u, const float* c, const float* Wg,
                                       const float* Wc, float* packed, float* dpc, float* dpg, float* rh, float* dh,
                                       float* const* dx, const float* nin, int T, int use_avg, int nx, int V, int D, int act,
                                       ggnn_stream_t stream) {
@@ -472,7 +535,7 @@ extern "C" int ggnn_gru_bwd_fused_f32(const float* g, const float* h, const floa
         GGNN_CHECK_ARG(h && r && u && c && dpc && dpg && rh && dh && dx && (!use_avg || nin), "null pointer");
         GGNN_CHECK_ARG(aligned16(g) && aligned16(h) && aligned16(r) && aligned16(u) && aligned16(c) && aligned16(dpc) && aligned16(dpg) &&
                        aligned16(rh) && aligned16(dh), "pointers must be 16-byte aligned");
-        a.g = g; a.h = h; a.r = r; a.u = u; a.c = c; a.dpc = dpc; a.dpg = dpg; a.rh = rh; a.dh = dh;
+        a.g = g; a.gz = gz; a.gz_heads = gz_heads; a.h = h; a.r = r; a.u = u; a.c = c; a.dpc = dpc; a.dpg = dpg; a.rh = rh; a.dh = dh;
         for (int s = 0; s < nx; ++s) { GGNN_CHECK_ARG(dx[s] && aligned16(dx[s]), "dx[%d] null or misaligned", s); a.dx[s] = dx[s]; }
         // (experiments, tools/gru_bwd_bench.py: wrong results on purpose) bit 0: every [V,D] output aliases dpc; bit 1: every input aliases g
         if (const char* e = getenv("GGNN_BWD_ALIAS")) {

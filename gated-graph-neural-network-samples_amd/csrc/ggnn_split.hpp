@@ -208,6 +208,9 @@ __device__ __forceinline__ f32x4 split_products(f32x4 acc, u32x4 wh, u32x4 wm, u
 // T0: first tile (the half-stage kernels multiply a stage in two calls, tiles [0, TA) from half A and [TA, NTILES) from half B,
 // each half at `img` / `img_b`; everyone else passes the whole image: img_b = img + HA).  Per accumulator the chain is the same
 // in both forms: chunks in order, then the remainder.
+#ifndef GGNN_SPLIT_PF
+#define GGNN_SPLIT_PF 0
+#endif
 #ifndef GGNN_SPLIT_WH2
 #define GGNN_SPLIT_WH2 0     // 1: the hi plane of the NEXT unit is fetched at the start of the current one into a second register
 #endif                       //    set (9 MFMAs ahead instead of 3; +4 registers) -- experiment, see DESIGN.md K3
@@ -232,6 +235,26 @@ __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT]
 #if GGNN_SPLIT_WH2
         u32x4 wh_n = wh;
 #endif
+#if GGNN_SPLIT_PF          // (experiment) all three planes of the NEXT unit fetched at the start of the current one: 6+ MFMAs ahead, +12 registers
+        u32x4 nh = wh, nm = wm, nl = wl;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int c2 = u / NTW, nt = T0 + u % NTW;
+            const bool more = u + 1 < NU;
+            f32x4 c = (ZERO && c2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt];
+            if (more) { nl = slot(u + 1, 2); nm = slot(u + 1, 1); nh = slot(u + 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            c = mfma_bf16(wl, a.hi[c2], c);
+            c = mfma_bf16(wm, a.mid[c2], c);
+            c = mfma_bf16(wm, a.hi[c2], c);
+            c = mfma_bf16(wh, a.lo[c2], c);
+            c = mfma_bf16(wh, a.mid[c2], c);
+            c = mfma_bf16(wh, a.hi[c2], c);
+            __builtin_amdgcn_sched_barrier(0);
+            wl = nl; wm = nm; wh = nh;
+            acc[nt] = c;
+        }
+#else
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int c2 = u / NTW, nt = T0 + u % NTW;
@@ -259,6 +282,7 @@ __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT]
 #endif
             acc[nt] = c;
         }
+#endif
     }
     // the D % 16 remainder k values on the f32 MFMA, their weights two tiles ahead (2 registers in flight)
     if constexpr (S::NR > 0 && NTW > 0) {

@@ -345,6 +345,14 @@ extern "C" int ggnn_sparse_train_backward_f32(
     // the first side-stream product of the step is ordered behind everything queued on the main stream so far (the zeroed gradients)
     if (int rc = order_after(side, st)) return rc;
 
+    // The per-node sum that closes a timestep's transform backward (dh[v] += sum_t Z[row(v,t)]) is taken by its CONSUMER: the fused
+    // GRU backward of the timestep processed next reads g[v] + the rows of Z its node's slot-head record names
+    // (ggnn_gru_bwd_fused_gather_f32) -- one launch and one pass over [V,D] less per timestep.  Needs the head records and at most
+    // four rows per node (T <= 4: a node has one compact row per edge type it sends on); GGNN_TRAIN_FUSE_NODE_SUM=0: stand-alone sums.
+    static const bool fuse_env = [] { const char* e = getenv("GGNN_TRAIN_FUSE_NODE_SUM"); return !e || atoi(e) != 0; }();
+    const bool fuse_node_sum = fuse_env && node_heads != nullptr && T <= 4;
+    bool z_pending = false;                         // Z holds rows that the next GRU backward still has to add to its g
+
     for (int l = num_layers - 1; l >= 0; --l) {
         const LayerPlan& P = plan[l];
         const int nx = P.nres + 1;
@@ -371,9 +379,16 @@ extern "C" int ggnn_sparse_train_backward_f32(
             dxp[nx - 1] = dinc;
             float* dpc = buf(L.dpc, k); float* rh = buf(L.rh, k);
             float* dpg = reinterpret_cast<float*>(base + L.dpg + (size_t)k * 2 * L.vd);
-            if (int rc = ggnn_gru_bwd_fused_f32(g, h_in, buf(L.r, k), buf(L.u, k), buf(L.c, k), nullptr, nullptr,
-                                                const_cast<float*>(gru_bwd_packed[l]), dpc, dpg, rh, dh_dst, dxp, nin, T, use_avg ? 1 : 0,
-                                                nx, V, D, act, stream)) return rc;
+            if (z_pending) {
+                if (int rc = ggnn_gru_bwd_fused_gather_f32(g, Z, node_heads, h_in, buf(L.r, k), buf(L.u, k), buf(L.c, k),
+                                                           const_cast<float*>(gru_bwd_packed[l]), dpc, dpg, rh, dh_dst, dxp, nin, T,
+                                                           use_avg ? 1 : 0, nx, V, D, act, stream)) return rc;
+                z_pending = false;
+            } else {
+                if (int rc = ggnn_gru_bwd_fused_f32(g, h_in, buf(L.r, k), buf(L.u, k), buf(L.c, k), nullptr, nullptr,
+                                                    const_cast<float*>(gru_bwd_packed[l]), dpc, dpg, rh, dh_dst, dxp, nin, T, use_avg ? 1 : 0,
+                                                    nx, V, D, act, stream)) return rc;
+            }
             for (int i = 0; i < P.nres; ++i) if (dx_direct[i]) has[P.res[i]] = true;
             if (dh_direct) has[l] = true;
 
@@ -414,12 +429,19 @@ extern "C" int ggnn_sparse_train_backward_f32(
             } else {
                 if (int rc = ggnn_gather_segment_sum_f32(dinc, rows_rp, rows_gather, nullptr, nullptr, 0, dHc, R, D, 1, stream)) return rc;
             }
-            if (int rc = ggnn_msg_transform_compact_f32(dHc, nullptr, identity_rows, type_row_off, Z, const_cast<float*>(edge_packed_t[l]),
-                                                        edge_img_bytes, R, D, T, stream)) return rc;
-            if (node_heads) {
-                if (int rc = ggnn_gather_segment_sum_heads_f32(Z, node_rp, node_order, node_heads, nullptr, nullptr, 0, dh_dst, V, D, 1, 1, stream)) return rc;
-            } else {
-                if (int rc = ggnn_gather_segment_sum_acc_f32(Z, node_rp, node_order, dh_dst, V, D, stream)) return rc;
+            // The gradient of the step's INPUT state: not needed for the very first timestep (h0 is data: nothing upstream of it is
+            // trained, and nobody reads d_state_ws[0]) -- its transform and node sum are not run at all.
+            const bool first_step = l == 0 && s == 0;
+            if (!first_step) {
+                if (int rc = ggnn_msg_transform_compact_f32(dHc, nullptr, identity_rows, type_row_off, Z, const_cast<float*>(edge_packed_t[l]),
+                                                            edge_img_bytes, R, D, T, stream)) return rc;
+                if (fuse_node_sum) {
+                    z_pending = true;                   // (the next timestep's GRU backward adds the rows while it loads g)
+                } else if (node_heads) {
+                    if (int rc = ggnn_gather_segment_sum_heads_f32(Z, node_rp, node_order, node_heads, nullptr, nullptr, 0, dh_dst, V, D, 1, 1, stream)) return rc;
+                } else {
+                    if (int rc = ggnn_gather_segment_sum_acc_f32(Z, node_rp, node_order, dh_dst, V, D, stream)) return rc;
+                }
             }
             // ---- edge-weight gradients, side stream (needs dHc: ordered behind the transform launch above, which also read it)
             if (int rc = order_after(side, st)) return rc;
@@ -429,10 +451,10 @@ extern "C" int ggnn_sparse_train_backward_f32(
                                               side)) return rc;
             }
             // ---- accumulate what went to temporaries
-            for (int i = 0; i < P.nres; ++i) {
-                if (!dx_direct[i]) { if (int rc = add_inplace(dstate[P.res[i]], dxp[i], nvd, st)) return rc; }
+            for (int i = 0; i < P.nres; ++i) {          // (sums into the gradient of h0 are not needed either)
+                if (!dx_direct[i] && P.res[i] != 0) { if (int rc = add_inplace(dstate[P.res[i]], dxp[i], nvd, st)) return rc; }
             }
-            if (s == 0 && !dh_direct) { if (int rc = add_inplace(dstate[l], dh_dst, nvd, st)) return rc; }
+            if (s == 0 && !dh_direct && l != 0) { if (int rc = add_inplace(dstate[l], dh_dst, nvd, st)) return rc; }
             g = dh_dst;
         }
     }

@@ -439,9 +439,11 @@ def gru_bwd_is_fused(D: int) -> bool:
     return bool(_lib.load().ggnn_gru_bwd_is_fused(D))
 
 
-def gru_bwd_fused(g, h, r, u, c, packed, nin, use_avg: bool, nx: int, activation: str):
+def gru_bwd_fused(g, h, r, u, c, packed, nin, use_avg: bool, nx: int, activation: str, gather=None):
     """The GRU backward of one timestep in one launch (ggnn_gru_bwd_fused_f32) -> (dpc, dpg, rh, dh, [dx_0 .. dx_{nx-1}]);
-    the last dx is d_incoming (already divided by the in-degree for mean aggregation)."""
+    the last dx is d_incoming (already divided by the in-degree for mean aggregation).
+    gather = (rows, heads): the incoming gradient is g[v] + the sum of the rows of `rows` named by the slot-head record heads[v]
+    (ggnn_gru_bwd_fused_gather_f32)."""
     lib = _lib.load()
     V, D = h.shape
     T = nin.shape[1] if nin is not None else 1
@@ -450,6 +452,13 @@ def gru_bwd_fused(g, h, r, u, c, packed, nin, use_avg: bool, nx: int, activation
     dpg = torch.empty((V, 2 * D), dtype=torch.float32, device=dev)
     dx = [torch.empty_like(h) for _ in range(nx)]
     dxp = (ctypes.c_void_p * nx)(*[t.data_ptr() for t in dx])
+    if gather is not None:
+        rows, heads = gather
+        _req(rows, torch.float32, "rows"); _req(heads, torch.int32, "heads")
+        _launch("gru_bwd_fused_gather[nx=%d]" % nx, lambda: lib.ggnn_gru_bwd_fused_gather_f32(
+            _ptr(g), _ptr(rows), _ptr(heads), _ptr(h), _ptr(r), _ptr(u), _ptr(c), _ptr(packed), _ptr(dpc), _ptr(dpg), _ptr(rh), _ptr(dh),
+            dxp, _ptr(nin), T, 1 if use_avg else 0, nx, V, D, ACT_IDS[activation.lower()], _stream()))
+        return dpc, dpg, rh, dh, dx
     _launch("gru_bwd_fused[nx=%d]" % nx, lambda: lib.ggnn_gru_bwd_fused_f32(
         _ptr(g), _ptr(h), _ptr(r), _ptr(u), _ptr(c), None, None, _ptr(packed), _ptr(dpc), _ptr(dpg), _ptr(rh), _ptr(dh), dxp,
         _ptr(nin), T, 1 if use_avg else 0, nx, V, D, ACT_IDS[activation.lower()], _stream()))

@@ -429,6 +429,16 @@ size_t ggnn_gru_bwd_packed_bytes(int D, int nx);
 int ggnn_gru_bwd_fused_f32(const float* g, const float* h, const float* r, const float* u, const float* c, const float* Wg,
                            const float* Wc, float* packed, float* dpc, float* dpg, float* rh, float* dh, float* const* dx,
                            const float* nin, int T, int use_avg, int nx, int V, int D, int act, ggnn_stream_t stream);
+/* ... with the incoming gradient gathered on load:  g_eff[v] = g[v] + sum of the rows of gz named by gz_heads[v] (one int4 slot-head
+ * record per node as ggnn_slot_heads_i32 builds them, -1 = no such slot) -- the per-node sum that closes the transform backward of
+ * the timestep processed BEFORE this one (dh[v] += sum_t Z[row(v,t)], chem_tensorflow_sparse.py:160-168 under autodiff), taken by
+ * its consumer instead of by a launch of its own.  Bit for bit ggnn_gather_segment_sum_heads_f32(gz, .., accumulate = 1) into g
+ * followed by ggnn_gru_bwd_fused_f32, for nodes with at most four rows (more than four slots: run the stand-alone sum).
+ * `packed` holds the stage images (no Wg / Wc form). */
+int ggnn_gru_bwd_fused_gather_f32(const float* g, const float* gz, const int32_t* gz_heads, const float* h, const float* r,
+                                  const float* u, const float* c, float* packed, float* dpc, float* dpg, float* rh, float* dh,
+                                  float* const* dx, const float* nin, int T, int use_avg, int nx, int V, int D, int act,
+                                  ggnn_stream_t stream);
 
 /* ---- optimiser: per-variable clip_by_norm + TF-1.3 Adam for ALL variables in two launches (chem_tensorflow.py:183-191) --------
  * grads / m / v are FLAT buffers of nblocks * ggnn_optim_block_floats() floats in which every variable starts on a block

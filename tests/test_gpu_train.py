@@ -348,3 +348,40 @@ def test_fused_weight_preparation_equals_per_layer_packing(pkg, oracle, cuda, ke
         for k in range(4):
             n = want[k].numel() if k >= 2 else (eb - 256) // 4          # (the edge buffers end in 256 bytes of alignment slack)
             assert torch.equal(imgs[k][l][:n], want[k][:n]), (l, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,D,nx,T", [(1000, 100, 1, 4), (777, 100, 2, 3), (530, 64, 1, 4), (400, 32, 3, 2), (1, 100, 1, 4)])
+def test_gru_backward_with_gathered_gradient_equals_sum_then_backward(pkg, cuda, V, D, nx, T):
+    """ggnn_gru_bwd_fused_gather_f32 (the per-node sum dh[v] += sum_t Z[row(v,t)] of the previous timestep's transform backward taken
+    while g is loaded) == ggnn_gather_segment_sum_heads_f32(accumulate) into g, then ggnn_gru_bwd_fused_f32 -- bit for bit (the same
+    adds in the same order), nodes with 0 .. 4 rows."""
+    ops = pkg.ops
+    gen = torch.Generator(device="cpu").manual_seed(V + D)
+    r = lambda *s: (torch.rand(*s, generator=gen) * 2 - 1).to(cuda)
+    g, h, c = r(V, D), r(V, D), r(V, D)
+    rr, u = ((r(V, D) + 1) / 2), ((r(V, D) + 1) / 2)
+    Wg, Wc = r((nx + 1) * D, 2 * D) * 0.2, r((nx + 1) * D, D) * 0.2
+    nin = torch.randint(0, 3, (V, T), generator=gen).float().to(cuda)
+    # a node owns between 0 and min(T, 4) rows of Z, rows of one node are not adjacent
+    counts = torch.randint(0, min(T, 4) + 1, (V,), generator=gen)
+    R = int(counts.sum())
+    perm = torch.randperm(max(R, 1), generator=gen)[:R].to(torch.int32)
+    row_ptr = torch.zeros(V + 1, dtype=torch.int32); row_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    Z = r(max(R, 1), D)
+    heads = torch.full((V, 4), -1, dtype=torch.int32)
+    for v in range(V):
+        for k in range(int(counts[v])):
+            heads[v, k] = perm[int(row_ptr[v]) + k]
+    heads = heads.to(cuda)
+    packed = ops.PackedWeights().gru_bwd(Wg, Wc, nx, D)
+    got = ops.gru_bwd_fused(g, h, rr, u, c, packed, nin, True, nx, "tanh", gather=(Z, heads))
+    g2 = g.clone()
+    lib = pkg._lib.load()
+    pkg._lib.check(lib.ggnn_gather_segment_sum_heads_f32(Z.data_ptr(), row_ptr.to(cuda).data_ptr(), perm.to(cuda).data_ptr(), heads.data_ptr(),
+                                                         None, None, 0, g2.data_ptr(), V, D, 1, 1, torch.cuda.current_stream().cuda_stream))
+    want = ops.gru_bwd_fused(g2, h, rr, u, c, packed, nin, True, nx, "tanh")
+    torch.cuda.synchronize()
+    flat = lambda o: [x for x in o[:4]] + list(o[4])
+    for a, b in zip(flat(got), flat(want)):
+        assert torch.equal(a, b)

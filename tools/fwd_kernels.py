@@ -8,6 +8,17 @@ model = pkg.SparseGGNNChemModel({"--quiet": True, "--device": "cuda:0", "train_d
 feeds = list(model.make_minibatch_iterator(model.valid_data, False))[:2]
 for f in feeds:
     f["initial_node_representation"] = torch.rand_like(f["initial_node_representation"]) * 2 - 1
+# GGNN_FWD_DATA=zero: all-zero states and weights (same instructions, no operand bit toggling) -- the power / clock side of a kernel time
+if os.environ.get("GGNN_FWD_DATA") == "zero":
+    for f in feeds:
+        f["initial_node_representation"] = torch.zeros_like(f["initial_node_representation"])
+    with torch.no_grad():
+        for v in model.trainable_variables.values():
+            v.zero_()
+elif os.environ.get("GGNN_FWD_DATA") == "small":      # weights and states scaled to 1e-3: products underflow nothing, few mantissa bits differ
+    with torch.no_grad():
+        for v in model.trainable_variables.values():
+            v.mul_(1e-3)
 with torch.no_grad():
     for i in range(6):
         model.feed(feeds[i % 2]); model.compute_final_node_representations()
