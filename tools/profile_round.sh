@@ -14,6 +14,13 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# the library that travelled with the snapshot must be the one these sources build (a profile of a stale binary names the wrong tree)
+python - <<PY || { echo "libggnn_hip.so is older than its sources: run __graft_entry__.build() before profiling"; exit 1; }
+import importlib, sys
+sys.path.insert(0, "$ROOT")
+b = importlib.import_module("gated-graph-neural-network-samples_amd.build")
+sys.exit(1 if b.needs_build() else 0)
+PY
 cd /tmp
 four_passes() {   # four_passes <prefix> <command...>
     local P=$1; shift
