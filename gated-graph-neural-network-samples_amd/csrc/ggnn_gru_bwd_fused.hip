@@ -22,6 +22,12 @@
 #include "ggnn_split.hpp"
 #include <type_traits>
 
+// 1: the stage products recompute the lane parts of their LDS addresses per call (stage_mma_split's REMAT): 52-72 -> 36 B of scratch
+// per lane at D = 100, R = 0 launch 167.8 -> 162.9 us (round 4, profiles/r04_experiments/remat_and_streams.txt)
+#ifndef GGNN_BWD_REMAT
+#define GGNN_BWD_REMAT 1
+#endif
+
 namespace ggnn {
 
 struct GruBwdArgs {
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(NW * 64, (RING == 1 && NW == 4) ? 2 : 1) void ggnn_
             const bool row_ok = ACT && row < a.V;
 
             auto mma = [&](auto zero_c, f32x4 (&acc)[NT], const Frag<D>& A, const SFrag<D>& S, const float* img) {
-                if constexpr (SPLIT) stage_mma_split<D, NT, decltype(zero_c)::value>(acc, S, A, img, li, kq);
+                if constexpr (SPLIT) stage_mma_split<D, NT, decltype(zero_c)::value, GGNN_BWD_REMAT>(acc, S, A, img, li, kq);
                 else stage_mma<D, NoHook, NT, decltype(zero_c)::value>(acc, A, img, li, kq);
             };
             auto stage = [&](auto zero_c, f32x4 (&acc)[NT], const Frag<D>& A, const SFrag<D>& S, int img_idx, auto&& before, auto&& after) {

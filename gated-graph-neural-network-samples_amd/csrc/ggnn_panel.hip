@@ -22,6 +22,12 @@
 // The transform is the same stage loop without the chain: a persistent workgroup is bound to ONE (edge type, panel),
 // keeps that panel image in LDS and walks 16-row tiles of the type's active (source node, type) pairs.
 #include "ggnn_split.hpp"
+// 1: panel_part_mma_split recomputes the lane part of its LDS / L2 addresses in every call (the lane coordinates pass through an empty asm).
+// Without it hipcc keeps a per-(stage, part) address register set alive across the whole pass and the split-form GRU comes out with
+// 152-492 B of scratch per lane at 256 registers; with it: no scratch, 208-228 registers; D = 256 launch 507.7 -> 497.5 us (round 4).
+#ifndef GGNN_PANEL_REMAT
+#define GGNN_PANEL_REMAT 1
+#endif
 #include <type_traits>
 
 namespace ggnn {
@@ -164,6 +170,9 @@ template <int D, bool ZERO, bool GLOBAL, int part>
 __device__ __forceinline__ void panel_part_mma_split(f32x4 (&acc)[4], const Frag<D>& a, const float* chunks, int li, int kq) {
     using C = PanelGruSplitCfg<D>;
     constexpr int NU = C::CP * 4;
+#if GGNN_PANEL_REMAT
+    asm volatile("" : "+v"(li), "+v"(kq));      // (the lane part of the address is recomputed per call, see stage_mma_split_at's REMAT)
+#endif
     const unsigned voff = (unsigned)(kq * 64 + li) * 16u;
     const unsigned long long gb = reinterpret_cast<unsigned long long>(chunks);
     const float* sbase = chunks;

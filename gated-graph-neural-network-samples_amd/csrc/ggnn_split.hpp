@@ -214,11 +214,15 @@ __device__ __forceinline__ f32x4 split_products(f32x4 acc, u32x4 wh, u32x4 wm, u
 #ifndef GGNN_SPLIT_WH2
 #define GGNN_SPLIT_WH2 0     // 1: the hi plane of the NEXT unit is fetched at the start of the current one into a second register
 #endif                       //    set (9 MFMAs ahead instead of 3; +4 registers) -- experiment, see DESIGN.md K3
-template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false, int T0 = 0>
+// REMAT: the lane parts of the LDS addresses are recomputed in every call (the lane coordinates pass through an empty asm, so the
+// compiler cannot keep the ~10 per-slot address registers of a multi-stage kernel alive across its stages -- a kernel at the
+// 256-register limit spills exactly those and reloads them in front of the remainder MFMAs).
+template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false, int T0 = 0, bool REMAT = false>
 __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT], const SFrag<D>& a, const Frag<D>& af,
                                                    const float* img, const float* img_b, int li, int kq) {
     using S = StageCfg<D>;
     using C = SplitCfg<D>;
+    if constexpr (REMAT) asm volatile("" : "+v"(li), "+v"(kq));
     constexpr int NTW = NTILES - T0;                                  // tiles walked
     constexpr int NU = C::NC2 * NTW;                                  // units, chunk-major
     if constexpr (NU > 0) {
@@ -305,10 +309,10 @@ __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT]
     }
 }
 
-template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false>
+template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false, bool REMAT = false>
 __device__ __forceinline__ void stage_mma_split(f32x4 (&acc)[StageCfg<D>::NT], const SFrag<D>& a, const Frag<D>& af,
                                                 const float* img, int li, int kq) {
-    stage_mma_split_at<D, NTILES, ZERO, 0>(acc, a, af, img, img + SplitCfg<D>::HA, li, kq);
+    stage_mma_split_at<D, NTILES, ZERO, 0, REMAT>(acc, a, af, img, img + SplitCfg<D>::HA, li, kq);
 }
 
 // ONE output tile (wave-uniform, run time) of the same product: the cooperative tail pass
