@@ -360,6 +360,24 @@ def secondary_dense(pkg, dev):
     return out
 
 
+def measure_sustained_mfma(pkg, dev, launches=60):
+    """Dense bf16 MFMA TFLOP/s and shader clock the chip sustains (ggnn_probe_mfma_rate): all-zero operands, random operands, and the
+    operand pattern of the 3-way split product.  ~60 launches of ~16 ms each per pattern, the last one reported."""
+    import ctypes
+    lib = pkg._lib.load()
+    nbytes = int(lib.ggnn_probe_mfma_workspace_bytes())
+    ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    res = {}
+    for name, mode in (("zero_operands", 0), ("random_operands", 1), ("split_pattern", 2)):
+        tf, mhz = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        pkg._lib.check(lib.ggnn_probe_mfma_rate(mode, launches, ws.data_ptr(), ws.numel() * 4, ctypes.byref(tf), ctypes.byref(mhz), st))
+        res[name] = {"tflops_bf16": tf.value, "shader_mhz": mhz.value, "frac_of_2500": tf.value / BF16_MFMA_PEAK_TFLOPS}
+    res["what"] = ("whole-chip v_mfma_f32_16x16x32_bf16 stream on register operands, 8 waves per CU, ~1 s per pattern (csrc/ggnn_probe.hip); "
+                   "f32-equivalent ceiling of a split-form kernel on this box = split_pattern.tflops_bf16 / %d" % SPLIT_PRODUCTS)
+    return res
+
+
 def ranks_seen(dist_ctx):
     """Size of the process group the ranks actually formed (1 without one)."""
     return torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
@@ -745,6 +763,17 @@ def main():
                 del src_c, dst_c
         dom = max(kernels, key=lambda k: kernels[k]["time_share"])
         out["roofline"] = dict(kernels[dom], kernel=dom)
+        # What the matrix pipe SUSTAINS on this box: `peak` above is the data-sheet figure (2.5 PF bf16 = every CU issuing an MFMA
+        # every 16 clocks at 2.4 GHz); under random operands the chip sits at its socket power limit at a lower clock.  Measured here,
+        # ~1 s per pattern, with the library's probe (csrc/ggnn_probe.hip: 8 waves per CU of back-to-back v_mfma_f32_16x16x32_bf16 on
+        # register operands -- nothing but MFMAs); `frac` stays the fraction of the data-sheet peak.
+        if SPLIT_ACTIVE and kernels[dom].get("pipe", "").startswith("bf16"):
+            try:
+                sus = measure_sustained_mfma(pkg, dev)
+                out["roofline"]["sustained_mfma"] = sus
+                out["roofline"]["frac_of_sustained_split_pattern"] = kernels[dom]["achieved"] / (sus["split_pattern"]["tflops_bf16"] / SPLIT_PRODUCTS)
+            except Exception as exc:                                   # (a measurement aid must never take the line down)
+                out["roofline"]["sustained_mfma"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if traffic_err:
             out["roofline"]["traffic_error"] = traffic_err
         out["config"]["active_source_type_pairs_per_batch"] = None if Rb is None else int(Rb)

@@ -117,6 +117,8 @@ SYMBOLS = {
     "ggnn_gru_bwd_fused_gather_f32": (c_int, [c_void_p] * 12 + [POINTER(c_void_p), c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ggnn_optim_block_floats": (c_int, []),
     "ggnn_clip_adam_f32": (c_int, [c_void_p] * 9 + [c_int, c_float, c_float, c_float, c_float, c_float, c_void_p]),
+    "ggnn_probe_mfma_workspace_bytes": (c_size_t, []),
+    "ggnn_probe_mfma_rate": (c_int, [c_int, c_int, c_void_p, c_size_t, POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_void_p]),
     "ggnn_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ggnn_gemm_tn_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ggnn_pack_batch_tables": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,

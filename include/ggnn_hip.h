@@ -542,6 +542,15 @@ int ggnn_sparse_train_backward_f32(const float* h0, int V, int D, int T, const i
 int ggnn_dropout_f32(const float* x, float* out, const int64_t* row_key, int64_t row_key_base, uint64_t seed, float keep_prob,
                      int64_t rows, int cols, ggnn_stream_t stream);
 
+/* ---- measurement aid (bench.py's roofline leg; not on the product path) --------------------------------------------------------
+ * The dense bf16 MFMA rate the chip SUSTAINS: `launches` back-to-back launches (~16 ms each) of v_mfma_f32_16x16x32_bf16 on
+ * register operands, 8 waves per CU; mode 0 all-zero operands, 1 random operands, 2 the operand pattern and planes of the 3-way
+ * split product (csrc/ggnn_split.hpp).  Reports the last launch: whole-chip dense TFLOP/s and the mean shader clock inside it
+ * (the data-sheet peak, 2.5 PF, is 256 CUs x 4 x 8192 flops / 16 clocks at 2.4 GHz; under random operands the chip runs at its
+ * socket power limit well below that clock).  ws: ggnn_probe_mfma_workspace_bytes() of device memory.  Synchronises `stream`. */
+size_t ggnn_probe_mfma_workspace_bytes(void);
+int ggnn_probe_mfma_rate(int mode, int launches, void* ws, size_t ws_bytes, double* tflops, double* shader_mhz, ggnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,26 @@
+"""The library's measurement aid (csrc/ggnn_probe.hip): sustained bf16 MFMA rate by operand pattern.  Sanity only -- the numbers
+themselves are hardware facts that bench.py reports, not something a test can pin."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mfma_rate_probe_reports_sane_numbers(pkg):
+    lib = pkg._lib.load()
+    dev = torch.device("cuda:0")
+    ws = torch.empty(int(lib.ggnn_probe_mfma_workspace_bytes()) // 4 + 64, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    got = {}
+    for mode in (0, 1, 2):
+        tf, mhz = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        pkg._lib.check(lib.ggnn_probe_mfma_rate(mode, 3, ws.data_ptr(), ws.numel() * 4, ctypes.byref(tf), ctypes.byref(mhz), st))
+        got[mode] = (tf.value, mhz.value)
+        assert 1000.0 < mhz.value < 2600.0, got
+        assert 500.0 < tf.value < 2600.0, got                  # never above the data-sheet peak (2.5 PF at 2.4 GHz)
+        # the stream is MFMA-bound: TFLOP/s == clock x 256 CUs x 4 SIMDs x 16384 flops / 16 clocks (within the launch's ramp)
+        assert abs(tf.value - mhz.value * 1e6 * 256 * 4 * 1024 / 1e12) / tf.value < 0.05, got
+    with pytest.raises(pkg._lib.GGNNError):
+        pkg._lib.check(lib.ggnn_probe_mfma_rate(7, 1, ws.data_ptr(), ws.numel() * 4, ctypes.byref(tf), ctypes.byref(mhz), st))
