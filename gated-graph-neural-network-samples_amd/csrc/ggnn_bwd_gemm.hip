@@ -293,6 +293,9 @@ __global__ __launch_bounds__(kXtyWaves * 64) void xty_kernel(XtyArgs a) {
 //     waves of a SIMD (w, w + 4) carry 46 / 45 / 39 / 39 pairs at 13 x 13 tiles.
 //   * the slab DMA goes out through inline assembly (the compiler does not see an LDS-DMA in flight, see dma_image_asm) and is
 //     waited for explicitly before the barrier that publishes the slab.
+#ifndef GGNN_XTY_INTER_MAX
+#define GGNN_XTY_INTER_MAX 24
+#endif
 constexpr int kXtySplitWaves = 8;
 constexpr int kXtySplitMaxI = 8;
 
@@ -491,6 +494,227 @@ __global__ __launch_bounds__(kXtySplitWaves * 64) void xty_split_kernel(XtyArgs 
     else run(I0{}, I0{});
 }
 
+// ---- X^T dY in split form with the operands split ONCE, into LDS planes (round 4) -------------------------------------------------
+// xty_split_kernel above splits an operand tile in EVERY wave that multiplies it (484 vector instructions and 88 ds_read_b32 per
+// wave and 32-row step next to 168 MFMAs; on this chip the vector and matrix instructions of a SIMD's two waves do not overlap --
+// DESIGN.md K3 -- so the splits are ~40 % of the loop).  Here a step's 32 rows x (X columns + dY columns) are fetched from global
+// memory ONE COLUMN x 8 ROWS per thread (coalesced dword loads, a step ahead, straight into registers: no f32 slab in LDS), split
+// once (44 vector instructions per 8 values) and written to LDS as the three bf16 planes in MFMA operand layout
+//     plane[p][g][column][8 x bf16]      (g = 8-row group of the step: lane (i, g) of a 16-column tile reads ONE ds_read_b128)
+// double-buffered: 2 x 192 (XC + YC) bytes (XC = 16 kb_tiles, YC = 16 n_tiles: 156 KiB at 13 + 13 tiles).  The split of step s + 1
+// is issued in the same barrier interval as the MFMAs of step s.  Tile groups, partial products and the reduction are
+// xty_split_kernel's (same XtyArgs / plan); within a 32-row step the rows sit in other MFMA k slots, so results agree with it to
+// f32 rounding, not bit for bit.  Ungathered X only (the training step's GRU weight gradients).
+template <int MTM, int NTM>
+__global__ __launch_bounds__(kXtySplitWaves * 64) void xty_planes_kernel(XtyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float slab[];     // [2][3 planes][4 groups][XC + YC] x 16 bytes
+    constexpr int nw = kXtySplitWaves, NTH = nw * 64, ROWS = 32, UMAX = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    int batch = 0;
+    while (batch + 1 < a.nbatch && (int)blockIdx.y >= a.wg_off[batch + 1]) ++batch;
+    const int split = (int)blockIdx.y - a.wg_off[batch], splits = a.wg_off[batch + 1] - a.wg_off[batch];
+    const int rb = a.row_off[batch], re = a.row_off[batch + 1];
+    int rows_per = (re - rb + splits - 1) / splits;
+    rows_per = (rows_per + ROWS - 1) / ROWS * ROWS;
+    const int r_beg = rb + split * rows_per;
+    const int r_end = min(re, r_beg + rows_per);
+    const int kcol0 = blockIdx.x * a.kb_tiles * 16;
+    const int XC = a.kb_tiles * 16, YC = a.n_tiles * 16, CT = XC + YC;
+    const unsigned plane_b = 4u * (unsigned)CT * 16u;                  // bytes of one plane (4 groups)
+    const unsigned buf_b = 3u * plane_b;
+    float* out = a.part + (size_t)blockIdx.y * a.Kout * a.N;
+
+    // this wave's tile groups (xty_split_kernel's)
+    int kt0, my_mt, nta0, cnta, ntb0, cntb;
+    xty_group(a.kb_tiles, wave >> 1, kt0, my_mt);
+    const int ga = ((wave >> 1) + 2 * (wave & 1)) & 3;
+    xty_group(a.n_tiles, ga, nta0, cnta);
+    xty_group(a.n_tiles, (ga + 1) & 3, ntb0, cntb);
+    const int my_nt = cnta + cntb;
+
+    // ---- producer side: unit u = (8-row group g, column c) of a step; thread t owns units t, t + NTH, ... (< 4 CT <= UMAX NTH) ----
+    // Every unit is a (pointer to its first row of the current step, byte stride between rows) pair and is fetched with eight
+    // unconditional loads: a data column walks its rows; the ones column (X column K when Kout == K + 1) and the padding columns
+    // of the last tiles read a constant 1 / 0 with stride 0 -- no per-kind control flow, no per-value selects.
+    // (udst: byte offset of the unit's 16-byte slot inside a plane, | its 8-row group g in bits 0-1, | 4 when the unit exists)
+    const char* urow[UMAX]; unsigned ustride[UMAX]; unsigned udst[UMAX];
+    const char* const zero_p = reinterpret_cast<const char*>(kXtyZeroChunk);
+#pragma unroll
+    for (int k = 0; k < UMAX; ++k) {
+        const int u = tid + k * NTH;
+        const bool on = u < 4 * CT;
+        const int g = on ? u / CT : 0, c = on ? u - g * CT : 0;
+        udst[k] = ((unsigned)g * (unsigned)CT + (unsigned)c) * 16u + (unsigned)g + (on ? 4u : 0u);
+        urow[k] = zero_p; ustride[k] = 0u;
+        if (on) {
+            const size_t row0 = (size_t)(r_beg + 8 * g);
+            if (c < XC) {
+                const int col = kcol0 + c;
+                if (col < a.K) {
+                    const int seg = col / a.Dseg;
+                    ustride[k] = (unsigned)a.ldx[seg] * 4u;
+                    urow[k] = reinterpret_cast<const char*>(a.X[seg] + (col - seg * a.Dseg)) + row0 * ustride[k];
+                } else if (col == a.K && a.Kout > a.K) urow[k] = reinterpret_cast<const char*>(kXtyOnesChunk);
+            } else if (c - XC < a.N) {
+                ustride[k] = (unsigned)a.ldy * 4u;
+                urow[k] = reinterpret_cast<const char*>(a.Y + (c - XC)) + row0 * ustride[k];
+            }
+        }
+    }
+    constexpr bool kLastUnitPartial = true;                                  // (k = UMAX - 1 exists for some waves only: wave-uniform test below)
+    const bool wave_has_last = (UMAX - 1) * NTH + wave * 64 < 4 * CT;
+    float stage[UMAX][8];                                                   // a step's values of this thread's units, fetched a step ahead
+    // FULL: all 32 rows of the step lie inside the range; else rows >= r_end read the zero constant (every operand: 0 x 0)
+    auto fetch_unit = [&](int r0, auto full_c, auto k_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
+        constexpr int k = decltype(k_c)::value;
+        {
+            if (k < UMAX - 1 || !kLastUnitPartial || wave_has_last) {
+                const char* q = urow[k];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const char* src = q;
+                    if constexpr (!FULL) { if (r0 + 8 * (int)(udst[k] & 3u) + j >= r_end) src = zero_p; }
+                    stage[k][j] = *(const __attribute__((address_space(1))) float*)src;       // (global_load, not a flat access)
+                    q += ustride[k];
+                }
+                urow[k] += (size_t)32 * ustride[k];
+            }
+        }
+    };
+    auto fetch = [&](int r0, auto full_c) __attribute__((always_inline)) {
+        fetch_unit(r0, full_c, std::integral_constant<int, 0>{}); fetch_unit(r0, full_c, std::integral_constant<int, 1>{});
+        fetch_unit(r0, full_c, std::integral_constant<int, 2>{}); fetch_unit(r0, full_c, std::integral_constant<int, 3>{});
+    };
+    static_assert(UMAX == 4, "fetch / put walk four units");
+    auto fetch_step = [&](int r0) __attribute__((always_inline)) {
+        if (r0 + ROWS <= r_end) fetch(r0, std::true_type{}); else fetch(r0, std::false_type{});
+    };
+    auto put_unit = [&](int buf, auto k_c) __attribute__((always_inline)) {    // split unit k's staged values, write its planes of slab[buf]
+        constexpr int k = decltype(k_c)::value;
+        char* base = reinterpret_cast<char*>(slab) + (size_t)buf * buf_b;
+        {
+            if (k < UMAX - 1 || !kLastUnitPartial || wave_has_last) {
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) split_pair(stage[k][2 * q], stage[k][2 * q + 1], h[q], m[q], l[q]);
+                if (udst[k] & 4u) {
+                    const unsigned d = udst[k] & ~15u;
+                    *reinterpret_cast<u32x4*>(base + d) = u32x4{h[0], h[1], h[2], h[3]};
+                    *reinterpret_cast<u32x4*>(base + plane_b + d) = u32x4{m[0], m[1], m[2], m[3]};
+                    *reinterpret_cast<u32x4*>(base + 2u * plane_b + d) = u32x4{l[0], l[1], l[2], l[3]};
+                }
+            }
+        }
+    };
+    auto put = [&](int buf) __attribute__((always_inline)) {
+        put_unit(buf, std::integral_constant<int, 0>{}); put_unit(buf, std::integral_constant<int, 1>{});
+        put_unit(buf, std::integral_constant<int, 2>{}); put_unit(buf, std::integral_constant<int, 3>{});
+    };
+    // unit k of the NEXT step (its planes, then the fetch of the step after it): cut into the MFMA stream below, one unit per
+    // NT / UMAX tiles -- in one wave's stream ~1 vector instruction per MFMA issues in the MFMAs' shadow (tools/issue_probe.hip)
+    auto advance_unit = [&](int buf, int r0, bool has_next, auto k_c) __attribute__((always_inline)) {
+        if (has_next) {
+            put_unit(buf ^ 1, k_c);
+            if (r0 + 2 * ROWS < r_end) {
+                if (r0 + 3 * ROWS <= r_end) fetch_unit(r0 + 2 * ROWS, std::true_type{}, k_c);
+                else fetch_unit(r0 + 2 * ROWS, std::false_type{}, k_c);
+            }
+        }
+    };
+
+    auto run = [&](auto mt_c, auto nt_c) __attribute__((always_inline)) {
+        constexpr int MT = decltype(mt_c)::value, NT = decltype(nt_c)::value;
+        constexpr bool ON = MT > 0 && NT > 0;
+        f32x4 acc[ON ? MT : 1][ON ? NT : 1];
+#pragma unroll
+        for (int mt = 0; mt < (ON ? MT : 1); ++mt)
+#pragma unroll
+            for (int nt = 0; nt < (ON ? NT : 1); ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto ycol = [&](int t) __attribute__((always_inline)) { return (t < cnta ? nta0 + t : ntb0 + (t - cnta)) * 16; };
+        if (r_beg < r_end) {
+            int buf = 0;
+            fetch_step(r_beg);
+            put(0);
+            if (r_beg + ROWS < r_end) fetch_step(r_beg + ROWS);
+            __syncthreads();
+            for (int r0 = r_beg; r0 < r_end; r0 += ROWS) {
+                const bool has_next = r0 + ROWS < r_end;
+                // the next step's planes (its values were fetched a step ago) and the fetch of the step after it: a wave with tiles
+                // spreads them over its MFMA stream (advance_unit), a wave without does them here
+                constexpr bool INTER = ON && MT * NT <= GGNN_XTY_INTER_MAX;   // (the widest waves have no registers for the staged values beside their tiles)
+                if constexpr (!INTER) { if (has_next) { put(buf ^ 1); if (r0 + 2 * ROWS < r_end) fetch_step(r0 + 2 * ROWS); } }
+                if constexpr (ON) {
+                    const char* pb = reinterpret_cast<const char*>(slab) + (size_t)buf * buf_b + ((unsigned)kq * (unsigned)CT + (unsigned)li) * 16u;
+                    auto planes = [&](int col, u32x4& hi, u32x4& mid, u32x4& lo) __attribute__((always_inline)) {
+                        const char* q = pb + (unsigned)col * 16u;
+                        hi = *reinterpret_cast<const u32x4*>(q); mid = *reinterpret_cast<const u32x4*>(q + plane_b);
+                        lo = *reinterpret_cast<const u32x4*>(q + 2u * plane_b);
+                    };
+                    u32x4 xh[MT], xm[MT], xl[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) planes((kt0 + mt) * 16, xh[mt], xm[mt], xl[mt]);
+                    u32x4 yh, ym, yl, zh, zm, zl;
+                    planes(XC + ycol(0), yh, ym, yl);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if (nt + 1 < NT) planes(XC + ycol(nt + 1), zh, zm, zl);
+#define GGNN_XS(XP, YP) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(XP[mt], YP, acc[mt][nt]);
+                        GGNN_XS(xl, yh) GGNN_XS(xm, ym) GGNN_XS(xm, yh) GGNN_XS(xh, yl) GGNN_XS(xh, ym) GGNN_XS(xh, yh)
+#undef GGNN_XS
+                        yh = zh; ym = zm; yl = zl;
+                        constexpr int PU = NT >= 2 * UMAX ? 2 : 1;          // tiles per unit slice
+                        if (INTER && nt % PU == 0 && nt / PU < UMAX) {
+                            if (nt / PU == 0) advance_unit(buf, r0, has_next, std::integral_constant<int, 0>{});
+                            if (nt / PU == 1) advance_unit(buf, r0, has_next, std::integral_constant<int, 1>{});
+                            if (nt / PU == 2) advance_unit(buf, r0, has_next, std::integral_constant<int, 2>{});
+                            if (nt / PU == 3) advance_unit(buf, r0, has_next, std::integral_constant<int, 3>{});
+                        }
+                    }
+                    // (fewer tiles than units: the rest of the units behind the last tile)
+                    if constexpr (INTER && NT < UMAX) {
+                        if (NT <= 1) advance_unit(buf, r0, has_next, std::integral_constant<int, 1>{});
+                        if (NT <= 2) advance_unit(buf, r0, has_next, std::integral_constant<int, 2>{});
+                        if (NT <= 3) advance_unit(buf, r0, has_next, std::integral_constant<int, 3>{});
+                    }
+                }
+                __syncthreads();                           // slab[buf] consumed by all waves, slab[buf ^ 1] written by all
+                buf ^= 1;
+            }
+        }
+        if constexpr (ON) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int k0 = kcol0 + (kt0 + mt) * 16;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = ycol(nt) + li;
+                    if (n < a.N) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = k0 + 4 * kq + e;
+                            if (k < a.Kout) out[(size_t)k * a.N + n] = acc[mt][nt][e];
+                        }
+                    }
+                }
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IM = std::integral_constant<int, MTM>; using IM1 = std::integral_constant<int, MTM - 1>;
+    using IN = std::integral_constant<int, 2 * NTM>; using IN1 = std::integral_constant<int, 2 * NTM - 1>;
+    using IN2 = std::integral_constant<int, 2 * NTM - 2>;
+    if (my_mt == MTM && my_nt == 2 * NTM) run(IM{}, IN{});
+    else if (my_mt == MTM && my_nt == 2 * NTM - 1) run(IM{}, IN1{});
+    else if (my_mt == MTM && my_nt == 2 * NTM - 2) run(IM{}, IN2{});
+    else if (my_mt == MTM - 1 && my_nt == 2 * NTM) run(IM1{}, IN{});
+    else if (my_mt == MTM - 1 && my_nt == 2 * NTM - 1) run(IM1{}, IN1{});
+    else if (my_mt == MTM - 1 && my_nt == 2 * NTM - 2) run(IM1{}, IN2{});
+    else run(I0{}, I0{});
+}
+
 // C[b][i] = sum over the workgroup rows of batch b of part[row][i], in row order.  With a separate bias destination the K weight rows
 // go to C [nbatch][K][N] and the ones row to Cb [nbatch][N]; accumulate: the sums are ADDED to what the destinations hold (the
 // gradient buffers of the training step: one launch less per product, and no torch add on the side stream).
@@ -569,6 +793,24 @@ static int launch_xty(const XtyArgs& a, const XtyPlan& p, float* C, float* Cb, i
     if (p.wg_rows > 0) {
         if (p.lds > 64 * 1024) GGNN_CHECK_HIP((allow_dynamic_lds(&xty_kernel<GATHER, ROWS, MTM, NTM>, p.lds, lds_ok)));
         hipLaunchKernelGGL((xty_kernel<GATHER, ROWS, MTM, NTM>), dim3(p.kblocks, p.wg_rows), dim3(kXtyWaves * 64), p.lds, st, a);
+        GGNN_CHECK_HIP(hipGetLastError());
+    }
+    XtyReduceArgs ra;
+    for (int b = 0; b <= kXtyMaxBatch; ++b) ra.wg_off[b] = a.wg_off[b <= a.nbatch ? b : a.nbatch];
+    const long long total = (long long)a.Kout * a.N * a.nbatch;
+    hipLaunchKernelGGL(xty_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, (const float*)a.part, C, Cb, a.Kout * a.N,
+                       a.K * a.N, a.nbatch, accumulate, ra);
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+template <int MTM, int NTM>
+static int launch_xty_planes(const XtyArgs& a, const XtyPlan& p, float* C, float* Cb, int accumulate, hipStream_t st) {
+    static std::atomic<unsigned long long> lds_ok{0};
+    const size_t lds = (size_t)2 * 192 * (size_t)(16 * (p.kb_tiles + p.n_tiles));
+    if (p.wg_rows > 0) {
+        if (lds > 64 * 1024) GGNN_CHECK_HIP((allow_dynamic_lds(&xty_planes_kernel<MTM, NTM>, lds, lds_ok)));
+        hipLaunchKernelGGL((xty_planes_kernel<MTM, NTM>), dim3(p.kblocks, p.wg_rows), dim3(kXtySplitWaves * 64), lds, st, a);
         GGNN_CHECK_HIP(hipGetLastError());
     }
     XtyReduceArgs ra;
@@ -695,6 +937,15 @@ extern "C" int ggnn_xty_acc_f32(const float* const* x_segs, int nseg, int Dseg, 
     static const bool xty_split = [] { const char* e = getenv("GGNN_XTY_SPLIT"); return !e || atoi(e) != 0; }();
     if (split_matrix_path() && xty_split && p.kb_tiles >= 4 && p.n_tiles >= 4 && (p.rows * p.px / 256 + kXtySplitWaves - 1) / kXtySplitWaves <= kXtySplitMaxI &&
         (p.rows * p.py / 256 + kXtySplitWaves - 1) / kXtySplitWaves <= kXtySplitMaxI) {
+        // operands split once into LDS planes (xty_planes_kernel; GGNN_XTY_PLANES=0: the per-wave split below): ungathered X, both
+        // plane buffers within the 160 KiB of LDS, every unit of a step owned by a thread
+        static const bool xty_planes = [] { const char* e = getenv("GGNN_XTY_PLANES"); return !e || atoi(e) != 0; }();
+        if (xty_planes && !g && (size_t)2 * 192 * 16 * (p.kb_tiles + p.n_tiles) <= (size_t)160 * 1024 &&
+            4 * 16 * (p.kb_tiles + p.n_tiles) <= 4 * kXtySplitWaves * 64) {
+#define GGNN_XTYP_CASE(M, Nn) if (mtm == M && ntm == Nn) return launch_xty_planes<M, Nn>(a, p, C, Cb, accumulate, st);
+            GGNN_XTYP_CASE(4, 4) GGNN_XTYP_CASE(3, 4) GGNN_XTYP_CASE(4, 2) GGNN_XTYP_CASE(3, 2)
+#undef GGNN_XTYP_CASE
+        }
 #define GGNN_XTYS_CASE(G, R, M, Nn) if (g == G && p.rows == R && mtm == M && ntm == Nn) return launch_xty_split<G, R, M, Nn>(a, p, C, Cb, accumulate, st);
         GGNN_XTYS_CASE(false, 32, 4, 4) GGNN_XTYS_CASE(false, 32, 3, 4) GGNN_XTYS_CASE(false, 64, 4, 2) GGNN_XTYS_CASE(false, 64, 3, 2)
         // (the row-gathered edge-weight products, 2 x 2 tile groups per wave, measure slower in split form -- 52 vs 48 us: with so
