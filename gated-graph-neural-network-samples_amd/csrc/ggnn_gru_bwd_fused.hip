@@ -77,6 +77,12 @@ __device__ __forceinline__ void store_frag(float* base, int row, int kq, const F
 // does not help either: the image's loads are younger than the fragment's, waiting for them waits for it (245 us, and the
 // register file overflows: 276 B of scratch).  Hiding the loads needs a load path whose completion is not ordered with the
 // weights' -- a loader wave would do, but a fifth wave halves the register budget of the other four.
+// 3 = the inputs spread over the stages that can carry them (round 4): g, u, c of the NEXT tile under the last three stages of a pass
+// (one fragment each: the f32 fragments of the current tile are dead there in split form, only their planes are live), h and r of the
+// CURRENT tile under stage 0, which multiplies dpc = f(g, u, c) alone -- the rest of the element-wise head (dpu, g u, h r (1 - r), the
+// r*h store) runs behind stage 0.  The chip's HBM share of a CU (6 TB/s / 256 = ~12 B per clock) makes the five fragments of a pass
+// (280 KB per CU) a 17-35k-clock phase when every workgroup fetches them at the top of its pass; spread over four stages they ride
+// under the MFMAs.
 // SPLIT: the products on the bf16 matrix pipe in 3-way split form (ggnn_split.hpp); dpc, dpr, dpu are split once, when complete,
 // and their planes serve all 1 + NX stages that multiply them.
 template <int D, int NX, int NW, int PREFETCH, int RING, bool SPLIT>
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(NW * 64, (RING == 1 && NW == 4) ? 2 : 1) void ggnn_
     auto publish = [&]() { if constexpr (SPLIT) dma_wait(); __syncthreads(); };
     if constexpr (RING == 2) dma(packed, ring);
     Raw raw_a, raw_b;                                            // (raw_b: PREFETCH == 2 only, the tile after the current one)
-    if (PREFETCH && (int)blockIdx.x < n_tk) { fetch_raw(raw_a, blockIdx.x, 0); fetch_raw(raw_a, blockIdx.x, 1); }
+    if (PREFETCH == 3) { if ((int)blockIdx.x < n_tk) { fetch_piece(raw_a, blockIdx.x, 0); fetch_piece(raw_a, blockIdx.x, 1); fetch_piece(raw_a, blockIdx.x, 2); } }
+    else if (PREFETCH && (int)blockIdx.x < n_tk) { fetch_raw(raw_a, blockIdx.x, 0); fetch_raw(raw_a, blockIdx.x, 1); }
     publish();
 
     // A wave has tiles in a PREFIX of its workgroup's passes (full tickets, then possibly a thin tail ticket), so the passes run
@@ -165,7 +172,11 @@ __global__ __launch_bounds__(NW * 64, (RING == 1 && NW == 4) ? 2 : 1) void ggnn_
                 if constexpr (SPLIT) stage_mma_split<D, NT, decltype(zero_c)::value, GGNN_BWD_REMAT>(acc, S, A, img, li, kq);
                 else stage_mma<D, NoHook, NT, decltype(zero_c)::value>(acc, A, img, li, kq);
             };
-            auto stage = [&](auto zero_c, f32x4 (&acc)[NT], const Frag<D>& A, const SFrag<D>& S, int img_idx, auto&& before, auto&& after) {
+            // keep_c: vector-memory instructions the EARLY waves issue in after() (behind the image DMA) that may stay in flight across the
+            // stage's barrier -- the load counter retires in order, so "at most keep outstanding" still proves the DMA pieces landed
+            auto stage = [&](auto zero_c, f32x4 (&acc)[NT], const Frag<D>& A, const SFrag<D>& S, int img_idx, auto&& before, auto&& after,
+                             auto keep_c) {
+                constexpr int KEEP = decltype(keep_c)::value;
                 const int nidx = img_idx + 1 < NSTAGE ? img_idx + 1 : 0;
                 const bool more = (img_idx + 1 < NSTAGE) || !last_pass;
                 const float* nsrc = packed + (size_t)nidx * I::IMG;
@@ -190,7 +201,17 @@ __global__ __launch_bounds__(NW * 64, (RING == 1 && NW == 4) ? 2 : 1) void ggnn_
                     __builtin_amdgcn_sched_barrier(0);
                     if (!late && more) dma(nsrc, ndst);
                     after();
-                    publish();
+                    if constexpr (KEEP > 0 && SPLIT) {
+                        static_assert(KEEP <= 7, "partial wait covers one fragment");
+                        // (only when the early waves DID issue their fragment behind the DMA: the fetch_next_* condition)
+                        if (!late && ACT && !last_pass) {
+                            if constexpr (KEEP == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+                            else if constexpr (KEEP == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                            else if constexpr (KEEP == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                        } else publish();
+                    } else publish();
                     cur ^= 1;
                 }
             };
@@ -208,6 +229,7 @@ __global__ __launch_bounds__(NW * 64, (RING == 1 && NW == 4) ? 2 : 1) void ggnn_
                     hz0 = hd.x; hz1 = hd.y; hz2 = hd.z; hz3 = hd.w;
                 }
                 if constexpr (!PREFETCH) { fetch_raw(raw, tk, 0); fetch_raw(raw, tk, 1); }
+                if constexpr (PREFETCH == 3) { fetch_piece(raw, tk, 3); fetch_piece(raw, tk, 4); }     // h, r: consumed behind stage 0
                 if (a.gz) {
                     // the sums of ggnn_gather_segment_sum_heads_f32(accumulate = 1), in its order: ((0 + z0) + z1 + z2 + z3) + g; slots 2, 3
                     // exist for few nodes (a node with three or more edge types): a second round that most tiles skip as a wave
@@ -237,6 +259,26 @@ __global__ __launch_bounds__(NW * 64, (RING == 1 && NW == 4) ? 2 : 1) void ggnn_
                 }
                 auto dact = [&](float cv) { return a.act == GGNN_ACT_TANH ? 1.0f - cv * cv : (cv > 0.f ? 1.0f : 0.f); };
                 const unsigned os = ((unsigned)row * (unsigned)D + 4u * (unsigned)kq) * 4u;
+                if constexpr (PREFETCH == 3) {                  // dpc alone (same expressions as below); the rest behind stage 0
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        const f32x4 gv = raw.g.v[cc], uv = raw.u.v[cc], cv = raw.c.v[cc];
+                        const f32x4 omu = 1.0f - uv;
+                        const f32x4 da = {dact(cv.x), dact(cv.y), dact(cv.z), dact(cv.w)};
+                        dpc.v[cc] = gv * omu * da;
+                        if (row_ok) st4_b(a.dpc, os + 64u * cc, dpc.v[cc]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) {
+                        const float gv = raw.g.r[q], uv = raw.u.r[q], cv = raw.c.r[q];
+                        const float omu = 1.0f - uv;
+                        dpc.r[q] = gv * omu * dact(cv);
+                        if (row_ok) {
+                            const unsigned o2 = ((unsigned)row * (unsigned)D + 16u * NC + 4u * q + (unsigned)kq) * 4u;
+                            *reinterpret_cast<float*>(reinterpret_cast<char*>(a.dpc) + o2) = dpc.r[q];
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) {
                     const f32x4 gv = raw.g.v[cc], uv = raw.u.v[cc], cv = raw.c.v[cc], hv = raw.h.v[cc], rv = raw.r.v[cc];
@@ -265,14 +307,41 @@ __global__ __launch_bounds__(NW * 64, (RING == 1 && NW == 4) ? 2 : 1) void ggnn_
                         *reinterpret_cast<float*>(reinterpret_cast<char*>(a.rh) + o2) = rv * hv;
                     }
                 }
+                }
             }
 
-            if constexpr (SPLIT && ACT) { split_frag<D>(sdpc, dpc); split_frag<D>(sdpu, dpu); }
+            if constexpr (SPLIT && ACT) { split_frag<D>(sdpc, dpc); if constexpr (PREFETCH != 3) split_frag<D>(sdpu, dpu); }
             // ---- stage 0: drh = dpc Wc^T[h block]; dpr = drh h r (1-r); dh_part = drh r  (accumulator layout) ----------------
             f32x4 acc[NT];
             GGNN_BT(1)
-            stage(std::true_type{}, acc, dpc, sdpc, 0, nothing, nothing);
+            stage(std::true_type{}, acc, dpc, sdpc, 0, nothing, nothing, std::integral_constant<int, 0>{});
             GGNN_BT(2)
+            if constexpr (ACT && PREFETCH == 3) {               // the rest of the head: h and r have landed under stage 0
+                auto dact = [&](float cv) { return a.act == GGNN_ACT_TANH ? 1.0f - cv * cv : (cv > 0.f ? 1.0f : 0.f); };
+                const unsigned os = ((unsigned)row * (unsigned)D + 4u * (unsigned)kq) * 4u;
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) {
+                    const f32x4 gv = raw.g.v[cc], uv = raw.u.v[cc], cv = raw.c.v[cc], hv = raw.h.v[cc], rv = raw.r.v[cc];
+                    const f32x4 omu = 1.0f - uv;
+                    dpu.v[cc] = gv * (hv - cv) * uv * omu;
+                    gu.v[cc] = gv * uv;
+                    rf.v[cc] = rv;
+                    hrr.v[cc] = hv * rv * (1.0f - rv);
+                    if (row_ok) st4_b(a.rh, os + 64u * cc, rv * hv);
+                }
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const float gv = raw.g.r[q], uv = raw.u.r[q], cv = raw.c.r[q], hv = raw.h.r[q], rv = raw.r.r[q];
+                    const float omu = 1.0f - uv;
+                    dpu.r[q] = gv * (hv - cv) * uv * omu;
+                    gu.r[q] = gv * uv; rf.r[q] = rv; hrr.r[q] = hv * rv * (1.0f - rv);
+                    if (row_ok) {
+                        const unsigned o2 = ((unsigned)row * (unsigned)D + 16u * NC + 4u * q + (unsigned)kq) * 4u;
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(a.rh) + o2) = rv * hv;
+                    }
+                }
+                if constexpr (SPLIT) split_frag<D>(sdpu, dpu);
+            }
             if constexpr (ACT) {
                 // accumulator tile nt == fragment chunk nt (same lanes, same columns); the remainder tile through rem_tile().
                 // dpr goes to its fragment, and the accumulator is re-used as the START value of the dh stages:
@@ -309,9 +378,9 @@ __global__ __launch_bounds__(NW * 64, (RING == 1 && NW == 4) ? 2 : 1) void ggnn_
             if constexpr (SPLIT && ACT) split_frag<D>(sdpr, dpr);
             // ---- stages 1, 2: the h blocks of Wg^T -> dh = g u + drh r + dpr Wg_r^T + dpu Wg_u^T ------------------------------------
             GGNN_BT(3)
-            stage(std::false_type{}, acc, dpr, sdpr, 1, nothing, nothing);
+            stage(std::false_type{}, acc, dpr, sdpr, 1, nothing, nothing, std::integral_constant<int, 0>{});
             GGNN_BT(4)
-            stage(std::false_type{}, acc, dpu, sdpu, 2, nothing, nothing);
+            stage(std::false_type{}, acc, dpu, sdpu, 2, nothing, nothing, std::integral_constant<int, 0>{});
             GGNN_BT(5)
             if constexpr (ACT) {
                 if (row_ok) {
@@ -329,14 +398,29 @@ __global__ __launch_bounds__(NW * 64, (RING == 1 && NW == 4) ? 2 : 1) void ggnn_
             GGNN_BT(6)
             auto fetch_next_a = [&] { if (PREFETCH == 1 && ACT && !last_pass) fetch_raw(raw, tk + nb, 0); };
             auto fetch_next_b = [&] { if (PREFETCH == 1 && ACT && !last_pass) fetch_raw(raw, tk + nb, 1); };
+            // (PREFETCH == 3) g, u, c of the next tile, one under each of the pass's last three stages (a wave whose next pass has no
+            // tile fetches row 0 of tile 0: harmless)
+            // The 25 load instructions of a fragment take ~3k clocks to ISSUE when all eight waves issue theirs at once (the CU's
+            // vector-memory path takes ~16 clocks per 1-KiB instruction), and a wave's MFMAs wait behind them in program order: the
+            // late waves issue before their burst (under the early waves' burst), the early waves after theirs -- the stage
+            // lambda's rule for the image DMA.
+            auto fetch_next_g = [&] { if (PREFETCH == 3 && ACT && !last_pass && late) fetch_piece(raw, tk + nb, 0); };
+            auto fetch_next_u = [&] { if (PREFETCH == 3 && ACT && !last_pass && late) fetch_piece(raw, tk + nb, 1); };
+            auto fetch_next_c = [&] { if (PREFETCH == 3 && ACT && !last_pass && late) fetch_piece(raw, tk + nb, 2); };
+            auto fetch_next_g2 = [&] { if (PREFETCH == 3 && ACT && !last_pass && !late) fetch_piece(raw, tk + nb, 0); };
+            auto fetch_next_u2 = [&] { if (PREFETCH == 3 && ACT && !last_pass && !late) fetch_piece(raw, tk + nb, 1); };
+            auto fetch_next_c2 = [&] { if (PREFETCH == 3 && ACT && !last_pass && !late) fetch_piece(raw, tk + nb, 2); };
 #define GGNN_BWD_SEG(S)                                                                                             \
             if constexpr ((S) < NX) {                                                                               \
-                stage(std::true_type{}, acc, dpc, sdpc, 3 + 3 * (S), nothing, nothing);                             \
+                if constexpr ((S) == NX - 1 && PREFETCH == 3) stage(std::true_type{}, acc, dpc, sdpc, 3 + 3 * (S), fetch_next_g, fetch_next_g2, std::integral_constant<int, (NC + NR == 7 || NC + NR == 4 || NC + NR == 2) ? NC + NR : 0>{}); \
+                else stage(std::true_type{}, acc, dpc, sdpc, 3 + 3 * (S), nothing, nothing, std::integral_constant<int, 0>{});                        \
                 if ((S) == 0) { GGNN_BT(8) }                                                                        \
-                stage(std::false_type{}, acc, dpr, sdpr, 4 + 3 * (S), nothing, nothing);                            \
+                if constexpr ((S) == NX - 1 && PREFETCH == 3) stage(std::false_type{}, acc, dpr, sdpr, 4 + 3 * (S), fetch_next_u, fetch_next_u2, std::integral_constant<int, (NC + NR == 7 || NC + NR == 4 || NC + NR == 2) ? NC + NR : 0>{}); \
+                else stage(std::false_type{}, acc, dpr, sdpr, 4 + 3 * (S), nothing, nothing, std::integral_constant<int, 0>{});                       \
                 if ((S) == 0) { GGNN_BT(9) }                                                                        \
-                if constexpr ((S) == NX - 1) stage(std::false_type{}, acc, dpu, sdpu, 5 + 3 * (S), fetch_next_a, fetch_next_b); \
-                else stage(std::false_type{}, acc, dpu, sdpu, 5 + 3 * (S), nothing, nothing);                       \
+                if constexpr ((S) == NX - 1 && PREFETCH == 3) stage(std::false_type{}, acc, dpu, sdpu, 5 + 3 * (S), fetch_next_c, fetch_next_c2, std::integral_constant<int, (NC + NR == 7 || NC + NR == 4 || NC + NR == 2) ? NC + NR : 0>{}); \
+                else if constexpr ((S) == NX - 1) stage(std::false_type{}, acc, dpu, sdpu, 5 + 3 * (S), fetch_next_a, fetch_next_b, std::integral_constant<int, 0>{}); \
+                else stage(std::false_type{}, acc, dpu, sdpu, 5 + 3 * (S), nothing, nothing, std::integral_constant<int, 0>{});                       \
                 if ((S) == 0) { GGNN_BT(10) }                                                                       \
                 if constexpr (ACT) {                                                                                \
                     if (row_ok) {                                                                                   \
@@ -426,10 +510,14 @@ static int launch_gru_bwd_split(const GruBwdArgs& a, const float* Wg, const floa
     // (round 4, MI355X, V = 100k: 164.7 us form 0, 163.8 form 2, 189.5 form 1; starting every other workgroup 5-25 us late moves
     // the launch time by -2 .. +4 us: with half the chip idle the rest clocks higher -- the launch is paced by the chip's power
     // budget, not by how its phases line up; profiles/r04_experiments/gru_bwd_forms_stagger.txt)
-    const int form = [] { const char* e = getenv("GGNN_BWD_FORM"); return e ? atoi(e) : 0; }();
+    // 3 (default since round 4): the inputs spread over the stages -- g, u, c of the next tile under the last three stages (early waves:
+    // behind their burst, left in flight across the barrier), h and r under stage 0: 150.8 us against 162.7 for form 0, bit-identical,
+    // 20 B of scratch instead of 36; what is left is the launch's 440 MB at ~3.8 TB/s inside the full rounds.  0: everything at the top.
+    const int form = [] { const char* e = getenv("GGNN_BWD_FORM"); return e ? atoi(e) : 3; }();
     if (form == 1) return launch_gru_bwd_variant<D, NX, 8, 1, 2, true>(a, packed, st);
     if (form == 2) return launch_gru_bwd_variant<D, NX, 4, 0, 1, true>(a, packed, st);     // two 4-wave workgroups per CU, one image each
-    return launch_gru_bwd_variant<D, NX, 8, 0, 2, true>(a, packed, st);
+    if (form == 0) return launch_gru_bwd_variant<D, NX, 8, 0, 2, true>(a, packed, st);
+    return launch_gru_bwd_variant<D, NX, 8, 3, 2, true>(a, packed, st);
 }
 template <int D>
 static int gru_bwd_split_d(int nx, const GruBwdArgs& a, const float* Wg, const float* Wc, float* packed, hipStream_t st) {

@@ -378,7 +378,10 @@ def test_gru_backward_with_gathered_gradient_equals_sum_then_backward(pkg, cuda,
     got = ops.gru_bwd_fused(g, h, rr, u, c, packed, nin, True, nx, "tanh", gather=(Z, heads))
     g2 = g.clone()
     lib = pkg._lib.load()
-    pkg._lib.check(lib.ggnn_gather_segment_sum_heads_f32(Z.data_ptr(), row_ptr.to(cuda).data_ptr(), perm.to(cuda).data_ptr(), heads.data_ptr(),
+    # (the device copies must outlive the launch: a temporary's block goes back to the caching allocator as soon as data_ptr() has
+    #  returned, and the next temporary can be handed the same block -- nodes with four rows then walk a slot range read from it)
+    row_ptr_d, perm_d = row_ptr.to(cuda), perm.to(cuda)
+    pkg._lib.check(lib.ggnn_gather_segment_sum_heads_f32(Z.data_ptr(), row_ptr_d.data_ptr(), perm_d.data_ptr(), heads.data_ptr(),
                                                          None, None, 0, g2.data_ptr(), V, D, 1, 1, torch.cuda.current_stream().cuda_stream))
     want = ops.gru_bwd_fused(g2, h, rr, u, c, packed, nin, True, nx, "tanh")
     torch.cuda.synchronize()
