@@ -497,18 +497,25 @@ __global__ __launch_bounds__(kXtySplitWaves * 64) void xty_split_kernel(XtyArgs 
 // ---- X^T dY in split form with the operands split ONCE, into LDS planes (round 4) -------------------------------------------------
 // xty_split_kernel above splits an operand tile in EVERY wave that multiplies it (484 vector instructions and 88 ds_read_b32 per
 // wave and 32-row step next to 168 MFMAs; on this chip the vector and matrix instructions of a SIMD's two waves do not overlap --
-// DESIGN.md K3 -- so the splits are ~40 % of the loop).  Here a step's 32 rows x (X columns + dY columns) are fetched from global
-// memory ONE COLUMN x 8 ROWS per thread (coalesced dword loads, a step ahead, straight into registers: no f32 slab in LDS), split
-// once (44 vector instructions per 8 values) and written to LDS as the three bf16 planes in MFMA operand layout
-//     plane[p][g][column][8 x bf16]      (g = 8-row group of the step: lane (i, g) of a 16-column tile reads ONE ds_read_b128)
-// double-buffered: 2 x 192 (XC + YC) bytes (XC = 16 kb_tiles, YC = 16 n_tiles: 156 KiB at 13 + 13 tiles).  The split of step s + 1
-// is issued in the same barrier interval as the MFMAs of step s.  Tile groups, partial products and the reduction are
-// xty_split_kernel's (same XtyArgs / plan); within a 32-row step the rows sit in other MFMA k slots, so results agree with it to
-// f32 rounding, not bit for bit.  Ungathered X only (the training step's GRU weight gradients).
+// DESIGN.md K3 -- so the splits were ~40 % of the loop).  Here a step's 32 rows x (X columns + dY columns) are fetched by ONE thread
+// per (8-row group, 4-column quad): eight 16-byte loads (coalesced: consecutive lanes = consecutive quads of a row), a step ahead,
+// straight into registers -- no f32 slab in LDS --, split once (44 vector instructions per column) and written to LDS as the
+// three bf16 planes in MFMA operand layout
+//     plane[p][g][column slot][8 x bf16]      (g = 8-row group of the step: lane (i, g) of a 16-column tile reads ONE ds_read_b128)
+// double-buffered: 2 x 192 (XC + YC) bytes (XC = 16 kb_tiles, YC = 16 n_tiles: 156 KiB at 13 + 13 tiles).  Column c of tile t sits in
+// slot 16 t + ((c + t) & 15): a rotation per tile, so that the 8 lanes of a ds_write_b128 phase -- quads of two neighbouring tiles,
+// same column within the quad -- hit 32 distinct banks; a tile read still covers its 16 slots once.  A quad is data (pointer to its
+// first row, byte stride), the chunk {1, 0, 0, 0} with stride 0 (the ones column K of Kout == K + 1: the bias gradient) or the zero
+// chunk (padding columns; every quad for rows past the range) -- K, N and the segment width are multiples of 4: no mixed quads, no
+// per-kind control flow.  The next step's columns are cut into the MFMA stream (one per tile or two) for waves with <= 24 tile pairs.
+// Tile groups, partial products and the reduction are xty_split_kernel's (same XtyArgs / plan); within a 32-row step the rows sit
+// in other MFMA k slots, so results agree with it to f32 rounding, not bit for bit.
+// Ungathered X only (the training step's GRU weight gradients; the row-gathered edge-weight products gain nothing from this form:
+// tools/attic/xty_planes_gather.patch.txt).
 template <int MTM, int NTM>
 __global__ __launch_bounds__(kXtySplitWaves * 64) void xty_planes_kernel(XtyArgs a) {
     extern __shared__ __attribute__((aligned(16))) float slab[];     // [2][3 planes][4 groups][XC + YC] x 16 bytes
-    constexpr int nw = kXtySplitWaves, NTH = nw * 64, ROWS = 32, UMAX = 4;
+    constexpr int nw = kXtySplitWaves, NTH = nw * 64, ROWS = 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(kXtySplitWaves * 64) void xty_planes_kernel(XtyArgs
     const int r_beg = rb + split * rows_per;
     const int r_end = min(re, r_beg + rows_per);
     const int kcol0 = blockIdx.x * a.kb_tiles * 16;
-    const int XC = a.kb_tiles * 16, YC = a.n_tiles * 16, CT = XC + YC;
+    const int XC = a.kb_tiles * 16, YC = a.n_tiles * 16, CT = XC + YC;      // CT <= NTH (one quad per thread and 8-row group)
     const unsigned plane_b = 4u * (unsigned)CT * 16u;                  // bytes of one plane (4 groups)
     const unsigned buf_b = 3u * plane_b;
     float* out = a.part + (size_t)blockIdx.y * a.Kout * a.N;
@@ -534,94 +541,77 @@ __global__ __launch_bounds__(kXtySplitWaves * 64) void xty_planes_kernel(XtyArgs
     xty_group(a.n_tiles, (ga + 1) & 3, ntb0, cntb);
     const int my_nt = cnta + cntb;
 
-    // ---- producer side: unit u = (8-row group g, column c) of a step; thread t owns units t, t + NTH, ... (< 4 CT <= UMAX NTH) ----
-    // Every unit is a (pointer to its first row of the current step, byte stride between rows) pair and is fetched with eight
-    // unconditional loads: a data column walks its rows; the ones column (X column K when Kout == K + 1) and the padding columns
-    // of the last tiles read a constant 1 / 0 with stride 0 -- no per-kind control flow, no per-value selects.
-    // (udst: byte offset of the unit's 16-byte slot inside a plane, | its 8-row group g in bits 0-1, | 4 when the unit exists)
-    const char* urow[UMAX]; unsigned ustride[UMAX]; unsigned udst[UMAX];
+    // ---- producer side: thread t < CT owns quad (t % (CT / 4)) of 8-row group t / (CT / 4) ------------------------------------------
     const char* const zero_p = reinterpret_cast<const char*>(kXtyZeroChunk);
-#pragma unroll
-    for (int k = 0; k < UMAX; ++k) {
-        const int u = tid + k * NTH;
-        const bool on = u < 4 * CT;
-        const int g = on ? u / CT : 0, c = on ? u - g * CT : 0;
-        udst[k] = ((unsigned)g * (unsigned)CT + (unsigned)c) * 16u + (unsigned)g + (on ? 4u : 0u);
-        urow[k] = zero_p; ustride[k] = 0u;
-        if (on) {
-            const size_t row0 = (size_t)(r_beg + 8 * g);
-            if (c < XC) {
-                const int col = kcol0 + c;
-                if (col < a.K) {
-                    const int seg = col / a.Dseg;
-                    ustride[k] = (unsigned)a.ldx[seg] * 4u;
-                    urow[k] = reinterpret_cast<const char*>(a.X[seg] + (col - seg * a.Dseg)) + row0 * ustride[k];
-                } else if (col == a.K && a.Kout > a.K) urow[k] = reinterpret_cast<const char*>(kXtyOnesChunk);
-            } else if (c - XC < a.N) {
-                ustride[k] = (unsigned)a.ldy * 4u;
-                urow[k] = reinterpret_cast<const char*>(a.Y + (c - XC)) + row0 * ustride[k];
-            }
+    const int QT = CT >> 2;
+    const bool uon = tid < 4 * QT;
+    const int ug = uon ? tid / QT : 0;                                  // 8-row group
+    const int uc = uon ? 4 * (tid - ug * QT) : 0;                       // first column of the quad, in [0, CT)
+    // slots of the quad's four columns: region base + 16 tile + ((column in tile + tile) & 15)
+    const int ureg = uc < XC ? 0 : XC, utile = (uc - ureg) >> 4;
+    const unsigned udbase = ((unsigned)ug * (unsigned)CT + (unsigned)ureg + 16u * (unsigned)utile) * 16u;
+    const unsigned urot = (unsigned)(((uc - ureg) & 15) + utile);       // (+ j, & 15: slot within the tile)
+    const char* urow = zero_p; unsigned ustride = 0u;
+    if (uon) {
+        const size_t row0 = (size_t)(r_beg + 8 * ug);
+        if (uc < XC) {
+            const int col = kcol0 + uc;
+            if (col < a.K) {
+                const int seg = col / a.Dseg;
+                ustride = (unsigned)a.ldx[seg] * 4u;
+                urow = reinterpret_cast<const char*>(a.X[seg] + (col - seg * a.Dseg)) + row0 * ustride;
+            } else if (col == a.K && a.Kout > a.K) urow = reinterpret_cast<const char*>(kXtyOnesChunk);
+        } else if (uc - XC < a.N) {
+            ustride = (unsigned)a.ldy * 4u;
+            urow = reinterpret_cast<const char*>(a.Y + (uc - XC)) + row0 * ustride;
         }
     }
-    constexpr bool kLastUnitPartial = true;                                  // (k = UMAX - 1 exists for some waves only: wave-uniform test below)
-    const bool wave_has_last = (UMAX - 1) * NTH + wave * 64 < 4 * CT;
-    float stage[UMAX][8];                                                   // a step's values of this thread's units, fetched a step ahead
-    // FULL: all 32 rows of the step lie inside the range; else rows >= r_end read the zero constant (every operand: 0 x 0)
-    auto fetch_unit = [&](int r0, auto full_c, auto k_c) __attribute__((always_inline)) {
+    const bool wave_on = wave * 64 < 4 * QT;                            // (wave-uniform: this wave owns quads)
+    f32x4 stage[8];                                                     // the quad's 8 rows of a step, fetched a step ahead
+    // FULL: all 32 rows of the step lie inside the range; else rows >= r_end read the zero chunk (every operand: 0 x 0)
+    auto fetch = [&](int r0, auto full_c) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_c)::value;
-        constexpr int k = decltype(k_c)::value;
-        {
-            if (k < UMAX - 1 || !kLastUnitPartial || wave_has_last) {
-                const char* q = urow[k];
+        if (wave_on) {
+            const char* q = urow;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const char* src = q;
-                    if constexpr (!FULL) { if (r0 + 8 * (int)(udst[k] & 3u) + j >= r_end) src = zero_p; }
-                    stage[k][j] = *(const __attribute__((address_space(1))) float*)src;       // (global_load, not a flat access)
-                    q += ustride[k];
-                }
-                urow[k] += (size_t)32 * ustride[k];
+            for (int j = 0; j < 8; ++j) {
+                const char* src = q;
+                if constexpr (!FULL) { if (r0 + 8 * ug + j >= r_end) src = zero_p; }
+                stage[j] = *(const __attribute__((address_space(1))) f32x4*)src;       // (global_load_dwordx4, not a flat access)
+                q += ustride;
             }
+            urow += (size_t)32 * ustride;
         }
     };
-    auto fetch = [&](int r0, auto full_c) __attribute__((always_inline)) {
-        fetch_unit(r0, full_c, std::integral_constant<int, 0>{}); fetch_unit(r0, full_c, std::integral_constant<int, 1>{});
-        fetch_unit(r0, full_c, std::integral_constant<int, 2>{}); fetch_unit(r0, full_c, std::integral_constant<int, 3>{});
-    };
-    static_assert(UMAX == 4, "fetch / put walk four units");
     auto fetch_step = [&](int r0) __attribute__((always_inline)) {
         if (r0 + ROWS <= r_end) fetch(r0, std::true_type{}); else fetch(r0, std::false_type{});
     };
-    auto put_unit = [&](int buf, auto k_c) __attribute__((always_inline)) {    // split unit k's staged values, write its planes of slab[buf]
+    // column k of the quad: split its eight staged values, write its planes of slab[buf]
+    auto put_col = [&](int buf, auto k_c) __attribute__((always_inline)) {
         constexpr int k = decltype(k_c)::value;
-        char* base = reinterpret_cast<char*>(slab) + (size_t)buf * buf_b;
-        {
-            if (k < UMAX - 1 || !kLastUnitPartial || wave_has_last) {
-                unsigned h[4], m[4], l[4];
+        if (wave_on) {
+            char* base = reinterpret_cast<char*>(slab) + (size_t)buf * buf_b;
+            unsigned h[4], m[4], l[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) split_pair(stage[k][2 * q], stage[k][2 * q + 1], h[q], m[q], l[q]);
-                if (udst[k] & 4u) {
-                    const unsigned d = udst[k] & ~15u;
-                    *reinterpret_cast<u32x4*>(base + d) = u32x4{h[0], h[1], h[2], h[3]};
-                    *reinterpret_cast<u32x4*>(base + plane_b + d) = u32x4{m[0], m[1], m[2], m[3]};
-                    *reinterpret_cast<u32x4*>(base + 2u * plane_b + d) = u32x4{l[0], l[1], l[2], l[3]};
-                }
+            for (int q = 0; q < 4; ++q) split_pair(stage[2 * q][k], stage[2 * q + 1][k], h[q], m[q], l[q]);
+            if (uon) {
+                const unsigned d = udbase + ((urot + (unsigned)k) & 15u) * 16u;
+                *reinterpret_cast<u32x4*>(base + d) = u32x4{h[0], h[1], h[2], h[3]};
+                *reinterpret_cast<u32x4*>(base + plane_b + d) = u32x4{m[0], m[1], m[2], m[3]};
+                *reinterpret_cast<u32x4*>(base + 2u * plane_b + d) = u32x4{l[0], l[1], l[2], l[3]};
             }
         }
     };
     auto put = [&](int buf) __attribute__((always_inline)) {
-        put_unit(buf, std::integral_constant<int, 0>{}); put_unit(buf, std::integral_constant<int, 1>{});
-        put_unit(buf, std::integral_constant<int, 2>{}); put_unit(buf, std::integral_constant<int, 3>{});
+        put_col(buf, std::integral_constant<int, 0>{}); put_col(buf, std::integral_constant<int, 1>{});
+        put_col(buf, std::integral_constant<int, 2>{}); put_col(buf, std::integral_constant<int, 3>{});
     };
-    // unit k of the NEXT step (its planes, then the fetch of the step after it): cut into the MFMA stream below, one unit per
-    // NT / UMAX tiles -- in one wave's stream ~1 vector instruction per MFMA issues in the MFMAs' shadow (tools/issue_probe.hip)
-    auto advance_unit = [&](int buf, int r0, bool has_next, auto k_c) __attribute__((always_inline)) {
+    // column k of the NEXT step's quad (behind the last one: the fetch of the step after it), cut into the MFMA stream below -- in one
+    // wave's stream ~1 vector instruction per MFMA issues in the MFMAs' shadow (tools/issue_probe.hip)
+    auto advance_col = [&](int buf, int r0, bool has_next, auto k_c) __attribute__((always_inline)) {
         if (has_next) {
-            put_unit(buf ^ 1, k_c);
-            if (r0 + 2 * ROWS < r_end) {
-                if (r0 + 3 * ROWS <= r_end) fetch_unit(r0 + 2 * ROWS, std::true_type{}, k_c);
-                else fetch_unit(r0 + 2 * ROWS, std::false_type{}, k_c);
-            }
+            put_col(buf ^ 1, k_c);
+            if (decltype(k_c)::value == 3 && r0 + 2 * ROWS < r_end) fetch_step(r0 + 2 * ROWS);
         }
     };
 
@@ -633,53 +623,61 @@ __global__ __launch_bounds__(kXtySplitWaves * 64) void xty_planes_kernel(XtyArgs
         for (int mt = 0; mt < (ON ? MT : 1); ++mt)
 #pragma unroll
             for (int nt = 0; nt < (ON ? NT : 1); ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto ycol = [&](int t) __attribute__((always_inline)) { return (t < cnta ? nta0 + t : ntb0 + (t - cnta)) * 16; };
+        auto ytile = [&](int t) __attribute__((always_inline)) { return t < cnta ? nta0 + t : ntb0 + (t - cnta); };
+        // the MFMAs of one step over slab[buf]; INTER: the next step's columns cut in (one per PU tiles)
+        auto mma_step = [&](int buf, int r0, bool has_next, auto inter_c) __attribute__((always_inline)) {
+            constexpr bool INTER = decltype(inter_c)::value;
+            if constexpr (ON) {
+                const char* pb = reinterpret_cast<const char*>(slab) + (size_t)buf * buf_b + (unsigned)kq * (unsigned)CT * 16u;
+                // tile T of a region (X: base 0, dY: base XC): lane li reads slot 16 T + ((li + T) & 15)
+                auto planes = [&](int reg, int T, u32x4& hi, u32x4& mid, u32x4& lo) __attribute__((always_inline)) {
+                    const char* q = pb + (unsigned)(reg + 16 * T + ((li + T) & 15)) * 16u;
+                    hi = *reinterpret_cast<const u32x4*>(q); mid = *reinterpret_cast<const u32x4*>(q + plane_b);
+                    lo = *reinterpret_cast<const u32x4*>(q + 2u * plane_b);
+                };
+                u32x4 xh[MT], xm[MT], xl[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) planes(0, kt0 + mt, xh[mt], xm[mt], xl[mt]);
+                u32x4 yh, ym, yl, zh, zm, zl;
+                planes(XC, ytile(0), yh, ym, yl);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (nt + 1 < NT) planes(XC, ytile(nt + 1), zh, zm, zl);
+                    // six products per tile pair, product-major over the X tiles (consecutive MFMAs hit different accumulators)
+#define GGNN_XS(XP, YP) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(XP[mt], YP, acc[mt][nt]);
+                    GGNN_XS(xl, yh) GGNN_XS(xm, ym) GGNN_XS(xm, yh) GGNN_XS(xh, yl) GGNN_XS(xh, ym) GGNN_XS(xh, yh)
+#undef GGNN_XS
+                    yh = zh; ym = zm; yl = zl;
+                    if constexpr (INTER) {
+                        constexpr int PU = NT >= 8 ? 2 : 1;              // tiles per column slice
+                        if (nt % PU == 0 && nt / PU < 4) {
+                            if (nt / PU == 0) advance_col(buf, r0, has_next, std::integral_constant<int, 0>{});
+                            if (nt / PU == 1) advance_col(buf, r0, has_next, std::integral_constant<int, 1>{});
+                            if (nt / PU == 2) advance_col(buf, r0, has_next, std::integral_constant<int, 2>{});
+                            if (nt / PU == 3) advance_col(buf, r0, has_next, std::integral_constant<int, 3>{});
+                        }
+                    }
+                }
+                if constexpr (INTER && NT < 4) {                         // (fewer tiles than columns: the rest behind the last tile)
+                    if (NT <= 1) advance_col(buf, r0, has_next, std::integral_constant<int, 1>{});
+                    if (NT <= 2) advance_col(buf, r0, has_next, std::integral_constant<int, 2>{});
+                    if (NT <= 3) advance_col(buf, r0, has_next, std::integral_constant<int, 3>{});
+                }
+            }
+        };
         if (r_beg < r_end) {
             int buf = 0;
             fetch_step(r_beg);
             put(0);
             if (r_beg + ROWS < r_end) fetch_step(r_beg + ROWS);
             __syncthreads();
+            constexpr bool INTER = ON && MT * NT <= GGNN_XTY_INTER_MAX;   // (the widest waves have no registers for the staged values beside their tiles)
             for (int r0 = r_beg; r0 < r_end; r0 += ROWS) {
                 const bool has_next = r0 + ROWS < r_end;
                 // the next step's planes (its values were fetched a step ago) and the fetch of the step after it: a wave with tiles
-                // spreads them over its MFMA stream (advance_unit), a wave without does them here
-                constexpr bool INTER = ON && MT * NT <= GGNN_XTY_INTER_MAX;   // (the widest waves have no registers for the staged values beside their tiles)
+                // to spare spreads them over its MFMA stream (advance_col), the others do them here
                 if constexpr (!INTER) { if (has_next) { put(buf ^ 1); if (r0 + 2 * ROWS < r_end) fetch_step(r0 + 2 * ROWS); } }
-                if constexpr (ON) {
-                    const char* pb = reinterpret_cast<const char*>(slab) + (size_t)buf * buf_b + ((unsigned)kq * (unsigned)CT + (unsigned)li) * 16u;
-                    auto planes = [&](int col, u32x4& hi, u32x4& mid, u32x4& lo) __attribute__((always_inline)) {
-                        const char* q = pb + (unsigned)col * 16u;
-                        hi = *reinterpret_cast<const u32x4*>(q); mid = *reinterpret_cast<const u32x4*>(q + plane_b);
-                        lo = *reinterpret_cast<const u32x4*>(q + 2u * plane_b);
-                    };
-                    u32x4 xh[MT], xm[MT], xl[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) planes((kt0 + mt) * 16, xh[mt], xm[mt], xl[mt]);
-                    u32x4 yh, ym, yl, zh, zm, zl;
-                    planes(XC + ycol(0), yh, ym, yl);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        if (nt + 1 < NT) planes(XC + ycol(nt + 1), zh, zm, zl);
-#define GGNN_XS(XP, YP) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(XP[mt], YP, acc[mt][nt]);
-                        GGNN_XS(xl, yh) GGNN_XS(xm, ym) GGNN_XS(xm, yh) GGNN_XS(xh, yl) GGNN_XS(xh, ym) GGNN_XS(xh, yh)
-#undef GGNN_XS
-                        yh = zh; ym = zm; yl = zl;
-                        constexpr int PU = NT >= 2 * UMAX ? 2 : 1;          // tiles per unit slice
-                        if (INTER && nt % PU == 0 && nt / PU < UMAX) {
-                            if (nt / PU == 0) advance_unit(buf, r0, has_next, std::integral_constant<int, 0>{});
-                            if (nt / PU == 1) advance_unit(buf, r0, has_next, std::integral_constant<int, 1>{});
-                            if (nt / PU == 2) advance_unit(buf, r0, has_next, std::integral_constant<int, 2>{});
-                            if (nt / PU == 3) advance_unit(buf, r0, has_next, std::integral_constant<int, 3>{});
-                        }
-                    }
-                    // (fewer tiles than units: the rest of the units behind the last tile)
-                    if constexpr (INTER && NT < UMAX) {
-                        if (NT <= 1) advance_unit(buf, r0, has_next, std::integral_constant<int, 1>{});
-                        if (NT <= 2) advance_unit(buf, r0, has_next, std::integral_constant<int, 2>{});
-                        if (NT <= 3) advance_unit(buf, r0, has_next, std::integral_constant<int, 3>{});
-                    }
-                }
+                mma_step(buf, r0, has_next, std::integral_constant<bool, INTER>{});
                 __syncthreads();                           // slab[buf] consumed by all waves, slab[buf ^ 1] written by all
                 buf ^= 1;
             }
@@ -690,7 +688,7 @@ __global__ __launch_bounds__(kXtySplitWaves * 64) void xty_planes_kernel(XtyArgs
                 const int k0 = kcol0 + (kt0 + mt) * 16;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int n = ycol(nt) + li;
+                    const int n = ytile(nt) * 16 + li;
                     if (n < a.N) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -941,7 +939,7 @@ extern "C" int ggnn_xty_acc_f32(const float* const* x_segs, int nseg, int Dseg, 
         // plane buffers within the 160 KiB of LDS, every unit of a step owned by a thread
         static const bool xty_planes = [] { const char* e = getenv("GGNN_XTY_PLANES"); return !e || atoi(e) != 0; }();
         if (xty_planes && !g && (size_t)2 * 192 * 16 * (p.kb_tiles + p.n_tiles) <= (size_t)160 * 1024 &&
-            4 * 16 * (p.kb_tiles + p.n_tiles) <= 4 * kXtySplitWaves * 64) {
+            16 * (p.kb_tiles + p.n_tiles) <= kXtySplitWaves * 64) {
 #define GGNN_XTYP_CASE(M, Nn) if (mtm == M && ntm == Nn) return launch_xty_planes<M, Nn>(a, p, C, Cb, accumulate, st);
             GGNN_XTYP_CASE(4, 4) GGNN_XTYP_CASE(3, 4) GGNN_XTYP_CASE(4, 2) GGNN_XTYP_CASE(3, 2)
 #undef GGNN_XTYP_CASE
