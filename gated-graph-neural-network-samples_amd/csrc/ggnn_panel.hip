@@ -703,14 +703,171 @@ __global__ __launch_bounds__(NW * 64) void msg_transform_panel_kernel(const floa
     }
 }
 
+// ---- the same transform with the panel images STREAMED and the rows read once (round 4, split form) ------------------------------
+// msg_transform_panel_kernel keeps ONE (type, panel) image per workgroup, so every state row is fetched once per panel (D = 256: four
+// times; 1.11 GB of traffic for 0.48 GB algorithmic) and split once per panel.  Here a workgroup is bound to a TYPE: a pass takes
+// one 16-row tile per wave, splits its fragment ONCE into resident bf16 planes (96 registers at D = 256; the f32 fragment's registers
+// then receive the next tile's rows) and walks the type's NP panels, whose images come through a two-slot LDS ring in
+// PanelGruSplitCfg::PARTS parts -- the panel GRU's chunk-major image format and ring (48 KiB parts at D = 256).  Per pass and CU
+// NP x 96 KiB of weights from L2 instead of (NP - 1) x 128 KiB of rows from HBM / Infinity Cache, and 352 instead of NP x 352
+// split instructions per tile.
+template <int D, bool ZERO, int part>
+__device__ __forceinline__ void panel_part_mma_planes(f32x4 (&acc)[4], const u32x4 (&ph)[PanelGruSplitCfg<D>::NC2], const u32x4 (&pm)[PanelGruSplitCfg<D>::NC2],
+                                                      const u32x4 (&pl)[PanelGruSplitCfg<D>::NC2], const float* chunks, int li, int kq) {
+    using C = PanelGruSplitCfg<D>;
+    constexpr int NU = C::CP * 4;
+    asm volatile("" : "+v"(li), "+v"(kq));      // (the lane part of the address is recomputed per call: GGNN_PANEL_REMAT's reason)
+    const unsigned voff = (unsigned)(kq * 64 + li) * 16u;
+    auto slot = [&](int u, int p) -> u32x4 {                        // unit u = (chunk cc, tile j), plane p
+        const unsigned off = voff + (unsigned)((((u / 4) * 3 + p) * 4) * 64 + (u % 4) * 16) * 16u;
+        return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(chunks) + off);
+    };
+    u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int cc = part * C::CP + u / 4, j = u % 4;
+        const bool more = u + 1 < NU;
+        f32x4 c = (ZERO && u / 4 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j];
+        c = mfma_bf16(wl, ph[cc], c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wl = slot(u + 1, 2);
+        c = mfma_bf16(wm, pm[cc], c);
+        c = mfma_bf16(wm, ph[cc], c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wm = slot(u + 1, 1);
+        c = mfma_bf16(wh, pl[cc], c);
+        c = mfma_bf16(wh, pm[cc], c);
+        c = mfma_bf16(wh, ph[cc], c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wh = slot(u + 1, 0);
+        acc[j] = c;
+    }
+}
+
+// pr.wg_off counts the workgroups of a type (NOT times NP); packed: [T][NP] images in pack_panel_gru_split_image's format
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void msg_transform_ring_kernel(const float* __restrict__ h, const int* __restrict__ pair_node,
+                                                                     PanelRows pr, const float* __restrict__ packed, float* __restrict__ Hc) {
+    using C = PanelCfg<D>;
+    using SC = PanelGruSplitCfg<D>;
+    constexpr int NP = C::NP, PARTS = SC::PARTS, SLOTF = SC::PART, IMGF = SC::IMG, NC2 = SC::NC2;
+    extern __shared__ __attribute__((aligned(16))) float ring[];     // [2][PART]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    int t = 0;
+    while (t + 1 < pr.T && (int)blockIdx.x >= pr.wg_off[t + 1]) ++t;
+    const int j = (int)blockIdx.x - pr.wg_off[t];
+    const int stride = (pr.wg_off[t + 1] - pr.wg_off[t]) * NW;
+    const int row_beg = pr.row_off[t], row_end = pr.row_off[t + 1];
+    const int n_wt = (row_end - row_beg + 15) / 16;
+    const int n_pass = j * NW < n_wt ? (n_wt - j * NW + stride - 1) / stride : 0;     // passes of this workgroup (its wave 0 has a tile in each)
+    int idx = j * NW + wave;
+    const float* timg = packed + (size_t)t * NP * IMGF;
+
+    auto row_of = [&](int i) { const int r = row_beg + i * 16 + li; return r < row_end ? r : row_end - 1; };
+    int cur = 0;
+    auto dma = [&](const float* src, float* dst) { dma_image_asm<SC::PART_BYTES, NW>(src, dst, wave, lane); };
+    auto publish = [&]() { dma_wait(); __syncthreads(); };
+    // the barrier of a round in which this wave issued `keep` vector-memory instructions BEHIND its DMA pieces (the next tile's rows,
+    // a panel's stores): the counter retires in order, so "at most keep outstanding" proves the pieces landed and leaves the rest in
+    // flight across the barrier (they have until the next round's barrier)
+    auto publish_keep = [&](int keep) {
+        switch (keep) {                                              // (wave-uniform; s_waitcnt takes an immediate)
+#define GGNN_WC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); break;
+            GGNN_WC(0) GGNN_WC(1) GGNN_WC(2) GGNN_WC(3) GGNN_WC(4) GGNN_WC(5) GGNN_WC(6) GGNN_WC(7) GGNN_WC(8) GGNN_WC(9) GGNN_WC(10)
+            GGNN_WC(11) GGNN_WC(12) GGNN_WC(13) GGNN_WC(14) GGNN_WC(15) GGNN_WC(16) GGNN_WC(17) GGNN_WC(18) GGNN_WC(19) GGNN_WC(20)
+            GGNN_WC(21) GGNN_WC(22) GGNN_WC(23) GGNN_WC(24) GGNN_WC(25) GGNN_WC(26)
+#undef GGNN_WC
+            default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    static_assert(C::NC == 8 || C::NC == 12 || C::NC == 16, "publish_keep knows the row-load counts of D = 128 / 192 / 256");
+    Frag<D> a;
+    int node_n = 0;
+    if (n_pass > 0) dma(timg, ring);
+    if (idx < n_wt) load_frag<D>(a, h, pair_node[row_of(idx)], kq);
+    if (idx + stride < n_wt) node_n = pair_node[row_of(idx + stride)];
+    publish();
+
+    // the rounds of one pass: NP panels x PARTS parts; ACT: this wave has a tile (else it only feeds the ring and meets the barriers)
+    auto run_pass = [&](auto active_c, bool last_pass) {
+        constexpr bool ACT = decltype(active_c)::value;
+        u32x4 ph[NC2], pm[NC2], pl[NC2];
+        const int r = row_beg + idx * 16 + li;
+        if constexpr (ACT) {
+#pragma unroll
+            for (int c2 = 0; c2 < NC2; ++c2) {
+                const f32x4 x = a.v[2 * c2], y = a.v[2 * c2 + 1];
+                unsigned hh[4], mm[4], ll[4];
+                split_pair(x.x, x.y, hh[0], mm[0], ll[0]); split_pair(x.z, x.w, hh[1], mm[1], ll[1]);
+                split_pair(y.x, y.y, hh[2], mm[2], ll[2]); split_pair(y.z, y.w, hh[3], mm[3], ll[3]);
+                ph[c2] = u32x4{hh[0], hh[1], hh[2], hh[3]}; pm[c2] = u32x4{mm[0], mm[1], mm[2], mm[3]}; pl[c2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+            }
+        }
+        // the next tile's rows go into the fragment's registers (dead now) in the pass's first round, BEHIND the round's DMA
+        const bool has_next = ACT && idx + stride < n_wt;
+        const int node_next = node_n;
+        if constexpr (ACT) { if (idx + 2 * stride < n_wt) node_n = pair_node[row_of(idx + 2 * stride)]; }    // (older than every DMA of the pass)
+        f32x4 acc[4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            auto round = [&](auto part_c) {
+                constexpr int part = decltype(part_c)::value;
+                const bool more = part + 1 < PARTS || p + 1 < NP || !last_pass;
+                const float* nsrc = part + 1 < PARTS ? timg + (size_t)p * IMGF + (size_t)(part + 1) * SLOTF
+                                                     : timg + (size_t)(p + 1 < NP ? p + 1 : 0) * IMGF;
+                // Every wave issues its pieces of the next part FIRST (a round is ~3k clocks of MFMAs for the SIMD's two waves: a part
+                // issued behind a burst would not land before the round's barrier), then -- first round of a pass -- the next tile's rows.
+                int keep = 0;
+                if (more) dma(nsrc, ring + (cur ^ 1) * SLOTF);
+                if constexpr (ACT) { if (p == 0 && part == 0 && has_next) { load_frag<D>(a, h, node_next, kq); keep += C::NC; } }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ACT) panel_part_mma_planes<D, part == 0, part>(acc, ph, pm, pl, ring + cur * SLOTF, li, kq);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ACT && part == PARTS - 1) {
+                    // (every tile has a valid first row: the four stores are issued by every wave with a tile)
+                    if (r < row_end) {
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) st4_b(Hc, ((unsigned)r * (unsigned)D + p * 64 + nt * 16 + 4 * kq) * 4u, acc[nt]);
+                    }
+                    keep += 4;
+                }
+                // the rows / the stores were issued BEHIND the round's DMA pieces: they may stay in flight across the barrier
+                publish_keep(keep);
+                cur ^= 1;
+            };
+            round(std::integral_constant<int, 0>{});
+            if constexpr (PARTS > 1) round(std::integral_constant<int, 1>{});
+            if constexpr (PARTS > 2) round(std::integral_constant<int, 2>{});
+        }
+        idx += stride;
+    };
+    int pass = 0;
+    for (; pass < n_pass && idx < n_wt; ++pass) run_pass(std::true_type{}, pass + 1 == n_pass);
+    for (; pass < n_pass; ++pass) run_pass(std::false_type{}, pass + 1 == n_pass);
+}
+
+// GGNN_PANEL_TRANSFORM: 1 (default) the ring kernel above (split path only), 0 the stationary-image kernel.  Read once: the packed
+// edge-weight images are in the format of the kernel that will multiply them.
+static bool transform_ring() {
+    static const bool v = [] { const char* e = getenv("GGNN_PANEL_TRANSFORM"); return !e || atoi(e) != 0; }();
+    return v && split_matrix_path();
+}
+
 template <int D, bool SPLIT>
-__global__ void edge_weight_panel_pack_kernel(const float* __restrict__ W, float* __restrict__ out) {
+__global__ void edge_weight_panel_pack_kernel(const float* __restrict__ W, float* __restrict__ out, int ring_format) {
     using C = PanelCfg<D>;
     const int t = blockIdx.y / C::NP, p = blockIdx.y % C::NP;
     const int first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    if constexpr (SPLIT) pack_panel_split_image<D>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * PanelSplitCfg<D>::IMG, first, stride);
-    else pack_panel_image<D>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * C::IMG, first, stride);
+    if constexpr (SPLIT) {
+        if (ring_format) pack_panel_gru_split_image<D>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * PanelGruSplitCfg<D>::IMG, first, stride);
+        else pack_panel_split_image<D>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * PanelSplitCfg<D>::IMG, first, stride);
+    } else pack_panel_image<D>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * C::IMG, first, stride);
 }
+static_assert(PanelGruSplitCfg<256>::IMG == PanelSplitCfg<256>::IMG && PanelGruSplitCfg<192>::IMG == PanelSplitCfg<192>::IMG &&
+              PanelGruSplitCfg<128>::IMG == PanelSplitCfg<128>::IMG, "both split image formats of the transform have one size");
 
 // floats of ONE (type, panel) image of the transform, in the process's matrix path
 int transform_panel_image_floats(int D) {
@@ -729,7 +886,7 @@ static int launch_transform_panel_m(const float* h, const float* W, const int* p
     using C = PanelCfg<D>;
     constexpr int NW = 8, NP = C::NP;
     if (W) {
-        hipLaunchKernelGGL((edge_weight_panel_pack_kernel<D, SPLIT>), dim3(8, T * NP), dim3(256), 0, st, W, packed);
+        hipLaunchKernelGGL((edge_weight_panel_pack_kernel<D, SPLIT>), dim3(8, T * NP), dim3(256), 0, st, W, packed, (int)(SPLIT && transform_ring()));
         GGNN_CHECK_HIP(hipGetLastError());
     }
     const int R = row_off[T];
@@ -752,6 +909,30 @@ static int launch_transform_panel_m(const float* h, const float* W, const int* p
         pr.wg_off[t + 1] = pr.wg_off[t] + (int)n * NP;
     }
     pr.row_off[T] = R;
+    if constexpr (SPLIT) {
+        if (transform_ring()) {
+            // workgroups per type in proportion to its rows (one per CU all types together), no more than it has 8-tile passes
+            PanelRows rr{};
+            rr.T = T; rr.wg_off[0] = 0;
+            for (int t = 0; t < T; ++t) {
+                rr.row_off[t] = row_off[t];
+                const long long rows = row_off[t + 1] - row_off[t];
+                long long n = rows * num_cus() / R;
+                const long long rounds = (rows + 16 * NW - 1) / (16 * NW);
+                if (n > rounds) n = rounds;
+                if (rows > 0 && n < 1) n = 1;
+                rr.wg_off[t + 1] = rr.wg_off[t] + (int)n;
+            }
+            rr.row_off[T] = R;
+            static std::atomic<unsigned long long> lds_ok_r{0};
+            constexpr size_t lds_r = (size_t)2 * PanelGruSplitCfg<D>::PART_BYTES;
+            if (lds_r > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&msg_transform_ring_kernel<D, NW>, lds_r, lds_ok_r));
+            hipLaunchKernelGGL((msg_transform_ring_kernel<D, NW>), dim3(rr.wg_off[T]), dim3(NW * 64), lds_r, st, h, pair_node, rr,
+                               (const float*)packed, Hc);
+            GGNN_CHECK_HIP(hipGetLastError());
+            return GGNN_OK;
+        }
+    }
     static std::atomic<unsigned long long> lds_ok{0};
     constexpr size_t lds = SPLIT ? PanelSplitCfg<D>::IMG_BYTES : C::IMG_BYTES;
     if (lds > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&msg_transform_panel_kernel<D, NW, SPLIT>, lds, lds_ok));
