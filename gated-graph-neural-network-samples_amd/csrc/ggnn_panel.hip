@@ -28,6 +28,10 @@
 #ifndef GGNN_PANEL_REMAT
 #define GGNN_PANEL_REMAT 1
 #endif
+#ifndef GGNN_PANEL_DMA_FIRST
+#define GGNN_PANEL_DMA_FIRST 1     // every wave of the panel GRU issues its DMA pieces before its burst (0: the early waves behind theirs,
+                                   // the D = 100 kernels' rule): a part issued behind a burst lands late in the round -- 497 -> 485-487 us at D = 256
+#endif
 #include <type_traits>
 
 namespace ggnn {
@@ -403,14 +407,15 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
                     const float* nsrc = part + 1 < PARTS ? packed + (size_t)img_idx * IMGF + (size_t)(part + 1) * SLOTF
                                                          : packed + (size_t)nidx * IMGF;
                     float* ndst = ring + (cur ^ 1) * SLOTF;
-                    if (late && more_p) dma(nsrc, ndst);
+                    const bool dma_first = late || GGNN_PANEL_DMA_FIRST;
+                    if (dma_first && more_p) dma(nsrc, ndst);
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (ACT) {
                         if constexpr (SPLIT) panel_part_mma_split<D, decltype(zero_c)::value && part == 0, false, part>(acc, A, ring + cur * SLOTF, li, kq);
                         else panel_mma<D, decltype(zero_c)::value>(acc, A, ring + cur * SLOTF, li, kq);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (!late && more_p) dma(nsrc, ndst);
+                    if (!dma_first && more_p) dma(nsrc, ndst);
                     if constexpr (ACT) { if constexpr (part == PARTS - 1) after(); }
                     publish();
                     cur ^= 1;
