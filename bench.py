@@ -227,7 +227,8 @@ def pmc_key(pmc, name, D):
     """bench kernel label -> key of tools/pmc_summary.py (short kernel name, template arguments for the fused GRUs)."""
     if name in ("msg_transform_compact", "dense_aggregate"):
         return next((k for k in pmc if k.startswith(name)), None) or \
-            (next((k for k in pmc if k.startswith("msg_transform_panel")), None) if name == "msg_transform_compact" else None)
+            (next((k for k in pmc if k.startswith("msg_transform_ring") or k.startswith("msg_transform_panel")), None)
+             if name == "msg_transform_compact" else None)
     if name == "msg_transform" or name.startswith("gru_gates") or name.startswith("gru_candidate"):
         # all three are instances of ggnn_gemm_kernel: separable by name only when the workload launched a single one
         # (the dense configs[2]: the message transform is its only GEMM-kernel launch)
