@@ -671,6 +671,31 @@ def test_xty_weight_gradient_product(pkg, cuda, M, nseg, Dseg, N):
     np.testing.assert_allclose(both[-1].cpu().numpy(), wide[:, 4:4 + N].astype(np.float64).sum(0), atol=1e-3 + 4e-7 * M, rtol=1e-5)
 
 
+@pytest.mark.parametrize("M", [1, 31, 33, 65, 8191])
+def test_xty_planes_kernel_short_and_ragged_row_ranges(pkg, cuda, M):
+    """The GRU weight-gradient shape (K = 200 + ones row, N = 200: xty_planes_kernel) on row counts around its 32-row steps: a single
+    partial step, workgroups without rows, a last step that mixes rows inside and outside the range -- and the same rows cut into
+    uneven batches (one of them empty), which must give the per-batch products."""
+    rng = np.random.default_rng(M)
+    xs = [rng.uniform(-1, 1, (M, 100)).astype(np.float32) for _ in range(2)]
+    dy = rng.uniform(-1, 1, (M, 200)).astype(np.float32)
+    dxs, ddy = [dev(x, cuda) for x in xs], dev(dy, cuda)
+    X = np.concatenate(xs, 1).astype(np.float64)
+    both = pkg.ops.xty(dxs, ddy, ones_row=True).cpu().numpy()
+    want = X.T @ dy.astype(np.float64)
+    bound = 4e-7 * (np.abs(X).T @ np.abs(dy).astype(np.float64)) + 1e-6
+    assert both.shape == (201, 200) and np.all(np.abs(both[:-1] - want) <= bound)
+    np.testing.assert_allclose(both[-1], dy.astype(np.float64).sum(0), atol=1e-4 + 4e-7 * M, rtol=1e-5)
+    if M >= 33:
+        off = [0, M // 3, M // 3, M - 1, M]
+        got = pkg.ops.xty(dxs, ddy, row_off=off).cpu().numpy()
+        assert got.shape == (4, 200, 200)
+        for b in range(4):
+            sl = slice(off[b], off[b + 1])
+            w = X[sl].T @ dy[sl].astype(np.float64)
+            assert np.all(np.abs(got[b] - w) <= 4e-7 * (np.abs(X[sl]).T @ np.abs(dy[sl]).astype(np.float64)) + 1e-6), b
+
+
 def test_xty_accumulates_into_gradient_buffers(pkg, cuda):
     """add_to / add_bias_to: the reduction kernel adds the product (and the ones row) into existing buffers -- the same
     floating-point operation as `buffer += xty(...)`, so the results are bit-identical."""
