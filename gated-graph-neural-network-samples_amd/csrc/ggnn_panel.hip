@@ -28,6 +28,9 @@
 #ifndef GGNN_PANEL_REMAT
 #define GGNN_PANEL_REMAT 1
 #endif
+#ifndef GGNN_PANEL_PLANES
+#define GGNN_PANEL_PLANES 1        // the panel GRU keeps a fragment's planes resident over the stages that multiply it in a row
+#endif
 #ifndef GGNN_PANEL_DMA_FIRST
 #define GGNN_PANEL_DMA_FIRST 1     // every wave of the panel GRU issues its DMA pieces before its burst (0: the early waves behind theirs,
                                    // the D = 100 kernels' rule): a part issued behind a burst lands late in the round -- 497 -> 485-487 us at D = 256
@@ -321,6 +324,41 @@ __global__ void gru_panel_pack_kernel(const float* __restrict__ Wg, const float*
     else pack_panel_image<D>(W, r0, c0, ldw, out + (size_t)i * C::IMG, first, stride);
 }
 
+// the same product on RESIDENT planes of the fragment (split once by the caller: the ring transform, and the panel GRU's stages
+// that multiply one fragment several times in a row)
+template <int D, bool ZERO, int part>
+__device__ __forceinline__ void panel_part_mma_planes(f32x4 (&acc)[4], const u32x4 (&ph)[PanelGruSplitCfg<D>::NC2], const u32x4 (&pm)[PanelGruSplitCfg<D>::NC2],
+                                                      const u32x4 (&pl)[PanelGruSplitCfg<D>::NC2], const float* chunks, int li, int kq) {
+    using C = PanelGruSplitCfg<D>;
+    constexpr int NU = C::CP * 4;
+    asm volatile("" : "+v"(li), "+v"(kq));      // (the lane part of the address is recomputed per call: GGNN_PANEL_REMAT's reason)
+    const unsigned voff = (unsigned)(kq * 64 + li) * 16u;
+    auto slot = [&](int u, int p) -> u32x4 {                        // unit u = (chunk cc, tile j), plane p
+        const unsigned off = voff + (unsigned)((((u / 4) * 3 + p) * 4) * 64 + (u % 4) * 16) * 16u;
+        return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(chunks) + off);
+    };
+    u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int cc = part * C::CP + u / 4, j = u % 4;
+        const bool more = u + 1 < NU;
+        f32x4 c = (ZERO && u / 4 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j];
+        c = mfma_bf16(wl, ph[cc], c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wl = slot(u + 1, 2);
+        c = mfma_bf16(wm, pm[cc], c);
+        c = mfma_bf16(wm, ph[cc], c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wm = slot(u + 1, 1);
+        c = mfma_bf16(wh, pl[cc], c);
+        c = mfma_bf16(wh, pm[cc], c);
+        c = mfma_bf16(wh, ph[cc], c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) wh = slot(u + 1, 0);
+        acc[j] = c;
+    }
+}
+
 // SPLIT: the products on the bf16 pipe in 3-way split form; an image comes through the ring in PanelGruSplitCfg::PARTS parts.
 template <int D, int NX, int NW, bool SAVE, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a, const float* __restrict__ packed) {
@@ -397,7 +435,26 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
             constexpr bool ACT = decltype(active_c)::value;
             // one stage: [late waves: DMA of the next image] MFMAs [early waves: DMA]; then `after()` (this wave's loads for
             // the NEXT stage: they fly while the partner wave multiplies) and the barrier that publishes the next image
-            auto stage = [&](auto zero_c, f32x4 (&acc)[4], const Frag<D>& A, int img_idx, auto&& after) {
+            // Resident planes of the fragment the next stages multiply (GGNN_PANEL_PLANES, split form): phase R multiplies a segment's
+            // fragment by NP panels in a row, phase UC multiplies an x segment's by its u and candidate panels back to back -- the
+            // fragment is split ONCE for such a run (10 of the 24 splits of an NX = 1 pass go) and its f32 registers are free for
+            // the next fragment's loads; stages that multiply a fragment once (h -> u, r*h -> c) split chunk by chunk as before.
+            constexpr bool PLANES = SPLIT && GGNN_PANEL_PLANES;
+            u32x4 qh[PLANES ? SC::NC2 : 1], qm[PLANES ? SC::NC2 : 1], ql[PLANES ? SC::NC2 : 1];
+            auto make_planes = [&](const Frag<D>& A) {
+                if constexpr (PLANES && ACT) {
+#pragma unroll
+                    for (int c2 = 0; c2 < SC::NC2; ++c2) {
+                        const f32x4 x = A.v[2 * c2], y = A.v[2 * c2 + 1];
+                        unsigned hh[4], mm[4], ll[4];
+                        split_pair(x.x, x.y, hh[0], mm[0], ll[0]); split_pair(x.z, x.w, hh[1], mm[1], ll[1]);
+                        split_pair(y.x, y.y, hh[2], mm[2], ll[2]); split_pair(y.z, y.w, hh[3], mm[3], ll[3]);
+                        qh[c2] = u32x4{hh[0], hh[1], hh[2], hh[3]}; qm[c2] = u32x4{mm[0], mm[1], mm[2], mm[3]}; ql[c2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+                    }
+                }
+            };
+            auto stage = [&](auto zero_c, f32x4 (&acc)[4], const Frag<D>& A, int img_idx, auto&& after, auto planes_c) {
+                constexpr bool USEP = PLANES && decltype(planes_c)::value;
                 const int nidx = img_idx + 1 < NSTAGE ? img_idx + 1 : 0;
                 const bool more = (img_idx + 1 < NSTAGE) || !last_pass;
                 auto round = [&](auto part_c) {
@@ -411,7 +468,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
                     if (dma_first && more_p) dma(nsrc, ndst);
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (ACT) {
-                        if constexpr (SPLIT) panel_part_mma_split<D, decltype(zero_c)::value && part == 0, false, part>(acc, A, ring + cur * SLOTF, li, kq);
+                        if constexpr (USEP) panel_part_mma_planes<D, decltype(zero_c)::value && part == 0, part>(acc, qh, qm, ql, ring + cur * SLOTF, li, kq);
+                        else if constexpr (SPLIT) panel_part_mma_split<D, decltype(zero_c)::value && part == 0, false, part>(acc, A, ring + cur * SLOTF, li, kq);
                         else panel_mma<D, decltype(zero_c)::value>(acc, A, ring + cur * SLOTF, li, kq);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -434,7 +492,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
                     if constexpr ((P) == NP - 1 && (S) + 1 < NS)                                                     \
                         load_frag<D>(af, (S) + 1 < NX ? a.x[(S) + 1 < NX ? (S) + 1 : 0] : a.h, rowc, kq);          \
                 };                                                                                                  \
-                stage(std::integral_constant<bool, (S) == 0>{}, acc_r[(P) < NP ? (P) : 0], af, (S) * NP + (P), next_seg); \
+                if constexpr ((P) == 0) make_planes(af);                                                            \
+                stage(std::integral_constant<bool, (S) == 0>{}, acc_r[(P) < NP ? (P) : 0], af, (S) * NP + (P), next_seg, std::true_type{}); \
             }
 #define GGNN_R_SEG(S) GGNN_R_STAGE(S, 0) GGNN_R_STAGE(S, 1) GGNN_R_STAGE(S, 2) GGNN_R_STAGE(S, 3)
             GGNN_R_SEG(0) GGNN_R_SEG(1) GGNN_R_SEG(2) GGNN_R_SEG(3)
@@ -464,16 +523,17 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
                 const bool last_panel = p + 1 == NP;
 #define GGNN_X_STAGES(S)                                                                                            \
                 if constexpr ((S) < NX) {                                                                           \
-                    stage(std::integral_constant<bool, (S) == 0>{}, acc_u, af, img0 + 2 * (S), nothing);            \
+                    make_planes(af);                                                                                \
+                    stage(std::integral_constant<bool, (S) == 0>{}, acc_u, af, img0 + 2 * (S), nothing, std::true_type{}); \
                     auto next_seg = [&] { load_frag<D>(af, (S) + 1 < NX ? a.x[(S) + 1 < NX ? (S) + 1 : 0] : a.h, rowc, kq); }; \
-                    stage(std::integral_constant<bool, (S) == 0>{}, acc_c, af, img0 + 2 * (S) + 1, next_seg);       \
+                    stage(std::integral_constant<bool, (S) == 0>{}, acc_c, af, img0 + 2 * (S) + 1, next_seg, std::true_type{}); \
                 }
                 GGNN_X_STAGES(0) GGNN_X_STAGES(1) GGNN_X_STAGES(2)
 #undef GGNN_X_STAGES
                 // h -> u columns; afterwards the fragment registers are free: the next panel's (or next pass's) x_0 goes there
                 auto after_h = [&] { load_frag<D>(af, a.x[0], last_panel ? rown : rowc, kq); };
-                stage(std::false_type{}, acc_u, af, img0 + 2 * NX, after_h);
-                stage(std::false_type{}, acc_c, rh, img0 + 2 * NX + 1, nothing);
+                stage(std::false_type{}, acc_u, af, img0 + 2 * NX, after_h, std::false_type{});
+                stage(std::false_type{}, acc_c, rh, img0 + 2 * NX + 1, nothing, std::false_type{});
                 if constexpr (ACT) {
                     if (row < a.V) {
                         // (the h columns of this panel are fetched here, not a stage ahead: 16 more live registers across the
@@ -716,39 +776,6 @@ __global__ __launch_bounds__(NW * 64) void msg_transform_panel_kernel(const floa
 // PanelGruSplitCfg::PARTS parts -- the panel GRU's chunk-major image format and ring (48 KiB parts at D = 256).  Per pass and CU
 // NP x 96 KiB of weights from L2 instead of (NP - 1) x 128 KiB of rows from HBM / Infinity Cache, and 352 instead of NP x 352
 // split instructions per tile.
-template <int D, bool ZERO, int part>
-__device__ __forceinline__ void panel_part_mma_planes(f32x4 (&acc)[4], const u32x4 (&ph)[PanelGruSplitCfg<D>::NC2], const u32x4 (&pm)[PanelGruSplitCfg<D>::NC2],
-                                                      const u32x4 (&pl)[PanelGruSplitCfg<D>::NC2], const float* chunks, int li, int kq) {
-    using C = PanelGruSplitCfg<D>;
-    constexpr int NU = C::CP * 4;
-    asm volatile("" : "+v"(li), "+v"(kq));      // (the lane part of the address is recomputed per call: GGNN_PANEL_REMAT's reason)
-    const unsigned voff = (unsigned)(kq * 64 + li) * 16u;
-    auto slot = [&](int u, int p) -> u32x4 {                        // unit u = (chunk cc, tile j), plane p
-        const unsigned off = voff + (unsigned)((((u / 4) * 3 + p) * 4) * 64 + (u % 4) * 16) * 16u;
-        return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(chunks) + off);
-    };
-    u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int cc = part * C::CP + u / 4, j = u % 4;
-        const bool more = u + 1 < NU;
-        f32x4 c = (ZERO && u / 4 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j];
-        c = mfma_bf16(wl, ph[cc], c);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) wl = slot(u + 1, 2);
-        c = mfma_bf16(wm, pm[cc], c);
-        c = mfma_bf16(wm, ph[cc], c);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) wm = slot(u + 1, 1);
-        c = mfma_bf16(wh, pl[cc], c);
-        c = mfma_bf16(wh, pm[cc], c);
-        c = mfma_bf16(wh, ph[cc], c);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) wh = slot(u + 1, 0);
-        acc[j] = c;
-    }
-}
-
 // pr.wg_off counts the workgroups of a type (NOT times NP); packed: [T][NP] images in pack_panel_gru_split_image's format
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void msg_transform_ring_kernel(const float* __restrict__ h, const int* __restrict__ pair_node,
