@@ -83,6 +83,19 @@ __host__ __device__ constexpr int gru_stage_image(int pos) {
     return (pos % 3) < 2 ? 2 * (pos / 3) + (pos % 3) : 2 * (NX + 1) + pos / 3;
 }
 
+// the gate epilogues on an accumulator of a SPLIT kernel: sigmoid4_scaled / tanh4_scaled with kSplitAccScale (1 unless the
+// translation unit is built with GGNN_SPLIT2, whose accumulators hold 2^16 x the sums) folded into the exponent's scaling constant
+template <bool SPLIT>
+__device__ __forceinline__ f32x4 sigmoid4_acc(f32x4 z, f32x4 b_scaled) {
+    constexpr float k = -kLog2e * (SPLIT ? kSplitAccScale : 1.0f);
+    return rcp_4(exp2_4(z * k + b_scaled) + 1.0f);
+}
+template <bool SPLIT>
+__device__ __forceinline__ f32x4 tanh4_acc(f32x4 z, f32x4 b_scaled) {
+    constexpr float k = 2.0f * kLog2e * (SPLIT ? kSplitAccScale : 1.0f);
+    return 1.0f - 2.0f * rcp_4(exp2_4(z * k + b_scaled) + 1.0f);
+}
+
 template <int D>
 __device__ __forceinline__ void frag_zero(Frag<D>& f) {
 #pragma unroll
@@ -606,8 +619,8 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
             // to LDS, every wave then reads the whole r*h fragment back; u and the h columns stay in acc_u[0] / acc_r[0].
             const int col = wave * 16 + 4 * kq;
             if (wave < NT && col < D && !(a.dbg & 2)) {
-                const f32x4 r = sigmoid4_scaled(acc_r[0], ld4(bias_s + col));
-                const f32x4 u = sigmoid4_scaled(acc_u[0], ld4(bias_s + D + col));
+                const f32x4 r = sigmoid4_acc<SPLIT>(acc_r[0], ld4(bias_s + col));
+                const f32x4 u = sigmoid4_acc<SPLIT>(acc_u[0], ld4(bias_s + D + col));
                 f32x4 hv;
                 if constexpr (COOP_REGS) hv = hv_pre;
                 else hv = ld4_b(a.h, ((unsigned)rowc * D + col) * 4u);
@@ -643,8 +656,8 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
                 if (col < D) {
                     // bias_s holds -log2(e)*bg: sigmoid(z + b) = 1 / (1 + 2^(-log2e z - log2e b)), the bias add folded
                     // into the scaling FMA; written on whole float4s so that the non-transcendental half packs (v_pk_*)
-                    const f32x4 r = sigmoid4_scaled(acc_r[nt], ld4(bias_s + col));
-                    const f32x4 u = sigmoid4_scaled(acc_u[nt], ld4(bias_s + D + col));
+                    const f32x4 r = sigmoid4_acc<SPLIT>(acc_r[nt], ld4(bias_s + col));
+                    const f32x4 u = sigmoid4_acc<SPLIT>(acc_u[nt], ld4(bias_s + D + col));
                     acc_r[nt] = r; acc_u[nt] = u;
                     if constexpr (SAVE) {
                         if (row < a.V && a.save_r) {
@@ -683,9 +696,9 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
             if (wave < NT && col < D && row < a.V && !(a.dbg & 4)) {
                 f32x4 c;
                 if (a.act == GGNN_ACT_TANH) {
-                    c = tanh4_scaled(acc_c[0], ld4(bias_s + 2 * D + col));
+                    c = tanh4_acc<SPLIT>(acc_c[0], ld4(bias_s + 2 * D + col));
                 } else {
-                    c = acc_c[0] + ld4(bias_s + 3 * D + col);
+                    c = acc_c[0] * (SPLIT ? kSplitAccScale : 1.0f) + ld4(bias_s + 3 * D + col);
                     c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
                 }
                 const f32x4 u = acc_u[0], hv = acc_r[0];
@@ -723,9 +736,9 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
                     else hv = hrem;
                     f32x4 c;
                     if (a.act == GGNN_ACT_TANH) {
-                        c = tanh4_scaled(acc_c[nt], ld4(bias_s + 2 * D + col));           // (2 log2e * bc)
+                        c = tanh4_acc<SPLIT>(acc_c[nt], ld4(bias_s + 2 * D + col));           // (2 log2e * bc)
                     } else {
-                        c = acc_c[nt] + ld4(bias_s + 3 * D + col);                         // (bc itself)
+                        c = acc_c[nt] * (SPLIT ? kSplitAccScale : 1.0f) + ld4(bias_s + 3 * D + col);   // (bc itself)
                         c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
                     }
                     const f32x4 u = acc_u[nt];

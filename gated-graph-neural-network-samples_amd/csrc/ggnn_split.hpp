@@ -36,6 +36,34 @@ namespace ggnn {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
+// GGNN_SPLIT2 (experiment, round 4; per translation unit, default off): the TWO-piece f16 form of the same idea.
+//     a 2^8 = a_hi + a_lo + e,   a_hi = RN_f16(a 2^8),  a_lo = RN_f16(a 2^8 - a_hi),  |e| <= 2^-22 |a 2^8|
+// (f16 carries 11 significand bits: two pieces hold 22 of an f32's 24), and the product keeps THREE of the four partial products
+//     a_hi b_hi + a_hi b_lo + a_lo b_hi            (a_lo b_lo < 2^-22 |a b| is dropped)
+// on v_mfma_f32_16x16x32_f16 -- the bf16 instruction's rate and lane layout: half the MFMAs of the six-product form, two operand
+// planes instead of three (a D = 100 stage image: 48 instead of 72 KiB), 8 instead of 11 vector instructions per split value pair.
+// NOT exact: each operand is rounded to 22 bits.  Measured in numpy against f64: rms error of a K = 100..300
+// GRU-shaped product 0.9-1.0 x the six-product form's and 0.4-0.5 x the f32 FMA chain's -- the chain rounds its running sum K times.
+// The 2^8 on both operands keeps the lo pieces of everything above 2^-11 out of f16's subnormal range (the pieces of an unscaled
+// 0.1 would sit at 5e-5, below f16's smallest normal 6.1e-5) and bounds the operands to |a| < 255 (f16 overflows at 65504); the
+// accumulators then hold 2^16 x the sums: the remainder weights (f32 MFMA) are packed x 2^16 and the consumer's epilogue scales by
+// kSplitAccScale, folded into a constant it multiplies by anyway.  Scaling by powers of two is exact.
+#ifndef GGNN_SPLIT2
+#define GGNN_SPLIT2 0
+#endif
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+#ifndef GGNN_SPLIT2_SCALED
+#define GGNN_SPLIT2_SCALED 1     // 0: no operand scaling (relies on the MFMA keeping f16 subnormals; experiment)
+#endif
+#if GGNN_SPLIT2 && GGNN_SPLIT2_SCALED
+constexpr float kSplitScale = 256.0f;                 // both operands
+constexpr float kSplitRemScale = 65536.0f;            // remainder weights (their activations stay unscaled)
+constexpr float kSplitAccScale = 1.0f / 65536.0f;     // accumulator -> sum
+#else
+constexpr float kSplitScale = 1.0f, kSplitRemScale = 1.0f, kSplitAccScale = 1.0f;
+#endif
+
 // Process-wide choice of the matrix path of the fused kernels (read once): GGNN_MATRIX=f32 selects the f32 MFMA forms.
 bool split_matrix_path();
 
@@ -45,9 +73,10 @@ struct SplitCfg {
     static constexpr bool OK = (S::NC % 2 == 0) && S::NC > 0;
     static constexpr int NC2 = S::NC / 2;
     static constexpr int TA = (S::NT + 1) / 2;                       // tiles in half A (D = 100: 4 of 7)
+    static constexpr int NP = GGNN_SPLIT2 ? 2 : 3;                   // operand planes (hi, mid, lo | GGNN_SPLIT2: hi, lo)
     // geometry of a half holding NTH tiles
     static constexpr int plane_bytes(int nth) { return NC2 * 4 * nth * 16 * 16; }
-    static constexpr int main_bytes(int nth) { return 3 * plane_bytes(nth); }
+    static constexpr int main_bytes(int nth) { return NP * plane_bytes(nth); }
     static constexpr int rem_bytes(int nth) { return S::NR * 4 * nth * 16 * 4; }
     static constexpr int half_bytes(int nth) { return (main_bytes(nth) + rem_bytes(nth) + 1023) / 1024 * 1024; }
     static constexpr int HA_BYTES = half_bytes(TA);                  // half A, whole KiB (D = 100: 37 KiB)
@@ -73,6 +102,13 @@ __device__ __forceinline__ float trunc_bf16_f(float x) { return __uint_as_float(
 // piece p (0 hi, 1 mid, 2 lo) of x as bf16 bits.  Truncation: every piece takes the next 8 significand bits, the three
 // together all 24 -- the split is exact and each residual subtraction is exact.
 __device__ __forceinline__ unsigned split_piece_bits(float x, int p) {
+#if GGNN_SPLIT2   // piece p (0 hi, 1 lo) of x 2^8 as f16 bits, round to nearest; the residual subtraction is exact
+    const float xs = x * kSplitScale;
+    const _Float16 h16 = (_Float16)xs;
+    if (p == 0) return (unsigned)__builtin_bit_cast(unsigned short, h16);
+    if (p == 1) return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(xs - (float)h16));
+    return 0u;
+#endif
     const float hi = trunc_bf16_f(x);
     if (p == 0) return __float_as_uint(hi) >> 16;
     const float r1 = x - hi, mid = trunc_bf16_f(r1);
@@ -121,7 +157,7 @@ __device__ __forceinline__ void pack_split_image(const Value& value, float* __re
             out = split_piece_bits(value(k0, n), plane) | (split_piece_bits(value(k0 + 1, n), plane) << 16);
         } else if (w_ < MW + RW) {
             const int j = w_ - MW;
-            out = __float_as_uint(value(16 * S::NC + j / bnh, n0 + j % bnh));       // j / bnh = q*4 + g
+            out = __float_as_uint(value(16 * S::NC + j / bnh, n0 + j % bnh) * kSplitRemScale);       // j / bnh = q*4 + g
         }
         img[i] = __uint_as_float(out);
     }
@@ -158,6 +194,15 @@ struct SFrag {
 
 // two floats -> one register of each plane (element 0 in the low half): 3 v_perm + 4 v_and + 4 v_sub
 __device__ __forceinline__ void split_pair(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+#if GGNN_SPLIT2   // hi / lo f16 pieces of a 2^8 in h / m (l unused): 2 v_mul + 2 conversions to f16 pairs + 2 v_cvt_f32_f16 + 2 v_sub
+    const float t0 = a0 * kSplitScale, t1 = a1 * kSplitScale;
+    const f16x2 hv = {(_Float16)t0, (_Float16)t1};
+    h = __builtin_bit_cast(unsigned, hv);
+    const f16x2 lv = {(_Float16)(t0 - (float)hv.x), (_Float16)(t1 - (float)hv.y)};
+    m = __builtin_bit_cast(unsigned, lv);
+    l = 0u;
+    return;
+#endif
     const unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1);
     h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
     const float r0 = a0 - __uint_as_float(u0 & 0xffff0000u), r1 = a1 - __uint_as_float(u1 & 0xffff0000u);
@@ -184,6 +229,9 @@ __device__ __forceinline__ void split_frag(SFrag<D>& s, const Frag<D>& f) {
 }
 
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 w, u32x4 a, f32x4 c) {
+#if GGNN_SPLIT2
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+#endif
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
 }
 
@@ -191,6 +239,12 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 w, u32x4 a, f32x4 c) {
 template <bool FIRST>
 __device__ __forceinline__ f32x4 split_products(f32x4 acc, u32x4 wh, u32x4 wm, u32x4 wl, u32x4 ah, u32x4 am, u32x4 al) {
     f32x4 c = FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc;
+#if GGNN_SPLIT2   // (wm, am: the lo pieces; wl, al unused)
+    c = mfma_bf16(wm, ah, c);
+    c = mfma_bf16(wh, am, c);
+    c = mfma_bf16(wh, ah, c);
+    return c;
+#endif
     c = mfma_bf16(wl, ah, c);
     c = mfma_bf16(wm, am, c);
     c = mfma_bf16(wm, ah, c);
@@ -235,6 +289,25 @@ __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT]
             const u32x4* b = C::half_of(nt) ? base_b : base_a;
             return b[p * (C::plane_bytes(nth) / 16) + c2 * 4 * nth * 16 + C::tile_in_half(nt) * 16];
         };
+#if GGNN_SPLIT2
+        // three products per unit, smallest first; both planes of the NEXT unit are fetched at the start of the current one (a whole
+        // unit = 3 MFMAs ahead of their first use; 16 weight registers in flight, and the lo plane of the activation is gone)
+        u32x4 wh = slot(0, 0), wm = slot(0, 1), nh = wh, nm = wm;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int c2 = u / NTW, nt = T0 + u % NTW;
+            const bool more = u + 1 < NU;
+            f32x4 c = (ZERO && c2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt];
+            if (more) { nm = slot(u + 1, 1); nh = slot(u + 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            c = mfma_bf16(wm, a.hi[c2], c);
+            c = mfma_bf16(wh, a.mid[c2], c);
+            c = mfma_bf16(wh, a.hi[c2], c);
+            __builtin_amdgcn_sched_barrier(0);
+            wm = nm; wh = nh;
+            acc[nt] = c;
+        }
+#else
         u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
 #if GGNN_SPLIT_WH2
         u32x4 wh_n = wh;
@@ -287,6 +360,7 @@ __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT]
             acc[nt] = c;
         }
 #endif
+#endif   // GGNN_SPLIT2
     }
     // the D % 16 remainder k values on the f32 MFMA, their weights two tiles ahead (2 registers in flight)
     if constexpr (S::NR > 0 && NTW > 0) {
@@ -330,17 +404,17 @@ __device__ __forceinline__ void stage_mma_one_split(f32x4& acc, const SFrag<D>& 
     const u32x4* base = reinterpret_cast<const u32x4*>(him) + kq * nth * 16 + li + til * 16;
     f32x4 cin = acc;
     if constexpr (ZERO) cin = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 w0 = base[0], w1 = base[PL], w2 = base[2 * PL];
+    u32x4 w0 = base[0], w1 = base[PL], w2 = C::NP > 2 ? base[(C::NP - 1) * PL] : w1;
 #pragma unroll
     for (int c2 = 0; c2 < C::NC2; ++c2) {
         const int cn = c2 + 1 < C::NC2 ? c2 + 1 : c2;
-        const u32x4 n0 = base[cn * CP], n1 = base[PL + cn * CP], n2 = base[2 * PL + cn * CP];
+        const u32x4 n0 = base[cn * CP], n1 = base[PL + cn * CP], n2 = C::NP > 2 ? base[(C::NP - 1) * PL + cn * CP] : n1;
         cin = split_products<false>(cin, w0, w1, w2, a.hi[c2], a.mid[c2], a.lo[c2]);
         w0 = n0; w1 = n1; w2 = n2;
     }
 #pragma unroll
     for (int q = 0; q < S::NR; ++q) {
-        const float wr = him[3 * PL * 4 + (q * 4 + kq) * nth * 16 + li + til * 16];
+        const float wr = him[C::NP * PL * 4 + (q * 4 + kq) * nth * 16 + li + til * 16];
         cin = __builtin_amdgcn_mfma_f32_16x16x4f32(wr, af.r[q], cin, 0, 0, 0);
     }
     acc = cin;

@@ -139,6 +139,29 @@ def split6_matmul(A, W, chunk=32):
     return acc
 
 
+def f16_split2(a, scale=256.0):
+    """a (float32) -> (hi, lo) as float32 arrays holding f16 values: hi = RN_f16(a * scale), lo = RN_f16(a * scale - hi).  The
+    residual subtraction is exact; hi + lo carries 22 of a * scale's 24 significand bits (csrc/ggnn_split.hpp, GGNN_SPLIT2 --
+    a round-4 EXPERIMENT, not the library's default matrix path).  `scale` is a power of two: exact."""
+    t = (np.ascontiguousarray(a, dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    hi = t.astype(np.float16).astype(np.float32)
+    lo = (t - hi).astype(np.float32).astype(np.float16).astype(np.float32)
+    return hi, lo
+
+
+def split3_f16_matmul(A, W, chunk=32, scale=256.0):
+    """A [M,K] x W [K,N] the way stage_mma_split accumulates it under GGNN_SPLIT2: per `chunk` of k, three dot products of f16
+    pieces (w_lo a_hi | w_hi a_lo | w_hi a_hi; every f16 x f16 product is exact in f32), each added to an f32 accumulator that
+    holds scale^2 x the sum; the consumer multiplies by scale^-2."""
+    a, w = f16_split2(A, scale), f16_split2(W, scale)
+    acc = np.zeros((A.shape[0], W.shape[1]), np.float32)
+    for c in range(0, A.shape[1], chunk):
+        for i, j in ((0, 1), (1, 0), (0, 0)):                        # (piece of A, piece of W)
+            d = a[i][:, c:c + chunk].astype(np.float64) @ w[j][c:c + chunk].astype(np.float64)
+            acc = (acc.astype(np.float64) + d).astype(np.float32)
+    return (acc.astype(np.float64) / (float(scale) ** 2)).astype(np.float32)
+
+
 def philox4x32_10(counter, key):
     """Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123) on uint32 arrays:
     counter [..., 4], key [..., 2] -> [..., 4].  Pinned by Random123's published known-answer vectors (tests/test_oracle.py)."""

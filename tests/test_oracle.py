@@ -226,6 +226,38 @@ def test_split_matrix_path_arithmetic(oracle):
     assert (np.abs(three - ref) / scale).max() > 2e-6
 
 
+def test_two_piece_f16_split_arithmetic(oracle):
+    """csrc/ggnn_split.hpp under GGNN_SPLIT2 (round-4 experiment) in numpy: an f32 operand as TWO f16 pieces of a * 2^8 and three
+    of the four partial products.  Not exact (22 of 24 significand bits per operand) -- but on GRU-shaped products its error against
+    f64 is of the six-product bf16 form's size and below the f32 FMA chain's, which rounds its running sum K times; without the
+    power-of-two scaling the lo pieces of operands below 0.125 fall into f16's subnormal range and it is no better than the chain."""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.standard_normal(4000).astype(np.float32) * s for s in (1e-3, 0.1, 1.0, 30.0)])
+    hi, lo = oracle.f16_split2(x)
+    for p in (hi, lo):
+        assert np.array_equal(p.astype(np.float16).astype(np.float32), p)                      # each piece is an f16 value
+    t = x.astype(np.float64) * 256.0
+    big = np.abs(t) >= 2.0 ** -3                                                               # lo piece normal: 22 bits kept
+    assert (np.abs(hi.astype(np.float64) + lo.astype(np.float64) - t)[big] <= 2.0 ** -22 * np.abs(t)[big]).all()
+    err = np.abs(hi.astype(np.float64) + lo.astype(np.float64) - t)
+    assert (err <= np.maximum(2.0 ** -22 * np.abs(t), 2.0 ** -25)).all()                       # (subnormal lo: half its spacing)
+    for K in (100, 300):
+        lim = np.sqrt(6.0 / (K + 100))
+        A = np.tanh(rng.standard_normal((512, K))).astype(np.float32)
+        W = rng.uniform(-lim, lim, (K, 100)).astype(np.float32)
+        ref = A.astype(np.float64) @ W.astype(np.float64)
+        scale = np.abs(A.astype(np.float64)) @ np.abs(W.astype(np.float64))
+        chain = np.zeros((512, 100), np.float32)
+        for k in range(K):
+            chain = (chain.astype(np.float64) + A[:, k:k + 1].astype(np.float64) * W[k:k + 1].astype(np.float64)).astype(np.float32)
+        rms = lambda y: float(np.sqrt(((y.astype(np.float64) - ref) ** 2).mean()))
+        e2, e6, ec, e2u = (rms(oracle.split3_f16_matmul(A, W)), rms(oracle.split6_matmul(A, W)), rms(chain),
+                           rms(oracle.split3_f16_matmul(A, W, scale=1.0)))
+        assert e2 <= 1.1 * e6 and e2 <= 0.7 * ec, (K, e2, e6, ec)
+        assert e2u > 1.5 * e2, (K, e2u, e2)                                                     # the scaling is what buys it
+        assert (np.abs(oracle.split3_f16_matmul(A, W) - ref) / scale).max() < 2e-7
+
+
 def test_philox_known_answers_and_counter_dropout(oracle):
     """The counter-based dropout mask (ggnn_dropout_f32) is Philox4x32-10: Random123's published known-answer vectors
     (kat_vectors: zero, all-ones, pi digits) pin the restatement; the mask keeps a fraction keep_prob, scales by 1/keep_prob, and
