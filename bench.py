@@ -66,6 +66,11 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 dense (2495 measu
 SPLIT_PRODUCTS = 6
 SPLIT_KERNELS = ("msg_transform_compact", "gru_fused")
 SPLIT_ACTIVE = False               # set from ggnn_matrix_path_is_split() in main()
+# The fused GRU forward at D = 32 / 64 / 100 multiplies in the TWO-piece f16 form since round 4 (ggnn_gru_forward_format() == 2): three
+# f16 MFMA products per f32 product -- its ceiling is the f16 pipe's peak (= the bf16 pipe's) / 3.  The column-panel GRU of the
+# wider hidden sizes (ggnn_panel.hip) stays on the six-product bf16 form.
+GRU_FWD_FORMAT = 3                 # set from ggnn_gru_forward_format() in main()
+F16X2_PRODUCTS = 3
 DENSE_SPLIT = False                # set from ggnn_dense_propagate_is_split() for the configs[2] shape in secondary_dense()
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 HBM_COPY_GBPS = 6290.0
@@ -185,6 +190,12 @@ def kernel_table(res, reps, V, M, D, T, R=None):
                                   "f32_mfma_peak": FP32_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                                   "matrix_path": "bf16x3 split: f32 operands as 3 bf16 pieces each, 6 bf16 MFMA products per f32 product, "
                                                  "f32 accumulation (error bound of an f32 FMA chain)"})
+            if name.startswith("gru_fused") and GRU_FWD_FORMAT == 2 and D in (32, 64, 100):
+                pipe = BF16_MFMA_PEAK_TFLOPS / F16X2_PRODUCTS
+                kernels[name].update({"peak": pipe, "frac": ach / pipe, "pipe": "f16 MFMA, 3 products per f32 product (2500 / 3 TF f32-equivalent)",
+                                      "matrix_path": "f16x2 split: f32 operands as 2 f16 pieces each (22 of 24 significand bits, round to nearest; "
+                                                     "weights packed x 2^8), 3 f16 MFMA products per f32 product, f32 accumulation; error against "
+                                                     "f64 below the bf16x3 form's and the f32 MFMA's (tests/test_gpu_split_precision.py)"})
         elif bound == "mfma":
             kernels[name]["pipe"] = "f32 MFMA"
     tot_ms = sum(float(np.sum(res[n])) for n in kernels)
@@ -456,8 +467,9 @@ def main():
         return dry_run(args, pkg, dist_ctx)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU implementation)"
     dev = dist_ctx.device
-    global SPLIT_ACTIVE
+    global SPLIT_ACTIVE, GRU_FWD_FORMAT
     SPLIT_ACTIVE = bool(pkg._lib.load().ggnn_matrix_path_is_split())
+    GRU_FWD_FORMAT = int(pkg._lib.load().ggnn_gru_forward_format())
 
     # ---- data: enough QM9-shaped molecules for `batches` distinct ~100k-node batches per rank ------
     mols_per_batch = int(100000 / args.mean_nodes * 1.02) + 8
@@ -582,8 +594,12 @@ def main():
         "value": value, "unit": "node-state updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / steps_timed * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "matrix_path": ("bf16x3 split (f32 in, f32 accumulate; every f32 product = 6 exact bf16 MFMA products of 3-way split operands; "
-                        "GGNN_MATRIX=f32 selects the f32 MFMA kernels)" if SPLIT_ACTIVE else "f32 MFMA"), "ranks_seen": ranks_seen(dist_ctx), "allreduce_us": None,
+        "matrix_path": ((("fused GRU forward: f16x2 split (f32 in, f32 accumulate; every f32 operand as two f16 pieces = 22 of its 24 significand "
+                          "bits, 3 f16 MFMA products per f32 product; measured error against f64 below the six-product form's and the f32 "
+                          "MFMA's; GGNN_GRU_FMT=3 selects the bf16x3 kernels); " if GRU_FWD_FORMAT == 2 else "") +
+                         "bf16x3 split (f32 in, f32 accumulate; every f32 product = 6 exact bf16 MFMA products of 3-way split operands; "
+                         "GGNN_MATRIX=f32 selects the f32 MFMA kernels)") if SPLIT_ACTIVE else "f32 MFMA"),
+        "gru_forward_format": {2: "f16x2", 3: "bf16x3", 0: "f32"}.get(GRU_FWD_FORMAT), "ranks_seen": ranks_seen(dist_ctx), "allreduce_us": None,
         "steps_timed": steps_timed, "timed_repeats": repeats, "timed_seconds": elapsed,
         "ms_per_step_one_stream": one_stream,
         "config": {"workload": what + ", full-QM9-sized synthetic batches (configs[%d])" % (3 if world > 1 else 1),
@@ -768,11 +784,12 @@ def main():
         # every 16 clocks at 2.4 GHz); under random operands the chip sits at its socket power limit at a lower clock.  Measured here,
         # ~1 s per pattern, with the library's probe (csrc/ggnn_probe.hip: 8 waves per CU of back-to-back v_mfma_f32_16x16x32_bf16 on
         # register operands -- nothing but MFMAs); `frac` stays the fraction of the data-sheet peak.
-        if SPLIT_ACTIVE and kernels[dom].get("pipe", "").startswith("bf16"):
+        if SPLIT_ACTIVE and kernels[dom].get("pipe", "").startswith(("bf16", "f16")):
             try:
                 sus = measure_sustained_mfma(pkg, dev)
                 out["roofline"]["sustained_mfma"] = sus
-                out["roofline"]["frac_of_sustained_split_pattern"] = kernels[dom]["achieved"] / (sus["split_pattern"]["tflops_bf16"] / SPLIT_PRODUCTS)
+                products = F16X2_PRODUCTS if kernels[dom]["pipe"].startswith("f16") else SPLIT_PRODUCTS     # (the f16 MFMA issues at the bf16 rate)
+                out["roofline"]["frac_of_sustained_split_pattern"] = kernels[dom]["achieved"] / (sus["split_pattern"]["tflops_bf16"] / products)
             except Exception as exc:                                   # (a measurement aid must never take the line down)
                 out["roofline"]["sustained_mfma"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if traffic_err:

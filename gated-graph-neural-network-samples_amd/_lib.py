@@ -19,6 +19,7 @@ ABI_VERSION = 2
 SYMBOLS = {
     "ggnn_abi_version": (c_int, []),
     "ggnn_matrix_path_is_split": (c_int, []),
+    "ggnn_gru_forward_format": (c_int, []),
     "ggnn_last_error": (c_char_p, []),
     "ggnn_csr_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "ggnn_build_target_csr": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int, c_int64, c_void_p, c_void_p,

@@ -37,8 +37,16 @@ bool split_matrix_path() {
     return v;
 }
 
+// Operand format of the fused GRU forward in split form (ggnn_split.hpp): 2 = two f16 pieces, three products (default since round
+// 4); GGNN_GRU_FMT=3 = the exact three-piece bf16 split, six products.  Read once: the packed GRU images are in the format.
+int gru_fwd_fmt() {
+    static const int v = [] { const char* e = getenv("GGNN_GRU_FMT"); return (e && atoi(e) == 3) ? 3 : 2; }();
+    return v;
+}
+
 }  // namespace ggnn
 
 extern "C" int ggnn_matrix_path_is_split(void) { return ggnn::split_matrix_path() ? 1 : 0; }
+extern "C" int ggnn_gru_forward_format(void) { return ggnn::split_matrix_path() ? ggnn::gru_fwd_fmt() : 0; }
 extern "C" int ggnn_abi_version(void) { return GGNN_ABI_VERSION; }
 extern "C" const char* ggnn_last_error(void) { return ggnn::error_buffer(); }

@@ -57,23 +57,23 @@ int gru_split_launch(int D, int nx, bool save, bool gather, const GruFusedArgs& 
 #ifndef GGNN_GRU_TU_SPLIT
 int gru_pack_floats(int D, int nx) {
     if (gru_panel_supported(D)) return gru_panel_pack_floats(D, nx);
-    const bool sp = split_matrix_path();
+    const bool sp = split_matrix_path(), f2 = gru_fwd_fmt() == kSplitF16x2;     // (the forward's images: its own operand format)
     switch (D) {
-        case 100: return 3 * (nx + 1) * (sp ? ImgCfg<100, true>::IMG : ImgCfg<100, false>::IMG);
-        case 64: return 3 * (nx + 1) * (sp ? ImgCfg<64, true>::IMG : ImgCfg<64, false>::IMG);
-        case 32: return 3 * (nx + 1) * (sp ? ImgCfg<32, true>::IMG : ImgCfg<32, false>::IMG);
+        case 100: return 3 * (nx + 1) * (sp ? (f2 ? ImgCfg<100, true, kSplitF16x2>::IMG : ImgCfg<100, true>::IMG) : ImgCfg<100, false>::IMG);
+        case 64: return 3 * (nx + 1) * (sp ? (f2 ? ImgCfg<64, true, kSplitF16x2>::IMG : ImgCfg<64, true>::IMG) : ImgCfg<64, false>::IMG);
+        case 32: return 3 * (nx + 1) * (sp ? (f2 ? ImgCfg<32, true, kSplitF16x2>::IMG : ImgCfg<32, true>::IMG) : ImgCfg<32, false>::IMG);
         default: return 0;
     }
 }
 #endif
 
 // image ci of the packed weights: gates (s = 0..nx) x {r,u}, then candidate (s = 0..nx)
-template <int D, bool SPLIT>
+template <int D, bool SPLIT, int FMT = kSplitBf16x3>
 __global__ void gru_pack_weights_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx,
                                         float* __restrict__ out) {
     const int ci = blockIdx.y;
-    float* img = out + (size_t)ci * ImgCfg<D, SPLIT>::IMG;
-    if constexpr (SPLIT) gru_fwd_image_pack_split<D>(Wg, Wc, nx, ci, img, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    float* img = out + (size_t)ci * ImgCfg<D, SPLIT, FMT>::IMG;
+    if constexpr (SPLIT) gru_fwd_image_pack_split<D, FMT>(Wg, Wc, nx, ci, img, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     else gru_fwd_image_pack<D>(Wg, Wc, nx, ci, img, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
@@ -83,16 +83,16 @@ __host__ __device__ constexpr int gru_stage_image(int pos) {
     return (pos % 3) < 2 ? 2 * (pos / 3) + (pos % 3) : 2 * (NX + 1) + pos / 3;
 }
 
-// the gate epilogues on an accumulator of a SPLIT kernel: sigmoid4_scaled / tanh4_scaled with kSplitAccScale (1 unless the
-// translation unit is built with GGNN_SPLIT2, whose accumulators hold 2^16 x the sums) folded into the exponent's scaling constant
-template <bool SPLIT>
+// the gate epilogues on an accumulator that holds 1 / acc_scale x the sum (SplitFmt<FMT>::acc_scale: 2^-8 for the f16 x 2 form, whose
+// weights are packed x 2^8; 1 otherwise): sigmoid4_scaled / tanh4_scaled with the scale folded into the exponent's scaling constant
+template <int FMT>
 __device__ __forceinline__ f32x4 sigmoid4_acc(f32x4 z, f32x4 b_scaled) {
-    constexpr float k = -kLog2e * (SPLIT ? kSplitAccScale : 1.0f);
+    constexpr float k = -kLog2e * SplitFmt<FMT>::acc_scale;
     return rcp_4(exp2_4(z * k + b_scaled) + 1.0f);
 }
-template <bool SPLIT>
+template <int FMT>
 __device__ __forceinline__ f32x4 tanh4_acc(f32x4 z, f32x4 b_scaled) {
-    constexpr float k = 2.0f * kLog2e * (SPLIT ? kSplitAccScale : 1.0f);
+    constexpr float k = 2.0f * kLog2e * SplitFmt<FMT>::acc_scale;
     return 1.0f - 2.0f * rcp_4(exp2_4(z * k + b_scaled) + 1.0f);
 }
 
@@ -139,11 +139,15 @@ __device__ __forceinline__ void frag_add(Frag<D>& f, const Frag<D>& t) {
 //      splits and DMA all switched off -- 18 stage barriers each waiting out one HBM round trip -- 63 us with only the MFMAs
 //      added, 63 us with only the side work added, 88 us with both: the three parts ran one after the other.
 // Same products in the same order per accumulator in every form: bit-identical results.
-template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE, int FORM = 0>
+// FMT (SPLIT kernels): operand format of the split products and of the images (ggnn_split.hpp) -- kSplitF16x2 by default since round 4
+// (two f16 pieces, three products: half the MFMAs, 48 KiB images), kSplitBf16x3 behind GGNN_GRU_FMT=3; f32 kernels: kSplitBf16x3
+// stands for "accumulators unscaled".
+template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE, int FORM = 0, int FMT = kSplitBf16x3>
 __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_kernel(GruFusedArgs a, const float* __restrict__ packed) {
+    static_assert(SPLIT || FMT == kSplitBf16x3, "the f32-MFMA kernels have no operand format");
     using C = StageCfg<D>;
-    using I = ImgCfg<D, SPLIT>;
-    using SC = SplitCfg<D>;
+    using I = ImgCfg<D, SPLIT, FMT>;
+    using SC = SplitCfg<D, FMT>;
     constexpr bool HALF = FORM != 0;                                  // stage images travel as halves
     constexpr bool DEEP = FORM == 2;
     constexpr int NSLOT = DEEP ? 3 : 2;
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
             if constexpr (GATHER && (POS) == G_U % NSTAGE) {   /* the fragment this stage multiplies */  \
                 if (active && (!G_NEXT || p > 0)) { g_finish(xf[GBUF]); if constexpr (SAVEX) { if (row < a.V && a.save_x) store_x(xf[GBUF], row); } } \
             }                                                                                            \
-            if constexpr ((POS) % 3 == 0 || (POS) == NSTAGE - 1) { if (active && !(a.dbg & 16)) split_frag<D>(sf, FRAG); } \
+            if constexpr ((POS) % 3 == 0 || (POS) == NSTAGE - 1) { if (active && !(a.dbg & 16)) split_frag<D, FMT>(sf, FRAG); } \
             /* ---- sub-stage A: tiles [0, TA) from slot cur */                                          \
             bool dma_a_ = false;                                                                         \
             if constexpr (DEEP) {                                                                        \
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
             __builtin_amdgcn_sched_barrier(0);                                                           \
             if (a.dbg & 32) __builtin_amdgcn_s_setprio(3);                                               \
             if (active && !(a.dbg & 1))                                                                  \
-                stage_mma_split_at<D, (ntl_ < SC::TA ? ntl_ : SC::TA), ((POS) < 3), 0>(ACC, sf, FRAG, ring + cur * SLOT, ring + cur * SLOT, li, kq); \
+                stage_mma_split_at<D, (ntl_ < SC::TA ? ntl_ : SC::TA), ((POS) < 3), 0, false, FMT>(ACC, sf, FRAG, ring + cur * SLOT, ring + cur * SLOT, li, kq); \
             if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);                                               \
             __builtin_amdgcn_sched_barrier(0);                                                           \
             GGNN_T(POS, 2)                                                                               \
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
                 GGNN_T2(POS, 0)                                                                          \
                 if (a.dbg & 32) __builtin_amdgcn_s_setprio(3);                                           \
                 if (active && !(a.dbg & 1))                                                              \
-                    stage_mma_split_at<D, ntl_, ((POS) < 3), SC::TA>(ACC, sf, FRAG, ring + cur * SLOT, ring + cur * SLOT, li, kq); \
+                    stage_mma_split_at<D, ntl_, ((POS) < 3), SC::TA, false, FMT>(ACC, sf, FRAG, ring + cur * SLOT, ring + cur * SLOT, li, kq); \
                 if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);                                           \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
                 GGNN_T2(POS, 1)                                                                          \
@@ -561,20 +565,20 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
                                   (C::TAILPACK3 && (POS) % 3 == 2 && (POS) < 3 * NX)) ? NT - 1 : NT;     \
             /* stages 0..2 open the three accumulator sets: they start from the constant 0 */            \
             /* SPLIT: a fragment is split into its bf16 planes before the first of its stages */         \
-            if constexpr (SPLIT && ((POS) % 3 == 0 || (POS) == NSTAGE - 1)) { if (active && !(a.dbg & 16)) split_frag<D>(sf, FRAG); } \
+            if constexpr (SPLIT && ((POS) % 3 == 0 || (POS) == NSTAGE - 1)) { if (active && !(a.dbg & 16)) split_frag<D, FMT>(sf, FRAG); } \
             if (a.dbg & 32) __builtin_amdgcn_s_setprio(3);                                               \
             if (active && !(a.dbg & 1)) {                                                                \
                 const float* img_ = ring + cur * I::IMG;                                                 \
                 if constexpr (!coop) {                                                                   \
-                    if constexpr (SPLIT) stage_mma_split<D, ntl_, ((POS) < 3)>(ACC, sf, FRAG, img_, li, kq); \
+                    if constexpr (SPLIT) stage_mma_split<D, ntl_, ((POS) < 3), false, FMT>(ACC, sf, FRAG, img_, li, kq); \
                     else stage_mma<D, NoHook, ntl_, ((POS) < 3)>(ACC, FRAG, img_, li, kq);               \
                 } else if (C::TAILPACK3 && (POS) == NSTAGE - 1 && wave == NT - 1) {                      \
                     f32x4 t_;        /* (same association as the tail-packed ordinary passes, see GGNN_COOP_STAGE) */ \
-                    if constexpr (SPLIT) stage_mma_one_split<D, true>(t_, sf, FRAG, img_, li, kq, wave); \
+                    if constexpr (SPLIT) stage_mma_one_split<D, true, FMT>(t_, sf, FRAG, img_, li, kq, wave); \
                     else stage_mma_one<D, true>(t_, FRAG, img_, li, kq, wave);                           \
                     ACC[0] = ACC[0] + t_;                                                                \
                 } else if (wave < NT) {                                                                  \
-                    if constexpr (SPLIT) stage_mma_one_split<D, ((POS) < 3)>(ACC[0], sf, FRAG, img_, li, kq, wave); \
+                    if constexpr (SPLIT) stage_mma_one_split<D, ((POS) < 3), FMT>(ACC[0], sf, FRAG, img_, li, kq, wave); \
                     else stage_mma_one<D, ((POS) < 3)>(ACC[0], FRAG, img_, li, kq, wave);                \
                 }                                                                                        \
             }                                                                                            \
@@ -619,8 +623,8 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
             // to LDS, every wave then reads the whole r*h fragment back; u and the h columns stay in acc_u[0] / acc_r[0].
             const int col = wave * 16 + 4 * kq;
             if (wave < NT && col < D && !(a.dbg & 2)) {
-                const f32x4 r = sigmoid4_acc<SPLIT>(acc_r[0], ld4(bias_s + col));
-                const f32x4 u = sigmoid4_acc<SPLIT>(acc_u[0], ld4(bias_s + D + col));
+                const f32x4 r = sigmoid4_acc<FMT>(acc_r[0], ld4(bias_s + col));
+                const f32x4 u = sigmoid4_acc<FMT>(acc_u[0], ld4(bias_s + D + col));
                 f32x4 hv;
                 if constexpr (COOP_REGS) hv = hv_pre;
                 else hv = ld4_b(a.h, ((unsigned)rowc * D + col) * 4u);
@@ -656,8 +660,8 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
                 if (col < D) {
                     // bias_s holds -log2(e)*bg: sigmoid(z + b) = 1 / (1 + 2^(-log2e z - log2e b)), the bias add folded
                     // into the scaling FMA; written on whole float4s so that the non-transcendental half packs (v_pk_*)
-                    const f32x4 r = sigmoid4_acc<SPLIT>(acc_r[nt], ld4(bias_s + col));
-                    const f32x4 u = sigmoid4_acc<SPLIT>(acc_u[nt], ld4(bias_s + D + col));
+                    const f32x4 r = sigmoid4_acc<FMT>(acc_r[nt], ld4(bias_s + col));
+                    const f32x4 u = sigmoid4_acc<FMT>(acc_u[nt], ld4(bias_s + D + col));
                     acc_r[nt] = r; acc_u[nt] = u;
                     if constexpr (SAVE) {
                         if (row < a.V && a.save_r) {
@@ -696,9 +700,9 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
             if (wave < NT && col < D && row < a.V && !(a.dbg & 4)) {
                 f32x4 c;
                 if (a.act == GGNN_ACT_TANH) {
-                    c = tanh4_acc<SPLIT>(acc_c[0], ld4(bias_s + 2 * D + col));
+                    c = tanh4_acc<FMT>(acc_c[0], ld4(bias_s + 2 * D + col));
                 } else {
-                    c = acc_c[0] * (SPLIT ? kSplitAccScale : 1.0f) + ld4(bias_s + 3 * D + col);
+                    c = acc_c[0] * SplitFmt<FMT>::acc_scale + ld4(bias_s + 3 * D + col);
                     c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
                 }
                 const f32x4 u = acc_u[0], hv = acc_r[0];
@@ -736,9 +740,9 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
                     else hv = hrem;
                     f32x4 c;
                     if (a.act == GGNN_ACT_TANH) {
-                        c = tanh4_acc<SPLIT>(acc_c[nt], ld4(bias_s + 2 * D + col));           // (2 log2e * bc)
+                        c = tanh4_acc<FMT>(acc_c[nt], ld4(bias_s + 2 * D + col));           // (2 log2e * bc)
                     } else {
-                        c = acc_c[nt] * (SPLIT ? kSplitAccScale : 1.0f) + ld4(bias_s + 3 * D + col);   // (bc itself)
+                        c = acc_c[nt] * SplitFmt<FMT>::acc_scale + ld4(bias_s + 3 * D + col);   // (bc itself)
                         c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
                     }
                     const f32x4 u = acc_u[nt];
@@ -758,15 +762,15 @@ __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_ker
     }
 }
 
-template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE, int FORM = 0>
+template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE, int FORM = 0, int FMT = kSplitBf16x3>
 static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream_t st) {
     using C = StageCfg<D>;
-    using I = ImgCfg<D, SPLIT>;
+    using I = ImgCfg<D, SPLIT, FMT>;
     GruFusedArgs a = a_in;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GGNN_GRU_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     { const char* e = getenv("GGNN_GRU_TPTR"); a.tdbg = e ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
     if (a.Wg) {   // raw weights given: build the stage images first (skipped when the caller pre-packed them)
-        hipLaunchKernelGGL((gru_pack_weights_kernel<D, SPLIT>), dim3(8, 3 * (NX + 1)), dim3(256), 0, st, a.Wg, a.Wc, NX, packed);
+        hipLaunchKernelGGL((gru_pack_weights_kernel<D, SPLIT, FMT>), dim3(8, 3 * (NX + 1)), dim3(256), 0, st, a.Wg, a.Wc, NX, packed);
         GGNN_CHECK_HIP(hipGetLastError());
     }
     if (a.h == nullptr) return GGNN_OK;   // pack-only call
@@ -774,8 +778,8 @@ static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream
         return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit byte offsets: V*D (and V*T*D for the gathered rows) "
                                         "must be < 2^30 (V=%d, D=%d)", a.V, D);
     constexpr size_t bias_b = (size_t)((4 * D + 4 + 63) / 64 * 64) * sizeof(float);                       // biases, ticket slots
-    const size_t lds = FORM == 1 ? (size_t)2 * SplitCfg<D>::HA_BYTES + bias_b                                   // two workgroups per CU
-                     : FORM == 2 ? (size_t)3 * SplitCfg<D>::HA_BYTES + bias_b
+    const size_t lds = FORM == 1 ? (size_t)2 * SplitCfg<D, FMT>::HA_BYTES + bias_b                              // two workgroups per CU
+                     : FORM == 2 ? (size_t)3 * SplitCfg<D, FMT>::HA_BYTES + bias_b
                                  : (size_t)2 * I::IMG_BYTES + bias_b + (size_t)16 * (C::BN + 4) * sizeof(float);  // + r*h exchange block
     const int wt_total = (a.V + 15) / 16;
     // one workgroup per CU; with fewer than NW tiles per CU the tiles are spread over ALL CUs as thin tickets (the
@@ -789,8 +793,8 @@ static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream
     static const int coop_small = [] { const char* e = getenv("GGNN_GRU_COOP_SMALL"); return e ? atoi(e) : 1; }();
     if (FORM == 0 && coop_small && wt_total > nb && wt_total <= 2 * nb && StageCfg<D>::NT <= NW) nb = wt_total;
     static std::atomic<unsigned long long> lds_ok{0};        // (one per template instantiation)
-    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX, FORM>, lds, lds_ok));
-    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX, FORM>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
+    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX, FORM, FMT>, lds, lds_ok));
+    hipLaunchKernelGGL((ggnn_gru_fused_kernel<D, NX, NW, SAVE, GATHER, SPLIT, SAVEX, FORM, FMT>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
@@ -808,40 +812,40 @@ static int gru_form(int nx) {
     return v >= 0 ? v : (nx >= 2 ? 1 : 0);
 }
 
-template <int D>
+template <int D, int FMT>
 static int split_launch_d(int nx, bool gather, const GruFusedArgs& a, float* packed, hipStream_t st) {
     if constexpr (SplitCfg<D>::OK) {
         if (gather && gru_form(nx) == 2) {
             switch (nx) {
-                case 1: return launch_gru_fused_m<D, 1, 8, true, true, true, true, 2>(a, packed, st);
-                case 2: return a.save_x ? launch_gru_fused_m<D, 2, 8, true, true, true, true, 2>(a, packed, st)
-                                        : launch_gru_fused_m<D, 2, 8, true, true, true, false, 2>(a, packed, st);
-                case 3: return a.save_x ? launch_gru_fused_m<D, 3, 8, true, true, true, true, 2>(a, packed, st)
-                                        : launch_gru_fused_m<D, 3, 8, true, true, true, false, 2>(a, packed, st);
+                case 1: return launch_gru_fused_m<D, 1, 8, true, true, true, true, 2, FMT>(a, packed, st);
+                case 2: return a.save_x ? launch_gru_fused_m<D, 2, 8, true, true, true, true, 2, FMT>(a, packed, st)
+                                        : launch_gru_fused_m<D, 2, 8, true, true, true, false, 2, FMT>(a, packed, st);
+                case 3: return a.save_x ? launch_gru_fused_m<D, 3, 8, true, true, true, true, 2, FMT>(a, packed, st)
+                                        : launch_gru_fused_m<D, 3, 8, true, true, true, false, 2, FMT>(a, packed, st);
             }
         }
         if (gather && gru_form(nx) == 1) {
             switch (nx) {
-                case 1: return launch_gru_fused_m<D, 1, 4, true, true, true, true, 1>(a, packed, st);
-                case 2: return a.save_x ? launch_gru_fused_m<D, 2, 4, true, true, true, true, 1>(a, packed, st)
-                                        : launch_gru_fused_m<D, 2, 4, true, true, true, false, 1>(a, packed, st);
-                case 3: return a.save_x ? launch_gru_fused_m<D, 3, 4, true, true, true, true, 1>(a, packed, st)
-                                        : launch_gru_fused_m<D, 3, 4, true, true, true, false, 1>(a, packed, st);
+                case 1: return launch_gru_fused_m<D, 1, 4, true, true, true, true, 1, FMT>(a, packed, st);
+                case 2: return a.save_x ? launch_gru_fused_m<D, 2, 4, true, true, true, true, 1, FMT>(a, packed, st)
+                                        : launch_gru_fused_m<D, 2, 4, true, true, true, false, 1, FMT>(a, packed, st);
+                case 3: return a.save_x ? launch_gru_fused_m<D, 3, 4, true, true, true, true, 1, FMT>(a, packed, st)
+                                        : launch_gru_fused_m<D, 3, 4, true, true, true, false, 1, FMT>(a, packed, st);
             }
         }
         if (gather) {
             switch (nx) {
-                case 1: return launch_gru_fused_m<D, 1, 8, true, true, true>(a, packed, st);        // (R = 0: no scratch either way)
-                case 2: return a.save_x ? launch_gru_fused_m<D, 2, 8, true, true, true, true>(a, packed, st)
-                                        : launch_gru_fused_m<D, 2, 8, true, true, true, false>(a, packed, st);
-                case 3: return a.save_x ? launch_gru_fused_m<D, 3, 8, true, true, true, true>(a, packed, st)
-                                        : launch_gru_fused_m<D, 3, 8, true, true, true, false>(a, packed, st);
+                case 1: return launch_gru_fused_m<D, 1, 8, true, true, true, true, 0, FMT>(a, packed, st);        // (R = 0: no scratch either way)
+                case 2: return a.save_x ? launch_gru_fused_m<D, 2, 8, true, true, true, true, 0, FMT>(a, packed, st)
+                                        : launch_gru_fused_m<D, 2, 8, true, true, true, false, 0, FMT>(a, packed, st);
+                case 3: return a.save_x ? launch_gru_fused_m<D, 3, 8, true, true, true, true, 0, FMT>(a, packed, st)
+                                        : launch_gru_fused_m<D, 3, 8, true, true, true, false, 0, FMT>(a, packed, st);
             }
         } else {
             switch (nx) {
-                case 1: return launch_gru_fused_m<D, 1, 8, true, false, true>(a, packed, st);
-                case 2: return launch_gru_fused_m<D, 2, 8, true, false, true>(a, packed, st);
-                case 3: return launch_gru_fused_m<D, 3, 8, true, false, true>(a, packed, st);
+                case 1: return launch_gru_fused_m<D, 1, 8, true, false, true, true, 0, FMT>(a, packed, st);
+                case 2: return launch_gru_fused_m<D, 2, 8, true, false, true, true, 0, FMT>(a, packed, st);
+                case 3: return launch_gru_fused_m<D, 3, 8, true, false, true, true, 0, FMT>(a, packed, st);
             }
         }
     }
@@ -856,12 +860,15 @@ int gru_split_launch(int D, int nx, bool save, bool gather, const GruFusedArgs& 
 #ifndef GGNN_PROBE_SAVEX
 #define GGNN_PROBE_SAVEX GGNN_PROBE_SAVE
 #endif
-    return launch_gru_fused_m<100, GGNN_PROBE_NX, 8, GGNN_PROBE_SAVE, true, true, GGNN_PROBE_SAVEX>(a, packed, st);
+#ifndef GGNN_PROBE_FMT
+#define GGNN_PROBE_FMT kSplitF16x2
+#endif
+    return launch_gru_fused_m<100, GGNN_PROBE_NX, 8, GGNN_PROBE_SAVE, true, true, GGNN_PROBE_SAVEX, 0, GGNN_PROBE_FMT>(a, packed, st);
 #else
     switch (D) {
-        case 100: return split_launch_d<100>(nx, gather, a, packed, st);
-        case 64: return split_launch_d<64>(nx, gather, a, packed, st);
-        case 32: return split_launch_d<32>(nx, gather, a, packed, st);
+        case 100: return gru_fwd_fmt() == kSplitF16x2 ? split_launch_d<100, kSplitF16x2>(nx, gather, a, packed, st) : split_launch_d<100, kSplitBf16x3>(nx, gather, a, packed, st);
+        case 64: return gru_fwd_fmt() == kSplitF16x2 ? split_launch_d<64, kSplitF16x2>(nx, gather, a, packed, st) : split_launch_d<64, kSplitBf16x3>(nx, gather, a, packed, st);
+        case 32: return gru_fwd_fmt() == kSplitF16x2 ? split_launch_d<32, kSplitF16x2>(nx, gather, a, packed, st) : split_launch_d<32, kSplitBf16x3>(nx, gather, a, packed, st);
         default: return fail(GGNN_E_UNSUPPORTED, "no split-form fused GRU for hidden size %d", D);
     }
 #endif

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = nt * 16 + 4 * kq;
-                if (col < D) st4_b(Hc, ((unsigned)r * (unsigned)D + col) * 4u, acc[nt] * (SPLIT ? kSplitAccScale : 1.0f));   // (1 unless GGNN_SPLIT2)
+                if (col < D) st4_b(Hc, ((unsigned)r * (unsigned)D + col) * 4u, acc[nt]);
             }
         }
         a = an;

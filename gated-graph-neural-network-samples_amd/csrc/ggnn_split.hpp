@@ -36,44 +36,57 @@ namespace ggnn {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-// GGNN_SPLIT2 (experiment, round 4; per translation unit, default off): the TWO-piece f16 form of the same idea.
-//     a 2^8 = a_hi + a_lo + e,   a_hi = RN_f16(a 2^8),  a_lo = RN_f16(a 2^8 - a_hi),  |e| <= 2^-22 |a 2^8|
-// (f16 carries 11 significand bits: two pieces hold 22 of an f32's 24), and the product keeps THREE of the four partial products
-//     a_hi b_hi + a_hi b_lo + a_lo b_hi            (a_lo b_lo < 2^-22 |a b| is dropped)
-// on v_mfma_f32_16x16x32_f16 -- the bf16 instruction's rate and lane layout: half the MFMAs of the six-product form, two operand
-// planes instead of three (a D = 100 stage image: 48 instead of 72 KiB), 8 instead of 11 vector instructions per split value pair.
-// NOT exact: each operand is rounded to 22 bits.  Measured in numpy against f64: rms error of a K = 100..300
-// GRU-shaped product 0.9-1.0 x the six-product form's and 0.4-0.5 x the f32 FMA chain's -- the chain rounds its running sum K times.
-// The 2^8 on both operands keeps the lo pieces of everything above 2^-11 out of f16's subnormal range (the pieces of an unscaled
-// 0.1 would sit at 5e-5, below f16's smallest normal 6.1e-5) and bounds the operands to |a| < 255 (f16 overflows at 65504); the
-// accumulators then hold 2^16 x the sums: the remainder weights (f32 MFMA) are packed x 2^16 and the consumer's epilogue scales by
-// kSplitAccScale, folded into a constant it multiplies by anyway.  Scaling by powers of two is exact.
-#ifndef GGNN_SPLIT2
-#define GGNN_SPLIT2 0
-#endif
+// Operand formats of a split product.
+//   kSplitBf16x3 (3): the exact three-piece bf16 split above, six products (every kernel but the fused GRU forward).
+//   kSplitF16x2 (2), round 4: TWO f16 pieces per operand and THREE products on v_mfma_f32_16x16x32_f16 -- the bf16 instruction's
+//     rate and lane layout, so half the MFMAs, two operand planes instead of three (a D = 100 stage image: 48 instead of 72 KiB)
+//     and 5 instead of 11 vector instructions per split value pair:
+//         a = a_hi + a_lo + e,   a_hi = RN_f16(a),  a_lo = RN_f16(a - a_hi),  |e| <= 2^-22 |a|       (f16: 11 significand bits)
+//         a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi                    (a_lo b_lo < 2^-22 |a b| is dropped)
+//     NOT exact -- each operand is rounded to 22 bits -- but f32-faithful where it is used: against f64 the fused GRU's error is
+//     BELOW the six-product form's and the f32 MFMA's (MI355X, tools/split_probe.py: h' rms 6.3e-8 / 7.3e-8 / 8.4e-8; numpy:
+//     oracle.split3_f16_matmul, tests/test_oracle.py) -- the f32 chain rounds its running sum K times, this form once per 32 terms.
+//     Range and scaling: f16 reaches 65504 and its normals stop at 6.1e-5.  WEIGHTS are packed x 2^8 (exact; free: once per weight
+//     version), which lifts the lo pieces of everything above 2^-11 out of the subnormal range (the lo piece of an unscaled 0.1
+//     sits at 5e-5 and would keep 9 bits: 2 x the error) and bounds |w| to 255 (beyond: saturated at pack time); ACTIVATIONS are
+//     not scaled (numpy: scaling them too buys 1 %) and are clamped to +-65504 before the split (v_med3_f32: a finite,
+//     saturated operand instead of Inf - Inf = NaN; the gates are saturated long before).  The MFMA keeps f16 subnormal inputs
+//     (tools/f16_mfma_denorm_probe.hip).  Accumulators hold 2^8 x the sums: the remainder weights (f32 MFMA) are packed x 2^8 and
+//     the consumer's epilogue scales by acc_scale, folded into a constant it multiplies by anyway.
+//     Used by the fused GRU FORWARD (kernel, both packers); GGNN_GRU_FMT=3 selects its bf16x3 instantiations (process-wide).
+constexpr int kSplitBf16x3 = 3, kSplitF16x2 = 2;
+template <int FMT> struct SplitFmt;
+template <> struct SplitFmt<kSplitBf16x3> {
+    static constexpr int NP = 3;                                   // operand planes: hi, mid, lo
+    static constexpr float w_scale = 1.0f, rem_scale = 1.0f, acc_scale = 1.0f;
+};
+template <> struct SplitFmt<kSplitF16x2> {
+    static constexpr int NP = 2;                                   // operand planes: hi, lo
+    static constexpr float w_scale = 256.0f;                       // weights as packed
+    static constexpr float rem_scale = 256.0f;                     // remainder weights (f32 MFMA; their activations are unscaled)
+    static constexpr float acc_scale = 1.0f / 256.0f;              // accumulator -> sum
+};
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-#ifndef GGNN_SPLIT2_SCALED
-#define GGNN_SPLIT2_SCALED 1     // 0: no operand scaling (relies on the MFMA keeping f16 subnormals; experiment)
+// 1: the f16 split of an activation pair in 5 hand-placed instructions (2 v_med3_f32, v_cvt_pk_f16_f32, v_fma_mixlo/hi_f16);
+// 0: left to hipcc (10: it converts each value twice)
+#ifndef GGNN_F16_SPLIT_ASM
+#define GGNN_F16_SPLIT_ASM 1
 #endif
-#if GGNN_SPLIT2 && GGNN_SPLIT2_SCALED
-constexpr float kSplitScale = 256.0f;                 // both operands
-constexpr float kSplitRemScale = 65536.0f;            // remainder weights (their activations stay unscaled)
-constexpr float kSplitAccScale = 1.0f / 65536.0f;     // accumulator -> sum
-#else
-constexpr float kSplitScale = 1.0f, kSplitRemScale = 1.0f, kSplitAccScale = 1.0f;
-#endif
+
+// Format of the fused GRU forward's images and products (read once; GGNN_GRU_FMT=3: bf16x3)
+int gru_fwd_fmt();
 
 // Process-wide choice of the matrix path of the fused kernels (read once): GGNN_MATRIX=f32 selects the f32 MFMA forms.
 bool split_matrix_path();
 
-template <int D>
+template <int D, int FMT = kSplitBf16x3>
 struct SplitCfg {
     using S = StageCfg<D>;
     static constexpr bool OK = (S::NC % 2 == 0) && S::NC > 0;
     static constexpr int NC2 = S::NC / 2;
     static constexpr int TA = (S::NT + 1) / 2;                       // tiles in half A (D = 100: 4 of 7)
-    static constexpr int NP = GGNN_SPLIT2 ? 2 : 3;                   // operand planes (hi, mid, lo | GGNN_SPLIT2: hi, lo)
+    static constexpr int NP = SplitFmt<FMT>::NP;                     // operand planes
     // geometry of a half holding NTH tiles
     static constexpr int plane_bytes(int nth) { return NC2 * 4 * nth * 16 * 16; }
     static constexpr int main_bytes(int nth) { return NP * plane_bytes(nth); }
@@ -91,9 +104,9 @@ struct SplitCfg {
 };
 
 // image geometry of a fused kernel: the f32 stage image or the split one
-template <int D, bool SPLIT>
+template <int D, bool SPLIT, int FMT = kSplitBf16x3>
 struct ImgCfg {
-    static constexpr int IMG_BYTES = SPLIT ? SplitCfg<D>::IMG_BYTES : StageCfg<D>::IMG_BYTES;
+    static constexpr int IMG_BYTES = SPLIT ? SplitCfg<D, FMT>::IMG_BYTES : StageCfg<D>::IMG_BYTES;
     static constexpr int IMG = IMG_BYTES / 4;
 };
 
@@ -101,14 +114,16 @@ __device__ __forceinline__ float trunc_bf16_f(float x) { return __uint_as_float(
 
 // piece p (0 hi, 1 mid, 2 lo) of x as bf16 bits.  Truncation: every piece takes the next 8 significand bits, the three
 // together all 24 -- the split is exact and each residual subtraction is exact.
+// FMT = kSplitF16x2: piece p (0 hi, 1 lo) of the WEIGHT x as f16 bits: x 2^8 saturated at +-65504, round to nearest; the residual
+// subtraction is exact.
+template <int FMT = kSplitBf16x3>
 __device__ __forceinline__ unsigned split_piece_bits(float x, int p) {
-#if GGNN_SPLIT2   // piece p (0 hi, 1 lo) of x 2^8 as f16 bits, round to nearest; the residual subtraction is exact
-    const float xs = x * kSplitScale;
-    const _Float16 h16 = (_Float16)xs;
-    if (p == 0) return (unsigned)__builtin_bit_cast(unsigned short, h16);
-    if (p == 1) return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(xs - (float)h16));
-    return 0u;
-#endif
+    if constexpr (FMT == kSplitF16x2) {
+        const float xs = fminf(fmaxf(x * SplitFmt<FMT>::w_scale, -65504.0f), 65504.0f);
+        const _Float16 h16 = (_Float16)xs;
+        if (p == 0) return (unsigned)__builtin_bit_cast(unsigned short, h16);
+        return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(xs - (float)h16));
+    }
     const float hi = trunc_bf16_f(x);
     if (p == 0) return __float_as_uint(hi) >> 16;
     const float r1 = x - hi, mid = trunc_bf16_f(r1);
@@ -138,9 +153,9 @@ struct StageValueT {
     __device__ __forceinline__ float operator()(int k, int n) const { return n < D ? W[(size_t)(r0 + n) * ldw + c0 + k] : 0.f; }
 };
 
-template <int D, class Value>
+template <int D, int FMT = kSplitBf16x3, class Value>
 __device__ __forceinline__ void pack_split_image(const Value& value, float* __restrict__ img, int first, int stride) {
-    using C = SplitCfg<D>;
+    using C = SplitCfg<D, FMT>;
     using S = StageCfg<D>;
     for (int i = first; i < C::IMG; i += stride) {
         unsigned out = 0u;
@@ -154,17 +169,17 @@ __device__ __forceinline__ void pack_split_image(const Value& value, float* __re
             const int n = n0 + slot % bnh, cg = slot / bnh, c2 = cg >> 2, g = cg & 3;
             const int j0 = 2 * pr;
             const int k0 = 32 * c2 + 16 * (j0 >> 2) + 4 * g + (j0 & 3);
-            out = split_piece_bits(value(k0, n), plane) | (split_piece_bits(value(k0 + 1, n), plane) << 16);
+            out = split_piece_bits<FMT>(value(k0, n), plane) | (split_piece_bits<FMT>(value(k0 + 1, n), plane) << 16);
         } else if (w_ < MW + RW) {
             const int j = w_ - MW;
-            out = __float_as_uint(value(16 * S::NC + j / bnh, n0 + j % bnh) * kSplitRemScale);       // j / bnh = q*4 + g
+            out = __float_as_uint(value(16 * S::NC + j / bnh, n0 + j % bnh) * SplitFmt<FMT>::rem_scale);       // j / bnh = q*4 + g
         }
         img[i] = __uint_as_float(out);
     }
 }
 
 // Image ci of the fused GRU's packed weights in split form: the same blocks and tail-riding columns as gru_fwd_image_pack.
-template <int D>
+template <int D, int FMT = kSplitBf16x3>
 __device__ __forceinline__ void gru_fwd_image_pack_split(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx, int ci,
                                                          float* __restrict__ img, int first, int stride) {
     StageValue<D> v{nullptr, 0, 0, 0, -1, Wc, 0, D, -1};
@@ -173,7 +188,7 @@ __device__ __forceinline__ void gru_fwd_image_pack_split(const float* __restrict
         if (StageCfg<D>::TAILPACK && (ci & 1) == 0) v.c_alt = D + (D / 16) * 16;
         if (StageCfg<D>::TAILPACK3 && (ci & 1) == 0 && (ci >> 1) < nx) { v.c_alt2 = (D / 16) * 16; v.r0_2 = (ci >> 1) * D; }
     } else { v.W = Wc; v.r0 = (ci - 2 * (nx + 1)) * D; v.c0 = 0; v.ldw = D; }
-    pack_split_image<D>(v, img, first, stride);
+    pack_split_image<D, FMT>(v, img, first, stride);
 }
 
 // Image i of the fused GRU backward's packed weights in split form (blocks as gru_bwd_image_pack: transposed reads)
@@ -184,7 +199,8 @@ __device__ __forceinline__ void gru_bwd_image_pack_split(const float* __restrict
     pack_split_image<D>(StageValueT<D>{which == 0 ? Wc : Wg, seg * D, which == 2 ? D : 0, which == 0 ? D : 2 * D}, img, first, stride);
 }
 
-// the three bf16 planes of an activation fragment's 32-chunks (the remainder floats stay in the Frag)
+// the three bf16 planes of an activation fragment's 32-chunks (the remainder floats stay in the Frag); kSplitF16x2: hi = the hi
+// pieces, mid = the lo pieces, lo unused
 template <int D>
 struct SFrag {
     u32x4 hi[SplitCfg<D>::NC2 > 0 ? SplitCfg<D>::NC2 : 1];
@@ -193,16 +209,27 @@ struct SFrag {
 };
 
 // two floats -> one register of each plane (element 0 in the low half): 3 v_perm + 4 v_and + 4 v_sub
+// kSplitF16x2: h = the f16 hi pieces, m = the f16 lo pieces of the two values clamped to +-65504 (l unused)
+template <int FMT = kSplitBf16x3>
 __device__ __forceinline__ void split_pair(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
-#if GGNN_SPLIT2   // hi / lo f16 pieces of a 2^8 in h / m (l unused): 2 v_mul + 2 conversions to f16 pairs + 2 v_cvt_f32_f16 + 2 v_sub
-    const float t0 = a0 * kSplitScale, t1 = a1 * kSplitScale;
-    const f16x2 hv = {(_Float16)t0, (_Float16)t1};
-    h = __builtin_bit_cast(unsigned, hv);
-    const f16x2 lv = {(_Float16)(t0 - (float)hv.x), (_Float16)(t1 - (float)hv.y)};
-    m = __builtin_bit_cast(unsigned, lv);
-    l = 0u;
-    return;
+    if constexpr (FMT == kSplitF16x2) {
+        const float t0 = __builtin_amdgcn_fmed3f(a0, -65504.0f, 65504.0f), t1 = __builtin_amdgcn_fmed3f(a1, -65504.0f, 65504.0f);
+#if GGNN_F16_SPLIT_ASM
+        // h = (RN_f16(t0), RN_f16(t1));  m = (RN_f16(t0 - h.lo), RN_f16(t1 - h.hi)): the mixed-precision FMA takes the f16 halves of h
+        // as its third source (op_sel_hi marks a source as f16, op_sel picks the half), computes t - h exactly in f32 and rounds once
+        asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+            "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(h), "=&v"(m) : "v"(t0), "v"(t1));
+#else
+        const f16x2 hv = {(_Float16)t0, (_Float16)t1};
+        h = __builtin_bit_cast(unsigned, hv);
+        const f16x2 lv = {(_Float16)(t0 - (float)hv.x), (_Float16)(t1 - (float)hv.y)};
+        m = __builtin_bit_cast(unsigned, lv);
 #endif
+        l = 0u;
+        return;
+    }
     const unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1);
     h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
     const float r0 = a0 - __uint_as_float(u0 & 0xffff0000u), r1 = a1 - __uint_as_float(u1 & 0xffff0000u);
@@ -212,39 +239,40 @@ __device__ __forceinline__ void split_pair(float a0, float a1, unsigned& h, unsi
     l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
-template <int D>
+template <int D, int FMT = kSplitBf16x3>
 __device__ __forceinline__ void split_frag(SFrag<D>& s, const Frag<D>& f) {
 #pragma unroll
     for (int c2 = 0; c2 < SplitCfg<D>::NC2; ++c2) {
         const f32x4 a = f.v[2 * c2], b = f.v[2 * c2 + 1];
         unsigned h[4], m[4], l[4];
-        split_pair(a.x, a.y, h[0], m[0], l[0]);
-        split_pair(a.z, a.w, h[1], m[1], l[1]);
-        split_pair(b.x, b.y, h[2], m[2], l[2]);
-        split_pair(b.z, b.w, h[3], m[3], l[3]);
+        split_pair<FMT>(a.x, a.y, h[0], m[0], l[0]);
+        split_pair<FMT>(a.z, a.w, h[1], m[1], l[1]);
+        split_pair<FMT>(b.x, b.y, h[2], m[2], l[2]);
+        split_pair<FMT>(b.z, b.w, h[3], m[3], l[3]);
         s.hi[c2] = u32x4{h[0], h[1], h[2], h[3]};
         s.mid[c2] = u32x4{m[0], m[1], m[2], m[3]};
         s.lo[c2] = u32x4{l[0], l[1], l[2], l[3]};
     }
 }
 
-__device__ __forceinline__ f32x4 mfma_bf16(u32x4 w, u32x4 a, f32x4 c) {
-#if GGNN_SPLIT2
+__device__ __forceinline__ f32x4 mfma_f16(u32x4 w, u32x4 a, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
-#endif
+}
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 w, u32x4 a, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
 }
 
 // the six products of one (32-chunk, tile), smallest terms first; FIRST: the accumulator is opened with C = 0
-template <bool FIRST>
+// kSplitF16x2: the three products (wm, am: the lo pieces; wl, al unused)
+template <bool FIRST, int FMT = kSplitBf16x3>
 __device__ __forceinline__ f32x4 split_products(f32x4 acc, u32x4 wh, u32x4 wm, u32x4 wl, u32x4 ah, u32x4 am, u32x4 al) {
     f32x4 c = FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc;
-#if GGNN_SPLIT2   // (wm, am: the lo pieces; wl, al unused)
-    c = mfma_bf16(wm, ah, c);
-    c = mfma_bf16(wh, am, c);
-    c = mfma_bf16(wh, ah, c);
-    return c;
-#endif
+    if constexpr (FMT == kSplitF16x2) {
+        c = mfma_f16(wm, ah, c);
+        c = mfma_f16(wh, am, c);
+        c = mfma_f16(wh, ah, c);
+        return c;
+    }
     c = mfma_bf16(wl, ah, c);
     c = mfma_bf16(wm, am, c);
     c = mfma_bf16(wm, ah, c);
@@ -271,11 +299,11 @@ __device__ __forceinline__ f32x4 split_products(f32x4 acc, u32x4 wh, u32x4 wm, u
 // REMAT: the lane parts of the LDS addresses are recomputed in every call (the lane coordinates pass through an empty asm, so the
 // compiler cannot keep the ~10 per-slot address registers of a multi-stage kernel alive across its stages -- a kernel at the
 // 256-register limit spills exactly those and reloads them in front of the remainder MFMAs).
-template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false, int T0 = 0, bool REMAT = false>
+template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false, int T0 = 0, bool REMAT = false, int FMT = kSplitBf16x3>
 __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT], const SFrag<D>& a, const Frag<D>& af,
                                                    const float* img, const float* img_b, int li, int kq) {
     using S = StageCfg<D>;
-    using C = SplitCfg<D>;
+    using C = SplitCfg<D, FMT>;
     if constexpr (REMAT) asm volatile("" : "+v"(li), "+v"(kq));
     constexpr int NTW = NTILES - T0;                                  // tiles walked
     constexpr int NU = C::NC2 * NTW;                                  // units, chunk-major
@@ -289,7 +317,7 @@ __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT]
             const u32x4* b = C::half_of(nt) ? base_b : base_a;
             return b[p * (C::plane_bytes(nth) / 16) + c2 * 4 * nth * 16 + C::tile_in_half(nt) * 16];
         };
-#if GGNN_SPLIT2
+      if constexpr (FMT == kSplitF16x2) {
         // three products per unit, smallest first; both planes of the NEXT unit are fetched at the start of the current one (a whole
         // unit = 3 MFMAs ahead of their first use; 16 weight registers in flight, and the lo plane of the activation is gone)
         u32x4 wh = slot(0, 0), wm = slot(0, 1), nh = wh, nm = wm;
@@ -300,14 +328,14 @@ __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT]
             f32x4 c = (ZERO && c2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nt];
             if (more) { nm = slot(u + 1, 1); nh = slot(u + 1, 0); }
             __builtin_amdgcn_sched_barrier(0);
-            c = mfma_bf16(wm, a.hi[c2], c);
-            c = mfma_bf16(wh, a.mid[c2], c);
-            c = mfma_bf16(wh, a.hi[c2], c);
+            c = mfma_f16(wm, a.hi[c2], c);
+            c = mfma_f16(wh, a.mid[c2], c);
+            c = mfma_f16(wh, a.hi[c2], c);
             __builtin_amdgcn_sched_barrier(0);
             wm = nm; wh = nh;
             acc[nt] = c;
         }
-#else
+      } else {
         u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
 #if GGNN_SPLIT_WH2
         u32x4 wh_n = wh;
@@ -360,7 +388,7 @@ __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT]
             acc[nt] = c;
         }
 #endif
-#endif   // GGNN_SPLIT2
+      }
     }
     // the D % 16 remainder k values on the f32 MFMA, their weights two tiles ahead (2 registers in flight)
     if constexpr (S::NR > 0 && NTW > 0) {
@@ -383,19 +411,19 @@ __device__ __forceinline__ void stage_mma_split_at(f32x4 (&acc)[StageCfg<D>::NT]
     }
 }
 
-template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false, bool REMAT = false>
+template <int D, int NTILES = StageCfg<D>::NT, bool ZERO = false, bool REMAT = false, int FMT = kSplitBf16x3>
 __device__ __forceinline__ void stage_mma_split(f32x4 (&acc)[StageCfg<D>::NT], const SFrag<D>& a, const Frag<D>& af,
                                                 const float* img, int li, int kq) {
-    stage_mma_split_at<D, NTILES, ZERO, 0, REMAT>(acc, a, af, img, img + SplitCfg<D>::HA, li, kq);
+    stage_mma_split_at<D, NTILES, ZERO, 0, REMAT, FMT>(acc, a, af, img, img + SplitCfg<D, FMT>::HA, li, kq);
 }
 
 // ONE output tile (wave-uniform, run time) of the same product: the cooperative tail pass
 #define NC2_PLANE_SLOTS(NC2_, NTH_) ((NC2_) * 4 * (NTH_) * 16)
-template <int D, bool ZERO>
+template <int D, bool ZERO, int FMT = kSplitBf16x3>
 __device__ __forceinline__ void stage_mma_one_split(f32x4& acc, const SFrag<D>& a, const Frag<D>& af, const float* img, int li,
                                                     int kq, int tile) {
     using S = StageCfg<D>;
-    using C = SplitCfg<D>;
+    using C = SplitCfg<D, FMT>;
     const bool hb = tile >= C::TA;                                    // (wave-uniform)
     const int nth = hb ? S::NT - C::TA : C::TA, til = hb ? tile - C::TA : tile;
     const float* him = hb ? img + C::HA : img;
@@ -409,7 +437,7 @@ __device__ __forceinline__ void stage_mma_one_split(f32x4& acc, const SFrag<D>& 
     for (int c2 = 0; c2 < C::NC2; ++c2) {
         const int cn = c2 + 1 < C::NC2 ? c2 + 1 : c2;
         const u32x4 n0 = base[cn * CP], n1 = base[PL + cn * CP], n2 = C::NP > 2 ? base[(C::NP - 1) * PL + cn * CP] : n1;
-        cin = split_products<false>(cin, w0, w1, w2, a.hi[c2], a.mid[c2], a.lo[c2]);
+        cin = split_products<false, FMT>(cin, w0, w1, w2, a.hi[c2], a.mid[c2], a.lo[c2]);
         w0 = n0; w1 = n1; w2 = n2;
     }
 #pragma unroll

@@ -119,8 +119,9 @@ struct PrepArgs {
     int T; float keep;
 };
 
-// SF: every image in split form (ggnn_split.hpp)
-template <int D, bool SF>
+// SF: every image in split form (ggnn_split.hpp); GF: operand format of the GRU FORWARD's images (gru_fwd_fmt(); the edge-weight
+// images -- whose transposes multiply gradients of any magnitude -- and the GRU backward's stay in the exact bf16 x 3 format)
+template <int D, bool SF, int GF = kSplitBf16x3>
 __global__ __launch_bounds__(256) void train_prepare_kernel(PrepArgs a) {
     using C = StageCfg<D>;
     const int l = blockIdx.z, i = blockIdx.y;
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(256) void train_prepare_kernel(PrepArgs a) {
         }
     } else if (i < 2 * T + ng) {
         const int ci = i - 2 * T;
-        float* img = a.gru_img[l] + (size_t)ci * ImgCfg<D, SF>::IMG;
-        if constexpr (SF) gru_fwd_image_pack_split<D>(a.Wg[l], a.Wc[l], a.nx[l], ci, img, first, stride);
+        float* img = a.gru_img[l] + (size_t)ci * ImgCfg<D, SF, GF>::IMG;
+        if constexpr (SF) gru_fwd_image_pack_split<D, GF>(a.Wg[l], a.Wc[l], a.nx[l], ci, img, first, stride);
         else gru_fwd_image_pack<D>(a.Wg[l], a.Wc[l], a.nx[l], ci, img, first, stride);
     } else if (i < 2 * T + 2 * ng) {
         const int bi = i - 2 * T - ng;
@@ -227,7 +228,8 @@ extern "C" int ggnn_sparse_train_prepare_f32(int num_layers, int T, int D, const
     const dim3 grid(8, max_images, num_layers);
     hipStream_t st = (hipStream_t)stream;
     const bool sf = split_matrix_path();
-#define GGNN_PREP(DD) if (sf) hipLaunchKernelGGL((train_prepare_kernel<DD, true>), grid, dim3(256), 0, st, a); \
+#define GGNN_PREP(DD) if (sf && gru_fwd_fmt() == kSplitF16x2) hipLaunchKernelGGL((train_prepare_kernel<DD, true, kSplitF16x2>), grid, dim3(256), 0, st, a); \
+                      else if (sf) hipLaunchKernelGGL((train_prepare_kernel<DD, true>), grid, dim3(256), 0, st, a); \
                       else hipLaunchKernelGGL((train_prepare_kernel<DD, false>), grid, dim3(256), 0, st, a);
     switch (D) {
         case 100: GGNN_PREP(100) break;

@@ -54,6 +54,16 @@ const char* ggnn_last_error(void);
  *   0 (GGNN_MATRIX=f32)  the f32 MFMA forms (v_mfma_f32_16x16x4_f32).
  * Packed weight images (ggnn_*_pack_*) are in the format of the mode and sized by the *_bytes functions. */
 int ggnn_matrix_path_is_split(void);
+/* Operand format of the fused GRU FORWARD (ggnn_gru_*_f32 at hidden sizes 32 / 64 / 100) under the split matrix path, fixed per
+ * process (environment GGNN_GRU_FMT, read at the first call):
+ *   2 (default, round 4)  every f32 operand as TWO f16 pieces (round to nearest: 22 of its 24 significand bits), THREE f16 MFMA
+ *                         products per f32 product, f32 accumulation; weights packed x 2^8 (|w| < 255, saturated beyond),
+ *                         activations clamped to +-65504.  Not exact, but measured against f64 its error is below the six-product
+ *                         form's and the f32 MFMA's (tests/test_gpu_split_precision.py); half the MFMAs, 48 KiB stage images;
+ *   3 (GGNN_GRU_FMT=3)    the exact three-piece bf16 split, six products (the format of every other split-form kernel);
+ *   0                     the matrix path is not split (GGNN_MATRIX=f32).
+ * ggnn_gru_packed_bytes / ggnn_gru_pack_weights_f32 / ggnn_sparse_train_prepare_f32 size and write the GRU images in this format. */
+int ggnn_gru_forward_format(void);
 
 /* ---- (a-1) message index prep: chem_tensorflow_sparse.py:120-129 -------------------------------
  * The reference concatenates the per-type target columns into message_targets[M] (type ascending,

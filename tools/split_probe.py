@@ -1,6 +1,7 @@
 """Error of the fused GRU launch against an f64 evaluation, and its duration, in the process's matrix mode
-(GGNN_MATRIX=f32 | default bf16x3 split).  Run once per mode and compare:
-    GGNN_MATRIX=f32 python tools/split_probe.py; python tools/split_probe.py
+(GGNN_MATRIX=f32 | default: split, the fused GRU forward in the f16 x 2 format | GGNN_GRU_FMT=3: the GRU in bf16 x 3 too).  Run once per
+mode and compare:
+    GGNN_MATRIX=f32 python tools/split_probe.py; python tools/split_probe.py; GGNN_GRU_FMT=3 python tools/split_probe.py
 """
 import importlib, os, sys, json
 import numpy as np, torch
@@ -10,7 +11,7 @@ ops = pkg.ops
 lib = pkg._lib.load()
 mode = "bf16x3" if lib.ggnn_matrix_path_is_split() else "f32"
 dev = "cuda:0"
-out = {"mode": mode}
+out = {"mode": mode, "gru_format": int(lib.ggnn_gru_forward_format())}     # 2: f16 x 2 pieces, 3 products (default); 3: bf16 x 3, 6 products (GGNN_GRU_FMT=3)
 for D, nx, V in ((100, 1, 40000), (100, 3, 20000), (64, 2, 20000), (32, 1, 20000)):
     g = torch.Generator(device="cpu").manual_seed(5 + D + nx)
     xs = [(torch.rand(V, D, generator=g) * 2 - 1) for _ in range(nx)]
