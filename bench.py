@@ -67,8 +67,8 @@ SPLIT_PRODUCTS = 6
 SPLIT_KERNELS = ("msg_transform_compact", "gru_fused")
 SPLIT_ACTIVE = False               # set from ggnn_matrix_path_is_split() in main()
 # The fused GRU forward at D = 32 / 64 / 100 multiplies in the TWO-piece f16 form since round 4 (ggnn_gru_forward_format() == 2): three
-# f16 MFMA products per f32 product -- its ceiling is the f16 pipe's peak (= the bf16 pipe's) / 3.  The column-panel GRU of the
-# wider hidden sizes (ggnn_panel.hip) stays on the six-product bf16 form.
+# f16 MFMA products per f32 product -- its ceiling is the f16 pipe's peak (= the bf16 pipe's) / 3.  So does the column-panel GRU of the
+# wider hidden sizes (ggnn_panel.hip); the transforms stay on the six-product bf16 form.
 GRU_FWD_FORMAT = 3                 # set from ggnn_gru_forward_format() in main()
 F16X2_PRODUCTS = 3
 DENSE_SPLIT = False                # set from ggnn_dense_propagate_is_split() for the configs[2] shape in secondary_dense()
@@ -190,7 +190,7 @@ def kernel_table(res, reps, V, M, D, T, R=None):
                                   "f32_mfma_peak": FP32_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                                   "matrix_path": "bf16x3 split: f32 operands as 3 bf16 pieces each, 6 bf16 MFMA products per f32 product, "
                                                  "f32 accumulation (error bound of an f32 FMA chain)"})
-            if name.startswith("gru_fused") and GRU_FWD_FORMAT == 2 and D in (32, 64, 100):
+            if name.startswith("gru_fused") and GRU_FWD_FORMAT == 2:          # (whole-block kernels at 32 / 64 / 100 and the column-panel GRU)
                 pipe = BF16_MFMA_PEAK_TFLOPS / F16X2_PRODUCTS
                 kernels[name].update({"peak": pipe, "frac": ach / pipe, "pipe": "f16 MFMA, 3 products per f32 product (2500 / 3 TF f32-equivalent)",
                                       "matrix_path": "f16x2 split: f32 operands as 2 f16 pieces each (22 of 24 significand bits, round to nearest; "

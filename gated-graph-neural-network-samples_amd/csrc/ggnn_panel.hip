@@ -132,11 +132,14 @@ __device__ __forceinline__ void panel_mma_split(f32x4 (&acc)[4], const Frag<D>& 
 // A split 64-column panel of a 256-row block is 96 KiB: two of them do not fit the LDS.  The ring therefore holds PARTS of an
 // image (D = 256: 2 x 4 chunks = 48 KiB each; 192: 3 x 2 chunks = 24 KiB; 128: the whole 48 KiB image) and a stage is PARTS
 // DMA / MFMA / barrier rounds over the same accumulators.
-template <int D>
+// FMT (ggnn_split.hpp): kSplitBf16x3 = three planes per chunk (12 KiB); kSplitF16x2 (the panel GRU since the end of round 4) = two
+// (8 KiB): a D = 256 image is 64 KiB and two WHOLE images fit the ring -- no parts at any width.
+template <int D, int FMT = kSplitBf16x3>
 struct PanelGruSplitCfg {
     static constexpr int NC2 = D / 32;
-    static constexpr int CHUNK_BYTES = 3 * 4 * 64 * 16;            // 12 KiB per 32-chunk
-    static constexpr int PARTS = D == 256 ? 2 : (D == 192 ? 3 : 1);
+    static constexpr int NPL = SplitFmt<FMT>::NP;                  // planes per chunk
+    static constexpr int CHUNK_BYTES = NPL * 4 * 64 * 16;          // 12 KiB per 32-chunk (two planes: 8)
+    static constexpr int PARTS = FMT == kSplitF16x2 ? 1 : (D == 256 ? 2 : (D == 192 ? 3 : 1));
     static constexpr int CP = NC2 / PARTS;                         // chunks per part
     static constexpr int PART_BYTES = CP * CHUNK_BYTES;
     static constexpr int PART = PART_BYTES / 4;
@@ -145,37 +148,39 @@ struct PanelGruSplitCfg {
     static_assert(NC2 % PARTS == 0 && PART_BYTES % 8192 == 0, "parts are whole chunks and whole KiB per wave of an 8-wave workgroup");
 };
 
-template <int D>
+template <int D, int FMT = kSplitBf16x3>
 __device__ __forceinline__ void pack_panel_gru_split_image(const float* __restrict__ W, int r0, int c0, int ldw, float* __restrict__ img,
                                                            int first, int stride) {
-    using C = PanelGruSplitCfg<D>;
+    using C = PanelGruSplitCfg<D, FMT>;
     for (int i = first; i < C::IMG; i += stride) {
-        const int slot = i >> 2, pr = i & 3;                       // 16-byte slot ((c2*3 + plane)*4 + g)*64 + n
-        const int n = slot % 64, g = (slot / 64) % 4, plane = (slot / 256) % 3, c2 = slot / 768;
+        const int slot = i >> 2, pr = i & 3;                       // 16-byte slot ((c2*NPL + plane)*4 + g)*64 + n
+        const int n = slot % 64, g = (slot / 64) % 4, plane = (slot / 256) % C::NPL, c2 = slot / (256 * C::NPL);
         const int j0 = 2 * pr;
         const int k0 = 32 * c2 + 16 * (j0 >> 2) + 4 * g + (j0 & 3);
         const float v0 = W[(size_t)(r0 + k0) * ldw + c0 + n], v1 = W[(size_t)(r0 + k0 + 1) * ldw + c0 + n];
-        img[i] = __uint_as_float(split_piece_bits(v0, plane) | (split_piece_bits(v1, plane) << 16));
+        img[i] = __uint_as_float(split_piece_bits<FMT>(v0, plane) | (split_piece_bits<FMT>(v1, plane) << 16));
     }
 }
 
+template <int FMT = kSplitBf16x3>
 __device__ __forceinline__ void frag_planes(f32x4 x, f32x4 y, u32x4& hi, u32x4& mid, u32x4& lo) {
     // The fragment is the same for every stage of its segment, so the compiler would split it ONCE and keep all planes live across
     // the stages (96 registers at D = 256: ~450 B of scratch).  The empty asm makes the inputs opaque: the split is redone per stage,
     // 44 vector instructions per 24 MFMAs, and only one chunk's planes are live.
     asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w), "+v"(y.x), "+v"(y.y), "+v"(y.z), "+v"(y.w));
     unsigned h[4], m[4], l[4];
-    split_pair(x.x, x.y, h[0], m[0], l[0]); split_pair(x.z, x.w, h[1], m[1], l[1]);
-    split_pair(y.x, y.y, h[2], m[2], l[2]); split_pair(y.z, y.w, h[3], m[3], l[3]);
+    split_pair<FMT>(x.x, x.y, h[0], m[0], l[0]); split_pair<FMT>(x.z, x.w, h[1], m[1], l[1]);
+    split_pair<FMT>(y.x, y.y, h[2], m[2], l[2]); split_pair<FMT>(y.z, y.w, h[3], m[3], l[3]);
     hi = u32x4{h[0], h[1], h[2], h[3]}; mid = u32x4{m[0], m[1], m[2], m[3]}; lo = u32x4{l[0], l[1], l[2], l[3]};
 }
 
 // acc[0..3] (+)= chunks [part*CP, (part+1)*CP) of the fragment x the same chunks of a split panel image; `chunks` points at the
 // first of them (in LDS: a ring slot; GLOBAL: the image in L2, cooperative tail pass).  The fragment's 8 values of a chunk are split
 // right before the chunk's 24 MFMAs (the next chunk's under the current one's); weight planes rotate through 12 registers.
-template <int D, bool ZERO, bool GLOBAL, int part>
+// FMT = kSplitF16x2: three products per unit (w_lo a_hi, w_hi a_lo, w_hi a_hi), both planes of the next unit fetched a unit ahead.
+template <int D, bool ZERO, bool GLOBAL, int part, int FMT = kSplitBf16x3>
 __device__ __forceinline__ void panel_part_mma_split(f32x4 (&acc)[4], const Frag<D>& a, const float* chunks, int li, int kq) {
-    using C = PanelGruSplitCfg<D>;
+    using C = PanelGruSplitCfg<D, FMT>;
     constexpr int NU = C::CP * 4;
 #if GGNN_PANEL_REMAT
     asm volatile("" : "+v"(li), "+v"(kq));      // (the lane part of the address is recomputed per call, see stage_mma_split_at's REMAT)
@@ -188,11 +193,30 @@ __device__ __forceinline__ void panel_part_mma_split(f32x4 (&acc)[4], const Frag
         sbase = reinterpret_cast<const float*>(((unsigned long long)ghi << 32) | glo);
     }
     auto slot = [&](int u, int p) -> u32x4 {                        // unit u = (chunk cc, tile j), plane p
-        const unsigned off = voff + (unsigned)((((u / 4) * 3 + p) * 4) * 64 + (u % 4) * 16) * 16u;
+        const unsigned off = voff + (unsigned)((((u / 4) * C::NPL + p) * 4) * 64 + (u % 4) * 16) * 16u;
         if constexpr (GLOBAL) return __builtin_bit_cast(u32x4, ld4_b(sbase, off));
         else return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(chunks) + off);
     };
     u32x4 ah, am, al;
+    if constexpr (FMT == kSplitF16x2) {
+        u32x4 wh = slot(0, 0), wm = slot(0, 1), nh = wh, nm = wm;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int cc = u / 4, j = u % 4;
+            const bool more = u + 1 < NU;
+            if (j == 0) frag_planes<FMT>(a.v[2 * (part * C::CP + cc)], a.v[2 * (part * C::CP + cc) + 1], ah, am, al);
+            f32x4 c = (ZERO && cc == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j];
+            if (more) { nm = slot(u + 1, 1); nh = slot(u + 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            c = mfma_f16(wm, ah, c);
+            c = mfma_f16(wh, am, c);
+            c = mfma_f16(wh, ah, c);
+            __builtin_amdgcn_sched_barrier(0);
+            wm = nm; wh = nh;
+            acc[j] = c;
+        }
+        return;
+    }
     u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -306,7 +330,7 @@ __device__ __forceinline__ void dma_block(const float* src, float* dst, int wave
 //   phase UC:  p < NP:  for s < NX: U (Wg rows s, cols D + 64p ..), C (Wc rows s, cols 64p ..);  U (Wg rows h);  C (Wc rows h = r*h)
 __host__ __device__ constexpr int panel_gru_images(int D, int nx) { return 3 * (nx + 1) * (D / 64); }
 
-template <int D, bool SPLIT>
+template <int D, bool SPLIT, int FMT = kSplitBf16x3>
 __global__ void gru_panel_pack_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, int nx, float* __restrict__ out) {
     using C = PanelCfg<D>;
     const int ns = nx + 1, NP = C::NP;
@@ -320,23 +344,41 @@ __global__ void gru_panel_pack_kernel(const float* __restrict__ Wg, const float*
         else { W = Wc; r0 = s * D; c0 = p * C::BN; ldw = D; }
     }
     const int first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    if constexpr (SPLIT) pack_panel_gru_split_image<D>(W, r0, c0, ldw, out + (size_t)i * PanelGruSplitCfg<D>::IMG, first, stride);
+    if constexpr (SPLIT) pack_panel_gru_split_image<D, FMT>(W, r0, c0, ldw, out + (size_t)i * PanelGruSplitCfg<D, FMT>::IMG, first, stride);
     else pack_panel_image<D>(W, r0, c0, ldw, out + (size_t)i * C::IMG, first, stride);
 }
 
 // the same product on RESIDENT planes of the fragment (split once by the caller: the ring transform, and the panel GRU's stages
 // that multiply one fragment several times in a row)
-template <int D, bool ZERO, int part>
+template <int D, bool ZERO, int part, int FMT = kSplitBf16x3>
 __device__ __forceinline__ void panel_part_mma_planes(f32x4 (&acc)[4], const u32x4 (&ph)[PanelGruSplitCfg<D>::NC2], const u32x4 (&pm)[PanelGruSplitCfg<D>::NC2],
                                                       const u32x4 (&pl)[PanelGruSplitCfg<D>::NC2], const float* chunks, int li, int kq) {
-    using C = PanelGruSplitCfg<D>;
+    using C = PanelGruSplitCfg<D, FMT>;
     constexpr int NU = C::CP * 4;
     asm volatile("" : "+v"(li), "+v"(kq));      // (the lane part of the address is recomputed per call: GGNN_PANEL_REMAT's reason)
     const unsigned voff = (unsigned)(kq * 64 + li) * 16u;
     auto slot = [&](int u, int p) -> u32x4 {                        // unit u = (chunk cc, tile j), plane p
-        const unsigned off = voff + (unsigned)((((u / 4) * 3 + p) * 4) * 64 + (u % 4) * 16) * 16u;
+        const unsigned off = voff + (unsigned)((((u / 4) * C::NPL + p) * 4) * 64 + (u % 4) * 16) * 16u;
         return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(chunks) + off);
     };
+    if constexpr (FMT == kSplitF16x2) {                             // (pm: the lo pieces; pl unused)
+        u32x4 wh = slot(0, 0), wm = slot(0, 1), nh = wh, nm = wm;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int cc = part * C::CP + u / 4, j = u % 4;
+            const bool more = u + 1 < NU;
+            f32x4 c = (ZERO && u / 4 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j];
+            if (more) { nm = slot(u + 1, 1); nh = slot(u + 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            c = mfma_f16(wm, ph[cc], c);
+            c = mfma_f16(wh, pm[cc], c);
+            c = mfma_f16(wh, ph[cc], c);
+            __builtin_amdgcn_sched_barrier(0);
+            wm = nm; wh = nh;
+            acc[j] = c;
+        }
+        return;
+    }
     u32x4 wh = slot(0, 0), wm = slot(0, 1), wl = slot(0, 2);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -360,10 +402,24 @@ __device__ __forceinline__ void panel_part_mma_planes(f32x4 (&acc)[4], const u32
 }
 
 // SPLIT: the products on the bf16 pipe in 3-way split form; an image comes through the ring in PanelGruSplitCfg::PARTS parts.
-template <int D, int NX, int NW, bool SAVE, bool SPLIT>
+// FMT (SPLIT): operand format of the products and images (ggnn_split.hpp): kSplitF16x2 by default since the end of round 4 (two f16
+// pieces, three products, whole 64 KiB images through the ring), kSplitBf16x3 behind GGNN_GRU_FMT=3.
+template <int FMT>
+__device__ __forceinline__ f32x4 panel_sigmoid4(f32x4 z, f32x4 b_scaled) {      // (sigmoid4_scaled on an accumulator of 1 / acc_scale x the sum)
+    constexpr float k = -kLog2e * SplitFmt<FMT>::acc_scale;
+    return rcp_4(exp2_4(z * k + b_scaled) + 1.0f);
+}
+template <int FMT>
+__device__ __forceinline__ f32x4 panel_tanh4(f32x4 z, f32x4 b_scaled) {
+    constexpr float k = 2.0f * kLog2e * SplitFmt<FMT>::acc_scale;
+    return 1.0f - 2.0f * rcp_4(exp2_4(z * k + b_scaled) + 1.0f);
+}
+
+template <int D, int NX, int NW, bool SAVE, bool SPLIT, int FMT = kSplitBf16x3>
 __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a, const float* __restrict__ packed) {
+    static_assert(SPLIT || FMT == kSplitBf16x3, "the f32-MFMA kernels have no operand format");
     using C = PanelCfg<D>;
-    using SC = PanelGruSplitCfg<D>;
+    using SC = PanelGruSplitCfg<D, FMT>;
     constexpr int IMGF = SPLIT ? SC::IMG : C::IMG;                   // floats per image in `packed`
     constexpr int SLOTF = SPLIT ? SC::PART : C::IMG;                 // floats per ring slot
     constexpr int PARTS = SPLIT ? SC::PARTS : 1;
@@ -447,8 +503,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
                     for (int c2 = 0; c2 < SC::NC2; ++c2) {
                         const f32x4 x = A.v[2 * c2], y = A.v[2 * c2 + 1];
                         unsigned hh[4], mm[4], ll[4];
-                        split_pair(x.x, x.y, hh[0], mm[0], ll[0]); split_pair(x.z, x.w, hh[1], mm[1], ll[1]);
-                        split_pair(y.x, y.y, hh[2], mm[2], ll[2]); split_pair(y.z, y.w, hh[3], mm[3], ll[3]);
+                        split_pair<FMT>(x.x, x.y, hh[0], mm[0], ll[0]); split_pair<FMT>(x.z, x.w, hh[1], mm[1], ll[1]);
+                        split_pair<FMT>(y.x, y.y, hh[2], mm[2], ll[2]); split_pair<FMT>(y.z, y.w, hh[3], mm[3], ll[3]);
                         qh[c2] = u32x4{hh[0], hh[1], hh[2], hh[3]}; qm[c2] = u32x4{mm[0], mm[1], mm[2], mm[3]}; ql[c2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
                     }
                 }
@@ -468,8 +524,8 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
                     if (dma_first && more_p) dma(nsrc, ndst);
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (ACT) {
-                        if constexpr (USEP) panel_part_mma_planes<D, decltype(zero_c)::value && part == 0, part>(acc, qh, qm, ql, ring + cur * SLOTF, li, kq);
-                        else if constexpr (SPLIT) panel_part_mma_split<D, decltype(zero_c)::value && part == 0, false, part>(acc, A, ring + cur * SLOTF, li, kq);
+                        if constexpr (USEP) panel_part_mma_planes<D, decltype(zero_c)::value && part == 0, part, FMT>(acc, qh, qm, ql, ring + cur * SLOTF, li, kq);
+                        else if constexpr (SPLIT) panel_part_mma_split<D, decltype(zero_c)::value && part == 0, false, part, FMT>(acc, A, ring + cur * SLOTF, li, kq);
                         else panel_mma<D, decltype(zero_c)::value>(acc, A, ring + cur * SLOTF, li, kq);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -507,7 +563,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
 #pragma unroll
                 for (int nt = 0; nt < NC; ++nt) {
                     const int col = nt * 16 + 4 * kq;
-                    const f32x4 r = sigmoid4_scaled(acc_r[nt / 4][nt % 4], ld4(bias_s + col));
+                    const f32x4 r = panel_sigmoid4<FMT>(acc_r[nt / 4][nt % 4], ld4(bias_s + col));
                     if constexpr (SAVE) { if (row < a.V) st4_b(a.save_r, ((unsigned)row * D + col) * 4u, r); }
                     rh.v[nt] = r * af.v[nt];
                     __builtin_amdgcn_sched_barrier(0);      // one tile at a time: no 16-deep batch of bias reads in flight
@@ -544,12 +600,12 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt) {
                             const int col = p * 64 + nt * 16 + 4 * kq;
-                            const f32x4 u = sigmoid4_scaled(acc_u[nt], ld4(bias_s + D + col));
+                            const f32x4 u = panel_sigmoid4<FMT>(acc_u[nt], ld4(bias_s + D + col));
                             f32x4 c;
                             if (a.act == GGNN_ACT_TANH) {
-                                c = tanh4_scaled(acc_c[nt], ld4(bias_s + 2 * D + col));
+                                c = panel_tanh4<FMT>(acc_c[nt], ld4(bias_s + 2 * D + col));
                             } else {
-                                c = acc_c[nt] + ld4(bias_s + 3 * D + col);
+                                c = acc_c[nt] * SplitFmt<FMT>::acc_scale + ld4(bias_s + 3 * D + col);
                                 c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
                             }
                             st4_b(a.h_out, ((unsigned)row * D + col) * 4u, u * hcol[nt] + (1.0f - u) * c);
@@ -578,9 +634,9 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
         auto gimg = [&](int img_idx) { return packed + (size_t)img_idx * IMGF; };
         auto gmma = [&](auto zero_c, f32x4 (&acc)[4], const Frag<D>& A, const float* img) {     // whole image, straight from L2
             if constexpr (SPLIT) {
-                panel_part_mma_split<D, decltype(zero_c)::value, true, 0>(acc, A, img, li, kq);
-                if constexpr (SC::PARTS > 1) panel_part_mma_split<D, false, true, 1>(acc, A, img + (size_t)SC::PART, li, kq);
-                if constexpr (SC::PARTS > 2) panel_part_mma_split<D, false, true, 2>(acc, A, img + (size_t)2 * SC::PART, li, kq);
+                panel_part_mma_split<D, decltype(zero_c)::value, true, 0, FMT>(acc, A, img, li, kq);
+                if constexpr (SC::PARTS > 1) panel_part_mma_split<D, false, true, 1, FMT>(acc, A, img + (size_t)SC::PART, li, kq);
+                if constexpr (SC::PARTS > 2) panel_part_mma_split<D, false, true, 2, FMT>(acc, A, img + (size_t)2 * SC::PART, li, kq);
             } else panel_mma_global<D, decltype(zero_c)::value>(acc, A, img, li, kq);
         };
         Frag<D> rh;
@@ -597,7 +653,7 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int col = p * 64 + nt * 16 + 4 * kq;
-                const f32x4 r = sigmoid4_scaled(accr[nt], ld4(bias_s + col));
+                const f32x4 r = panel_sigmoid4<FMT>(accr[nt], ld4(bias_s + col));
                 const f32x4 hv = ld4_b(a.h, ((unsigned)rowc * D + col) * 4u);
                 if constexpr (SAVE) { if (row < a.V) st4_b(a.save_r, ((unsigned)row * D + col) * 4u, r); }
                 *reinterpret_cast<f32x4*>(rh_x + li * RHP + col) = r * hv;
@@ -626,12 +682,12 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
                 for (int nt = 0; nt < 4; ++nt) {
                     const int col = p * 64 + nt * 16 + 4 * kq;
                     const f32x4 hcol = ld4_b(a.h, ((unsigned)row * D + col) * 4u);
-                    const f32x4 u = sigmoid4_scaled(acc_u[nt], ld4(bias_s + D + col));
+                    const f32x4 u = panel_sigmoid4<FMT>(acc_u[nt], ld4(bias_s + D + col));
                     f32x4 c;
                     if (a.act == GGNN_ACT_TANH) {
-                        c = tanh4_scaled(acc_c[nt], ld4(bias_s + 2 * D + col));
+                        c = panel_tanh4<FMT>(acc_c[nt], ld4(bias_s + 2 * D + col));
                     } else {
-                        c = acc_c[nt] + ld4(bias_s + 3 * D + col);
+                        c = acc_c[nt] * SplitFmt<FMT>::acc_scale + ld4(bias_s + 3 * D + col);
                         c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
                     }
                     st4_b(a.h_out, ((unsigned)row * D + col) * 4u, u * hcol + (1.0f - u) * c);
@@ -645,35 +701,36 @@ __global__ __launch_bounds__(NW * 64) void ggnn_gru_panel_kernel(GruFusedArgs a,
     }
 }
 
-template <int D, int NX, bool SAVE, bool SPLIT>
+template <int D, int NX, bool SAVE, bool SPLIT, int FMT = kSplitBf16x3>
 static int launch_gru_panel_m(const GruFusedArgs& a_in, float* packed, hipStream_t st) {
     using C = PanelCfg<D>;
     constexpr int NW = 8;
     GruFusedArgs a = a_in;
     if (a.Wg) {   // raw weights given: build the stage images first
-        hipLaunchKernelGGL((gru_panel_pack_kernel<D, SPLIT>), dim3(8, panel_gru_images(D, NX)), dim3(256), 0, st, a.Wg, a.Wc, NX, packed);
+        hipLaunchKernelGGL((gru_panel_pack_kernel<D, SPLIT, FMT>), dim3(8, panel_gru_images(D, NX)), dim3(256), 0, st, a.Wg, a.Wc, NX, packed);
         GGNN_CHECK_HIP(hipGetLastError());
     }
     if (a.h == nullptr) return GGNN_OK;   // pack-only call
     if ((unsigned long long)a.V * D >= (1ULL << 30))
         return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit byte offsets: V*D must be < 2^30 (V=%d, D=%d)", a.V, D);
     // ring: two images (f32) / two parts of an image (split); the cooperative tail's r*h exchange block [16][D + 4] shares it
-    size_t ringb = (size_t)2 * (SPLIT ? PanelGruSplitCfg<D>::PART_BYTES : C::IMG_BYTES);
+    size_t ringb = (size_t)2 * (SPLIT ? PanelGruSplitCfg<D, FMT>::PART_BYTES : C::IMG_BYTES);
     if (ringb < (size_t)16 * (D + 4) * sizeof(float)) ringb = (size_t)16 * (D + 4) * sizeof(float);
     const size_t lds = ringb + (size_t)((4 * D + 63) / 64 * 64) * sizeof(float);
     const int wt_total = (a.V + 15) / 16;
     int nb = num_cus();
     if (nb > wt_total) nb = wt_total;
     static std::atomic<unsigned long long> lds_ok{0};
-    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_panel_kernel<D, NX, NW, SAVE, SPLIT>, lds, lds_ok));
-    hipLaunchKernelGGL((ggnn_gru_panel_kernel<D, NX, NW, SAVE, SPLIT>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
+    if (lds > 64 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_panel_kernel<D, NX, NW, SAVE, SPLIT, FMT>, lds, lds_ok));
+    hipLaunchKernelGGL((ggnn_gru_panel_kernel<D, NX, NW, SAVE, SPLIT, FMT>), dim3(nb), dim3(NW * 64), lds, st, a, (const float*)packed);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
 
 template <int D, int NX, bool SAVE>
 static int launch_gru_panel(const GruFusedArgs& a, float* packed, hipStream_t st) {
-    if (split_matrix_path()) return launch_gru_panel_m<D, NX, SAVE, true>(a, packed, st);
+    if (split_matrix_path()) return gru_fwd_fmt() == kSplitF16x2 ? launch_gru_panel_m<D, NX, SAVE, true, kSplitF16x2>(a, packed, st)
+                                                                 : launch_gru_panel_m<D, NX, SAVE, true>(a, packed, st);
     return launch_gru_panel_m<D, NX, SAVE, false>(a, packed, st);
 }
 
@@ -695,7 +752,10 @@ int gru_panel_supported(int D) { return D == 128 || D == 192 || D == 256; }
 
 int gru_panel_pack_floats(int D, int nx) {
     if (!gru_panel_supported(D)) return 0;
-    const int img = !split_matrix_path() ? D * 64 : (D == 128 ? PanelGruSplitCfg<128>::IMG : (D == 192 ? PanelGruSplitCfg<192>::IMG : PanelGruSplitCfg<256>::IMG));
+    const bool f2 = gru_fwd_fmt() == kSplitF16x2;
+    const int img = !split_matrix_path() ? D * 64
+                  : f2 ? (D == 128 ? PanelGruSplitCfg<128, kSplitF16x2>::IMG : (D == 192 ? PanelGruSplitCfg<192, kSplitF16x2>::IMG : PanelGruSplitCfg<256, kSplitF16x2>::IMG))
+                       : (D == 128 ? PanelGruSplitCfg<128>::IMG : (D == 192 ? PanelGruSplitCfg<192>::IMG : PanelGruSplitCfg<256>::IMG));
     return panel_gru_images(D, nx) * img;
 }
 

@@ -12,7 +12,7 @@ lib = pkg._lib.load()
 mode = "bf16x3" if lib.ggnn_matrix_path_is_split() else "f32"
 dev = "cuda:0"
 out = {"mode": mode, "gru_format": int(lib.ggnn_gru_forward_format())}     # 2: f16 x 2 pieces, 3 products (default); 3: bf16 x 3, 6 products (GGNN_GRU_FMT=3)
-for D, nx, V in ((100, 1, 40000), (100, 3, 20000), (64, 2, 20000), (32, 1, 20000)):
+for D, nx, V in ((100, 1, 40000), (100, 3, 20000), (64, 2, 20000), (32, 1, 20000), (256, 1, 8000), (128, 2, 8000)):     # (128 / 256: the column-panel GRU)
     g = torch.Generator(device="cpu").manual_seed(5 + D + nx)
     xs = [(torch.rand(V, D, generator=g) * 2 - 1) for _ in range(nx)]
     h = torch.rand(V, D, generator=g) * 2 - 1
