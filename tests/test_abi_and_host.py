@@ -46,8 +46,11 @@ def test_argument_validation_without_gpu(pkg):
     assert lib.ggnn_gru_workspace_bytes(1000, 100) >= 2 * 1000 * 100 * 4      # un-fused scratch (+ packed weight images)
     assert lib.ggnn_gru_workspace_bytes(1000, 200) == 2 * 1000 * 200 * 4      # no fused path at D=200: r*h and u only
     assert lib.ggnn_gru_is_fused(100) == 1 and lib.ggnn_gru_is_fused(256) == 2 and lib.ggnn_gru_is_fused(200) == 0
-    # column-panel images of the three gates: f32, or three bf16 planes (1.5x the bytes) in the split matrix path
-    assert lib.ggnn_gru_packed_bytes(256, 1) == 3 * 2 * 256 * 256 * (6 if lib.ggnn_matrix_path_is_split() else 4)
+    # column-panel images of the three gates: f32 (4 bytes per weight), two f16 planes (4: the GRU forward's default format in the
+    # split matrix path) or three bf16 planes (6: GGNN_GRU_FMT=3)
+    fmt = lib.ggnn_gru_forward_format()
+    assert fmt == (int(os.environ.get("GGNN_GRU_FMT", "2")) if lib.ggnn_matrix_path_is_split() else 0) and fmt in (0, 2, 3)
+    assert lib.ggnn_gru_packed_bytes(256, 1) == 3 * 2 * 256 * 256 * {0: 4, 2: 4, 3: 6}[fmt]
     assert lib.ggnn_msg_transform_compact_supported(256) == 1 and lib.ggnn_msg_transform_compact_supported(200) == 0
     assert lib.ggnn_csr_workspace_bytes(0, 10) > 0
 
