@@ -1,4 +1,8 @@
 #!/bin/bash
+# HISTORICAL (commit "Experiment: f32 products as TWO f16 pieces x three MFMAs"): the first measurement of the two-piece f16 split, then a
+# per-translation-unit build switch (-DGGNN_SPLIT2=1), on the fused GRU and the compacted transform; its logs are
+# profiles/r04_experiments/split2_first_run/.  The format has since become a template parameter (SplitFmt<FMT>, csrc/ggnn_split.hpp) and
+# the fused GRU forward's default: tools/exp_fmt.sh / tools/exp_panel.sh are the runs of the final form.  The build lines below no longer apply.
 # Round-4 experiment: the two-piece f16 split (GGNN_SPLIT2, csrc/ggnn_split.hpp) on the fused GRU and the compacted transform --
 # INFERENCE ONLY (the training step packs its images in ggnn_train.hip, which the variant libraries leave in the bf16 x 3 format).
 #   tools/variant_lib.sh s2  ggnn_gru_fused_split.hip,ggnn_msg_compact.hip -DGGNN_SPLIT2=1
