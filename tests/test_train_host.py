@@ -421,3 +421,27 @@ def test_dropout_seed_is_a_pure_function_of_seed_step_site(pkg):
     assert len({ds(0, 3, "edge_weights", 2), ds(1, 3, "edge_weights", 2), ds(0, 4, "edge_weights", 2), ds(0, 3, "edge_weights", 1),
                 ds(0, 3, "state", 2, 0)}) == 5
     assert a == 0xeb003e833a661aac                                                         # platform-independent (blake2b of the repr)
+
+
+def test_bench_prices_kernels_against_the_pipe_of_their_operand_format():
+    """bench.py's per-kernel roofline records (round-3 review, weak #1: no `frac` above 1, `peak` = the pipe the kernel runs on): an
+    f32-MFMA kernel against 157.3 TF, a six-product bf16 kernel against 2500 / 6, the fused GRU in the two-piece f16 format (round 4)
+    against 2500 / 3 -- the same achieved rate, three different ceilings."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    V, M, D, T, R = 100000, 200000, 100, 4, 120000
+    res = {"gru_fused_gather[nx=1]": [0.070] * 6, "msg_transform_compact": [0.025] * 8}
+    want = 6.0 * V * 2 * D * D / 70e-6 / 1e12                         # TF of f32-equivalent work
+    for split, fmt, peak in ((False, 0, 157.3), (True, 3, 2500.0 / 6), (True, 2, 2500.0 / 3)):
+        bench.SPLIT_ACTIVE, bench.GRU_FWD_FORMAT = split, fmt
+        k, tot = bench.kernel_table(res, 1, V, M, D, T, R)
+        g = k["gru_fused_gather[nx=1]"]
+        assert abs(g["achieved"] - want) < 1e-6 * want and abs(g["peak"] - peak) < 1e-9 and abs(g["frac"] - want / peak) < 1e-9
+        assert g["frac"] <= 1.0 or not split
+        t = k["msg_transform_compact"]                                 # the transform stays on the six-product form
+        assert abs(t["peak"] - (2500.0 / 6 if split else 157.3)) < 1e-9
+        assert abs(tot - (6 * 0.070 + 8 * 0.025)) < 1e-12
+    assert g["pipe"].startswith("f16 MFMA") and "f16x2" in g["matrix_path"]
