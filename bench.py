@@ -390,6 +390,26 @@ def measure_sustained_mfma(pkg, dev, launches=60):
     return res
 
 
+def exact_format_reference(args, value, run=subprocess.run):
+    """The same timed forward with the fused GRU in the EXACT three-piece bf16 format (GGNN_GRU_FMT=3; the format is fixed per process: a
+    child process), so that the line carries both numbers of one box and one run -- `value` is with the two-piece f16 format (22-bit
+    operands, three products; error against f64 measured below the exact form's, tests/test_gpu_split_precision.py).  A reference leg
+    must never take the headline down: any failure comes back as {"error": ...}."""
+    try:
+        env = dict(os.environ, GGNN_GRU_FMT="3", GGNN_BENCH_CHILD="1")
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--min-time", "0.3", "--streams", str(args.streams), "--batches", str(args.batches), "--mean-nodes", str(args.mean_nodes),
+               "--no-secondary", "--no-cpu-baseline", "--no-roofline"]
+        r = run(cmd, env=env, capture_output=True, text=True, timeout=120)
+        c = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"what": "the same timed forward in a child process with GGNN_GRU_FMT=3: the fused GRU in the exact three-piece bf16 format, six "
+                        "products per f32 product (the format of every other split-form kernel)",
+                "value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"], "ms_per_step_one_stream": c.get("ms_per_step_one_stream"),
+                "gru_forward_format": c.get("gru_forward_format"), "value_ratio_default_over_exact": value / c["value"]}
+    except Exception as exc:
+        return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+
+
 def ranks_seen(dist_ctx):
     """Size of the process group the ranks actually formed (1 without one)."""
     return torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
@@ -808,24 +828,8 @@ def main():
                 sec[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             torch.cuda.empty_cache()
         out["secondary"] = sec
-        # The same timed forward with the fused GRU in the EXACT three-piece bf16 format (GGNN_GRU_FMT=3; the format is fixed per process:
-        # a child process), so that the line carries both numbers of one box and one run: `value` above is with the two-piece f16 format
-        # (22-bit operands, three products; error against f64 measured below the exact form's, tests/test_gpu_split_precision.py).
         if SPLIT_ACTIVE and GRU_FWD_FORMAT == 2 and not os.environ.get("GGNN_BENCH_CHILD"):
-            try:
-                env = dict(os.environ, GGNN_GRU_FMT="3", GGNN_BENCH_CHILD="1")
-                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
-                       "--min-time", "0.3", "--streams", str(args.streams), "--batches", str(args.batches), "--mean-nodes", str(args.mean_nodes),
-                       "--no-secondary", "--no-cpu-baseline", "--no-roofline"]
-                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
-                c = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-                out["exact_bf16x3_gru_reference"] = {
-                    "what": "the same timed forward in a child process with GGNN_GRU_FMT=3: the fused GRU in the exact three-piece bf16 format, six "
-                            "products per f32 product (the format of every other split-form kernel)",
-                    "value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"], "ms_per_step_one_stream": c.get("ms_per_step_one_stream"),
-                    "gru_forward_format": c.get("gru_forward_format"), "value_ratio_default_over_exact": value / c["value"]}
-            except Exception as exc:                                   # (a reference leg must never take the headline down)
-                out["exact_bf16x3_gru_reference"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+            out["exact_bf16x3_gru_reference"] = exact_format_reference(args, value)
 
     # ---- CPU baseline leg: torch-CPU port of the reference op order, bounded sample (rank 0, N=1) ---------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -445,3 +445,32 @@ def test_bench_prices_kernels_against_the_pipe_of_their_operand_format():
         assert abs(t["peak"] - (2500.0 / 6 if split else 157.3)) < 1e-9
         assert abs(tot - (6 * 0.070 + 8 * 0.025)) < 1e-12
     assert g["pipe"].startswith("f16 MFMA") and "f16x2" in g["matrix_path"]
+
+
+def test_bench_exact_format_reference_leg_never_raises():
+    """bench.py's `exact_bf16x3_gru_reference`: the child's JSON line is parsed into the record; a child that dies, hangs or prints
+    nothing yields an error record, never an exception (the leg must not take the headline down)."""
+    import importlib.util, json, os, subprocess, types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = types.SimpleNamespace(steps=20, warmup=5, streams=2, batches=6, mean_nodes=18.0)
+    seen = {}
+
+    def ok_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        line = {"value": 9.5e8, "unit": "node-state updates/s", "ms_per_step": 0.84, "ms_per_step_one_stream": 0.97, "gru_forward_format": "bf16x3"}
+        return types.SimpleNamespace(returncode=0, stdout="noise\n" + json.dumps(line) + "\n", stderr="")
+    rec = bench.exact_format_reference(args, 1.2e9, run=ok_run)
+    assert rec["value"] == 9.5e8 and rec["gru_forward_format"] == "bf16x3" and abs(rec["value_ratio_default_over_exact"] - 1.2e9 / 9.5e8) < 1e-12
+    assert seen["env"]["GGNN_GRU_FMT"] == "3" and seen["env"]["GGNN_BENCH_CHILD"] == "1"          # (the child must not spawn a child)
+    assert "--no-secondary" in seen["cmd"] and "--no-roofline" in seen["cmd"] and "--no-cpu-baseline" in seen["cmd"]
+
+    def dead_run(cmd, **kw):
+        return types.SimpleNamespace(returncode=1, stdout="", stderr="boom")
+
+    def hung_run(cmd, **kw):
+        raise subprocess.TimeoutExpired(cmd, 120)
+    assert "error" in bench.exact_format_reference(args, 1.2e9, run=dead_run)
+    assert "error" in bench.exact_format_reference(args, 1.2e9, run=hung_run)
