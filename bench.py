@@ -198,6 +198,17 @@ def kernel_table(res, reps, V, M, D, T, R=None):
                                                      "f64 below the bf16x3 form's and the f32 MFMA's (tests/test_gpu_split_precision.py)"})
         elif bound == "mfma":
             kernels[name]["pipe"] = "f32 MFMA"
+        if bound == "mfma":
+            # Which roof is the kernel under?  Its arithmetic intensity (algorithmic flops per algorithmic byte) against the ridge point
+            # of the pipe it runs on (pipe peak / HBM peak): below the ridge the HBM roof is the nearer one -- `bound`, `achieved`,
+            # `peak`, `unit`, `frac` are then the HBM figures (= hbm_frac) and the matrix pipe's stay beside them as mfma_*.  (The fused
+            # GRU at h = 100 has 74-99 flop/B: above the six-product bf16 form's ridge of 52, below the three-product f16 form's 104;
+            # the compacted transform's 27 flop/B is below both and above the f32 MFMA's 20.)
+            rec = kernels[name]
+            rec.update({"arithmetic_intensity": work / by, "ridge_point": rec["peak"] * 1e12 / (HBM_PEAK_GBPS * 1e9),
+                        "mfma_achieved": rec["achieved"], "mfma_peak": rec["peak"], "mfma_frac": rec["frac"]})
+            if rec["arithmetic_intensity"] < rec["ridge_point"]:
+                rec.update({"bound": "hbm", "achieved": by / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": rec["hbm_frac"]})
     tot_ms = sum(float(np.sum(res[n])) for n in kernels)
     for name in kernels:
         kernels[name]["time_share"] = float(np.sum(res[name])) / tot_ms if tot_ms else None
@@ -809,7 +820,7 @@ def main():
                 sus = measure_sustained_mfma(pkg, dev)
                 out["roofline"]["sustained_mfma"] = sus
                 products = F16X2_PRODUCTS if kernels[dom]["pipe"].startswith("f16") else SPLIT_PRODUCTS     # (the f16 MFMA issues at the bf16 rate)
-                out["roofline"]["frac_of_sustained_split_pattern"] = kernels[dom]["achieved"] / (sus["split_pattern"]["tflops_bf16"] / products)
+                out["roofline"]["frac_of_sustained_split_pattern"] = kernels[dom]["mfma_achieved"] / (sus["split_pattern"]["tflops_bf16"] / products)
             except Exception as exc:                                   # (a measurement aid must never take the line down)
                 out["roofline"]["sustained_mfma"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if traffic_err:

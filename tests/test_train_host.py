@@ -426,7 +426,9 @@ def test_dropout_seed_is_a_pure_function_of_seed_step_site(pkg):
 def test_bench_prices_kernels_against_the_pipe_of_their_operand_format():
     """bench.py's per-kernel roofline records (round-3 review, weak #1: no `frac` above 1, `peak` = the pipe the kernel runs on): an
     f32-MFMA kernel against 157.3 TF, a six-product bf16 kernel against 2500 / 6, the fused GRU in the two-piece f16 format (round 4)
-    against 2500 / 3 -- the same achieved rate, three different ceilings."""
+    against 2500 / 3 -- the same achieved rate, three different ceilings -- and `bound` = the roof the kernel's arithmetic intensity
+    puts it under: the GRU's 74 flop/B lie above the ridge of the f32 MFMA (20) and of the six-product form (52), below the
+    three-product form's (104), where the HBM roof is the nearer one."""
     import importlib.util, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
@@ -435,14 +437,21 @@ def test_bench_prices_kernels_against_the_pipe_of_their_operand_format():
     V, M, D, T, R = 100000, 200000, 100, 4, 120000
     res = {"gru_fused_gather[nx=1]": [0.070] * 6, "msg_transform_compact": [0.025] * 8}
     want = 6.0 * V * 2 * D * D / 70e-6 / 1e12                         # TF of f32-equivalent work
-    for split, fmt, peak in ((False, 0, 157.3), (True, 3, 2500.0 / 6), (True, 2, 2500.0 / 3)):
+    gbytes = float(2 * V * D * 4 + M * D * 4 + M * 4 + V * 4 + V * T * 4)
+    for split, fmt, peak, gbound in ((False, 0, 157.3, "mfma"), (True, 3, 2500.0 / 6, "mfma"), (True, 2, 2500.0 / 3, "hbm")):
         bench.SPLIT_ACTIVE, bench.GRU_FWD_FORMAT = split, fmt
         k, tot = bench.kernel_table(res, 1, V, M, D, T, R)
         g = k["gru_fused_gather[nx=1]"]
-        assert abs(g["achieved"] - want) < 1e-6 * want and abs(g["peak"] - peak) < 1e-9 and abs(g["frac"] - want / peak) < 1e-9
-        assert g["frac"] <= 1.0 or not split
-        t = k["msg_transform_compact"]                                 # the transform stays on the six-product form
-        assert abs(t["peak"] - (2500.0 / 6 if split else 157.3)) < 1e-9
+        assert abs(g["mfma_achieved"] - want) < 1e-6 * want and abs(g["mfma_peak"] - peak) < 1e-9 and abs(g["mfma_frac"] - want / peak) < 1e-9
+        assert g["mfma_frac"] <= 1.0 or not split
+        assert abs(g["arithmetic_intensity"] - 6.0 * V * 2 * D * D / gbytes) < 1e-9 and abs(g["ridge_point"] - peak * 1e12 / 8e12) < 1e-9
+        assert g["bound"] == gbound
+        if gbound == "hbm":
+            assert g["unit"] == "GB/s" and g["peak"] == 8000.0 and abs(g["achieved"] - gbytes / 70e-6 / 1e9) < 1e-6 and g["frac"] == g["hbm_frac"] < 1.0
+        else:
+            assert g["unit"] == "TFLOP/s" and g["achieved"] == g["mfma_achieved"] and g["frac"] == g["mfma_frac"]
+        t = k["msg_transform_compact"]                                 # the transform stays on the six-product form: 27 flop/B
+        assert abs(t["mfma_peak"] - (2500.0 / 6 if split else 157.3)) < 1e-9 and t["bound"] == ("hbm" if split else "mfma")
         assert abs(tot - (6 * 0.070 + 8 * 0.025)) < 1e-12
     assert g["pipe"].startswith("f16 MFMA") and "f16x2" in g["matrix_path"]
 
