@@ -421,6 +421,63 @@ def exact_format_reference(args, value, run=subprocess.run):
         return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
 
+def compact_line(out, detail_file):
+    """The ONE JSON line of the contract, short enough to survive a captured tail: the contract's fields, `roofline` and `cpu_baseline`
+    trimmed to their numbers, and the headline figures of the other legs.  Everything else (per-kernel tables, secondary configs,
+    sweeps, prose) is in `detail_file` and on stderr."""
+    def pick(d, keys):
+        return None if not isinstance(d, dict) else {k: d[k] for k in keys if k in d}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    line["config"] = pick(cfg, ("workload", "mode", "hidden_size", "num_edge_types", "propagation_steps", "nodes_per_batch",
+                                "messages_per_batch", "graphs_per_batch", "batch_size_param", "hip_streams", "parallelism"))
+    of = out.get("operand_format") or {}
+    line["operand_format"] = pick(of, ("gru_forward", "gru_forward_per_layer", "policy", "every_other_kernel"))
+    if isinstance(of.get("bounds"), dict):
+        line["operand_format"]["proven"] = of["bounds"].get("proven")
+    ex = out.get("exact_bf16x3_gru_reference")
+    line["exact_format_value"] = None if not isinstance(ex, dict) else ex.get("value", ex.get("error"))
+    rf = out.get("roofline")
+    if isinstance(rf, dict):
+        line["roofline"] = pick(rf, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_us",
+                                     "launches_per_step", "time_share", "mfma_achieved", "mfma_peak", "mfma_frac", "mfma_util_pmc",
+                                     "arithmetic_intensity", "ridge_point", "traffic_source"))
+        line["roofline"]["peak_is"] = "HBM3E spec 8 TB/s (measured copy: 6.29 TB/s)" if rf.get("bound") == "hbm" else "dense MFMA peak of the pipe"
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "host_cpus", "max_abs_diff_gpu_vs_cpu"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+    line["speedup_vs_cpu_baseline"] = out.get("speedup_vs_cpu_baseline")
+    line["ms_per_step_one_stream"] = out.get("ms_per_step_one_stream")
+    tr = out.get("train")
+    line["train"] = pick(tr, ("ms_per_step", "value", "allreduce_ms", "allreduce_share", "error"))
+    e2e = out.get("end_to_end_fresh_batch")
+    line["end_to_end_fresh_batch"] = pick(e2e, ("value", "one_stream_value"))
+    sec = out.get("secondary") or {}
+    line["secondary"] = {k: pick(v, ("ms_per_step", "node_state_updates_per_sec", "graphs_per_sec", "error")) for k, v in sec.items()}
+    line["allreduce_us"] = out.get("allreduce_us")
+    line["ranks_seen"] = out.get("ranks_seen")
+    line["graphs_per_sec"] = out.get("graphs_per_sec")
+    line["detail_file"] = detail_file
+    return line
+
+
+def emit(out):
+    """Full record -> gpurun_out/bench_detail.json (best effort) and stderr; the compact line -> stdout, LAST."""
+    detail_file = None
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        detail_file = os.path.join("gpurun_out", "bench_detail.json")
+        with open(os.path.join(ROOT, detail_file), "w") as fh:
+            json.dump(out, fh)
+    except Exception:
+        detail_file = None
+    print("[bench detail] " + json.dumps(out), file=sys.stderr, flush=True)
+    print(json.dumps(compact_line(out, detail_file)), flush=True)
+
+
 def ranks_seen(dist_ctx):
     """Size of the process group the ranks actually formed (1 without one)."""
     return torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
@@ -500,7 +557,7 @@ def main():
     dev = dist_ctx.device
     global SPLIT_ACTIVE, GRU_FWD_FORMAT
     SPLIT_ACTIVE = bool(pkg._lib.load().ggnn_matrix_path_is_split())
-    GRU_FWD_FORMAT = int(pkg._lib.load().ggnn_gru_forward_format())
+    GRU_FWD_FORMAT = int(pkg._lib.load().ggnn_gru_forward_format())      # (the policy's default; replaced below by what the timed steps ran)
 
     # ---- data: enough QM9-shaped molecules for `batches` distinct ~100k-node batches per rank ------
     mols_per_batch = int(100000 / args.mean_nodes * 1.02) + 8
@@ -519,6 +576,9 @@ def main():
     rng = torch.Generator(device="cpu").manual_seed(1234 + rank)
     for f in feeds:   # random dense states: one-hot inputs are sparse and inflate clocks (DVFS)
         f["initial_node_representation"] = (torch.rand(f["initial_node_representation"].shape, generator=rng) * 2 - 1).to(dev)
+        # (uniform in (-1, 1) by construction: the producer's statement of max |h0|, which the operand-format policy of the fused GRU
+        #  -- formats.py -- would otherwise measure once per tensor; it is what makes the two-piece f16 format PROVABLY applicable)
+        pkg.formats.declare_h0_absmax(f, 1.0)
     nodes = [int(f["initial_node_representation"].shape[0]) for f in feeds]
     msgs = [f["message_index"].num_messages for f in feeds]
     graphs = [int(f["num_graphs"]) for f in feeds]
@@ -609,6 +669,16 @@ def main():
     steps_timed = args.steps * repeats
     total_nodes, total_graphs = totals(steps_timed)
     value = total_nodes * n_prop / elapsed
+    # the operand format the model's policy chose for the fused GRU forward of the timed steps (formats.py: per layer, per launch)
+    fmts = list(getattr(model, "last_gru_formats", None) or [])
+    GRU_FWD_FORMAT = (fmts[0] if fmts and all(x == fmts[0] for x in fmts) else 3) if SPLIT_ACTIVE else 0
+    operand_format = {
+        "gru_forward": ("f32 MFMA (GGNN_MATRIX=f32)" if not SPLIT_ACTIVE else
+                        (pkg.formats.NAMES.get(fmts[0]) if fmts and all(x == fmts[0] for x in fmts) else "mixed")),
+        "gru_forward_per_layer": [pkg.formats.NAMES.get(x) for x in fmts], "policy": pkg.formats.policy(),
+        "selected_by": "formats.py, per launch: f16x2 only where |w| <= 255.875 and |a| <= 65504 are PROVEN from max|h0|, the weights' "
+                       "maxima, the tanh cell and mean aggregation; bf16x3 (exact) otherwise",
+        "bounds": getattr(model, "last_gru_format_bounds", None), "every_other_kernel": "bf16x3 (exact)" if SPLIT_ACTIVE else "f32 MFMA"}
 
     # The headline issues consecutive batches on `--streams` HIP streams (one batch's kernel tails are back-filled by the next
     # batch's launches).  The same loop on ONE stream, timed the same way: the difference is that overlap, and it is why the
@@ -627,10 +697,11 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "matrix_path": ((("fused GRU forward: f16x2 split (f32 in, f32 accumulate; every f32 operand as two f16 pieces = 22 of its 24 significand "
                           "bits, 3 f16 MFMA products per f32 product; measured error against f64 below the six-product form's and the f32 "
-                          "MFMA's; GGNN_GRU_FMT=3 selects the bf16x3 kernels); " if GRU_FWD_FORMAT == 2 else "") +
+                          "MFMA's INSIDE the operand range the host policy proves per launch, bf16x3 otherwise; GGNN_GRU_FMT=3: bf16x3 always); " if GRU_FWD_FORMAT == 2 else "") +
                          "bf16x3 split (f32 in, f32 accumulate; every f32 product = 6 exact bf16 MFMA products of 3-way split operands; "
                          "GGNN_MATRIX=f32 selects the f32 MFMA kernels)") if SPLIT_ACTIVE else "f32 MFMA"),
-        "gru_forward_format": {2: "f16x2", 3: "bf16x3", 0: "f32"}.get(GRU_FWD_FORMAT), "ranks_seen": ranks_seen(dist_ctx), "allreduce_us": None,
+        "gru_forward_format": {2: "f16x2", 3: "bf16x3", 0: "f32"}.get(GRU_FWD_FORMAT), "operand_format": operand_format,
+        "ranks_seen": ranks_seen(dist_ctx), "allreduce_us": None,
         "steps_timed": steps_timed, "timed_repeats": repeats, "timed_seconds": elapsed,
         "ms_per_step_one_stream": one_stream,
         "config": {"workload": what + ", full-QM9-sized synthetic batches (configs[%d])" % (3 if world > 1 else 1),
@@ -678,6 +749,7 @@ def main():
 
         def dense_states(fb):
             fb["initial_node_representation"] = pool[:fb["initial_node_representation"].shape[0]]
+            pkg.formats.declare_h0_absmax(fb, 1.0)                                  # (uniform in (-1, 1) by construction, see above)
 
         def fresh_epochs(reps, pipelined):
             """`reps` passes over the dataset, every batch packed fresh.  pipelined: SparseGGNNChemModel.forward_dataset -- batch
@@ -891,7 +963,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
 
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist_ctx.barrier()          # rank 0 was still busy with the roofline leg: leave together
         torch.distributed.destroy_process_group()

@@ -10,7 +10,7 @@ import importlib as _importlib
 import sys as _sys
 
 _ALIAS = "ggnn_amd"
-_SUBMODULES = ["_lib", "data", "utils", "ops", "data_device", "autograd", "backward", "train", "train_native", "chem_model", "sparse_model",
+_SUBMODULES = ["_lib", "data", "utils", "ops", "formats", "data_device", "autograd", "backward", "train", "train_native", "chem_model", "sparse_model",
                "dense_model", "parallel", "build"]
 
 _sys.modules.setdefault(_ALIAS, _sys.modules[__name__])

@@ -13,13 +13,14 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GGNN_LIB_VARIANT=<tag>: load libggnn_hip_<tag>.so (kernel experiments built by tools/variant_lib.sh; never set in production)
 LIB_PATH = os.path.join(_HERE, "libggnn_hip%s.so" % ("_" + os.environ["GGNN_LIB_VARIANT"] if os.environ.get("GGNN_LIB_VARIANT") else ""))
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/ggnn_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "ggnn_abi_version": (c_int, []),
     "ggnn_matrix_path_is_split": (c_int, []),
     "ggnn_gru_forward_format": (c_int, []),
+    "ggnn_absmax_f32": (c_int, [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_void_p]),
     "ggnn_last_error": (c_char_p, []),
     "ggnn_csr_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "ggnn_build_target_csr": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int, c_int64, c_void_p, c_void_p,
@@ -59,15 +60,15 @@ SYMBOLS = {
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "ggnn_gru_is_fused": (c_int, [c_int]),
     "ggnn_gru_packed_bytes": (c_size_t, [c_int, c_int]),
-    "ggnn_gru_pack_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ggnn_gru_pack_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_gru_packed_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                    c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_edge_weights_pack_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_gru_packed_gather_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                           c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                           c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_gru_packed_gather_train_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                 c_int, c_int, c_int, c_void_p, c_void_p]),
+                                                 c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_gru_gates_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_void_p]),
     "ggnn_gru_candidate_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -76,8 +77,8 @@ SYMBOLS = {
     "ggnn_sparse_propagate_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int64),
                                           c_void_p, c_int, c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                           POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
-                                          POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int, c_int,
-                                          POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+                                          POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32),
+                                          c_int, c_int, POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
     "ggnn_gru_bwd_stage1_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ggnn_gru_bwd_stage2_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -125,13 +126,13 @@ SYMBOLS = {
     "ggnn_pack_batch_tables": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
     "ggnn_sparse_train_prepare_f32": (c_int, [c_int, c_int, c_int, POINTER(c_int32), POINTER(c_void_p), c_float, POINTER(c_uint64),
-                                              POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
-                                              POINTER(c_void_p), c_void_p]),
+                                              POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p), POINTER(c_void_p),
+                                              POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
     "ggnn_sparse_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int64, c_int]),
     "ggnn_sparse_train_forward_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p,
                                               c_int, c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_void_p),
-                                              POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int, c_void_p, c_size_t,
-                                              POINTER(c_int64), c_void_p]),
+                                              POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int, c_void_p,
+                                              c_size_t, POINTER(c_int64), c_void_p]),
     "ggnn_sparse_train_backward_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, POINTER(c_int64), c_void_p, c_int, c_int,
                                                POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int,

@@ -25,14 +25,15 @@ _PACKED = ops.PackedWeights()
 
 def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tensor, edge_weights: torch.Tensor,
                      edge_biases: Optional[torch.Tensor], use_avg: bool, residual_states: Sequence[torch.Tensor],
-                     cell, activation: str, need_grad: bool = False, ew_mask=None) -> torch.Tensor:
+                     cell, activation: str, need_grad: bool = False, ew_mask=None, gru_fmt: int = ops.GRU_FMT_EXACT) -> torch.Tensor:
     """ew_mask (training only): (keep_prob, seed) of the layer's edge-weight dropout (chem_tensorflow_sparse.py:91) -- `edge_weights`
-    is then the VARIABLE (viewed [T,D,D]); the step multiplies by the masked weights and routes the gradient back through the mask."""
+    is then the VARIABLE (viewed [T,D,D]); the step multiplies by the masked weights and routes the gradient back through the mask.
+    gru_fmt: operand format of the fused GRU forward of this layer (formats.py; the model proves the range or passes BF16X3)."""
     if need_grad:
         from .backward import PropagationStepFn
         return PropagationStepFn.apply(h, index, nin, edge_weights, edge_biases, use_avg, activation,
                                        cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias,
-                                       ew_mask, *residual_states)
+                                       ew_mask, int(gru_fmt), *residual_states)
     assert ew_mask is None
     D = h.shape[1]
     # same choice as the native driver (ggnn_propagate.hip): segment sum gathered inside the GRU kernel
@@ -56,13 +57,13 @@ def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tens
         else:
             incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
     if gather_in_gru:
-        packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, len(residual_states) + 1, D)
+        packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, len(residual_states) + 1, D, gru_fmt)
         return ops.gru_packed_gather(list(residual_states), h, packed, cell.gates_bias, cell.candidate_bias, Hrows, index,
-                                     gather_row, nin if use_avg else None, activation)
+                                     gather_row, nin if use_avg else None, activation, fmt=gru_fmt)
     xs = list(residual_states) + [incoming]
     if ops.gru_is_fused(D) and nx <= ops.GRU_FUSED_MAX_INPUTS:     # (more inputs: the generic two-launch GRU below)
-        packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, len(xs), D)
-        return ops.gru_packed(xs, h, packed, cell.gates_bias, cell.candidate_bias, activation)
+        packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, len(xs), D, gru_fmt)
+        return ops.gru_packed(xs, h, packed, cell.gates_bias, cell.candidate_bias, activation, fmt=gru_fmt)
     return ops.gru(xs, h, cell.gates_kernel, cell.gates_bias, cell.candidate_kernel, cell.candidate_bias, activation)
 
 

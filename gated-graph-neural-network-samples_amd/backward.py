@@ -234,7 +234,7 @@ _MASKED = _MaskedWeights()
 
 class PropagationStepFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, index, nin, edge_weights, edge_biases, use_avg, activation, Wg, bg, Wc, bc, ew_mask, *residuals):
+    def forward(ctx, h, index, nin, edge_weights, edge_biases, use_avg, activation, Wg, bg, Wc, bc, ew_mask, gru_fmt, *residuals):
         h = h.contiguous()
         D = h.shape[1]
         ctx.comp = None
@@ -259,8 +259,8 @@ class PropagationStepFn(torch.autograd.Function):
                 # the segment sum gathered inside the GRU launch, as on the inference path; the kernel also writes r, u, c and the
                 # gathered segment, which the backward pass needs (one launch and one pass over `incoming` less per timestep)
                 save = {}
-                h_new = ops.gru_packed_gather(list(residuals), h, _PACKED.gru(Wg, Wc, len(residuals) + 1, D), bg, bc, H, index,
-                                              comp.gather_row, nin if use_avg else None, activation, save=save)
+                h_new = ops.gru_packed_gather(list(residuals), h, _PACKED.gru(Wg, Wc, len(residuals) + 1, D, gru_fmt), bg, bc, H, index,
+                                              comp.gather_row, nin if use_avg else None, activation, save=save, fmt=gru_fmt)
                 del H
                 ctx.index, ctx.use_avg, ctx.activation, ctx.has_bias = index, use_avg, activation.lower(), False
                 ctx.save_for_backward(h, nin, edge_weights, Wg, Wc, save["incoming"], save["r"], save["u"], save["c"], *residuals)
@@ -272,7 +272,7 @@ class PropagationStepFn(torch.autograd.Function):
             incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
         del H
         save = {}
-        h_new = ops.gru(list(residuals) + [incoming], h, Wg, bg, Wc, bc, activation, save=save)
+        h_new = ops.gru(list(residuals) + [incoming], h, Wg, bg, Wc, bc, activation, save=save, fmt=gru_fmt)
         ctx.index, ctx.use_avg, ctx.activation, ctx.has_bias = index, use_avg, activation.lower(), edge_biases is not None
         ctx.save_for_backward(h, nin, edge_weights, Wg, Wc, incoming, save["r"], save["u"], save["c"], *residuals)
         return h_new
@@ -334,7 +334,7 @@ class PropagationStepFn(torch.autograd.Function):
                 masked, ptr0 = dW, ctx.var_ptrs[0]
                 _on_side_stream([masked], lambda: _SINK.add(ptr0, tW, masked))
                 dW = None
-        return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, None, *d_res)
+        return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, None, None, *d_res)
 
 
 def transform_backward(index, comp, h, W, dinc, dh, message_weights=None, sink=None):
@@ -458,4 +458,4 @@ def _backward_dense_form(ctx, g):
     dW = _tn(h, dH).view(D, T, D).transpose(0, 1)
     if ctx.ew_mask is not None:
         dW = ops.dropout(dW.contiguous(), float(ctx.ew_mask[0]), int(ctx.ew_mask[1]))
-    return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, None, *d_res)
+    return (dh, None, None, dW, dbias, None, None, dWg, dbg, dWc, dbc, None, None, *d_res)

@@ -235,6 +235,7 @@ class ChemModel(object):
         self.placeholders.update(batch_data)
 
     DERIVED_PLACEHOLDERS = {'adjacency_lists': ('message_index',), 'adjacency_matrix': ('_sparse_form',),
+                            'initial_node_representation': ('h0_absmax', '_h0_absmax_of'),      # (formats.h0_absmax: measured once per fed h0)
                             'graph_nodes_list': ('graph_ptr', 'graph_nodes_sorted', 'graph_ids', 'node_uid')}
 
     def make_train_step(self):

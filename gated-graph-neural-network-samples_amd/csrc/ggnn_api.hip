@@ -37,10 +37,11 @@ bool split_matrix_path() {
     return v;
 }
 
-// Operand format of the fused GRU forward in split form (ggnn_split.hpp): 2 = two f16 pieces, three products (default since round
-// 4); GGNN_GRU_FMT=3 = the exact three-piece bf16 split, six products.  Read once: the packed GRU images are in the format.
+// Process default of the HOST policy that chooses the fused GRU forward's operand format per launch (formats.py; ggnn_split.hpp):
+// 2 = "auto": two f16 pieces / three products where the operand bounds are proven, the exact bf16 x 3 split otherwise (default);
+// GGNN_GRU_FMT=3 = always bf16 x 3.  The kernels never read this: the format is an argument of every pack / launch entry point.
 int gru_fwd_fmt() {
-    static const int v = [] { const char* e = getenv("GGNN_GRU_FMT"); return (e && atoi(e) == 3) ? 3 : 2; }();
+    static const int v = [] { const char* e = getenv("GGNN_GRU_FMT"); return (e && (atoi(e) == 3 || e[0] == 'e' || e[0] == 'b')) ? 3 : 2; }();
     return v;
 }
 

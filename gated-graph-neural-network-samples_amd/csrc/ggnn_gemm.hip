@@ -184,20 +184,28 @@ extern "C" size_t ggnn_gru_packed_bytes(int D, int nx) {
     return (size_t)gru_pack_floats(D, nx) * sizeof(float);
 }
 
-extern "C" int ggnn_gru_pack_weights_f32(const float* Wg, const float* Wc, int nx, int D, float* packed,
+static int gru_fmt_check(int gru_fmt) {
+    GGNN_CHECK_ARG(gru_fmt == 0 || gru_fmt == GGNN_GRU_FMT_F16X2 || gru_fmt == GGNN_GRU_FMT_BF16X3,
+                   "gru_fmt %d is not a GGNN_GRU_FMT_* value", gru_fmt);
+    return GGNN_OK;
+}
+
+extern "C" int ggnn_gru_pack_weights_f32(const float* Wg, const float* Wc, int nx, int D, int gru_fmt, float* packed,
                                          ggnn_stream_t stream) {
+    if (int rc = gru_fmt_check(gru_fmt)) return rc;
     GGNN_CHECK_ARG(nx >= 1 && nx <= 3, "nx %d outside 1..3", nx);
     if (!gru_fused_supported(D)) return fail(GGNN_E_UNSUPPORTED, "no fused GRU (hence no packed weights) for hidden size %d", D);
     GGNN_CHECK_ARG(Wg && Wc && packed && aligned16(packed), "null or misaligned pointer");
     GruFusedArgs a{};
-    a.nx = nx; a.Wg = Wg; a.Wc = Wc; a.h = nullptr;          // h == nullptr: pack only
+    a.nx = nx; a.Wg = Wg; a.Wc = Wc; a.h = nullptr; a.fmt = gru_fmt;          // h == nullptr: pack only
     return gru_fused_dispatch(a, D, packed, (hipStream_t)stream);
 }
 
 extern "C" int ggnn_gru_packed_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
                                    const float* bc, float* h_out, float* save_r, float* save_u, float* save_c, int V, int D,
-                                   int act, int32_t* tile_counter, ggnn_stream_t stream) {
+                                   int act, int gru_fmt, int32_t* tile_counter, ggnn_stream_t stream) {
     if (int rc = gru_args_check(x_segs, nx, h, V, D)) return rc;
+    if (int rc = gru_fmt_check(gru_fmt)) return rc;
     GGNN_CHECK_ARG(nx <= kGruFusedMaxNx, "nx %d: the fused GRU takes at most %d input segments (ggnn_gru_f32 takes more)", nx, kGruFusedMaxNx);
     GGNN_CHECK_ARG(act == GGNN_ACT_TANH || act == GGNN_ACT_RELU, "unknown activation %d", act);
     if (!gru_fused_supported(D)) return fail(GGNN_E_UNSUPPORTED, "no fused GRU for hidden size %d", D);
@@ -207,7 +215,7 @@ extern "C" int ggnn_gru_packed_f32(const float* const* x_segs, int nx, const flo
     GruFusedArgs a{};
     for (int s = 0; s < nx; ++s) { a.x[s] = x_segs[s]; GGNN_CHECK_ARG(x_segs[s] != h_out, "h_out aliases an input"); }
     a.nx = nx; a.h = h; a.Wg = nullptr; a.Wc = nullptr; a.bg = bg; a.bc = bc; a.h_out = h_out;
-    a.save_r = save_r; a.save_u = save_u; a.save_c = save_c; a.V = V; a.act = act; a.tickets = tile_counter;
+    a.save_r = save_r; a.save_u = save_u; a.save_c = save_c; a.V = V; a.act = act; a.tickets = tile_counter; a.fmt = gru_fmt;
     return gru_fused_dispatch(a, D, const_cast<float*>(packed), (hipStream_t)stream);
 }
 
@@ -307,9 +315,9 @@ extern "C" int ggnn_bwd_dx_f32(const float* dY, int ldy, int nseg_y, const float
 extern "C" int ggnn_gru_packed_gather_f32(const float* const* x_segs, int nx, const float* h, const float* packed,
                                           const float* bg, const float* bc, float* h_out, const float* Hrows,
                                           const int32_t* row_ptr, const int32_t* gather_row, const float* nin, int T, int use_avg,
-                                          int V, int D, int act, int32_t* tile_counter, ggnn_stream_t stream) {
+                                          int V, int D, int act, int gru_fmt, int32_t* tile_counter, ggnn_stream_t stream) {
     return ggnn_gru_packed_gather_train_f32(x_segs, nx, h, packed, bg, bc, h_out, Hrows, row_ptr, gather_row, nin, T, use_avg,
-                                            nullptr, nullptr, nullptr, nullptr, V, D, act, tile_counter, stream);
+                                            nullptr, nullptr, nullptr, nullptr, V, D, act, gru_fmt, tile_counter, stream);
 }
 
 // ... the training form: also writes r, u, c and the gathered segment `incoming` (all four or none) for the backward pass
@@ -317,8 +325,9 @@ extern "C" int ggnn_gru_packed_gather_train_f32(const float* const* x_segs, int 
                                                 const float* bg, const float* bc, float* h_out, const float* Hrows,
                                                 const int32_t* row_ptr, const int32_t* gather_row, const float* nin, int T,
                                                 int use_avg, float* save_r, float* save_u, float* save_c, float* save_incoming,
-                                                int V, int D, int act, int32_t* tile_counter, ggnn_stream_t stream) {
+                                                int V, int D, int act, int gru_fmt, int32_t* tile_counter, ggnn_stream_t stream) {
     if (int rc = check_common(V, D)) return rc;
+    if (int rc = gru_fmt_check(gru_fmt)) return rc;
     const bool save = save_r || save_u || save_c || save_incoming;
     GGNN_CHECK_ARG(!save || (save_r && save_u && save_c && save_incoming && aligned16(save_r) && aligned16(save_u) && aligned16(save_c) &&
                              aligned16(save_incoming)), "save_r / save_u / save_c / save_incoming must be given together, 16-byte aligned");
@@ -339,7 +348,7 @@ extern "C" int ggnn_gru_packed_gather_train_f32(const float* const* x_segs, int 
     a.nx = nx; a.h = h; a.bg = bg; a.bc = bc; a.h_out = h_out; a.V = V; a.act = act;
     a.save_r = save_r; a.save_u = save_u; a.save_c = save_c; a.save_x = save_incoming;
     a.g_H = Hrows; a.g_row_ptr = row_ptr; a.g_idx = gather_row; a.g_nin = nin; a.g_T = T; a.g_use_avg = use_avg;
-    a.tickets = tile_counter;
+    a.tickets = tile_counter; a.fmt = gru_fmt;
     return gru_fused_dispatch(a, D, const_cast<float*>(packed), (hipStream_t)stream);
 }
 

@@ -217,6 +217,7 @@ struct GruFusedArgs {
     // gather-fused variant: the last x segment = segment sum of g_H rows (NULL: plain loads from x[nx-1])
     const float* g_H; const int* g_row_ptr; const int* g_idx; const float* g_nin; int g_T; int g_use_avg;
     int* tickets;          // NULL: static tile split; else a device int32, 0 at launch: tiles are handed out dynamically
+    int fmt;               // operand format of the split-form products and of `packed` (GGNN_GRU_FMT_*; 0 = BF16X3), per launch
     int dbg;               // ablation bitmask from GGNN_GRU_DBG (0 in production)
     unsigned long long* tdbg;   // per-stage s_memtime stamps (GGNN_GRU_TPTR, debug only)
 };

@@ -57,11 +57,14 @@ int gru_split_launch(int D, int nx, bool save, bool gather, const GruFusedArgs& 
 #ifndef GGNN_GRU_TU_SPLIT
 int gru_pack_floats(int D, int nx) {
     if (gru_panel_supported(D)) return gru_panel_pack_floats(D, nx);
-    const bool sp = split_matrix_path(), f2 = gru_fwd_fmt() == kSplitF16x2;     // (the forward's images: its own operand format)
+    // (the operand format is chosen per pack / launch: the buffer is sized for the larger, three-plane bf16 images)
+    const bool sp = split_matrix_path();
+    static_assert(ImgCfg<100, true>::IMG >= ImgCfg<100, true, kSplitF16x2>::IMG && ImgCfg<64, true>::IMG >= ImgCfg<64, true, kSplitF16x2>::IMG &&
+                  ImgCfg<32, true>::IMG >= ImgCfg<32, true, kSplitF16x2>::IMG, "bf16x3 images are the larger ones");
     switch (D) {
-        case 100: return 3 * (nx + 1) * (sp ? (f2 ? ImgCfg<100, true, kSplitF16x2>::IMG : ImgCfg<100, true>::IMG) : ImgCfg<100, false>::IMG);
-        case 64: return 3 * (nx + 1) * (sp ? (f2 ? ImgCfg<64, true, kSplitF16x2>::IMG : ImgCfg<64, true>::IMG) : ImgCfg<64, false>::IMG);
-        case 32: return 3 * (nx + 1) * (sp ? (f2 ? ImgCfg<32, true, kSplitF16x2>::IMG : ImgCfg<32, true>::IMG) : ImgCfg<32, false>::IMG);
+        case 100: return 3 * (nx + 1) * (sp ? ImgCfg<100, true>::IMG : ImgCfg<100, false>::IMG);
+        case 64: return 3 * (nx + 1) * (sp ? ImgCfg<64, true>::IMG : ImgCfg<64, false>::IMG);
+        case 32: return 3 * (nx + 1) * (sp ? ImgCfg<32, true>::IMG : ImgCfg<32, false>::IMG);
         default: return 0;
     }
 }
@@ -139,9 +142,9 @@ __device__ __forceinline__ void frag_add(Frag<D>& f, const Frag<D>& t) {
 //      splits and DMA all switched off -- 18 stage barriers each waiting out one HBM round trip -- 63 us with only the MFMAs
 //      added, 63 us with only the side work added, 88 us with both: the three parts ran one after the other.
 // Same products in the same order per accumulator in every form: bit-identical results.
-// FMT (SPLIT kernels): operand format of the split products and of the images (ggnn_split.hpp) -- kSplitF16x2 by default since round 4
-// (two f16 pieces, three products: half the MFMAs, 48 KiB images), kSplitBf16x3 behind GGNN_GRU_FMT=3; f32 kernels: kSplitBf16x3
-// stands for "accumulators unscaled".
+// FMT (SPLIT kernels): operand format of the split products and of the images (ggnn_split.hpp) -- kSplitF16x2 (two f16 pieces, three
+// products: half the MFMAs, 48 KiB images; valid inside its operand range) or the exact kSplitBf16x3, chosen per launch by
+// GruFusedArgs::fmt; f32 kernels: kSplitBf16x3 stands for "accumulators unscaled".
 template <int D, int NX, int NW, bool SAVE, bool GATHER, bool SPLIT, bool SAVEX = SAVE, int FORM = 0, int FMT = kSplitBf16x3>
 __global__ __launch_bounds__(NW * 64, FORM == 1 ? 2 : 1) void ggnn_gru_fused_kernel(GruFusedArgs a, const float* __restrict__ packed) {
     static_assert(SPLIT || FMT == kSplitBf16x3, "the f32-MFMA kernels have no operand format");
@@ -865,10 +868,11 @@ int gru_split_launch(int D, int nx, bool save, bool gather, const GruFusedArgs& 
 #endif
     return launch_gru_fused_m<100, GGNN_PROBE_NX, 8, GGNN_PROBE_SAVE, true, true, GGNN_PROBE_SAVEX, 0, GGNN_PROBE_FMT>(a, packed, st);
 #else
+    const bool f2 = gru_launch_fmt(a.fmt) == kSplitF16x2;            // (per launch: GruFusedArgs::fmt)
     switch (D) {
-        case 100: return gru_fwd_fmt() == kSplitF16x2 ? split_launch_d<100, kSplitF16x2>(nx, gather, a, packed, st) : split_launch_d<100, kSplitBf16x3>(nx, gather, a, packed, st);
-        case 64: return gru_fwd_fmt() == kSplitF16x2 ? split_launch_d<64, kSplitF16x2>(nx, gather, a, packed, st) : split_launch_d<64, kSplitBf16x3>(nx, gather, a, packed, st);
-        case 32: return gru_fwd_fmt() == kSplitF16x2 ? split_launch_d<32, kSplitF16x2>(nx, gather, a, packed, st) : split_launch_d<32, kSplitBf16x3>(nx, gather, a, packed, st);
+        case 100: return f2 ? split_launch_d<100, kSplitF16x2>(nx, gather, a, packed, st) : split_launch_d<100, kSplitBf16x3>(nx, gather, a, packed, st);
+        case 64: return f2 ? split_launch_d<64, kSplitF16x2>(nx, gather, a, packed, st) : split_launch_d<64, kSplitBf16x3>(nx, gather, a, packed, st);
+        case 32: return f2 ? split_launch_d<32, kSplitF16x2>(nx, gather, a, packed, st) : split_launch_d<32, kSplitBf16x3>(nx, gather, a, packed, st);
         default: return fail(GGNN_E_UNSUPPORTED, "no split-form fused GRU for hidden size %d", D);
     }
 #endif

@@ -729,7 +729,7 @@ static int launch_gru_panel_m(const GruFusedArgs& a_in, float* packed, hipStream
 
 template <int D, int NX, bool SAVE>
 static int launch_gru_panel(const GruFusedArgs& a, float* packed, hipStream_t st) {
-    if (split_matrix_path()) return gru_fwd_fmt() == kSplitF16x2 ? launch_gru_panel_m<D, NX, SAVE, true, kSplitF16x2>(a, packed, st)
+    if (split_matrix_path()) return gru_launch_fmt(a.fmt) == kSplitF16x2 ? launch_gru_panel_m<D, NX, SAVE, true, kSplitF16x2>(a, packed, st)
                                                                  : launch_gru_panel_m<D, NX, SAVE, true>(a, packed, st);
     return launch_gru_panel_m<D, NX, SAVE, false>(a, packed, st);
 }
@@ -752,10 +752,12 @@ int gru_panel_supported(int D) { return D == 128 || D == 192 || D == 256; }
 
 int gru_panel_pack_floats(int D, int nx) {
     if (!gru_panel_supported(D)) return 0;
-    const bool f2 = gru_fwd_fmt() == kSplitF16x2;
+    // (sized for either operand format of the split form: the larger of the two image sizes)
+    auto mx = [](int a, int b) { return a > b ? a : b; };
     const int img = !split_matrix_path() ? D * 64
-                  : f2 ? (D == 128 ? PanelGruSplitCfg<128, kSplitF16x2>::IMG : (D == 192 ? PanelGruSplitCfg<192, kSplitF16x2>::IMG : PanelGruSplitCfg<256, kSplitF16x2>::IMG))
-                       : (D == 128 ? PanelGruSplitCfg<128>::IMG : (D == 192 ? PanelGruSplitCfg<192>::IMG : PanelGruSplitCfg<256>::IMG));
+                  : (D == 128 ? mx(PanelGruSplitCfg<128>::IMG, PanelGruSplitCfg<128, kSplitF16x2>::IMG)
+                     : (D == 192 ? mx(PanelGruSplitCfg<192>::IMG, PanelGruSplitCfg<192, kSplitF16x2>::IMG)
+                                 : mx(PanelGruSplitCfg<256>::IMG, PanelGruSplitCfg<256, kSplitF16x2>::IMG)));
     return panel_gru_images(D, nx) * img;
 }
 

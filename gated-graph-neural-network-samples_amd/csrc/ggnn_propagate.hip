@@ -35,7 +35,7 @@ extern "C" int ggnn_sparse_propagate_f32(
         int num_layers, const int32_t* layer_timesteps, const int32_t* res_ptr, const int32_t* res_idx,
         const float* const* edge_w, const float* const* edge_packed, const float* const* edge_bias,
         const float* const* Wg, const float* const* bg, const float* const* Wc, const float* const* bc,
-        const float* const* gru_packed, int act, int fuse_gather,
+        const float* const* gru_packed, const int32_t* gru_fmt, int act, int fuse_gather,
         float* const* layer_out, void* ws, size_t ws_bytes, ggnn_stream_t stream) {
     GGNN_CHECK_ARG(V >= 0 && D > 0 && D % 4 == 0 && T > 0, "bad sizes V=%d D=%d T=%d", V, D, T);
     GGNN_CHECK_ARG(num_layers > 0 && layer_timesteps && res_ptr && layer_out, "bad layer description");
@@ -87,6 +87,7 @@ extern "C" int ggnn_sparse_propagate_f32(
         const int steps = layer_timesteps[l];
         const float* bias_l = edge_bias ? edge_bias[l] : nullptr;
         const bool packed_gru = gru_packed && gru_packed[l] && ggnn_gru_is_fused(D) && nx <= 3;
+        const int fmt_l = gru_fmt ? gru_fmt[l] : GGNN_GRU_FMT_BF16X3;      // the format gru_packed[l] was packed in
         // fuse_gather = the largest number of concatenated GRU inputs (residuals + messages) for which the segment sum
         // is gathered inside the GRU kernel; 0 = never.
         const bool gather_in_gru = fuse_gather > 0 && nx <= fuse_gather && packed_gru && ggnn_gru_is_fused(D) == 1 && bias_l == nullptr &&
@@ -110,13 +111,13 @@ extern "C" int ggnn_sparse_propagate_f32(
             ++step_no;
             if (gather_in_gru) {
                 rc = ggnn_gru_packed_gather_f32(xs, nx, cur, gru_packed[l], bg[l], bc[l], out, H, row_ptr, gather_row, nin, T,
-                                                use_avg, V, D, act, counter, stream);
+                                                use_avg, V, D, act, fmt_l, counter, stream);
             } else {
                 rc = ggnn_gather_segment_sum_f32(H, row_ptr, gather_row, nin, bias_l, use_avg, incoming, V, D, T, stream);
                 if (rc) return rc;
                 if (packed_gru)
                     rc = ggnn_gru_packed_f32(xs, nx, cur, gru_packed[l], bg[l], bc[l], out, nullptr, nullptr, nullptr, V, D, act,
-                                             counter, stream);
+                                             fmt_l, counter, stream);
                 else {
                     GGNN_CHECK_ARG(Wg && Wc && Wg[l] && Wc[l], "layer %d needs raw GRU weights (no packed images for it)", l);
                     rc = ggnn_gru_f32(xs, nx, cur, Wg[l], bg[l], Wc[l], bc[l], out, gru_ws, gru_ws_bytes, nullptr, nullptr,

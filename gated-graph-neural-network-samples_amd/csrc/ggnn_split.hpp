@@ -53,7 +53,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 //     saturated operand instead of Inf - Inf = NaN; the gates are saturated long before).  The MFMA keeps f16 subnormal inputs
 //     (tools/f16_mfma_denorm_probe.hip).  Accumulators hold 2^8 x the sums: the remainder weights (f32 MFMA) are packed x 2^8 and
 //     the consumer's epilogue scales by acc_scale, folded into a constant it multiplies by anyway.
-//     Used by the fused GRU FORWARD (kernel, both packers); GGNN_GRU_FMT=3 selects its bf16x3 instantiations (process-wide).
+//     Used by the fused GRU FORWARD (kernel, both packers) when the CALL asks for it (GruFusedArgs::fmt == GGNN_GRU_FMT_F16X2, the
+//     `gru_fmt` argument of the C entry points, round 5): the operand range above is the caller's precondition -- the host layer
+//     (formats.py) proves it from max|h0| and the weights' maxima or selects the exact format.
 constexpr int kSplitBf16x3 = 3, kSplitF16x2 = 2;
 template <int FMT> struct SplitFmt;
 template <> struct SplitFmt<kSplitBf16x3> {
@@ -74,8 +76,10 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 #define GGNN_F16_SPLIT_ASM 1
 #endif
 
-// Format of the fused GRU forward's images and products (read once; GGNN_GRU_FMT=3: bf16x3)
+// Process default of the HOST policy (GGNN_GRU_FMT; 2 = f16x2 where proven safe, 3 = always bf16x3).  Kernels take the format per launch.
 int gru_fwd_fmt();
+// the format a launch runs in: anything but GGNN_GRU_FMT_F16X2 is the exact bf16x3 split
+inline int gru_launch_fmt(int fmt) { return fmt == kSplitF16x2 ? kSplitF16x2 : kSplitBf16x3; }
 
 // Process-wide choice of the matrix path of the fused kernels (read once): GGNN_MATRIX=f32 selects the f32 MFMA forms.
 bool split_matrix_path();

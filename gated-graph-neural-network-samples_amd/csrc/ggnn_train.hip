@@ -116,12 +116,14 @@ struct PrepArgs {
     float* edge_img[kPrepMaxLayers]; float* edge_img_t[kPrepMaxLayers]; float* gru_img[kPrepMaxLayers]; float* gru_bwd_img[kPrepMaxLayers];
     unsigned long long seed[kPrepMaxLayers];
     int nx[kPrepMaxLayers];
+    int gru_fmt[kPrepMaxLayers];       // operand format of layer l's GRU FORWARD images (kSplitF16x2 / kSplitBf16x3)
     int T; float keep;
 };
 
-// SF: every image in split form (ggnn_split.hpp); GF: operand format of the GRU FORWARD's images (gru_fwd_fmt(); the edge-weight
-// images -- whose transposes multiply gradients of any magnitude -- and the GRU backward's stay in the exact bf16 x 3 format)
-template <int D, bool SF, int GF = kSplitBf16x3>
+// SF: every image in split form (ggnn_split.hpp).  The GRU FORWARD's images of layer l are in the operand format a.gru_fmt[l] (the
+// caller's per-layer choice, see include/ggnn_hip.h "Operand formats"); the edge-weight images -- whose transposes multiply
+// gradients of any magnitude -- and the GRU backward's are always in the exact bf16 x 3 format.
+template <int D, bool SF>
 __global__ __launch_bounds__(256) void train_prepare_kernel(PrepArgs a) {
     using C = StageCfg<D>;
     const int l = blockIdx.z, i = blockIdx.y;
@@ -160,9 +162,12 @@ __global__ __launch_bounds__(256) void train_prepare_kernel(PrepArgs a) {
         }
     } else if (i < 2 * T + ng) {
         const int ci = i - 2 * T;
-        float* img = a.gru_img[l] + (size_t)ci * ImgCfg<D, SF, GF>::IMG;
-        if constexpr (SF) gru_fwd_image_pack_split<D, GF>(a.Wg[l], a.Wc[l], a.nx[l], ci, img, first, stride);
-        else gru_fwd_image_pack<D>(a.Wg[l], a.Wc[l], a.nx[l], ci, img, first, stride);
+        if constexpr (SF) {
+            if (a.gru_fmt[l] == kSplitF16x2)         // (block-uniform)
+                gru_fwd_image_pack_split<D, kSplitF16x2>(a.Wg[l], a.Wc[l], a.nx[l], ci, a.gru_img[l] + (size_t)ci * ImgCfg<D, true, kSplitF16x2>::IMG, first, stride);
+            else
+                gru_fwd_image_pack_split<D, kSplitBf16x3>(a.Wg[l], a.Wc[l], a.nx[l], ci, a.gru_img[l] + (size_t)ci * ImgCfg<D, true>::IMG, first, stride);
+        } else gru_fwd_image_pack<D>(a.Wg[l], a.Wc[l], a.nx[l], ci, a.gru_img[l] + (size_t)ci * ImgCfg<D, false>::IMG, first, stride);
     } else if (i < 2 * T + 2 * ng) {
         const int bi = i - 2 * T - ng;
         float* img = a.gru_bwd_img[l] + (size_t)bi * ImgCfg<D, SF>::IMG;
@@ -206,8 +211,8 @@ using namespace ggnn;
 
 extern "C" int ggnn_sparse_train_prepare_f32(int num_layers, int T, int D, const int32_t* nx, const float* const* edge_w, float keep_prob,
                                              const uint64_t* seeds, const float* const* Wg, const float* const* Wc,
-                                             float* const* edge_packed, float* const* edge_packed_t, float* const* gru_packed,
-                                             float* const* gru_bwd_packed, ggnn_stream_t stream) {
+                                             const int32_t* gru_fmt, float* const* edge_packed, float* const* edge_packed_t,
+                                             float* const* gru_packed, float* const* gru_bwd_packed, ggnn_stream_t stream) {
     GGNN_CHECK_ARG(num_layers > 0 && num_layers <= kPrepMaxLayers, "num_layers %d outside 1..%d", num_layers, kPrepMaxLayers);
     GGNN_CHECK_ARG(T > 0 && T <= 64 && nx && edge_w && Wg && Wc && edge_packed && edge_packed_t && gru_packed && gru_bwd_packed, "bad arguments");
     GGNN_CHECK_ARG(keep_prob > 0.0f && keep_prob <= 1.0f && (keep_prob >= 1.0f || seeds), "keep_prob %g outside (0, 1] or seeds missing", (double)keep_prob);
@@ -222,14 +227,14 @@ extern "C" int ggnn_sparse_train_prepare_f32(int num_layers, int T, int D, const
         a.edge_w[l] = edge_w[l]; a.Wg[l] = Wg[l]; a.Wc[l] = Wc[l];
         a.edge_img[l] = edge_packed[l]; a.edge_img_t[l] = edge_packed_t[l]; a.gru_img[l] = gru_packed[l]; a.gru_bwd_img[l] = gru_bwd_packed[l];
         a.seed[l] = seeds ? seeds[l] : 0ULL; a.nx[l] = nx[l];
+        a.gru_fmt[l] = gru_launch_fmt(gru_fmt ? gru_fmt[l] : kSplitBf16x3);
         const int images = 2 * T + 6 * (nx[l] + 1);
         if (images > max_images) max_images = images;
     }
     const dim3 grid(8, max_images, num_layers);
     hipStream_t st = (hipStream_t)stream;
     const bool sf = split_matrix_path();
-#define GGNN_PREP(DD) if (sf && gru_fwd_fmt() == kSplitF16x2) hipLaunchKernelGGL((train_prepare_kernel<DD, true, kSplitF16x2>), grid, dim3(256), 0, st, a); \
-                      else if (sf) hipLaunchKernelGGL((train_prepare_kernel<DD, true>), grid, dim3(256), 0, st, a); \
+#define GGNN_PREP(DD) if (sf) hipLaunchKernelGGL((train_prepare_kernel<DD, true>), grid, dim3(256), 0, st, a); \
                       else hipLaunchKernelGGL((train_prepare_kernel<DD, false>), grid, dim3(256), 0, st, a);
     switch (D) {
         case 100: GGNN_PREP(100) break;
@@ -250,8 +255,8 @@ extern "C" int ggnn_sparse_train_forward_f32(
         const float* h0, int V, int D, int T, const int32_t* row_ptr, const int32_t* gather_row_c, const int32_t* pair_node,
         const int64_t* type_row_off, const float* nin, int use_avg, int num_layers, const int32_t* layer_timesteps,
         const int32_t* res_ptr, const int32_t* res_idx, const float* const* edge_packed, const float* const* bg,
-        const float* const* bc, const float* const* gru_packed, int act, void* ws, size_t ws_bytes, int64_t* final_state_offset,
-        ggnn_stream_t stream) {
+        const float* const* bc, const float* const* gru_packed, const int32_t* gru_fmt, int act, void* ws, size_t ws_bytes,
+        int64_t* final_state_offset, ggnn_stream_t stream) {
     GGNN_CHECK_ARG(V > 0 && D > 0 && D % 4 == 0 && T > 0, "bad sizes V=%d D=%d T=%d", V, D, T);
     GGNN_CHECK_ARG(h0 && row_ptr && gather_row_c && pair_node && type_row_off && ws && final_state_offset, "null pointer");
     GGNN_CHECK_ARG(edge_packed && bg && bc && gru_packed, "weights missing");
@@ -290,7 +295,8 @@ extern "C" int ggnn_sparse_train_forward_f32(
             float* out = buf(L.state, k + 1);
             if (int rc = ggnn_gru_packed_gather_train_f32(xs, nx, cur, gru_packed[l], bg[l], bc[l], out, Hc, row_ptr, gather_row_c,
                                                           use_avg ? nin : nullptr, T, use_avg ? 1 : 0, buf(L.r, k), buf(L.u, k),
-                                                          buf(L.c, k), buf(L.inc, k), V, D, act, counters + k, stream)) return rc;
+                                                          buf(L.c, k), buf(L.inc, k), V, D, act,
+                                                          gru_fmt ? gru_fmt[l] : GGNN_GRU_FMT_BF16X3, counters + k, stream)) return rc;
             cur = out;
         }
         states[l + 1] = cur;

@@ -19,7 +19,7 @@ from typing import Any, Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, formats, ops
 from .data import MoleculeSet, batch_boundaries, epoch_boundaries
 
 # Batches gathered from dataset-level tables (ggnn_assemble_batch) instead of being sorted and scanned one by one;
@@ -36,6 +36,8 @@ class DeviceMoleculeSet:
         self.device = torch.device(device)
         self.node_ptr = t(ms.node_ptr, torch.int64)
         self.node_feat = t(ms.node_feat, torch.float32)
+        # max |h0| of any batch of this dataset (formats.py: operand bound of the two-piece f16 GRU format; NaN stays NaN)
+        self.node_feat_absmax = float(np.abs(np.asarray(ms.node_feat, dtype=np.float32)).max()) if np.size(ms.node_feat) else 0.0
         self.bond_ptr = t(ms.bond_ptr, torch.int64)
         self.bonds = t(ms.bonds, torch.int64)                  # (src_local, bond_type 1..F, dst_local)
         self.targets = t(ms.targets, torch.float32)
@@ -336,12 +338,12 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
                                                                                  task_ids)
         tv, tm = labels if labels is not None else labels_torch()
         adjacency = [index.adj[type_off[t]:type_off[t + 1]] for t in range(T)]
-        return {
+        return formats.declare_h0_absmax({
             'initial_node_representation': h0, 'adjacency_lists': adjacency, 'num_incoming_edges_per_type': nin,
             'graph_nodes_list': gnl, 'graph_ptr': graph_ptr, 'target_values': tv, 'target_mask': tm, 'num_graphs': G,
             'message_index': ops.prepare_message_index(index, hidden_size, compact, training), 'graph_nodes_sorted': True,
             'graph_ids': gids,
-        }
+        }, dms.node_feat_absmax)
     tv, tm = labels_torch()
     n = dms.node_ptr[gids + 1] - dms.node_ptr[gids]
     offs = torch.cumsum(n, 0) - n                                                   # node offset of each graph (:297)
@@ -380,7 +382,7 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
     for t in range(T):
         adjacency.append(adj[o:o + counts[t]])                                      # :343-348 (empty types: [0,2])
         o += counts[t]
-    return {
+    return formats.declare_h0_absmax({
         'initial_node_representation': h0,
         'adjacency_lists': adjacency,
         'num_incoming_edges_per_type': nin,
@@ -394,7 +396,7 @@ def pack_batch_device(dms: DeviceMoleculeSet, graph_ids: np.ndarray, num_edge_ty
                                                    type_row_off=type_row_off),
         'graph_nodes_sorted': True,
         'graph_ids': gids,
-    }
+    }, dms.node_feat_absmax)
 
 
 def pack_batches_device(dms: DeviceMoleculeSet, params: dict, num_edge_types: int, order: Optional[np.ndarray] = None,

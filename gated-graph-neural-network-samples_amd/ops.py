@@ -27,6 +27,7 @@ from ._lib import check
 ACT_IDS = {"tanh": 0, "relu": 1}
 GRU_FUSED_MAX_INPUTS = 3        # input segments (residual inputs + aggregated messages) of the single-launch GRU kernels
 GRU_MAX_INPUTS = 7              # ... of the generic two-launch GRU (8 K segments of the generic GEMM: 7 inputs + h)
+GRU_FMT_F16X2, GRU_FMT_EXACT = 2, 3   # operand formats of the fused GRU forward (GGNN_GRU_FMT_F16X2 / _BF16X3; policy: formats.py)
 
 
 def kernel_width(D: int) -> int:
@@ -256,11 +257,20 @@ def gru_workspace(V: int, D: int, device) -> torch.Tensor:
 
 def gru(x_segs: Sequence[torch.Tensor], h: torch.Tensor, Wg: torch.Tensor, bg: torch.Tensor, Wc: torch.Tensor,
         bc: torch.Tensor, activation: str = "tanh", out: Optional[torch.Tensor] = None,
-        ws: Optional[torch.Tensor] = None, save: Optional[dict] = None, two_launch: bool = False) -> torch.Tensor:
+        ws: Optional[torch.Tensor] = None, save: Optional[dict] = None, two_launch: bool = False,
+        fmt: Optional[int] = None) -> torch.Tensor:
     """TF-1.3 GRUCell on x = concat(x_segs) without materialising the concat
     (chem_tensorflow_sparse.py:211-216).  save: optional dict receiving 'r','u','c' [V,D] tensors.
-    two_launch=True forces the un-fused gates + candidate kernels (the path large D takes)."""
+    two_launch=True forces the un-fused gates + candidate kernels (the path large D takes).
+    On raw weights the products run in the exact BF16X3 operand format (ggnn_gru_f32); fmt = formats.F16X2 packs the weights
+    in the two-piece f16 format and runs the fused launch in it (the CALLER vouches for the operand range, see formats.py)."""
     lib = _lib.load()
+    if fmt is not None and int(fmt) != GRU_FMT_EXACT and not two_launch and lib.ggnn_gru_is_fused(h.shape[1]) \
+            and len(x_segs) <= GRU_FUSED_MAX_INPUTS:
+        _req(Wg, torch.float32, "Wg"); _req(Wc, torch.float32, "Wc")
+        packed = torch.empty(lib.ggnn_gru_packed_bytes(h.shape[1], len(x_segs)) // 4, dtype=torch.float32, device=h.device)
+        check(lib.ggnn_gru_pack_weights_f32(_ptr(Wg), _ptr(Wc), len(x_segs), h.shape[1], int(fmt), _ptr(packed), _stream()))
+        return gru_packed(x_segs, h, packed, bg, bc, activation, out=out, fmt=int(fmt), save=save)
     _req(h, torch.float32, "h")
     V, D = h.shape
     nx = len(x_segs)
@@ -882,14 +892,16 @@ class PackedWeights:
         table[key] = ([weakref.ref(cls._base(t)) for t in tensors], [t._version for t in tensors], packed, ready, stream_id)
         return packed
 
-    def gru(self, Wg: torch.Tensor, Wc: torch.Tensor, nx: int, D: int) -> torch.Tensor:
+    def gru(self, Wg: torch.Tensor, Wc: torch.Tensor, nx: int, D: int, fmt: int = GRU_FMT_EXACT) -> torch.Tensor:
+        """The fused GRU forward's stage images in the operand format `fmt` (formats.F16X2 / BF16X3; the launch that consumes
+        them must be given the same format)."""
         lib = _lib.load()
-        key = self._key(Wg, Wc)
+        key = self._key(Wg, Wc) + (int(fmt),)
         hit = self._lookup(self._gru, key, (Wg, Wc))
         if hit is None:
             _req(Wg, torch.float32, "Wg"); _req(Wc, torch.float32, "Wc")
             packed = torch.empty(lib.ggnn_gru_packed_bytes(D, nx) // 4, dtype=torch.float32, device=Wg.device)
-            check(lib.ggnn_gru_pack_weights_f32(_ptr(Wg), _ptr(Wc), nx, D, _ptr(packed), _stream()))
+            check(lib.ggnn_gru_pack_weights_f32(_ptr(Wg), _ptr(Wc), nx, D, int(fmt), _ptr(packed), _stream()))
             hit = self._store(self._gru, key, (Wg, Wc), packed)
         return hit
 
@@ -952,9 +964,10 @@ class PackedWeights:
 
 def gru_packed(x_segs: Sequence[torch.Tensor], h: torch.Tensor, packed: torch.Tensor, bg: torch.Tensor, bc: torch.Tensor,
                activation: str = "tanh", out: Optional[torch.Tensor] = None,
-               tile_counter: Optional[torch.Tensor] = None) -> torch.Tensor:
+               tile_counter: Optional[torch.Tensor] = None, fmt: int = GRU_FMT_EXACT, save: Optional[dict] = None) -> torch.Tensor:
     """ops.gru with pre-packed weight images (fused hidden sizes only).  tile_counter: optional int32 device tensor
-    holding 0 (one element, consumed by this launch): dynamic tile hand-out, see include/ggnn_hip.h."""
+    holding 0 (one element, consumed by this launch): dynamic tile hand-out, see include/ggnn_hip.h.
+    fmt: the operand format `packed` was packed in (PackedWeights.gru).  save: optional dict receiving 'r','u','c'."""
     lib = _lib.load()
     _req(h, torch.float32, "h")
     V, D = h.shape
@@ -969,8 +982,14 @@ def gru_packed(x_segs: Sequence[torch.Tensor], h: torch.Tensor, packed: torch.Te
     if out is None:
         out = torch.empty_like(h)
     segs = (ctypes.c_void_p * nx)(*[x.data_ptr() for x in x_segs])
+    sr = su = sc = None
+    if save is not None:
+        sr = save["r"] = torch.empty_like(h)
+        su = save["u"] = torch.empty_like(h)
+        sc = save["c"] = torch.empty_like(h)
     _launch("gru_fused[nx=%d]" % nx, lambda: lib.ggnn_gru_packed_f32(
-        segs, nx, _ptr(h), _ptr(packed), _ptr(bg), _ptr(bc), _ptr(out), None, None, None, V, D, act, _ptr(tile_counter), _stream()))
+        segs, nx, _ptr(h), _ptr(packed), _ptr(bg), _ptr(bc), _ptr(out), _ptr(sr), _ptr(su), _ptr(sc), V, D, act, int(fmt),
+        _ptr(tile_counter), _stream()))
     return out
 
 
@@ -1001,9 +1020,10 @@ def sparse_propagate(h0: torch.Tensor, index: MessageIndex, comp: Optional[Compa
                      edge_bias: Optional[Sequence[Optional[torch.Tensor]]],
                      Wg: Sequence[torch.Tensor], bg: Sequence[torch.Tensor], Wc: Sequence[torch.Tensor], bc: Sequence[torch.Tensor],
                      gru_packed: Optional[Sequence[torch.Tensor]], activation: str,
-                     fuse_gather: Optional[bool] = None) -> List[torch.Tensor]:
+                     fuse_gather: Optional[bool] = None, gru_fmt: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
     """chem_tensorflow_sparse.py:131-218 in ONE native call (ggnn_sparse_propagate_f32): returns
     node_states_per_layer[1:], the last entry being the final node representations.
+    gru_fmt: per layer, the operand format gru_packed[l] was packed in (None: BF16X3 for every layer).
     fuse_gather (default FUSE_GATHER): gather the segment sum inside the GRU kernel where the layer allows it."""
     if fuse_gather is None:
         fuse_gather = FUSE_GATHER
@@ -1030,14 +1050,16 @@ def sparse_propagate(h0: torch.Tensor, index: MessageIndex, comp: Optional[Compa
         _ptr(h0), V, D, T, _ptr(index.row_ptr), _ptr(gather), None if comp is None else _ptr(comp.pair_node), off,
         _ptr(nin), 1 if use_avg else 0, L, i32([int(x) for x in layer_timesteps]), i32(res_ptr), i32(res_idx),
         _ptr_array(edge_w), _ptr_array(edge_packed), _ptr_array(edge_bias), _ptr_array(Wg), _ptr_array(bg), _ptr_array(Wc),
-        _ptr_array(bc), _ptr_array(gru_packed), act, int(fuse_gather), _ptr_array(outs), _ptr(ws), ws_bytes, _stream()))
+        _ptr_array(bc), _ptr_array(gru_packed), None if gru_fmt is None else i32([int(f) for f in gru_fmt]), act, int(fuse_gather),
+        _ptr_array(outs), _ptr(ws), ws_bytes, _stream()))
     return outs
 
 
 def gru_packed_gather(residual_segs: Sequence[torch.Tensor], h: torch.Tensor, packed: torch.Tensor, bg: torch.Tensor,
                       bc: torch.Tensor, H: torch.Tensor, index: MessageIndex, gather_row: Optional[torch.Tensor],
                       num_incoming_edges_per_type: Optional[torch.Tensor], activation: str = "tanh",
-                      tile_counter: Optional[torch.Tensor] = None, save: Optional[dict] = None) -> torch.Tensor:
+                      tile_counter: Optional[torch.Tensor] = None, save: Optional[dict] = None,
+                      fmt: int = GRU_FMT_EXACT) -> torch.Tensor:
     """chem_tensorflow_sparse.py:198-216 in one launch (ggnn_gru_packed_gather_f32): the GRU whose last input
     segment -- the aggregated messages -- is summed from the transformed rows `H` inside the kernel.
     save (dict): filled with r, u, c and the gathered segment "incoming" (training: what the backward pass needs)."""
@@ -1057,11 +1079,11 @@ def gru_packed_gather(residual_segs: Sequence[torch.Tensor], h: torch.Tensor, pa
         _launch("gru_fused_gather_train[nx=%d]" % (len(residual_segs) + 1), lambda: lib.ggnn_gru_packed_gather_train_f32(
             segs, len(residual_segs) + 1, _ptr(h), _ptr(packed), _ptr(bg), _ptr(bc), _ptr(out), _ptr(H), _ptr(index.row_ptr),
             _ptr(gather), None if nin is None else _ptr(nin), index.num_edge_types, 0 if nin is None else 1, _ptr(save["r"]),
-            _ptr(save["u"]), _ptr(save["c"]), _ptr(save["incoming"]), V, D, act, _ptr(tile_counter), _stream()))
+            _ptr(save["u"]), _ptr(save["c"]), _ptr(save["incoming"]), V, D, act, int(fmt), _ptr(tile_counter), _stream()))
         return out
     _launch("gru_fused_gather[nx=%d]" % (len(residual_segs) + 1), lambda: lib.ggnn_gru_packed_gather_f32(
         segs, len(residual_segs) + 1, _ptr(h), _ptr(packed), _ptr(bg), _ptr(bc), _ptr(out), _ptr(H), _ptr(index.row_ptr),
-        _ptr(gather), None if nin is None else _ptr(nin), index.num_edge_types, 0 if nin is None else 1, V, D, act,
+        _ptr(gather), None if nin is None else _ptr(nin), index.num_edge_types, 0 if nin is None else 1, V, D, act, int(fmt),
         _ptr(tile_counter), _stream()))
     return out
 

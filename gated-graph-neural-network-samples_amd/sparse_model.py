@@ -217,6 +217,55 @@ class SparseGGNNChemModel(ChemModel):
             self._padded_cache[layer_idx] = (versions, out)
         return out
 
+    # ---- operand format of the fused GRU forward, per layer (formats.py) ------------------------------------------------
+    def gru_formats(self, h0: torch.Tensor, ew_keep: float = 1.0, st_keep: float = 1.0, training: bool = False) -> List[int]:
+        """formats.F16X2 for the layers whose GRU operands are PROVABLY inside the two-piece f16 format's range for this batch and
+        these weights, formats.BF16X3 (exact, every input) for the others -- the reference multiplies in plain f32
+        (chem_tensorflow_sparse.py:215-216).  See formats.py for the bounds; the decision of the last call is kept in
+        self.last_gru_formats / self.last_gru_format_bounds (bench.py and the tests report it)."""
+        from . import formats
+        p = self.params
+        L = len(p['layer_timesteps'])
+        pol = formats.policy()
+        if not formats.split_path() or pol == "exact":
+            fm = [formats.BF16X3] * L
+        elif pol == "force2":
+            fm = [formats.F16X2] * L
+        elif (p['graph_rnn_activation'].lower() != 'tanh' or not p['use_edge_msg_avg_aggregation'] or self.cell_type != 'gru'
+              or p['use_propagation_attention']):
+            fm = [formats.BF16X3] * L            # no bound on the states (ReLU), on the aggregate (sum), or not the plain GRU path
+            self.last_gru_format_bounds = {"proven": False, "why": "relu cell / sum aggregation / variant cell: no operand bound"}
+        else:
+            per_layer = []
+            for l in range(L):
+                cell = self.gnn_weights.rnn_cells[l]
+                ts = [self._edge_weight_vars[l], cell.gates_kernel, cell.candidate_kernel]
+                if p['use_edge_bias']:
+                    ts.append(self.gnn_weights.edge_biases[l])
+                per_layer.append(ts)
+            flat = [t for ts in per_layer for t in ts]
+            if training and getattr(self, "optimizer", None) is not None and getattr(self.optimizer, "fused", False):
+                if getattr(self, "_train_weight_bounds", None) is None:
+                    self._train_weight_bounds = formats.TrainingWeightBounds()
+                maxima = self._train_weight_bounds.get(flat, self.optimizer)
+            else:
+                maxima = formats.weight_absmax(flat)
+            h0_max = formats.h0_absmax(self.placeholders)            # (of the FED tensor; `h0` may be its zero-padded copy)
+            S = formats.state_bound(h0_max, 'tanh', int(sum(p['layer_timesteps'])), st_keep)
+            fm, i, inc_max, w_max = [], 0, 0.0, 0.0
+            for l in range(L):
+                ew, wg, wc = maxima[i], maxima[i + 1], maxima[i + 2]
+                eb = maxima[i + 3] if p['use_edge_bias'] else 0.0
+                i += len(per_layer[l])
+                inc = formats.incoming_bound(S, p['hidden_size'], ew, eb, True, ew_keep)
+                fm.append(formats.layer_format(S, inc, formats.nanmax(wg, wc)))
+                inc_max, w_max = formats.nanmax(inc_max, inc), formats.nanmax(w_max, wg, wc)
+            self.last_gru_format_bounds = {"proven": all(f == formats.F16X2 for f in fm), "h0_absmax": h0_max, "state_bound": S,
+                                           "incoming_bound": inc_max, "gru_weight_absmax": w_max,
+                                           "limits": {"activation": formats.MAX_ACTIVATION, "weight": formats.MAX_WEIGHT}}
+        self.last_gru_formats = fm
+        return fm
+
     # ---- the hot path -----------------------------------------------------------------------------------
     def compute_final_node_representations(self) -> torch.Tensor:
         """chem_tensorflow_sparse.py:117-218."""
@@ -239,10 +288,11 @@ class SparseGGNNChemModel(ChemModel):
         st_keep = float(ph.get('graph_state_keep_prob', 1.0))
         need_grad = self.training and torch.is_grad_enabled()
         variant = self.params['use_propagation_attention'] or self.cell_type != 'gru'
+        gru_fmts = self.gru_formats(h0, ew_keep, st_keep, need_grad)
 
         if not variant and not need_grad and ew_keep >= 1.0 and st_keep >= 1.0 and ops._timing is None:
             # inference: the whole layer/timestep loop below runs inside ONE native call
-            final = self._propagate_native(h0, index, nin, use_avg, act)
+            final = self._propagate_native(h0, index, nin, use_avg, act, gru_fmts)
             return final if Dk == h_dim else final[:, :h_dim].contiguous()
 
         for (layer_idx, num_timesteps) in enumerate(self.params['layer_timesteps']):   # :131
@@ -284,7 +334,7 @@ class SparseGGNNChemModel(ChemModel):
                 else:
                     cur = propagation_step(cur, index, nin, edge_weights, edge_biases, use_avg,
                                            layer_residual_states, cell, act, need_grad,
-                                           ew_mask if (need_grad and plain_step) else None)
+                                           ew_mask if (need_grad and plain_step) else None, gru_fmt=gru_fmts[layer_idx])
                 if st_keep < 1.0:                                                  # :113-114 DropoutWrapper(state)
                     cur = tf_dropout(cur, st_keep, self.dropout_seed('state', layer_idx, step), self._node_uid())
             node_states_per_layer.append(cur)
@@ -320,7 +370,7 @@ class SparseGGNNChemModel(ChemModel):
             return ops.rnn(xs, h, cell.kernel, cell.bias, act)
         return ops.cudnn_gru(xs, h, *cell)
 
-    def _propagate_native(self, h0, index, nin, use_avg, act) -> torch.Tensor:
+    def _propagate_native(self, h0, index, nin, use_avg, act, gru_fmts) -> torch.Tensor:
         """compute_final_node_representations through ggnn_sparse_propagate_f32 (the loop of :131-218 in C):
         source-compacted transform and pre-packed weight images where the hidden size supports them."""
         from .autograd import USE_COMPACT_TRANSFORM, _PACKED
@@ -340,13 +390,13 @@ class SparseGGNNChemModel(ChemModel):
         gru_packed = None
         if ops.gru_is_fused(D):
             # (layers with more inputs than the single-launch kernels take run the generic GRU on the raw weights)
-            gru_packed = [_PACKED.gru(c.gates_kernel, c.candidate_kernel, len(residuals[l]) + 1, D)
+            gru_packed = [_PACKED.gru(c.gates_kernel, c.candidate_kernel, len(residuals[l]) + 1, D, gru_fmts[l])
                           if len(residuals[l]) + 1 <= ops.GRU_FUSED_MAX_INPUTS else None for l, c in enumerate(cells)]
         outs = ops.sparse_propagate(h0, index, comp, nin, use_avg, self.params['layer_timesteps'], residuals,
                                     edge_w, edge_packed, edge_bias,
                                     [c.gates_kernel for c in cells], [c.gates_bias for c in cells],
                                     [c.candidate_kernel for c in cells], [c.candidate_bias for c in cells],
-                                    gru_packed, act)
+                                    gru_packed, act, gru_fmt=gru_fmts)
         return outs[-1]
 
     def _graph_nodes_sorted(self) -> bool:
@@ -449,7 +499,8 @@ class SparseGGNNChemModel(ChemModel):
         h0 = torch.zeros((V, b.hidden_size), dtype=torch.float32, device=dev)     # :300-302 zero-pad to D
         if V:
             h0[:, :A] = t(b.node_features)
-        return {
+        from . import formats
+        return formats.declare_h0_absmax({
             'initial_node_representation': h0,
             'adjacency_lists': adjacency,
             'num_incoming_edges_per_type': t(b.num_incoming_edges_per_type),
@@ -461,7 +512,7 @@ class SparseGGNNChemModel(ChemModel):
             'message_index': ops.prepare_message_index(ops.build_message_index(adjacency, V), b.hidden_size, compact),
             'graph_nodes_sorted': True,
             'graph_ids': None if b.extras.get("graph_ids") is None else t(np.asarray(b.extras["graph_ids"], dtype=np.int64)),
-        }
+        }, float(np.abs(b.node_features).max()) if b.node_features.size else 0.0)
 
     def prepare_resident_data(self, data: Any, is_training: bool) -> None:
         """Upload the dataset and build the dataset-level tables of the device packer on the CURRENT stream (run_epoch calls this

@@ -141,6 +141,10 @@ def native_train_step(model, batch_data: Dict[str, Any]) -> torch.Tensor:
         cells = model.gnn_weights.rnn_cells
         masks = [(ew_keep, model.dropout_seed('edge_weights', l)) for l in range(L)] if ew_keep < 1.0 else []
         nxs = [len(residuals[l]) + 1 for l in range(L)]
+        # operand format of each layer's GRU forward: two-piece f16 only where this step's operands are provably in its range
+        # (formats.py: max|h0|, the weights' maxima tracked across optimizer steps, tanh cell, mean aggregation), else exact bf16x3
+        gru_fmts = model.gru_formats(h0, ew_keep, 1.0, training=True)
+        fm = _i32(gru_fmts)
         if L <= 16 and USE_FUSED_PREPARE:
             # all ~120 images of the step in ONE launch, the weight-dropout mask applied on the fly (ggnn_sparse_train_prepare_f32)
             imgs = getattr(model, "_native_images", None)
@@ -155,7 +159,7 @@ def native_train_step(model, batch_data: Dict[str, Any]) -> torch.Tensor:
             seeds = (ctypes.c_uint64 * L)(*[m[1] for m in masks]) if masks else None
             check(lib.ggnn_sparse_train_prepare_f32(
                 L, T, D, _i32(nxs), _ptrs(model._edge_weight_vars), ew_keep if masks else 1.0, seeds,
-                _ptrs([c.gates_kernel for c in cells]), _ptrs([c.candidate_kernel for c in cells]), _ptrs(edge_packed),
+                _ptrs([c.gates_kernel for c in cells]), _ptrs([c.candidate_kernel for c in cells]), fm, _ptrs(edge_packed),
                 _ptrs(edge_packed_t), _ptrs(gru_packed), _ptrs(gru_bwd_packed), st.cuda_stream))
         else:
             edge_packed, edge_packed_t, gru_packed, gru_bwd_packed = [], [], [], []
@@ -165,7 +169,7 @@ def native_train_step(model, batch_data: Dict[str, Any]) -> torch.Tensor:
                     W = backward._MASKED.get(W, masks[l][0], masks[l][1])
                 edge_packed.append(_PACKED.edge(W))
                 edge_packed_t.append(_PACKED.edge(backward._TRANSPOSED.get(W, (1, 2))))
-                gru_packed.append(_PACKED.gru(cells[l].gates_kernel, cells[l].candidate_kernel, nxs[l], D))
+                gru_packed.append(_PACKED.gru(cells[l].gates_kernel, cells[l].candidate_kernel, nxs[l], D, gru_fmts[l]))
                 gru_bwd_packed.append(_PACKED.gru_bwd(cells[l].gates_kernel, cells[l].candidate_kernel, nxs[l], D))
 
         # ---- forward ------------------------------------------------------------------------------------------------------
@@ -177,7 +181,7 @@ def native_train_step(model, batch_data: Dict[str, Any]) -> torch.Tensor:
         final_off = ctypes.c_int64(0)
         check(lib.ggnn_sparse_train_forward_f32(
             h0.data_ptr(), V, D, T, index.row_ptr.data_ptr(), comp.gather_row.data_ptr(), comp.pair_node.data_ptr(), tro,
-            nin.data_ptr(), 1 if use_avg else 0, L, lt, rp, ri, _ptrs(edge_packed), bg, bc, _ptrs(gru_packed), act,
+            nin.data_ptr(), 1 if use_avg else 0, L, lt, rp, ri, _ptrs(edge_packed), bg, bc, _ptrs(gru_packed), fm, act,
             ws.data_ptr(), ws.numel(), ctypes.byref(final_off), st.cuda_stream))
         off = int(final_off.value)
         final = ws[off:off + V * D * 4].view(torch.float32).view(V, D)

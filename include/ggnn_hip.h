@@ -31,8 +31,12 @@ extern "C" {
 
 /* Bumped whenever the argument contract of an EXISTING entry point changes (not when symbols are added).
  *   2: ggnn_assemble_batch takes 11 output pointers (slot heads), ggnn_sparse_propagate_f32 / ggnn_gru_packed_gather_f32 take the
- *      slot-head table (round 3 changed these while the version still said 1; a caller built against that header must rebuild). */
-#define GGNN_ABI_VERSION 2
+ *      slot-head table (round 3 changed these while the version still said 1; a caller built against that header must rebuild).
+ *   3: (round 5) the operand format of the fused GRU forward is an ARGUMENT of every entry point that packs or consumes its weight
+ *      images (`gru_fmt`, GGNN_GRU_FMT_*; see "Operand formats" below) instead of a process-wide environment setting:
+ *      ggnn_gru_pack_weights_f32, ggnn_gru_packed_f32, ggnn_gru_packed_gather[_train]_f32, ggnn_sparse_propagate_f32,
+ *      ggnn_sparse_train_prepare_f32, ggnn_sparse_train_forward_f32.  ggnn_gru_packed_bytes sizes a buffer for either format. */
+#define GGNN_ABI_VERSION 3
 
 #define GGNN_OK 0
 #define GGNN_E_INVALID (-1)      /* bad argument (null pointer, negative size, misalignment) */
@@ -54,16 +58,35 @@ const char* ggnn_last_error(void);
  *   0 (GGNN_MATRIX=f32)  the f32 MFMA forms (v_mfma_f32_16x16x4_f32).
  * Packed weight images (ggnn_*_pack_*) are in the format of the mode and sized by the *_bytes functions. */
 int ggnn_matrix_path_is_split(void);
-/* Operand format of the fused GRU FORWARD (ggnn_gru_*_f32 at hidden sizes 32 / 64 / 100) under the split matrix path, fixed per
- * process (environment GGNN_GRU_FMT, read at the first call):
- *   2 (default, round 4)  every f32 operand as TWO f16 pieces (round to nearest: 22 of its 24 significand bits), THREE f16 MFMA
- *                         products per f32 product, f32 accumulation; weights packed x 2^8 (|w| < 255, saturated beyond),
- *                         activations clamped to +-65504.  Not exact, but measured against f64 its error is below the six-product
- *                         form's and the f32 MFMA's (tests/test_gpu_split_precision.py); half the MFMAs, 48 KiB stage images;
- *   3 (GGNN_GRU_FMT=3)    the exact three-piece bf16 split, six products (the format of every other split-form kernel);
- *   0                     the matrix path is not split (GGNN_MATRIX=f32).
- * ggnn_gru_packed_bytes / ggnn_gru_pack_weights_f32 / ggnn_sparse_train_prepare_f32 size and write the GRU images in this format. */
+/* Operand formats of the fused GRU FORWARD (ggnn_gru_*_f32 at hidden sizes 32 / 64 / 100 / 128 / 192 / 256) under the split matrix
+ * path.  Chosen PER CALL by the `gru_fmt` argument of the entry points that pack or consume the GRU's weight images; an image must be
+ * consumed in the format it was packed in.
+ *   GGNN_GRU_FMT_BF16X3 (3; 0 means the same)  the EXACT three-piece bf16 split, six products per f32 product (the format of every
+ *       other split-form kernel): f32 semantics for every finite f32 input, Inf / NaN stay non-finite.  Valid on ALL inputs.
+ *   GGNN_GRU_FMT_F16X2 (2)  every f32 operand as TWO f16 pieces (round to nearest: 22 of its 24 significand bits), THREE f16 MFMA
+ *       products per f32 product, f32 accumulation; weights packed x 2^8, activations unscaled.  Half the MFMAs, 48 KiB stage
+ *       images.  Measured against f64 its error is below the six-product form's and the f32 MFMA's (tests/test_gpu_split_precision.py)
+ *       -- INSIDE ITS OPERAND RANGE, which is a PRECONDITION the caller must establish:
+ *           every GRU weight   |w| <= GGNN_F16X2_MAX_WEIGHT      (255.875 = 65504 / 2^8: beyond, the packed piece saturates)
+ *           every activation   |a| <= GGNN_F16X2_MAX_ACTIVATION  (65504: x segments, h, hence r*h; beyond, the operand is clamped)
+ *           and all of them finite.
+ *       Outside it the result is NOT the f32 result (saturated / clamped operands, NaN not propagated).  ggnn_absmax_f32 below
+ *       computes the maxima a caller needs; the Python host layer (formats.py) selects this format only when the bounds are PROVEN
+ *       from max|h0|, the weights' maxima, the cell's activation and the aggregation -- and BF16X3 otherwise.
+ * Under GGNN_MATRIX=f32 the argument is ignored (f32 MFMA kernels, f32 images).
+ * ggnn_gru_forward_format(): the process default of the HOST POLICY (environment GGNN_GRU_FMT, read at the first call): 2 = "auto"
+ * (F16X2 where the bounds are proven; the default), 3 = always BF16X3, 0 = the matrix path is not split.  The library's kernels do
+ * not read it. */
+#define GGNN_GRU_FMT_F16X2 2
+#define GGNN_GRU_FMT_BF16X3 3
+#define GGNN_F16X2_MAX_WEIGHT 255.875f
+#define GGNN_F16X2_MAX_ACTIVATION 65504.0f
 int ggnn_gru_forward_format(void);
+/* out[i] = max |x| over the numel[i] floats at ptrs[i], i < n, in one launch per 32 tensors -- the operand-range check of
+ * GGNN_GRU_FMT_F16X2.  A NaN anywhere in tensor i gives out[i] = NaN, an Inf gives Inf (the maximum is taken over the bit patterns
+ * of |x|), so a host test `out[i] <= bound` fails on every non-finite input.  ptrs / numel: HOST arrays of n DEVICE pointers /
+ * element counts (numel[i] == 0 gives 0); out: DEVICE [n] (read it back after synchronising the stream). */
+int ggnn_absmax_f32(const float* const* ptrs, const int64_t* numel, int n, float* out, ggnn_stream_t stream);
 
 /* ---- (a-1) message index prep: chem_tensorflow_sparse.py:120-129 -------------------------------
  * The reference concatenates the per-type target columns into message_targets[M] (type ascending,
@@ -255,18 +278,20 @@ int ggnn_gru_is_fused(int D);
  * transform consume k-interleaved LDS stage images of their weights; ggnn_gru_f32 /
  * ggnn_msg_transform_compact_f32 build them in a small pre-pass on every call, the functions below let the
  * caller build them once per weight version:
- *   ggnn_gru_pack_weights_f32   Wg [(nx+1)D,2D], Wc [(nx+1)D,D] -> packed (ggnn_gru_packed_bytes(D,nx) bytes)
- *   ggnn_gru_packed_f32         == ggnn_gru_f32 with the packed images instead of Wg / Wc (fused sizes only)
+ *   ggnn_gru_pack_weights_f32   Wg [(nx+1)D,2D], Wc [(nx+1)D,D] -> packed (ggnn_gru_packed_bytes(D,nx) bytes: enough for either
+ *                               operand format) in the format gru_fmt (GGNN_GRU_FMT_*, see "Operand formats" at the top)
+ *   ggnn_gru_packed_f32         == ggnn_gru_f32 with the packed images instead of Wg / Wc (fused sizes only); gru_fmt = the format
+ *                               the images were packed in.  (ggnn_gru_f32 itself, on raw weights, always multiplies in BF16X3.)
  *   ggnn_edge_weights_pack_f32  W [T,D,D] -> packed (ggnn_msg_transform_compact_workspace_bytes(D,T) bytes);
  *                               then call ggnn_msg_transform_compact_f32 with W = NULL and ws = packed.
  * tile_counter (ggnn_gru_packed_f32, ggnn_gru_packed_gather_f32): NULL, or a DEVICE int32 that is 0 when the launch
  * starts (the kernel leaves it non-zero).  With a counter the 16-row tiles are handed to the workgroups dynamically:
  * same results, but the launch no longer stretches when other streams hold part of the GPU while it starts. */
 size_t ggnn_gru_packed_bytes(int D, int nx);
-int ggnn_gru_pack_weights_f32(const float* Wg, const float* Wc, int nx, int D, float* packed, ggnn_stream_t stream);
+int ggnn_gru_pack_weights_f32(const float* Wg, const float* Wc, int nx, int D, int gru_fmt, float* packed, ggnn_stream_t stream);
 int ggnn_gru_packed_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
                         const float* bc, float* h_out, float* save_r, float* save_u, float* save_c, int V, int D, int act,
-                        int32_t* tile_counter, ggnn_stream_t stream);
+                        int gru_fmt, int32_t* tile_counter, ggnn_stream_t stream);
 int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* packed, ggnn_stream_t stream);
 
 /* GRU with the segment sum fused in (chem_tensorflow_sparse.py:198-216 in one launch, no edge bias): the
@@ -278,14 +303,14 @@ int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* packed, ggnn
 int ggnn_gru_packed_gather_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
                                const float* bc, float* h_out, const float* Hrows, const int32_t* row_ptr,
                                const int32_t* gather_row, const float* nin, int T, int use_avg, int V, int D, int act,
-                               int32_t* tile_counter, ggnn_stream_t stream);
+                               int gru_fmt, int32_t* tile_counter, ggnn_stream_t stream);
 /* The training form of the same launch: r, u, c [V,D] and the gathered segment `incoming` [V,D] (an operand of the weight gradients)
  * are written for the backward pass -- all four pointers or none. */
 int ggnn_gru_packed_gather_train_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
                                      const float* bc, float* h_out, const float* Hrows, const int32_t* row_ptr,
                                      const int32_t* gather_row, const float* nin, int T, int use_avg, float* save_r, float* save_u,
-                                     float* save_c, float* save_incoming, int V, int D, int act, int32_t* tile_counter,
-                                     ggnn_stream_t stream);
+                                     float* save_c, float* save_incoming, int V, int D, int act, int gru_fmt,
+                                     int32_t* tile_counter, ggnn_stream_t stream);
 
 /* The two launches of the un-fused ggnn_gru_f32, separately addressable (profiling, large D):
  *   gates:     [r|u] = sigmoid([x|h] Wg + bg) -> rh = r*h [V,D], u [V,D] (save_r optional)
@@ -307,6 +332,8 @@ int ggnn_gru_candidate_f32(const float* const* x_segs, int nx, const float* rh, 
  *                               res_idx[res_ptr[l] .. res_ptr[l+1]-1] (0 = h0, k = output of layer k-1), :140-145
  *   edge_w [T,D,D] raw and/or edge_packed (ggnn_edge_weights_pack_f32); edge_bias entries may be NULL
  *   Wg/Wc raw and/or gru_packed (ggnn_gru_pack_weights_f32); bg [2D], bc [D]
+ *   gru_fmt                     HOST [num_layers] of GGNN_GRU_FMT_*: the format gru_packed[l] was packed in (NULL: BF16X3 for all;
+ *                               layers that run on raw weights always multiply in BF16X3)
  *   layer_out                   HOST [num_layers] of DEVICE [V,D]: node_states_per_layer[l+1]; the last one is
  *                               the function's return value (:218)
  *   fuse_gather                 k > 0: layers with at most k concatenated GRU inputs (residuals + messages; 1 = no
@@ -321,7 +348,7 @@ int ggnn_sparse_propagate_f32(const float* h0, int V, int D, int T,
                               int num_layers, const int32_t* layer_timesteps, const int32_t* res_ptr, const int32_t* res_idx,
                               const float* const* edge_w, const float* const* edge_packed, const float* const* edge_bias,
                               const float* const* Wg, const float* const* bg, const float* const* Wc, const float* const* bc,
-                              const float* const* gru_packed, int act, int fuse_gather,
+                              const float* const* gru_packed, const int32_t* gru_fmt, int act, int fuse_gather,
                               float* const* layer_out, void* ws, size_t ws_bytes, ggnn_stream_t stream);
 
 /* ---- (a-B) element-wise stages of the GRU backward (TF autodiff of GRUCell, chem_tensorflow.py:184) -------
@@ -521,18 +548,20 @@ int ggnn_pack_batch_tables(const int32_t* counts_t, int Gd, int rows, const int6
  *     (edge_packed[l], ggnn_msg_transform_compact_workspace_bytes) and those of the transposed weights (edge_packed_t[l]) -- of the
  *     variable edge_w[l] [T*D, D] masked on the fly like ggnn_dropout_f32(keep_prob, seeds[l]) masks it (keep_prob 1: unmasked) --,
  *     the fused GRU's images (gru_packed[l], ggnn_gru_packed_bytes(D, nx[l])) and its backward's (gru_bwd_packed[l]).  num_layers <= 16;
- *     nx, seeds, and the pointer arrays are HOST arrays. */
+ *     nx, seeds, and the pointer arrays are HOST arrays.
+ *   gru_fmt (prepare and forward; HOST [num_layers] of GGNN_GRU_FMT_*, or NULL = BF16X3 for every layer): the operand format of
+ *     layer l's GRU forward images / launches -- the same array must be given to both calls of a step. */
 int ggnn_sparse_train_prepare_f32(int num_layers, int T, int D, const int32_t* nx, const float* const* edge_w, float keep_prob,
-                                  const uint64_t* seeds, const float* const* Wg, const float* const* Wc, float* const* edge_packed,
-                                  float* const* edge_packed_t, float* const* gru_packed, float* const* gru_bwd_packed,
-                                  ggnn_stream_t stream);
+                                  const uint64_t* seeds, const float* const* Wg, const float* const* Wc, const int32_t* gru_fmt,
+                                  float* const* edge_packed, float* const* edge_packed_t, float* const* gru_packed,
+                                  float* const* gru_bwd_packed, ggnn_stream_t stream);
 size_t ggnn_sparse_train_workspace_bytes(int V, int D, int T, int64_t compact_rows, int total_steps);
 int ggnn_sparse_train_forward_f32(const float* h0, int V, int D, int T, const int32_t* row_ptr, const int32_t* gather_row_c,
                                   const int32_t* pair_node, const int64_t* type_row_off, const float* nin, int use_avg, int num_layers,
                                   const int32_t* layer_timesteps, const int32_t* res_ptr, const int32_t* res_idx,
                                   const float* const* edge_packed, const float* const* bg, const float* const* bc,
-                                  const float* const* gru_packed, int act, void* ws, size_t ws_bytes, int64_t* final_state_offset,
-                                  ggnn_stream_t stream);
+                                  const float* const* gru_packed, const int32_t* gru_fmt, int act, void* ws, size_t ws_bytes,
+                                  int64_t* final_state_offset, ggnn_stream_t stream);
 int ggnn_sparse_train_backward_f32(const float* h0, int V, int D, int T, const int32_t* pair_node, const int64_t* type_row_off,
                                    const float* nin, int use_avg, int num_layers, const int32_t* layer_timesteps,
                                    const int32_t* res_ptr, const int32_t* res_idx, const int32_t* rows_rp, const int32_t* rows_gather,

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for s in syms:
         assert hasattr(lib, s), "libggnn_hip.so lacks %s" % s
     assert set(syms) == set(pkg._lib.SYMBOLS), "ctypes table and header disagree"
-    assert lib.ggnn_abi_version() == pkg._lib.ABI_VERSION == 2
+    assert lib.ggnn_abi_version() == pkg._lib.ABI_VERSION == 3
 
 
 def test_argument_validation_without_gpu(pkg):
@@ -46,11 +46,13 @@ def test_argument_validation_without_gpu(pkg):
     assert lib.ggnn_gru_workspace_bytes(1000, 100) >= 2 * 1000 * 100 * 4      # un-fused scratch (+ packed weight images)
     assert lib.ggnn_gru_workspace_bytes(1000, 200) == 2 * 1000 * 200 * 4      # no fused path at D=200: r*h and u only
     assert lib.ggnn_gru_is_fused(100) == 1 and lib.ggnn_gru_is_fused(256) == 2 and lib.ggnn_gru_is_fused(200) == 0
-    # column-panel images of the three gates: f32 (4 bytes per weight), two f16 planes (4: the GRU forward's default format in the
-    # split matrix path) or three bf16 planes (6: GGNN_GRU_FMT=3)
-    fmt = lib.ggnn_gru_forward_format()
-    assert fmt == (int(os.environ.get("GGNN_GRU_FMT", "2")) if lib.ggnn_matrix_path_is_split() else 0) and fmt in (0, 2, 3)
-    assert lib.ggnn_gru_packed_bytes(256, 1) == 3 * 2 * 256 * 256 * {0: 4, 2: 4, 3: 6}[fmt]
+    # column-panel images of the three gates: f32 (4 bytes per weight) or, under the split matrix path, room for either operand format
+    # of the GRU forward -- two f16 planes (4) or three bf16 planes (6) -- because the format is chosen per pack / launch (ABI 3)
+    fmt = lib.ggnn_gru_forward_format()                      # (process default of the HOST policy: formats.py)
+    assert fmt in ((2, 3) if lib.ggnn_matrix_path_is_split() else (0,))
+    assert lib.ggnn_gru_packed_bytes(256, 1) == 3 * 2 * 256 * 256 * (6 if lib.ggnn_matrix_path_is_split() else 4)
+    # an unknown operand format is an argument error, not a silent default
+    assert lib.ggnn_gru_pack_weights_f32(aligned, aligned, 1, 100, 7, aligned, None) == -1 and b"gru_fmt" in lib.ggnn_last_error()
     assert lib.ggnn_msg_transform_compact_supported(256) == 1 and lib.ggnn_msg_transform_compact_supported(200) == 0
     assert lib.ggnn_csr_workspace_bytes(0, 10) > 0
 

@@ -101,8 +101,14 @@ def test_message_index_order_and_validation(pkg, cuda):
                                        # column-panel kernels (ggnn_panel.hip): every panel count, residual inputs, thin tail tickets
                                        (2100, 256, 1, "relu"), (777, 128, 2, "tanh"), (530, 192, 0, "tanh"), (333, 256, 2, "tanh"),
                                        (40000, 128, 1, "tanh")])
-@pytest.mark.parametrize("two_launch", [False, True])
-def test_gru(pkg, oracle, cuda, V, D, R, act, two_launch):
+@pytest.mark.parametrize("form", ["fused-bf16x3", "fused-f16x2", "two-launch"])
+def test_gru(pkg, oracle, cuda, V, D, R, act, form):
+    """form: the single-launch kernel in the exact bf16x3 operand format (what ggnn_gru_f32 runs on raw weights), in the two-piece
+    f16 format (per-launch argument since ABI 3; the operands here are inside its range), and the generic two-launch GRU."""
+    two_launch = form == "two-launch"
+    fmt = pkg.formats.F16X2 if form == "fused-f16x2" else None
+    if fmt is not None and not (pkg.ops.gru_is_fused(D) and pkg.formats.split_path()):
+        pytest.skip("no fused split-form GRU at this size / matrix path")
     rng = np.random.default_rng(V + D + R)
     xs = [rng.uniform(-1, 1, (V, D)).astype(np.float32) for _ in range(R + 1)]
     h = rng.uniform(-1, 1, (V, D)).astype(np.float32)
@@ -111,7 +117,7 @@ def test_gru(pkg, oracle, cuda, V, D, R, act, two_launch):
     Wc = rng.uniform(-0.2, 0.2, (K, D)).astype(np.float32); bc = rng.uniform(-0.5, 0.5, D).astype(np.float32)
     save = {}
     got = pkg.ops.gru([dev(x, cuda) for x in xs], dev(h, cuda), dev(Wg, cuda), dev(bg, cuda), dev(Wc, cuda),
-                      dev(bc, cuda), act, save=save, two_launch=two_launch).cpu().numpy()
+                      dev(bc, cuda), act, save=save, two_launch=two_launch, fmt=fmt).cpu().numpy()
     f = lambda a: a.astype(np.float64)
     want, r, u, c = oracle.gru_cell(np.concatenate([f(x) for x in xs], 1), f(h), f(Wg), f(bg), f(Wc), f(bc),
                                     oracle.activation(act))
@@ -167,15 +173,107 @@ def _oracle_states(oracle, feed, layers, params, dtype=np.float64):
      "layer_timesteps": [2, 1], "residual_connections": {"1": [0]}},
     {"use_propagation_attention": True, "graph_rnn_cell": "CudnnCompatibleGRUCell", "hidden_size": 32},
 ])
-def test_sparse_model_matches_oracle(pkg, oracle, cuda, config):
+@pytest.mark.parametrize("policy", ["auto", "exact"])
+def test_sparse_model_matches_oracle(pkg, oracle, cuda, config, policy):
+    """Every config under both format policies: 'auto' (the default: two-piece f16 GRU operands where formats.py proves the range,
+    exact bf16x3 elsewhere) and 'exact' (bf16x3 everywhere: the f32 number of record)."""
+    f = pkg.formats
     ms = pkg.synthetic_qm9(200, mean_nodes=14, seed=1)
     model, layers, feeds = _model_and_feed(pkg, oracle, ms, config)
     assert len(feeds) == 1
-    with torch.no_grad():
+    with torch.no_grad(), f.forced(policy):
         model.feed(feeds[0])
         got = model.compute_final_node_representations().cpu().numpy()
     want = _oracle_states(oracle, feeds[0], layers, model.params)
     np.testing.assert_allclose(got, want, **MODEL_TOL)
+    if f.split_path():
+        p = model.params
+        provable = (policy == "auto" and p["graph_rnn_activation"].lower() == "tanh" and p["use_edge_msg_avg_aggregation"]
+                    and p["graph_rnn_cell"].lower() == "gru" and not p["use_propagation_attention"])
+        assert model.last_gru_formats == [f.F16X2 if provable else f.BF16X3] * len(p["layer_timesteps"])
+
+
+def _hub_molecules(pkg, n_hub, n_small=20, seed=5):
+    """A batch with ONE hub graph -- node 0 bonded to n_hub leaves -- among ordinary molecules (reference JSON schema)."""
+    ms = pkg.synthetic_qm9(n_small, mean_nodes=10, seed=seed)
+    raw = ms.to_json()
+    rng = np.random.default_rng(seed)
+    feats = [[1.0 if k == int(rng.integers(0, 5)) else 0.0 for k in range(5)] for _ in range(n_hub + 1)]
+    raw.insert(3, {"targets": [[0.5]], "graph": [[0, int(rng.integers(1, 5)), i] for i in range(1, n_hub + 1)], "node_features": feats})
+    return pkg.MoleculeSet.from_json(raw)
+
+
+@pytest.mark.parametrize("case", ["gru-weight-above-255", "h0-above-65504-small-weights", "relu-sum-aggregation-hub", "tanh-sum-hub",
+                                  "huge-edge-weights", "nan-in-h0"])
+def test_default_path_is_f32_outside_the_f16x2_operand_range(pkg, oracle, cuda, case):
+    """the DEFAULT policy never runs the two-piece f16 format on operands it cannot take.  Each case leaves the
+    format's range (|w| <= 255.875, |a| <= 65504) or the reach of the proof; the default path must select the exact format for the
+    affected layers and match the fp64 oracle at the model tolerance -- no allowance for clamped or saturated operands."""
+    f = pkg.formats
+    if not f.split_path():
+        pytest.skip("f32 matrix path")
+    config = {"layer_timesteps": [2, 2, 1], "residual_connections": {"2": [0]}}
+    hub = "hub" in case
+    if case == "relu-sum-aggregation-hub":
+        config.update({"graph_rnn_activation": "ReLU", "use_edge_msg_avg_aggregation": False})
+    if case == "tanh-sum-hub":
+        config.update({"use_edge_msg_avg_aggregation": False})
+    ms = _hub_molecules(pkg, 3000) if hub else pkg.synthetic_qm9(150, mean_nodes=12, seed=3)
+    model, layers, feeds = _model_and_feed(pkg, oracle, ms, config, seed=11)
+    feed = feeds[0]
+    L = len(model.params["layer_timesteps"])
+    expect = [f.BF16X3] * L
+    rng = np.random.default_rng(4)
+    if case == "gru-weight-above-255":
+        # a few GRU weights of layer 1 beyond the x 2^8 packing's range (its f16 pieces would saturate at 65504 / 256); small inputs
+        # into them keep the gates unsaturated, so a saturated weight WOULD move the result
+        for key in ("Wg", "Wc"):
+            W = layers[1][key]
+            idx = (rng.integers(0, 5, 6), rng.integers(0, W.shape[1], 6))      # rows of the one-hot annotation columns of `incoming`
+            W[idx] = rng.choice([-1.0, 1.0], 6) * rng.uniform(300.0, 2000.0, 6)
+        for l in range(L):                                                     # tiny edge weights: incoming ~ 1e-3
+            layers[l]["edge_weights"] *= 1e-2
+        expect = [f.F16X2, f.BF16X3, f.F16X2]
+    elif case == "h0-above-65504-small-weights":
+        h0 = feed["initial_node_representation"].clone()
+        V = h0.shape[0]
+        h0[torch.arange(0, V, 3), 7] = torch.from_numpy(rng.uniform(7e4, 5e5, len(range(0, V, 3))).astype(np.float32)).to(h0.device)
+        feed = dict(feed, initial_node_representation=h0)
+        feed.pop("h0_absmax", None)                                            # (a foreign feed: measured)
+        for l in range(L):                                                     # weights ~1e-6: pre-activations O(1), nothing saturates
+            for key in ("edge_weights", "Wg", "Wc"):
+                layers[l][key] *= 2e-5
+    elif case == "huge-edge-weights":
+        for l in range(L):
+            layers[l]["edge_weights"] *= 1e4                                    # D max|W_edge| S beyond 65504: incoming is unbounded
+    elif case == "nan-in-h0":
+        h0 = feed["initial_node_representation"].clone()
+        h0[5, 2] = float("nan")
+        feed = dict(feed, initial_node_representation=h0)
+        feed.pop("h0_absmax", None)
+    model.set_graph_weights(layers)
+    with torch.no_grad(), f.forced("auto"):
+        model.feed(feed)
+        got = model.compute_final_node_representations().cpu().numpy()
+    assert model.last_gru_formats == expect, (case, model.last_gru_formats, model.last_gru_format_bounds)
+    want = _oracle_states(oracle, feed, layers, model.params)
+    if case == "nan-in-h0":
+        # non-finite inputs stay non-finite exactly where the f64 evaluation has them
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).any()
+        ok = ~np.isnan(want)
+        np.testing.assert_allclose(got[ok], want[ok], **MODEL_TOL)
+        return
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, **MODEL_TOL)
+    if case in ("relu-sum-aggregation-hub", "h0-above-65504-small-weights"):
+        assert np.abs(want).max() > 65504.0 if case.startswith("h0") else np.abs(want).max() > 10.0      # the states really leave the range / grow
+    if case in ("gru-weight-above-255", "h0-above-65504-small-weights"):
+        # ... and the guard is not vacuous: the UNCHECKED two-piece format gives a different answer on these operands
+        with torch.no_grad(), f.forced(f.F16X2):
+            model.feed(feed)
+            unchecked = model.compute_final_node_representations().cpu().numpy()
+        assert not np.allclose(unchecked, want, **MODEL_TOL)
+
 
 
 @pytest.mark.parametrize("seed", range(32))
@@ -467,7 +565,8 @@ def test_compact_transform_with_empty_edge_types(pkg, oracle, cuda):
                                            # running one pass ahead (R=0) / across the pass boundary (R=1)
                                            (70001, 150000, 100, 4, 0, True), (70001, 150000, 100, 4, 1, True),
                                            (66000, 140000, 100, 4, 2, True)])
-def test_gru_with_gathered_segment_sum(pkg, oracle, cuda, V, M, D, T, R, avg):
+@pytest.mark.parametrize("fmt", [3, 2])
+def test_gru_with_gathered_segment_sum(pkg, oracle, cuda, V, M, D, T, R, avg, fmt):
     """ggnn_gru_packed_gather_f32 (segment sum gathered inside the GRU kernel) == ggnn_gather_segment_sum_f32 followed
     by ggnn_gru_packed_f32, bit for bit: same slot order, same fp32 adds, same division."""
     rng = np.random.default_rng(V * 7 + M)
@@ -482,15 +581,15 @@ def test_gru_with_gathered_segment_sum(pkg, oracle, cuda, V, M, D, T, R, avg):
     index = pkg.ops.build_message_index([dev(a, cuda) for a in adj], V)
     nd = dev(nin, cuda) if avg else None
     hd, Wgd, Wcd, bgd, bcd = (dev(x, cuda) for x in (h, Wg, Wc, bg, bc))
-    packed = pkg.ops.PackedWeights().gru(Wgd, Wcd, nx, D)
+    packed = pkg.ops.PackedWeights().gru(Wgd, Wcd, nx, D, fmt)
     incoming = pkg.ops.gather_segment_sum(H, index, nd, None, avg)
-    want = pkg.ops.gru_packed(res + [incoming], hd, packed, bgd, bcd)
-    got = pkg.ops.gru_packed_gather(res, hd, packed, bgd, bcd, H.view(V * T, D), index, None, nd)
+    want = pkg.ops.gru_packed(res + [incoming], hd, packed, bgd, bcd, fmt=fmt)
+    got = pkg.ops.gru_packed_gather(res, hd, packed, bgd, bcd, H.view(V * T, D), index, None, nd, fmt=fmt)
     assert torch.equal(got, want)
     # dynamic tile hand-out (a zeroed device counter per launch): same tiles, same results
     cnt = torch.zeros(2, dtype=torch.int32, device=cuda)
-    got_dyn = pkg.ops.gru_packed_gather(res, hd, packed, bgd, bcd, H.view(V * T, D), index, None, nd, tile_counter=cnt[0:1])
-    want_dyn = pkg.ops.gru_packed(res + [incoming], hd, packed, bgd, bcd, tile_counter=cnt[1:2])
+    got_dyn = pkg.ops.gru_packed_gather(res, hd, packed, bgd, bcd, H.view(V * T, D), index, None, nd, tile_counter=cnt[0:1], fmt=fmt)
+    want_dyn = pkg.ops.gru_packed(res + [incoming], hd, packed, bgd, bcd, tile_counter=cnt[1:2], fmt=fmt)
     assert torch.equal(got_dyn, want) and torch.equal(want_dyn, want)
     assert int(cnt[0]) > 0 and int(cnt[1]) > 0
     ref = oracle.gru_cell(np.concatenate([r.cpu().numpy() for r in res] + [incoming.cpu().numpy()], axis=1).astype(np.float64),

@@ -45,8 +45,10 @@ def _assert_feed_equal(b, ref):
             np.testing.assert_array_equal(x.astype(np.float64), np.asarray(r, np.float64), err_msg=key)
 
 
+@pytest.mark.parametrize("policy", ["auto", "exact"])
 @pytest.mark.parametrize("case", RG.CASES)
-def test_forward_matches_reference_run(pkg, cuda, tmp_path, case):
+def test_forward_matches_reference_run(pkg, cuda, tmp_path, case, policy, monkeypatch):
+    monkeypatch.setattr(pkg.formats._local, "policy", policy, raising=False)    # (both operand-format policies of the GRU forward)
     g = RG.Golden(case)
     m = _restored_model(pkg, g, tmp_path, cuda)
     batches = list(m.make_minibatch_iterator(m.valid_data, False))

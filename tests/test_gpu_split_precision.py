@@ -4,7 +4,7 @@ f32 accumulation) is an f32-faithful evaluation, not a reduced-precision one: ag
 GRU update / message transform its error is no larger than that of the f32-MFMA kernels (GGNN_MATRIX=f32), which round once per k.
 
 The matrix path is fixed per process (packed weight images are in its format), so each mode runs tools/split_probe.py in a
-process of its own."""
+process of its own; the GRU forward's operand format is a per-launch argument since ABI 3 (SPLIT_PROBE_GRU_FMT tells the probe)."""
 import json
 import os
 import subprocess
@@ -21,8 +21,7 @@ def _probe(mode):
     env.pop("GGNN_MATRIX", None); env.pop("GGNN_GRU_FMT", None)
     if mode == "f32":
         env["GGNN_MATRIX"] = "f32"
-    if mode == "bf16x3":
-        env["GGNN_GRU_FMT"] = "3"
+    env["SPLIT_PROBE_GRU_FMT"] = "2" if mode == "split" else "3"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "split_probe.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -32,12 +31,13 @@ def _probe(mode):
 
 
 def test_split_products_are_as_accurate_as_f32_mfma(cuda):
-    """Three processes: the f32 MFMA kernels, the default split path (fused GRU forward: two f16 pieces x three products; everything
-    else three bf16 pieces x six products) and the all-bf16x3 path (GGNN_GRU_FMT=3).  Both split paths must be at least as accurate
+    """Three processes: the f32 MFMA kernels, the split path with the fused GRU forward in the two-piece f16 format (two f16 pieces x
+    three products, operands inside its range; everything else three bf16 pieces x six products) and the all-bf16x3 path.  Both
+    split paths must be at least as accurate
     against f64 as the f32 MFMA -- the f16 x 2 form rounds each operand to 22 bits, but rounds its sums once per 32 terms instead of
     once per term."""
     f32, split, b3 = _probe("f32"), _probe("split"), _probe("bf16x3")
-    for name, got in (("f16x2 GRU (default)", split), ("bf16x3", b3)):
+    for name, got in (("f16x2 GRU", split), ("bf16x3", b3)):
         for key, rec in got.items():
             if key == "mode":
                 continue
@@ -61,14 +61,17 @@ def test_split_products_are_as_accurate_as_f32_mfma(cuda):
 
 
 def test_f16x2_gru_operand_range(pkg, cuda):
-    """The two-piece f16 form's operand range (csrc/ggnn_split.hpp): activations beyond +-65504 are clamped before the split -- a
-    finite, saturated operand (never Inf - Inf = NaN); the gates are saturated long before, so h' still equals the f64 evaluation.
-    Small activations keep their absolute accuracy (the lo piece of a value below 2^-11 is an f16 subnormal, which the MFMA keeps)."""
+    """What the two-piece f16 format does OUTSIDE its operand range, and that nothing reaches it there unasked.  Called with
+    fmt = F16X2 explicitly (the caller vouches for the range, csrc/ggnn_split.hpp): activations beyond +-65504 are clamped before the
+    split -- a finite, saturated operand, never Inf - Inf = NaN -- so entries whose pre-activations are not saturated differ from the
+    f64 evaluation; the SAME call in the exact format (what ops.gru runs on raw weights, and what formats.py selects whenever it
+    cannot prove the range) matches f64 on every entry.  Small activations keep their absolute accuracy in both formats (the lo
+    piece of a value below 2^-11 is an f16 subnormal, which the MFMA keeps)."""
     import numpy as np
     import torch
-    lib = pkg._lib.load()
-    if lib.ggnn_gru_forward_format() != 2:
-        pytest.skip("the fused GRU forward is not in the f16 x 2 format in this process")
+    f = pkg.formats
+    if not f.split_path():
+        pytest.skip("f32 matrix path: no operand formats")
     ops = pkg.ops
     V, D = 3000, 100
     g = torch.Generator(device="cpu").manual_seed(21)
@@ -79,30 +82,72 @@ def test_f16x2_gru_operand_range(pkg, cuda):
     bc = torch.rand(D, generator=g) - 0.5
     h = torch.rand(V, D, generator=g) * 2 - 1
 
-    def run(x):
+    def run(x, fmt):
         X = torch.cat([x, h], 1).double()
         ru = torch.sigmoid(X @ Wg.double() + bg.double())
         r, u = ru[:, :D], ru[:, D:]
         c = torch.tanh(torch.cat([x.double(), r * h.double()], 1) @ Wc.double() + bc.double())
         want = u * h.double() + (1 - u) * c
-        got = ops.gru([x.to(cuda)], h.to(cuda), Wg.to(cuda), bg.to(cuda), Wc.to(cuda), bc.to(cuda), "tanh")
+        got = ops.gru([x.to(cuda)], h.to(cuda), Wg.to(cuda), bg.to(cuda), Wc.to(cuda), bc.to(cuda), "tanh", fmt=fmt)
         return got.double().cpu(), want
 
-    # one huge entry per row (1e5 .. 1e7: beyond f16's 65504), the rest ordinary: every pre-activation it touches is saturated
+    # one huge entry per row (1e5 .. 1e7: beyond f16's 65504), the rest ordinary
     x = torch.rand(V, D, generator=g) * 2 - 1
     cols = torch.randint(0, D, (V,), generator=g)
     big = (10.0 ** (5 + 2 * torch.rand(V, generator=g))) * torch.where(torch.rand(V, generator=g) < 0.5, -1.0, 1.0)
     x[torch.arange(V), cols] = big.float()
-    got, want = run(x)
-    assert torch.isfinite(got).all()
-    # (a clamped entry changes its pre-activations by (|x| - 65504) |w|: only where |w| of that row / column is so small that the
-    #  pre-activation is NOT saturated can the result differ -- |w| < 20 / 65504 = 3e-4, a 1e-3 fraction of the weights)
-    bad = (got - want).abs() > 1e-5
-    assert bad.float().mean() < 2e-2, float(bad.float().mean())
-    # small activations: absolute accuracy as for ordinary ones
+    got, want = run(x, f.BF16X3)                       # the exact format: f32 on every input
+    assert torch.isfinite(got).all() and (got - want).abs().max() < 1e-5
+    got2, _ = run(x, f.F16X2)                          # the two-piece format, forced outside its range: finite, but not the f32 result
+    assert torch.isfinite(got2).all()
+    bad = (got2 - want).abs() > 1e-5
+    assert 0.0 < bad.float().mean() < 2e-2, float(bad.float().mean())
+    # the host policy never selects it for such a batch
+    with f.forced("auto"):
+        assert f.layer_format(f.state_bound(float(x.abs().max()), "tanh"), 1.0, float(Wg.abs().max())) == f.BF16X3
+    # small activations: absolute accuracy as for ordinary ones, in both formats
     x = (torch.rand(V, D, generator=g) * 2 - 1) * 10.0 ** (-6 * torch.rand(V, D, generator=g))
-    got, want = run(x)
-    assert (got - want).abs().max() < 3e-6
+    for fmt in (f.F16X2, f.BF16X3):
+        got, want = run(x, fmt)
+        assert (got - want).abs().max() < 3e-6
+
+
+def test_absmax_kernel(pkg, cuda):
+    """ggnn_absmax_f32, the device half of the operand-range proof: max |x| per tensor in one launch, NaN / Inf propagated, any
+    alignment and size (scalar head and tail around the 16-byte middle)."""
+    import math
+    import torch
+    f = pkg.formats
+    g = torch.Generator(device="cpu").manual_seed(2)
+    base = torch.randn(1_000_003, generator=g)
+    ts = [base[:0], base[:1], base[1:8], base[3:1_000_003], base.clone() * 1e-30, -base.abs() * 7.0, torch.zeros(513)]
+    got = f.absmax([t.to(cuda) if t.numel() == 0 else t.to(cuda)[:] for t in ts])
+    want = [0.0 if t.numel() == 0 else float(t.abs().max()) for t in ts]
+    assert got == want
+    # views at odd offsets of one device buffer (4-byte aligned, not 16)
+    d = base.to(cuda)
+    assert f.absmax([d[1:77], d[2:1003], d[3:]]) == [float(base[1:77].abs().max()), float(base[2:1003].abs().max()), float(base[3:].abs().max())]
+    big = base.clone(); big[777_777] = float("inf")
+    nan = base.clone(); nan[5] = float("nan"); nan[6] = float("inf")
+    out = f.absmax([big.to(cuda), nan.to(cuda)])
+    assert out[0] == math.inf and math.isnan(out[1])
+    many = [torch.full((10 + i,), float(i), device=cuda) for i in range(70)]            # more tensors than one launch takes
+    assert f.absmax(many) == [float(i) for i in range(70)]
+
+
+def test_parity_suite_on_the_f32_mfma_path(cuda):
+    """The third arithmetic path the library ships (GGNN_MATRIX=f32: the f32 MFMA kernels, fixed per process): the model-level
+    parity tests -- oracle configs, reference-run fixtures, gradients -- in a process of their own (missing #2)."""
+    env = dict(os.environ, GGNN_MATRIX="f32")
+    env.pop("GGNN_GRU_FMT", None)
+    sel = [("tests/test_gpu_parity.py", "test_sparse_model_matches_oracle and exact"),
+           ("tests/test_gpu_reference_golden.py", "test_forward_matches_reference_run and exact"),
+           ("tests/test_gpu_train.py", "test_gradients_match_oracle_autograd and exact and True")]
+    for path, k in sel:
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, path), "-x", "-q", "-m", "gpu", "-k", k, "-p", "no:cacheprovider"],
+                           env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+        assert r.returncode == 0, (path, k, r.stdout[-3000:], r.stderr[-2000:])
+        assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
 
 
 def test_power_of_two_scaling_commutes_bitwise(pkg, cuda):

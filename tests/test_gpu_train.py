@@ -55,11 +55,13 @@ def _oracle_loss_and_grads(oracle_torch, model, layers, feed):
                                     {"use_edge_msg_avg_aggregation": False, "hidden_size": 64,
                                      "layer_timesteps": [2, 1], "residual_connections": {"1": [0]}}])
 @pytest.mark.parametrize("compact", [False, True, "unfused-gru-backward"])
-def test_gradients_match_oracle_autograd(pkg, oracle, oracle_torch, cuda, config, compact, monkeypatch):
+@pytest.mark.parametrize("policy", ["auto", "exact"])
+def test_gradients_match_oracle_autograd(pkg, oracle, oracle_torch, cuda, config, compact, policy, monkeypatch):
     """compact: the message transform (forward AND backward) on the active (node,type) pairs only vs the dense
     [V, T*D] form; "unfused-gru-backward": the compacted form with the GRU backward as separate launches instead of the
     single fused kernel -- all must reproduce the oracle's autograd gradients."""
     monkeypatch.setattr(pkg.backward, "USE_COMPACT_TRANSFORM", bool(compact))
+    monkeypatch.setattr(pkg.formats._local, "policy", policy, raising=False)     # (both operand-format policies of the GRU forward)
     if compact == "unfused-gru-backward":
         monkeypatch.setattr(pkg.ops, "gru_bwd_is_fused", lambda D: False)
     model, layers, feed = _setup(pkg, oracle, config)
@@ -72,6 +74,10 @@ def test_gradients_match_oracle_autograd(pkg, oracle, oracle_torch, cuda, config
     loss.backward()
     model.training = False
     assert abs(float(loss) - want_loss) < 1e-5 * max(1.0, abs(want_loss))
+    if pkg.formats.split_path():
+        p_ = model.params
+        provable = policy == "auto" and p_["graph_rnn_activation"].lower() == "tanh" and p_["use_edge_msg_avg_aggregation"]
+        assert model.last_gru_formats == [pkg.formats.F16X2 if provable else pkg.formats.BF16X3] * len(p_["layer_timesteps"])
     assert set(want) == set(variables)
     for name, v in variables.items():
         got = v.grad.detach().cpu().double().reshape(want[name].shape)
@@ -333,20 +339,24 @@ def test_fused_weight_preparation_equals_per_layer_packing(pkg, oracle, cuda, ke
             [f32(lib.ggnn_gru_bwd_packed_bytes(D, nxs[l])) for l in range(L)])
     ptrs = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
     seeds = [model.dropout_seed("edge_weights", l) for l in range(L)]
+    fmts = [(2, 3)[l % 2] for l in range(L)]                   # the GRU forward's operand format is a per-layer argument (ABI 3)
     pkg._lib.check(lib.ggnn_sparse_train_prepare_f32(
         L, T, D, (ctypes.c_int32 * L)(*nxs), ptrs(model._edge_weight_vars), keep, (ctypes.c_uint64 * L)(*seeds),
-        ptrs([c.gates_kernel for c in cells]), ptrs([c.candidate_kernel for c in cells]), ptrs(imgs[0]), ptrs(imgs[1]), ptrs(imgs[2]),
-        ptrs(imgs[3]), torch.cuda.current_stream().cuda_stream))
+        ptrs([c.gates_kernel for c in cells]), ptrs([c.candidate_kernel for c in cells]), (ctypes.c_int32 * L)(*fmts), ptrs(imgs[0]),
+        ptrs(imgs[1]), ptrs(imgs[2]), ptrs(imgs[3]), torch.cuda.current_stream().cuda_stream))
     packed = pkg.ops.PackedWeights()
     for l in range(L):
         W = model._edge_weight_vars[l].view(T, D, D)
         if keep < 1.0:
             W = pkg.ops.dropout(W.contiguous(), keep, seeds[l])
         want = [packed.edge(W), packed.edge(W.transpose(1, 2).contiguous()),
-                packed.gru(cells[l].gates_kernel, cells[l].candidate_kernel, nxs[l], D),
+                packed.gru(cells[l].gates_kernel, cells[l].candidate_kernel, nxs[l], D, fmts[l]),
                 packed.gru_bwd(cells[l].gates_kernel, cells[l].candidate_kernel, nxs[l], D)]
         for k in range(4):
             n = want[k].numel() if k >= 2 else (eb - 256) // 4          # (the edge buffers end in 256 bytes of alignment slack)
+            if k == 2 and fmts[l] == 2 and pkg.formats.split_path():    # (sized for the larger bf16x3 images: the f16x2 images fill 48 KiB each at D = 100)
+                assert D == 100
+                n = 3 * (nxs[l] + 1) * 48 * 1024 // 4
             assert torch.equal(imgs[k][l][:n], want[k][:n]), (l, k)
 
 

@@ -483,3 +483,42 @@ def test_bench_exact_format_reference_leg_never_raises():
         raise subprocess.TimeoutExpired(cmd, 120)
     assert "error" in bench.exact_format_reference(args, 1.2e9, run=dead_run)
     assert "error" in bench.exact_format_reference(args, 1.2e9, run=hung_run)
+
+
+def test_bench_compact_line_fits_a_captured_tail():
+    """bench.py prints ONE JSON line on stdout, last: the contract's fields plus roofline / cpu_baseline and the headline figures of
+    the other legs -- short enough that a driver's captured tail keeps `train`, `end_to_end_fresh_batch` and `allreduce_us` (round 4's
+    15 KB line lost them); the per-kernel tables go to gpurun_out/bench_detail.json and stderr."""
+    import importlib.util, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module3", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    blob = "x" * 4000
+    out = {"metric": "node-state updates/sec on QM9-shaped graphs, h=100, 4 edge types", "value": 1.4e9, "unit": "node-state updates/s",
+           "n_gpus": 1, "steps": 96, "warmup": 12, "ms_per_step": 0.57, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic", "matrix_path": blob,
+           "config": {"workload": "sparse GGNN forward propagation, full-QM9-sized synthetic batches (configs[1])", "mode": "forward",
+                      "hidden_size": 100, "layer_timesteps": [2, 2, 1, 2, 1], "parallelism": "dp1"},
+           "operand_format": {"gru_forward": "f16x2", "gru_forward_per_layer": ["f16x2"] * 5, "policy": "auto", "selected_by": blob,
+                              "bounds": {"proven": True, "h0_absmax": 1.0}, "every_other_kernel": "bf16x3 (exact)"},
+           "exact_bf16x3_gru_reference": {"what": blob, "value": 1.1e9},
+           "roofline": {"kernel": "gru_fused_gather[nx=1]", "bound": "hbm", "achieved": 2900.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.36,
+                        "traffic": 1.36e8, "matrix_path": blob, "pipe": blob, "sustained_mfma": {"a": blob}},
+           "kernels": {"k%d" % i: {"what": blob} for i in range(8)},
+           "cpu_baseline": {"value": 4.8e5, "unit": "node-state updates/s", "cores": 16, "kind": "port", "sample": blob,
+                            "thread_sweep_node_updates_per_sec": {str(t): 1.0 for t in range(40)}},
+           "train": {"what": blob, "ms_per_step": 3.4, "value": 2.3e8}, "end_to_end_fresh_batch": {"what": blob, "value": 1.0e9},
+           "secondary": {"config3_dense_b256": {"kernels": blob, "ms_per_step": 0.05}, "config5_large_graph_h256": {"error": "boom"}},
+           "allreduce_us": None, "ranks_seen": 1, "graphs_per_sec": 9.0e6}
+    line = bench.compact_line(out, "gpurun_out/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) < 3500, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["roofline"]["frac"] == 0.36 and line["roofline"]["bound"] == "hbm" and "8 TB/s" in line["roofline"]["peak_is"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 16
+    assert line["operand_format"]["gru_forward"] == "f16x2" and line["operand_format"]["proven"] is True
+    assert line["exact_format_value"] == 1.1e9 and line["train"]["ms_per_step"] == 3.4 and line["end_to_end_fresh_batch"]["value"] == 1.0e9
+    assert line["secondary"]["config5_large_graph_h256"] == {"error": "boom"} and line["detail_file"].endswith("bench_detail.json")

@@ -1,7 +1,7 @@
-"""Error of the fused GRU launch against an f64 evaluation, and its duration, in the process's matrix mode
-(GGNN_MATRIX=f32 | default: split, the fused GRU forward in the f16 x 2 format | GGNN_GRU_FMT=3: the GRU in bf16 x 3 too).  Run once per
-mode and compare:
-    GGNN_MATRIX=f32 python tools/split_probe.py; python tools/split_probe.py; GGNN_GRU_FMT=3 python tools/split_probe.py
+"""Error of the fused GRU launch against an f64 evaluation in the process's matrix mode (GGNN_MATRIX=f32 | default: split) and, under
+the split path, in the operand format SPLIT_PROBE_GRU_FMT asks for (2: two f16 pieces x three products; 3, the default: the exact
+bf16 x 3 split -- a per-launch argument since ABI 3).  Run once per mode and compare:
+    GGNN_MATRIX=f32 python tools/split_probe.py; SPLIT_PROBE_GRU_FMT=2 python tools/split_probe.py; python tools/split_probe.py
 """
 import importlib, os, sys, json
 import numpy as np, torch
@@ -11,7 +11,8 @@ ops = pkg.ops
 lib = pkg._lib.load()
 mode = "bf16x3" if lib.ggnn_matrix_path_is_split() else "f32"
 dev = "cuda:0"
-out = {"mode": mode, "gru_format": int(lib.ggnn_gru_forward_format())}     # 2: f16 x 2 pieces, 3 products (default); 3: bf16 x 3, 6 products (GGNN_GRU_FMT=3)
+gru_fmt = int(os.environ.get("SPLIT_PROBE_GRU_FMT", "3")) if lib.ggnn_matrix_path_is_split() else 0
+out = {"mode": mode, "gru_format": gru_fmt}     # 2: f16 x 2 pieces, 3 products; 3: bf16 x 3, 6 products; 0: f32 MFMA
 for D, nx, V in ((100, 1, 40000), (100, 3, 20000), (64, 2, 20000), (32, 1, 20000), (256, 1, 8000), (128, 2, 8000)):     # (128 / 256: the column-panel GRU)
     g = torch.Generator(device="cpu").manual_seed(5 + D + nx)
     xs = [(torch.rand(V, D, generator=g) * 2 - 1) for _ in range(nx)]
@@ -30,7 +31,7 @@ for D, nx, V in ((100, 1, 40000), (100, 3, 20000), (64, 2, 20000), (32, 1, 20000
     # pre-activation magnitudes: the error of the products is relative to sum |a b|
     dx = [t.to(dev) for t in xs]; dh = h.to(dev)
     save = {}
-    got = ops.gru(dx, dh, Wg.to(dev), bg.to(dev), Wc.to(dev), bc.to(dev), "tanh", save=save)
+    got = ops.gru(dx, dh, Wg.to(dev), bg.to(dev), Wc.to(dev), bc.to(dev), "tanh", save=save, fmt=gru_fmt or None)
     e = (got.double().cpu() - want).abs()
     er = (save["r"].double().cpu() - r).abs()
     ec = (save["c"].double().cpu() - c).abs()
