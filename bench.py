@@ -451,7 +451,7 @@ def compact_line(out, detail_file):
     line["speedup_vs_cpu_baseline"] = out.get("speedup_vs_cpu_baseline")
     line["ms_per_step_one_stream"] = out.get("ms_per_step_one_stream")
     tr = out.get("train")
-    line["train"] = pick(tr, ("ms_per_step", "value", "allreduce_ms", "allreduce_share", "error"))
+    line["train"] = pick(tr, ("ms_per_step", "value", "n_gpus", "allreduce_ms", "allreduce_share", "error"))
     e2e = out.get("end_to_end_fresh_batch")
     line["end_to_end_fresh_batch"] = pick(e2e, ("value", "one_stream_value"))
     sec = out.get("secondary") or {}

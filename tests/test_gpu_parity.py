@@ -21,7 +21,7 @@ def dev(a, cuda):
 
 def test_library_loaded(pkg, cuda):
     lib = pkg._lib.load()
-    assert lib.ggnn_abi_version() == 2
+    assert lib.ggnn_abi_version() == 3
 
 
 @pytest.mark.parametrize("V,D,T", [(1, 100, 4), (17, 100, 4), (1000, 100, 4), (4097, 100, 4), (513, 64, 4),
@@ -203,18 +203,40 @@ def _hub_molecules(pkg, n_hub, n_small=20, seed=5):
     return pkg.MoleculeSet.from_json(raw)
 
 
-@pytest.mark.parametrize("case", ["gru-weight-above-255", "h0-above-65504-small-weights", "relu-sum-aggregation-hub", "tanh-sum-hub",
-                                  "huge-edge-weights", "nan-in-h0"])
+def _positive_relu_layers(layers, rng, scale):
+    """Weights under which every pre-activation of a ReLU GRU with sum aggregation is a sum of SAME-SIGN terms (no cancellation, so
+    an f32 evaluation stays within the model tolerance of f64 although the states grow by orders of magnitude): edge weights and
+    candidate weights positive, reset-gate columns positive (r -> 1), update-gate columns negative (u -> 0: h' ~ c)."""
+    for L in layers:
+        D = L["Wc"].shape[1]
+        L["edge_weights"][...] = np.abs(L["edge_weights"]) * scale
+        L["Wc"][...] = np.abs(L["Wc"]) * scale
+        L["Wg"][:, :D] = np.abs(L["Wg"][:, :D])
+        L["Wg"][:, D:] = -np.abs(L["Wg"][:, D:])
+        L["bg"][...] = 0.0
+        L["bc"][...] = np.abs(L["bc"])
+    return layers
+
+
+@pytest.mark.parametrize("case", ["gru-weight-above-255", "h0-above-65504-small-weights", "relu-sum-aggregation-hub",
+                                  "relu-sum-hub-random-weights", "tanh-sum-hub", "huge-edge-weights", "nan-in-h0"])
 def test_default_path_is_f32_outside_the_f16x2_operand_range(pkg, oracle, cuda, case):
     """the DEFAULT policy never runs the two-piece f16 format on operands it cannot take.  Each case leaves the
     format's range (|w| <= 255.875, |a| <= 65504) or the reach of the proof; the default path must select the exact format for the
-    affected layers and match the fp64 oracle at the model tolerance -- no allowance for clamped or saturated operands."""
+    affected layers and give the f32 result -- no allowance for clamped or saturated operands.
+
+    Criterion.  Where the case is well conditioned (the first three: same-sign sums or O(1) pre-activations) the result must match the
+    fp64 oracle at the model tolerance.  The last four are ILL conditioned by construction -- a 3000-term signed sum feeding
+    unsaturated gates, pre-activations of 1e4 that cancel to O(1) -- so that ANY f32 evaluation, the reference's included, sits
+    1e-4 .. O(1) from f64 (tools/edge_debug.py: the NumPy-f32 oracle violates the model tolerance on as many entries as the GPU).
+    There the measure is the oracle evaluated in f32 in the reference's op order: the GPU's error against f64 must not exceed it by
+    more than the noise between two f32 summation orders (rms within 2x, maximum within 3x)."""
     f = pkg.formats
     if not f.split_path():
         pytest.skip("f32 matrix path")
     config = {"layer_timesteps": [2, 2, 1], "residual_connections": {"2": [0]}}
     hub = "hub" in case
-    if case == "relu-sum-aggregation-hub":
+    if case.startswith("relu-sum"):
         config.update({"graph_rnn_activation": "ReLU", "use_edge_msg_avg_aggregation": False})
     if case == "tanh-sum-hub":
         config.update({"use_edge_msg_avg_aggregation": False})
@@ -224,12 +246,13 @@ def test_default_path_is_f32_outside_the_f16x2_operand_range(pkg, oracle, cuda, 
     L = len(model.params["layer_timesteps"])
     expect = [f.BF16X3] * L
     rng = np.random.default_rng(4)
+    well_conditioned = case in ("gru-weight-above-255", "h0-above-65504-small-weights", "relu-sum-aggregation-hub", "nan-in-h0")
     if case == "gru-weight-above-255":
         # a few GRU weights of layer 1 beyond the x 2^8 packing's range (its f16 pieces would saturate at 65504 / 256); small inputs
         # into them keep the gates unsaturated, so a saturated weight WOULD move the result
         for key in ("Wg", "Wc"):
             W = layers[1][key]
-            idx = (rng.integers(0, 5, 6), rng.integers(0, W.shape[1], 6))      # rows of the one-hot annotation columns of `incoming`
+            idx = (rng.integers(0, 5, 6), rng.integers(0, W.shape[1], 6))      # rows of the first columns of `incoming`
             W[idx] = rng.choice([-1.0, 1.0], 6) * rng.uniform(300.0, 2000.0, 6)
         for l in range(L):                                                     # tiny edge weights: incoming ~ 1e-3
             layers[l]["edge_weights"] *= 1e-2
@@ -238,11 +261,12 @@ def test_default_path_is_f32_outside_the_f16x2_operand_range(pkg, oracle, cuda, 
         h0 = feed["initial_node_representation"].clone()
         V = h0.shape[0]
         h0[torch.arange(0, V, 3), 7] = torch.from_numpy(rng.uniform(7e4, 5e5, len(range(0, V, 3))).astype(np.float32)).to(h0.device)
-        feed = dict(feed, initial_node_representation=h0)
-        feed.pop("h0_absmax", None)                                            # (a foreign feed: measured)
+        feed = dict(feed, initial_node_representation=h0)                      # (a foreign feed: its maximum is measured)
         for l in range(L):                                                     # weights ~1e-6: pre-activations O(1), nothing saturates
             for key in ("edge_weights", "Wg", "Wc"):
                 layers[l][key] *= 2e-5
+    elif case == "relu-sum-aggregation-hub":
+        _positive_relu_layers(layers, rng, 0.12)
     elif case == "huge-edge-weights":
         for l in range(L):
             layers[l]["edge_weights"] *= 1e4                                    # D max|W_edge| S beyond 65504: incoming is unbounded
@@ -250,7 +274,6 @@ def test_default_path_is_f32_outside_the_f16x2_operand_range(pkg, oracle, cuda, 
         h0 = feed["initial_node_representation"].clone()
         h0[5, 2] = float("nan")
         feed = dict(feed, initial_node_representation=h0)
-        feed.pop("h0_absmax", None)
     model.set_graph_weights(layers)
     with torch.no_grad(), f.forced("auto"):
         model.feed(feed)
@@ -264,16 +287,22 @@ def test_default_path_is_f32_outside_the_f16x2_operand_range(pkg, oracle, cuda, 
         np.testing.assert_allclose(got[ok], want[ok], **MODEL_TOL)
         return
     assert np.isfinite(got).all()
-    np.testing.assert_allclose(got, want, **MODEL_TOL)
-    if case in ("relu-sum-aggregation-hub", "h0-above-65504-small-weights"):
-        assert np.abs(want).max() > 65504.0 if case.startswith("h0") else np.abs(want).max() > 10.0      # the states really leave the range / grow
-    if case in ("gru-weight-above-255", "h0-above-65504-small-weights"):
+    if well_conditioned:
+        np.testing.assert_allclose(got, want, **MODEL_TOL)
+    else:
+        want32 = _oracle_states(oracle, feed, layers, model.params, dtype=np.float32).astype(np.float64)
+        e, e32 = np.abs(got - want), np.abs(want32 - want)
+        assert e32.max() > 1e-5                                                # (the case IS ill conditioned: f32 itself leaves the tolerance)
+        rms = lambda x: float(np.sqrt(np.mean(x * x)))
+        assert rms(e) <= 2.0 * rms(e32) + 1e-6 and e.max() <= 3.0 * e32.max() + 1e-5, (case, rms(e), rms(e32), e.max(), e32.max())
+    if case == "relu-sum-aggregation-hub":
+        assert np.abs(want).max() > 65504.0                                    # the states really leave the two-piece format's range
+    if case in ("gru-weight-above-255", "h0-above-65504-small-weights", "relu-sum-aggregation-hub"):
         # ... and the guard is not vacuous: the UNCHECKED two-piece format gives a different answer on these operands
         with torch.no_grad(), f.forced(f.F16X2):
             model.feed(feed)
             unchecked = model.compute_final_node_representations().cpu().numpy()
         assert not np.allclose(unchecked, want, **MODEL_TOL)
-
 
 
 @pytest.mark.parametrize("seed", range(32))
