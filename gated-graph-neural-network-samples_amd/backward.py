@@ -358,7 +358,18 @@ def transform_backward(index, comp, h, W, dinc, dh, message_weights=None, sink=N
         dHc = ops.segment_sum_rows_by_index(dinc, bwd.rows_index)                              # [R,D], transpose gather
     else:
         dHc = ops.weighted_segment_sum(dinc, bwd.rows_index, bwd.rows_index.msg, message_weights)
-    Z = ops.msg_transform_compact_packed(dHc, _PACKED.edge(_TRANSPOSED.get(W, (1, 2))), T, bwd.identity)       # dHc W_t^T
+    D_ = h.shape[1]
+    if ops.compact_supported(D_):
+        Z = ops.msg_transform_compact_packed(dHc, _PACKED.edge(_TRANSPOSED.get(W, (1, 2))), T, bwd.identity)   # dHc W_t^T
+    else:
+        # hidden sizes without a compacted transform kernel (96, 160, 200, 224, 288, 300 ...: the reference accepts any,
+        # chem_tensorflow_sparse.py:46-50): the rows of a type are one contiguous range -> one generic GEMM per type
+        WT = _TRANSPOSED.get(W, (1, 2))
+        Z = torch.empty((max(R, 1), D_), dtype=torch.float32, device=h.device)
+        for t in range(T):
+            lo, hi = int(comp.type_row_off[t]), int(comp.type_row_off[t + 1])
+            if hi > lo:
+                ops.gemm([dHc[lo:hi]], WT[t], out=Z[lo:hi])
     ops.segment_sum_rows_acc(Z[:R], bwd.node_index, dh)                                      # sum over a node's types
     D = h.shape[1]
     if D > 128:

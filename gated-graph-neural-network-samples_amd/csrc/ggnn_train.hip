@@ -466,5 +466,8 @@ extern "C" int ggnn_sparse_train_backward_f32(
             g = dh_dst;
         }
     }
+    // every deferred node sum was consumed by the GRU backward of the timestep before it (the only step that defers without a
+    // consumer would be the very first one, which runs no transform): a pending one here means a gradient was dropped
+    GGNN_CHECK_ARG(!z_pending, "internal: a deferred node sum of the transform backward was never added (fuse_node_sum invariant)");
     return order_after(st, side);          // the caller's next launches (optimizer, next forward) see every product
 }

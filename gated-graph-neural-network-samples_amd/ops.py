@@ -347,6 +347,16 @@ def gemm_tn(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
         raise ValueError("x and dy must have the same number of rows")
     if M == 0:
         return torch.zeros((K, N), dtype=torch.float32, device=x.device)
+    if N > 512 or N % 4 != 0:
+        # the kernel takes N <= 512, N % 4 == 0: wider products go through in 512-column views (it takes any row stride), a ragged
+        # tail (N % 4 columns: readout widths like 1 or 2) through a zero-padded copy of those columns
+        n4 = N // 4 * 4
+        parts = [gemm_tn(x, dy[:, c:min(c + 512, n4)]) for c in range(0, n4, 512)]
+        if n4 < N:
+            tail = torch.zeros((M, 4), dtype=torch.float32, device=dy.device)
+            tail[:, :N - n4] = dy[:, n4:]
+            parts.append(gemm_tn(x, tail)[:, :N - n4])
+        return torch.cat(parts, dim=1)
     lda = x.stride(0) if M > 1 else K
     ldb = dy.stride(0) if M > 1 else N
     out = torch.empty((K, N), dtype=torch.float32, device=x.device)
@@ -429,6 +439,8 @@ def colsum(dy: torch.Tensor) -> torch.Tensor:
     """Deterministic column sums of a [M, N] float32 matrix (bias gradients)."""
     lib = _lib.load()
     M, N = dy.shape
+    if N > 1024:                                       # (ggnn_colsum_f32 takes N <= 1024: wider matrices in 1024-column views)
+        return torch.cat([colsum(dy[:, c:min(c + 1024, N)]) for c in range(0, N, 1024)])
     out = torch.empty(N, dtype=torch.float32, device=dy.device)
     ws_bytes = lib.ggnn_colsum_workspace_bytes(N)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)

@@ -43,10 +43,7 @@ class VariantStepFn(torch.autograd.Function):
         else:
             incoming = ops.gather_segment_sum(H, index, nin, edge_biases, use_avg)
         xs = list(residuals) + [incoming]
-        D = h.shape[1]
-        if not ops.compact_supported(D):
-            raise NotImplementedError("training of the attention / RNN / CudnnGRU variants needs a hidden size with a compacted "
-                                      "transform kernel (32, 64, 100, 128, 192, 256 or a size that pads to one): got %d" % D)
+        D = h.shape[1]       # (any kernel width: sizes without a compacted transform kernel take the per-type GEMM in transform_backward)
         ctx.hip_backward = BACKWARD_ORACLE is None
         extra = []                                              # what the hand-written backward needs beyond the inputs
         if cell_type == 'gru':

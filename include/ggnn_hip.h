@@ -542,7 +542,8 @@ int ggnn_pack_batch_tables(const int32_t* counts_t, int Gd, int rows, const int6
  *     the compacted transform with the images of W^T (edge_packed_t[l]) on identity_rows = 0..R-1, the per-node sum over
  *     (node_rp, node_order[, node_heads]); on `side_stream` the weight-gradient products, ADDED into g_edge[l] [T,D,D], g_Wg[l]
  *     [(nx+1)D, 2D], g_bg[l] [2D], g_Wc[l] [(nx+1)D, D], g_bc[l] [D] (the caller zeroes them; under weight dropout it masks g_edge
- *     afterwards).  d_state_ws[l] [V,D] (l < num_layers): scratch for the gradients of the layer inputs.  Returns with `stream`
+ *     afterwards).  d_state_ws[l] [V,D] (l < num_layers): scratch for the gradients of the layer inputs; their contents are UNDEFINED
+ *     on return (d_state_ws[0], the gradient of h0, is not even completed: h0 is data).  Returns with `stream`
  *     ordered behind the side stream's last product.  Events come from a per-device pool the library creates on first use.
  *   prepare: ALL of a step's stage images in one launch (the weights change every step): per layer l the T edge-weight images
  *     (edge_packed[l], ggnn_msg_transform_compact_workspace_bytes) and those of the transposed weights (edge_packed_t[l]) -- of the
