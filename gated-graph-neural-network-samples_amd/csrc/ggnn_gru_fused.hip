@@ -807,18 +807,21 @@ static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream
 // serves inference too (it is also the one that comes out of the register allocator with less scratch).
 // GGNN_GRU_FORM: ring form of the gather-fused launches (the kernel's FORM): 0 whole images / 8 waves (the form before round 4),
 // 1 two 4-wave workgroups per CU on half-image rings, 2 8 waves on a 3-slot half-image ring with partial waits
-// Default (-1): form 0 for the single-input launches (6 of the 8 of a forward), form 1 for the launches with residual inputs: over
-// the round's boxes the three forms time within 1 % of each other at R = 0, and with residual inputs form 1 is the one the
-// register allocator leaves without scratch (forms 0 / 2: 28-84 B per lane; R = 1 / 2 launches 111 / 141 us against 117 / 161).
-static int gru_form(int nx) {
+// Default (-1): form 1, except the single-input launch in the exact bf16x3 format.  Round 5, two-piece f16 format
+// (profiles/r05_experiments/gru_forms_f16x2.txt): without a tail round every form takes 63-64 us at R = 0; the reference's
+// 100,000-node batches leave 106 of 6250 tiles for a fourth round, which costs 7.6 us as form 0's cooperative pass and 3.8 us as
+// form 1's single-wave tickets on 512 independent workgroups (R = 0 launch 71.2 -> 66.9 us); with residual inputs form 1 is also
+// the one the register allocator leaves without scratch (88 / 109 us against 99 / 121).  In the exact bf16x3 format form 0 was 3 %
+// ahead of form 1 at R = 0 (round 4).
+static int gru_form(int nx, int fmt) {
     static const int v = [] { const char* e = getenv("GGNN_GRU_FORM"); return e ? atoi(e) : -1; }();
-    return v >= 0 ? v : (nx >= 2 ? 1 : 0);
+    return v >= 0 ? v : ((nx >= 2 || fmt == kSplitF16x2) ? 1 : 0);
 }
 
 template <int D, int FMT>
 static int split_launch_d(int nx, bool gather, const GruFusedArgs& a, float* packed, hipStream_t st) {
     if constexpr (SplitCfg<D>::OK) {
-        if (gather && gru_form(nx) == 2) {
+        if (gather && gru_form(nx, FMT) == 2) {
             switch (nx) {
                 case 1: return launch_gru_fused_m<D, 1, 8, true, true, true, true, 2, FMT>(a, packed, st);
                 case 2: return a.save_x ? launch_gru_fused_m<D, 2, 8, true, true, true, true, 2, FMT>(a, packed, st)
@@ -827,7 +830,7 @@ static int split_launch_d(int nx, bool gather, const GruFusedArgs& a, float* pac
                                         : launch_gru_fused_m<D, 3, 8, true, true, true, false, 2, FMT>(a, packed, st);
             }
         }
-        if (gather && gru_form(nx) == 1) {
+        if (gather && gru_form(nx, FMT) == 1) {
             switch (nx) {
                 case 1: return launch_gru_fused_m<D, 1, 4, true, true, true, true, 1, FMT>(a, packed, st);
                 case 2: return a.save_x ? launch_gru_fused_m<D, 2, 4, true, true, true, true, 1, FMT>(a, packed, st)
