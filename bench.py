@@ -70,6 +70,7 @@ SPLIT_ACTIVE = False               # set from ggnn_matrix_path_is_split() in mai
 # f16 MFMA products per f32 product -- its ceiling is the f16 pipe's peak (= the bf16 pipe's) / 3.  So does the column-panel GRU of the
 # wider hidden sizes (ggnn_panel.hip); the transforms stay on the six-product bf16 form.
 GRU_FWD_FORMAT = 3                 # set from ggnn_gru_forward_format() in main()
+EDGE_FORMAT = 3                    # operand format of the compacted message transform of the timed steps (model.last_edge_formats)
 F16X2_PRODUCTS = 3
 DENSE_SPLIT = False                # set from ggnn_dense_propagate_is_split() for the configs[2] shape in secondary_dense()
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
@@ -190,7 +191,7 @@ def kernel_table(res, reps, V, M, D, T, R=None):
                                   "f32_mfma_peak": FP32_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                                   "matrix_path": "bf16x3 split: f32 operands as 3 bf16 pieces each, 6 bf16 MFMA products per f32 product, "
                                                  "f32 accumulation (error bound of an f32 FMA chain)"})
-            if name.startswith("gru_fused") and GRU_FWD_FORMAT == 2:          # (whole-block kernels at 32 / 64 / 100 and the column-panel GRU)
+            if (name.startswith("gru_fused") and GRU_FWD_FORMAT == 2) or (name == "msg_transform_compact" and EDGE_FORMAT == 2 and D in (32, 64, 100)):
                 pipe = BF16_MFMA_PEAK_TFLOPS / F16X2_PRODUCTS
                 kernels[name].update({"peak": pipe, "frac": ach / pipe, "pipe": "f16 MFMA, 3 products per f32 product (2500 / 3 TF f32-equivalent)",
                                       "matrix_path": "f16x2 split: f32 operands as 2 f16 pieces each (22 of 24 significand bits, round to nearest; "
@@ -433,7 +434,7 @@ def compact_line(out, detail_file):
     line["config"] = pick(cfg, ("workload", "mode", "hidden_size", "num_edge_types", "propagation_steps", "nodes_per_batch",
                                 "messages_per_batch", "graphs_per_batch", "batch_size_param", "hip_streams", "parallelism"))
     of = out.get("operand_format") or {}
-    line["operand_format"] = pick(of, ("gru_forward", "gru_forward_per_layer", "policy", "every_other_kernel"))
+    line["operand_format"] = pick(of, ("gru_forward", "gru_forward_per_layer", "message_transform", "policy", "every_other_kernel"))
     if isinstance(of.get("bounds"), dict):
         line["operand_format"]["proven"] = of["bounds"].get("proven")
     ex = out.get("exact_bf16x3_gru_reference")
@@ -555,7 +556,7 @@ def main():
         return dry_run(args, pkg, dist_ctx)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU implementation)"
     dev = dist_ctx.device
-    global SPLIT_ACTIVE, GRU_FWD_FORMAT
+    global SPLIT_ACTIVE, GRU_FWD_FORMAT, EDGE_FORMAT
     SPLIT_ACTIVE = bool(pkg._lib.load().ggnn_matrix_path_is_split())
     GRU_FWD_FORMAT = int(pkg._lib.load().ggnn_gru_forward_format())      # (the policy's default; replaced below by what the timed steps ran)
 
@@ -672,13 +673,19 @@ def main():
     # the operand format the model's policy chose for the fused GRU forward of the timed steps (formats.py: per layer, per launch)
     fmts = list(getattr(model, "last_gru_formats", None) or [])
     GRU_FWD_FORMAT = (fmts[0] if fmts and all(x == fmts[0] for x in fmts) else 3) if SPLIT_ACTIVE else 0
+    efmts = list(getattr(model, "last_edge_formats", None) or [])
+    EDGE_FORMAT = (efmts[0] if efmts and all(x == efmts[0] for x in efmts) else 3) if SPLIT_ACTIVE else 0
     operand_format = {
         "gru_forward": ("f32 MFMA (GGNN_MATRIX=f32)" if not SPLIT_ACTIVE else
                         (pkg.formats.NAMES.get(fmts[0]) if fmts and all(x == fmts[0] for x in fmts) else "mixed")),
-        "gru_forward_per_layer": [pkg.formats.NAMES.get(x) for x in fmts], "policy": pkg.formats.policy(),
+        "gru_forward_per_layer": [pkg.formats.NAMES.get(x) for x in fmts],
+        "message_transform": ("f32 MFMA (GGNN_MATRIX=f32)" if not SPLIT_ACTIVE else
+                              (pkg.formats.NAMES.get(efmts[0]) if efmts and all(x == efmts[0] for x in efmts) else "mixed")),
+        "policy": pkg.formats.policy(),
         "selected_by": "formats.py, per launch: f16x2 only where |w| <= 255.875 and |a| <= 65504 are PROVEN from max|h0|, the weights' "
                        "maxima, the tanh cell and mean aggregation; bf16x3 (exact) otherwise",
-        "bounds": getattr(model, "last_gru_format_bounds", None), "every_other_kernel": "bf16x3 (exact)" if SPLIT_ACTIVE else "f32 MFMA"}
+        "bounds": getattr(model, "last_gru_format_bounds", None),
+        "every_other_kernel": "bf16x3 (exact: every backward kernel, the dense and h = 128..256 transforms)" if SPLIT_ACTIVE else "f32 MFMA"}
 
     # The headline issues consecutive batches on `--streams` HIP streams (one batch's kernel tails are back-filled by the next
     # batch's launches).  The same loop on ONE stream, timed the same way: the difference is that overlap, and it is why the

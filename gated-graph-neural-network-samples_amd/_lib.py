@@ -34,7 +34,7 @@ SYMBOLS = {
     "ggnn_remap_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "ggnn_msg_transform_compact_workspace_bytes": (c_size_t, [c_int, c_int]),
     "ggnn_msg_transform_compact_f32": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int64), c_void_p, c_void_p, c_size_t,
-                                               c_int, c_int, c_int, c_void_p]),
+                                               c_int, c_int, c_int, c_int, c_void_p]),
     "ggnn_gather_segment_sum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                             c_int, c_int, c_int, c_void_p]),
     "ggnn_build_slot_heads": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
@@ -63,7 +63,7 @@ SYMBOLS = {
     "ggnn_gru_pack_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_gru_packed_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "ggnn_edge_weights_pack_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ggnn_edge_weights_pack_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_gru_packed_gather_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ggnn_gru_packed_gather_train_f32": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -78,7 +78,7 @@ SYMBOLS = {
                                           c_void_p, c_int, c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                           POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                           POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32),
-                                          c_int, c_int, POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+                                          POINTER(c_int32), c_int, c_int, POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
     "ggnn_gru_bwd_stage1_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ggnn_gru_bwd_stage2_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -25,10 +25,12 @@ _PACKED = ops.PackedWeights()
 
 def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tensor, edge_weights: torch.Tensor,
                      edge_biases: Optional[torch.Tensor], use_avg: bool, residual_states: Sequence[torch.Tensor],
-                     cell, activation: str, need_grad: bool = False, ew_mask=None, gru_fmt: int = ops.GRU_FMT_EXACT) -> torch.Tensor:
+                     cell, activation: str, need_grad: bool = False, ew_mask=None, gru_fmt: int = ops.GRU_FMT_EXACT,
+                     edge_fmt: int = ops.GRU_FMT_EXACT) -> torch.Tensor:
     """ew_mask (training only): (keep_prob, seed) of the layer's edge-weight dropout (chem_tensorflow_sparse.py:91) -- `edge_weights`
     is then the VARIABLE (viewed [T,D,D]); the step multiplies by the masked weights and routes the gradient back through the mask.
-    gru_fmt: operand format of the fused GRU forward of this layer (formats.py; the model proves the range or passes BF16X3)."""
+    gru_fmt / edge_fmt: operand format of the fused GRU forward / of the compacted message transform of this layer (formats.py; the
+    model proves the range or passes BF16X3); the training step (need_grad) keeps its transforms in the exact format."""
     if need_grad:
         from .backward import PropagationStepFn
         return PropagationStepFn.apply(h, index, nin, edge_weights, edge_biases, use_avg, activation,
@@ -45,7 +47,7 @@ def propagation_step(h: torch.Tensor, index: "ops.MessageIndex", nin: torch.Tens
         if comp is None:
             comp = index._compact = ops.build_compact_sources(index)
         ew = edge_weights.contiguous()
-        Hc = ops.msg_transform_compact_packed(h, _PACKED.edge(ew), ew.shape[0], comp)
+        Hc = ops.msg_transform_compact_packed(h, _PACKED.edge(ew, edge_fmt), ew.shape[0], comp, fmt=edge_fmt)
         if gather_in_gru:
             Hrows, gather_row = Hc, comp.gather_row
         else:

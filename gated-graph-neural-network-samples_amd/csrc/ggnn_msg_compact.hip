@@ -55,12 +55,12 @@ static size_t scan_temp_bytes(long long n) {
 }
 
 // ---- weights -> stage images ------------------------------------------------------------------------------
-template <int D, bool SPLIT>
+template <int D, bool SPLIT, int FMT = kSplitBf16x3>
 __global__ void edge_weight_pack_kernel(const float* __restrict__ W, float* __restrict__ out) {
     const int t = blockIdx.y;
-    float* img = out + (size_t)t * ImgCfg<D, SPLIT>::IMG;
+    float* img = out + (size_t)t * ImgCfg<D, SPLIT, FMT>::IMG;
     const int first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    if constexpr (SPLIT) pack_split_image<D>(StageValue<D>{W + (size_t)t * D * D, 0, 0, D, -1, nullptr, 0, 0, -1}, img, first, stride);
+    if constexpr (SPLIT) pack_split_image<D, FMT>(StageValue<D>{W + (size_t)t * D * D, 0, 0, D, -1, nullptr, 0, 0, -1}, img, first, stride);
     else pack_stage_image<D>(W + (size_t)t * D * D, 0, 0, D, img, first, stride);
 }
 
@@ -75,11 +75,15 @@ __global__ void edge_weight_pack_kernel(const float* __restrict__ W, float* __re
 // (+-1) across ALL types (launch_compact).
 // SPLIT: the product on the bf16 matrix pipe in 3-way split form (ggnn_split.hpp): the type's image is the 72 KiB split one, a
 // tile's rows are split in registers before its MFMAs.
-template <int D, int NW, bool SPLIT>
+// FMT (SPLIT; round 5): operand format of the products and of the images, per launch -- the exact kSplitBf16x3 (default; the backward's
+// Z = dHc W^T multiplies gradients of any magnitude and always runs in it) or kSplitF16x2 (two f16 pieces, three products, 48 KiB
+// images) for a forward transform whose operands the caller has PROVEN inside that format's range (|h| <= 65504, |W| <= 255.875:
+// formats.py, the same proof as the fused GRU's).
+template <int D, int NW, bool SPLIT, int FMT = kSplitBf16x3>
 __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per CU */ void msg_transform_compact_kernel(
         const float* __restrict__ h, const int* __restrict__ pair_node, TypeRows tr, const float* __restrict__ packed, float* __restrict__ Hc) {
     using C = StageCfg<D>;
-    using I = ImgCfg<D, SPLIT>;
+    using I = ImgCfg<D, SPLIT, FMT>;
     constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) float img[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
         __builtin_amdgcn_sched_barrier(0);                  // the fetches are issued BEFORE the MFMA block
         if constexpr (SPLIT) {
             SFrag<D> sf;
-            split_frag<D>(sf, a);
-            stage_mma_split<D, NT, true>(acc, sf, a, img, li, kq);
+            split_frag<D, FMT>(sf, a);
+            stage_mma_split<D, NT, true, false, FMT>(acc, sf, a, img, li, kq);
         } else {
             stage_mma<D, NoHook, NT, true>(acc, a, img, li, kq);    // (first MFMA of each tile starts from C = 0)
             stage_tail_reduce<D>(acc);
@@ -131,7 +135,10 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = nt * 16 + 4 * kq;
-                if (col < D) st4_b(Hc, ((unsigned)r * (unsigned)D + col) * 4u, acc[nt]);
+                if (col < D) {
+                    if constexpr (SPLIT && SplitFmt<FMT>::acc_scale != 1.0f) st4_b(Hc, ((unsigned)r * (unsigned)D + col) * 4u, acc[nt] * SplitFmt<FMT>::acc_scale);
+                    else st4_b(Hc, ((unsigned)r * (unsigned)D + col) * 4u, acc[nt]);
+                }
             }
         }
         a = an;
@@ -142,16 +149,16 @@ __global__ __launch_bounds__(NW * 64, 4) /* 4 waves per SIMD = 2 workgroups per 
     K1C_T(7)
 }
 
-template <int D, bool SPLIT>
+template <int D, bool SPLIT, int FMT = kSplitBf16x3>
 static int launch_compact_m(const float* h, const float* W, const int* pair_node, TypeRows& tr, float* packed, float* Hc,
                             hipStream_t st) {
     // waves per workgroup: 8, two workgroups per CU.  (One 16-wave workgroup per CU halves the image DMA and evens out
     // the prologues -- the second workgroup of a CU otherwise starts 5 us late behind the first one's MFMA bursts --
     // but measures the same alone (32.8 us) and 2 % slower with two streams: 608 vs 621 M node-updates/s.)
     constexpr int NW = 8;
-    using C = ImgCfg<D, SPLIT>;
+    using C = ImgCfg<D, SPLIT, FMT>;
     if (W) {      // raw [T,D,D] weights given: build the T stage images (skipped when the caller pre-packed them)
-        hipLaunchKernelGGL((edge_weight_pack_kernel<D, SPLIT>), dim3(8, tr.T), dim3(256), 0, st, W, packed);
+        hipLaunchKernelGGL((edge_weight_pack_kernel<D, SPLIT, FMT>), dim3(8, tr.T), dim3(256), 0, st, W, packed);
         GGNN_CHECK_HIP(hipGetLastError());
     }
     if (tr.row_off[tr.T] == 0 || h == nullptr) return GGNN_OK;
@@ -176,17 +183,20 @@ static int launch_compact_m(const float* h, const float* W, const int* pair_node
     for (int t = 0; t < tr.T; ++t)
         tr.tile_off[t + 1] = tr.tile_off[t] + (int)(((tr.row_off[t + 1] - tr.row_off[t] + 15) / 16 + R * NW - 1) / (R * NW));
     static std::atomic<unsigned long long> lds_ok{0};
-    if (C::IMG_BYTES > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&msg_transform_compact_kernel<D, NW, SPLIT>, C::IMG_BYTES, lds_ok));
+    if (C::IMG_BYTES > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&msg_transform_compact_kernel<D, NW, SPLIT, FMT>, C::IMG_BYTES, lds_ok));
     { const char* e = getenv("GGNN_K1C_TPTR"); tr.tdbg = e ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
-    hipLaunchKernelGGL((msg_transform_compact_kernel<D, NW, SPLIT>), dim3(tr.tile_off[tr.T]), dim3(NW * 64), C::IMG_BYTES, st, h, pair_node,
+    hipLaunchKernelGGL((msg_transform_compact_kernel<D, NW, SPLIT, FMT>), dim3(tr.tile_off[tr.T]), dim3(NW * 64), C::IMG_BYTES, st, h, pair_node,
                        tr, (const float*)packed, Hc);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
 
 template <int D>
-static int launch_compact(const float* h, const float* W, const int* pair_node, TypeRows& tr, float* packed, float* Hc, hipStream_t st) {
-    if (SplitCfg<D>::OK && split_matrix_path()) return launch_compact_m<D, true>(h, W, pair_node, tr, packed, Hc, st);
+static int launch_compact(const float* h, const float* W, const int* pair_node, TypeRows& tr, float* packed, float* Hc, int fmt,
+                          hipStream_t st) {
+    if (SplitCfg<D>::OK && split_matrix_path())
+        return gru_launch_fmt(fmt) == kSplitF16x2 ? launch_compact_m<D, true, kSplitF16x2>(h, W, pair_node, tr, packed, Hc, st)
+                                                  : launch_compact_m<D, true>(h, W, pair_node, tr, packed, Hc, st);
     return launch_compact_m<D, false>(h, W, pair_node, tr, packed, Hc, st);
 }
 
@@ -262,8 +272,9 @@ extern "C" size_t ggnn_msg_transform_compact_workspace_bytes(int D, int T) {
     return (size_t)stage_img_floats(D) * sizeof(float) * (size_t)(T > 0 ? T : 0) + 256;
 }
 
-extern "C" int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* packed, ggnn_stream_t stream) {
+extern "C" int ggnn_edge_weights_pack_f32(const float* W, int T, int D, int fmt, float* packed, ggnn_stream_t stream) {
     GGNN_CHECK_ARG(T > 0 && T <= kMaxTypesC, "bad T=%d", T);
+    GGNN_CHECK_ARG(fmt == 0 || fmt == GGNN_GRU_FMT_F16X2 || fmt == GGNN_GRU_FMT_BF16X3, "fmt %d is not a GGNN_GRU_FMT_* value", fmt);
     if (!ggnn_msg_transform_compact_supported(D))
         return fail(GGNN_E_UNSUPPORTED, "no packed edge weights for hidden size %d", D);
     GGNN_CHECK_ARG(W && packed && aligned16(packed), "null or misaligned pointer");
@@ -272,9 +283,9 @@ extern "C" int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* p
     hipStream_t st = (hipStream_t)stream;
     if (gru_panel_supported(D)) return transform_panel_dispatch(nullptr, W, nullptr, tr.row_off, T, 0, D, packed, nullptr, st);
     switch (D) {
-        case 100: return launch_compact<100>(nullptr, W, nullptr, tr, packed, nullptr, st);
-        case 64: return launch_compact<64>(nullptr, W, nullptr, tr, packed, nullptr, st);
-        default: return launch_compact<32>(nullptr, W, nullptr, tr, packed, nullptr, st);
+        case 100: return launch_compact<100>(nullptr, W, nullptr, tr, packed, nullptr, fmt, st);
+        case 64: return launch_compact<64>(nullptr, W, nullptr, tr, packed, nullptr, fmt, st);
+        default: return launch_compact<32>(nullptr, W, nullptr, tr, packed, nullptr, fmt, st);
     }
 }
 
@@ -282,8 +293,9 @@ extern "C" int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* p
 // constant across batches, so the pack pre-pass is paid once per weight version instead of once per call).
 extern "C" int ggnn_msg_transform_compact_f32(const float* h, const float* W, const int32_t* pair_node,
                                               const int64_t* type_row_off, float* Hc, void* ws, size_t ws_bytes, int V, int D,
-                                              int T, ggnn_stream_t stream) {
+                                              int T, int fmt, ggnn_stream_t stream) {
     GGNN_CHECK_ARG(V >= 0 && D > 0 && D % 4 == 0 && T > 0 && T <= kMaxTypesC, "bad sizes V=%d D=%d T=%d", V, D, T);
+    GGNN_CHECK_ARG(fmt == 0 || fmt == GGNN_GRU_FMT_F16X2 || fmt == GGNN_GRU_FMT_BF16X3, "fmt %d is not a GGNN_GRU_FMT_* value", fmt);
     GGNN_CHECK_ARG(type_row_off, "null pointer");
     if (!ggnn_msg_transform_compact_supported(D))
         return fail(GGNN_E_UNSUPPORTED, "compacted message transform supports hidden sizes 32, 64, 100, 128, 192, 256 (got %d)", D);
@@ -307,8 +319,8 @@ extern "C" int ggnn_msg_transform_compact_f32(const float* h, const float* W, co
     float* packed = static_cast<float*>(ws);
     if (gru_panel_supported(D)) return transform_panel_dispatch(h, W, pair_node, tr.row_off, T, V, D, packed, Hc, st);
     switch (D) {
-        case 100: return launch_compact<100>(h, W, pair_node, tr, packed, Hc, st);
-        case 64: return launch_compact<64>(h, W, pair_node, tr, packed, Hc, st);
-        default: return launch_compact<32>(h, W, pair_node, tr, packed, Hc, st);
+        case 100: return launch_compact<100>(h, W, pair_node, tr, packed, Hc, fmt, st);
+        case 64: return launch_compact<64>(h, W, pair_node, tr, packed, Hc, fmt, st);
+        default: return launch_compact<32>(h, W, pair_node, tr, packed, Hc, fmt, st);
     }
 }

@@ -35,7 +35,7 @@ extern "C" int ggnn_sparse_propagate_f32(
         int num_layers, const int32_t* layer_timesteps, const int32_t* res_ptr, const int32_t* res_idx,
         const float* const* edge_w, const float* const* edge_packed, const float* const* edge_bias,
         const float* const* Wg, const float* const* bg, const float* const* Wc, const float* const* bc,
-        const float* const* gru_packed, const int32_t* gru_fmt, int act, int fuse_gather,
+        const float* const* gru_packed, const int32_t* gru_fmt, const int32_t* edge_fmt, int act, int fuse_gather,
         float* const* layer_out, void* ws, size_t ws_bytes, ggnn_stream_t stream) {
     GGNN_CHECK_ARG(V >= 0 && D > 0 && D % 4 == 0 && T > 0, "bad sizes V=%d D=%d T=%d", V, D, T);
     GGNN_CHECK_ARG(num_layers > 0 && layer_timesteps && res_ptr && layer_out, "bad layer description");
@@ -99,7 +99,7 @@ extern "C" int ggnn_sparse_propagate_f32(
                 rc = ggnn_msg_transform_compact_f32(cur, packed ? nullptr : edge_w[l], pair_node, type_row_off, H,
                                                     packed ? const_cast<float*>(edge_packed[l]) : gru_ws,
                                                     packed ? ggnn_msg_transform_compact_workspace_bytes(D, T) : gru_ws_bytes,
-                                                    V, D, T, stream);
+                                                    V, D, T, (packed && edge_fmt) ? edge_fmt[l] : GGNN_GRU_FMT_BF16X3, stream);
             } else {
                 GGNN_CHECK_ARG(edge_w && edge_w[l], "dense transform needs raw edge weights");
                 rc = ggnn_msg_transform_f32(cur, D, edge_w[l], H, V, D, T, stream);

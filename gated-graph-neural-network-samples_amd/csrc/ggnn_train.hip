@@ -291,7 +291,7 @@ extern "C" int ggnn_sparse_train_forward_f32(
         for (int s = 0; s < P.steps; ++s) {                                     // :153
             const int k = P.first_step + s;
             if (int rc = ggnn_msg_transform_compact_f32(cur, nullptr, pair_node, type_row_off, Hc, const_cast<float*>(edge_packed[l]),
-                                                        edge_img_bytes, V, D, T, stream)) return rc;
+                                                        edge_img_bytes, V, D, T, GGNN_GRU_FMT_BF16X3, stream)) return rc;
             float* out = buf(L.state, k + 1);
             if (int rc = ggnn_gru_packed_gather_train_f32(xs, nx, cur, gru_packed[l], bg[l], bc[l], out, Hc, row_ptr, gather_row_c,
                                                           use_avg ? nin : nullptr, T, use_avg ? 1 : 0, buf(L.r, k), buf(L.u, k),
@@ -442,7 +442,7 @@ extern "C" int ggnn_sparse_train_backward_f32(
             const bool first_step = l == 0 && s == 0;
             if (!first_step) {
                 if (int rc = ggnn_msg_transform_compact_f32(dHc, nullptr, identity_rows, type_row_off, Z, const_cast<float*>(edge_packed_t[l]),
-                                                            edge_img_bytes, R, D, T, stream)) return rc;
+                                                            edge_img_bytes, R, D, T, GGNN_GRU_FMT_BF16X3, stream)) return rc;
                 if (fuse_node_sum) {
                     z_pending = true;                   // (the next timestep's GRU backward adds the rows while it loads g)
                 } else if (node_heads) {

@@ -810,9 +810,10 @@ def compact_backward(index: MessageIndex, comp: CompactSources) -> CompactBackwa
 
 
 def msg_transform_compact(h: torch.Tensor, edge_weights: torch.Tensor, comp: CompactSources,
-                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          out: Optional[torch.Tensor] = None, fmt: int = GRU_FMT_EXACT) -> torch.Tensor:
     """Hc[r] = h[pair_node[r]] @ edge_weights[type(r)] for the active (node,type) pairs only
-    (chem_tensorflow_sparse.py:160-164 without the duplicate / unused rows).  -> [R, D]."""
+    (chem_tensorflow_sparse.py:160-164 without the duplicate / unused rows).  -> [R, D].
+    fmt: operand format of the products (formats.BF16X3 exact, the default; F16X2 when the caller has proven its range)."""
     lib = _lib.load()
     _req(h, torch.float32, "h"); _req(edge_weights, torch.float32, "edge_weights")
     V, D = h.shape
@@ -826,7 +827,7 @@ def msg_transform_compact(h: torch.Tensor, edge_weights: torch.Tensor, comp: Com
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=h.device)
     off = (ctypes.c_int64 * (T + 1))(*comp.type_row_off)
     _launch("msg_transform_compact", lambda: lib.ggnn_msg_transform_compact_f32(
-        _ptr(h), _ptr(edge_weights), _ptr(comp.pair_node), off, _ptr(out), _ptr(ws), ws_bytes, V, D, T, _stream()))
+        _ptr(h), _ptr(edge_weights), _ptr(comp.pair_node), off, _ptr(out), _ptr(ws), ws_bytes, V, D, T, int(fmt), _stream()))
     return out
 
 
@@ -961,15 +962,17 @@ class PackedWeights:
             hit = self._store(self._gru_bwd, key, (Wg, Wc), packed)
         return hit
 
-    def edge(self, W: torch.Tensor) -> torch.Tensor:
+    def edge(self, W: torch.Tensor, fmt: int = GRU_FMT_EXACT) -> torch.Tensor:
+        """The compacted transform's stage images of W [T, D, D] in the operand format `fmt` (the launch that consumes them must be
+        given the same format)."""
         lib = _lib.load()
-        key = self._key(W)
+        key = self._key(W) + (int(fmt),)
         hit = self._lookup(self._edge, key, (W,))
         if hit is None:
             _req(W, torch.float32, "edge_weights")
             T, D = W.shape[0], W.shape[1]
             packed = torch.empty(lib.ggnn_msg_transform_compact_workspace_bytes(D, T) // 4, dtype=torch.float32, device=W.device)
-            check(lib.ggnn_edge_weights_pack_f32(_ptr(W), T, D, _ptr(packed), _stream()))
+            check(lib.ggnn_edge_weights_pack_f32(_ptr(W), T, D, int(fmt), _ptr(packed), _stream()))
             hit = self._store(self._edge, key, (W,), packed)
         return hit
 
@@ -1006,8 +1009,8 @@ def gru_packed(x_segs: Sequence[torch.Tensor], h: torch.Tensor, packed: torch.Te
 
 
 def msg_transform_compact_packed(h: torch.Tensor, packed: torch.Tensor, T: int, comp: CompactSources,
-                                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """ops.msg_transform_compact with pre-packed edge-weight images."""
+                                 out: Optional[torch.Tensor] = None, fmt: int = GRU_FMT_EXACT) -> torch.Tensor:
+    """ops.msg_transform_compact with pre-packed edge-weight images (PackedWeights.edge(W, fmt): same fmt here)."""
     lib = _lib.load()
     _req(h, torch.float32, "h")
     V, D = h.shape
@@ -1016,7 +1019,7 @@ def msg_transform_compact_packed(h: torch.Tensor, packed: torch.Tensor, T: int, 
         out = torch.empty((max(R, 1), D), dtype=torch.float32, device=h.device)
     off = (ctypes.c_int64 * (T + 1))(*comp.type_row_off)
     _launch("msg_transform_compact", lambda: lib.ggnn_msg_transform_compact_f32(
-        _ptr(h), None, _ptr(comp.pair_node), off, _ptr(out), _ptr(packed), packed.numel() * 4, V, D, T, _stream()))
+        _ptr(h), None, _ptr(comp.pair_node), off, _ptr(out), _ptr(packed), packed.numel() * 4, V, D, T, int(fmt), _stream()))
     return out
 
 
@@ -1032,10 +1035,11 @@ def sparse_propagate(h0: torch.Tensor, index: MessageIndex, comp: Optional[Compa
                      edge_bias: Optional[Sequence[Optional[torch.Tensor]]],
                      Wg: Sequence[torch.Tensor], bg: Sequence[torch.Tensor], Wc: Sequence[torch.Tensor], bc: Sequence[torch.Tensor],
                      gru_packed: Optional[Sequence[torch.Tensor]], activation: str,
-                     fuse_gather: Optional[bool] = None, gru_fmt: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+                     fuse_gather: Optional[bool] = None, gru_fmt: Optional[Sequence[int]] = None,
+                     edge_fmt: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
     """chem_tensorflow_sparse.py:131-218 in ONE native call (ggnn_sparse_propagate_f32): returns
     node_states_per_layer[1:], the last entry being the final node representations.
-    gru_fmt: per layer, the operand format gru_packed[l] was packed in (None: BF16X3 for every layer).
+    gru_fmt / edge_fmt: per layer, the operand format gru_packed[l] / edge_packed[l] was packed in (None: BF16X3 for every layer).
     fuse_gather (default FUSE_GATHER): gather the segment sum inside the GRU kernel where the layer allows it."""
     if fuse_gather is None:
         fuse_gather = FUSE_GATHER
@@ -1062,7 +1066,8 @@ def sparse_propagate(h0: torch.Tensor, index: MessageIndex, comp: Optional[Compa
         _ptr(h0), V, D, T, _ptr(index.row_ptr), _ptr(gather), None if comp is None else _ptr(comp.pair_node), off,
         _ptr(nin), 1 if use_avg else 0, L, i32([int(x) for x in layer_timesteps]), i32(res_ptr), i32(res_idx),
         _ptr_array(edge_w), _ptr_array(edge_packed), _ptr_array(edge_bias), _ptr_array(Wg), _ptr_array(bg), _ptr_array(Wc),
-        _ptr_array(bc), _ptr_array(gru_packed), None if gru_fmt is None else i32([int(f) for f in gru_fmt]), act, int(fuse_gather),
+        _ptr_array(bc), _ptr_array(gru_packed), None if gru_fmt is None else i32([int(f) for f in gru_fmt]),
+        None if edge_fmt is None else i32([int(f) for f in edge_fmt]), act, int(fuse_gather),
         _ptr_array(outs), _ptr(ws), ws_bytes, _stream()))
     return outs
 

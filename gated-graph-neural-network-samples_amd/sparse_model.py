@@ -221,20 +221,22 @@ class SparseGGNNChemModel(ChemModel):
     def gru_formats(self, h0: torch.Tensor, ew_keep: float = 1.0, st_keep: float = 1.0, training: bool = False) -> List[int]:
         """formats.F16X2 for the layers whose GRU operands are PROVABLY inside the two-piece f16 format's range for this batch and
         these weights, formats.BF16X3 (exact, every input) for the others -- the reference multiplies in plain f32
-        (chem_tensorflow_sparse.py:215-216).  See formats.py for the bounds; the decision of the last call is kept in
-        self.last_gru_formats / self.last_gru_format_bounds (bench.py and the tests report it)."""
+        (chem_tensorflow_sparse.py:215-216).  See formats.py for the bounds.  The same proof decides the operand format of each
+        layer's compacted message transform (:160-164; its operands are the states and the edge weights, whatever the
+        aggregation): self.last_edge_formats.  The decision of the last call is kept in self.last_gru_formats /
+        self.last_edge_formats / self.last_gru_format_bounds (bench.py and the tests report it)."""
         from . import formats
         p = self.params
         L = len(p['layer_timesteps'])
         pol = formats.policy()
+        plain_gru = self.cell_type == 'gru' and not p['use_propagation_attention']
         if not formats.split_path() or pol == "exact":
-            fm = [formats.BF16X3] * L
+            fm, em = [formats.BF16X3] * L, [formats.BF16X3] * L
         elif pol == "force2":
-            fm = [formats.F16X2] * L
-        elif (p['graph_rnn_activation'].lower() != 'tanh' or not p['use_edge_msg_avg_aggregation'] or self.cell_type != 'gru'
-              or p['use_propagation_attention']):
-            fm = [formats.BF16X3] * L            # no bound on the states (ReLU), on the aggregate (sum), or not the plain GRU path
-            self.last_gru_format_bounds = {"proven": False, "why": "relu cell / sum aggregation / variant cell: no operand bound"}
+            fm, em = [formats.F16X2] * L, [formats.F16X2] * L
+        elif p['graph_rnn_activation'].lower() != 'tanh' or not plain_gru:
+            fm, em = [formats.BF16X3] * L, [formats.BF16X3] * L     # no bound on the states (ReLU), or not the plain GRU path
+            self.last_gru_format_bounds = {"proven": False, "why": "relu cell / variant cell: no bound on the states"}
         else:
             per_layer = []
             for l in range(L):
@@ -252,18 +254,21 @@ class SparseGGNNChemModel(ChemModel):
                 maxima = formats.weight_absmax(flat)
             h0_max = formats.h0_absmax(self.placeholders)            # (of the FED tensor; `h0` may be its zero-padded copy)
             S = formats.state_bound(h0_max, 'tanh', int(sum(p['layer_timesteps'])), st_keep)
-            fm, i, inc_max, w_max = [], 0, 0.0, 0.0
+            use_avg = bool(p['use_edge_msg_avg_aggregation'])
+            fm, em, i, inc_max, w_max = [], [], 0, 0.0, 0.0
             for l in range(L):
                 ew, wg, wc = maxima[i], maxima[i + 1], maxima[i + 2]
                 eb = maxima[i + 3] if p['use_edge_bias'] else 0.0
                 i += len(per_layer[l])
-                inc = formats.incoming_bound(S, p['hidden_size'], ew, eb, True, ew_keep)
+                inc = formats.incoming_bound(S, p['hidden_size'], ew, eb, use_avg, ew_keep)      # (sum aggregation: inf)
                 fm.append(formats.layer_format(S, inc, formats.nanmax(wg, wc)))
+                # the transform's operands: the states (<= S) and the (weight-dropout-masked: / keep) edge weights
+                em.append(formats.layer_format(S, 0.0, ew / min(max(ew_keep, 1e-30), 1.0)))
                 inc_max, w_max = formats.nanmax(inc_max, inc), formats.nanmax(w_max, wg, wc)
             self.last_gru_format_bounds = {"proven": all(f == formats.F16X2 for f in fm), "h0_absmax": h0_max, "state_bound": S,
                                            "incoming_bound": inc_max, "gru_weight_absmax": w_max,
                                            "limits": {"activation": formats.MAX_ACTIVATION, "weight": formats.MAX_WEIGHT}}
-        self.last_gru_formats = fm
+        self.last_gru_formats, self.last_edge_formats = fm, em
         return fm
 
     # ---- the hot path -----------------------------------------------------------------------------------
@@ -334,7 +339,8 @@ class SparseGGNNChemModel(ChemModel):
                 else:
                     cur = propagation_step(cur, index, nin, edge_weights, edge_biases, use_avg,
                                            layer_residual_states, cell, act, need_grad,
-                                           ew_mask if (need_grad and plain_step) else None, gru_fmt=gru_fmts[layer_idx])
+                                           ew_mask if (need_grad and plain_step) else None, gru_fmt=gru_fmts[layer_idx],
+                                           edge_fmt=ops.GRU_FMT_EXACT if need_grad else self.last_edge_formats[layer_idx])
                 if st_keep < 1.0:                                                  # :113-114 DropoutWrapper(state)
                     cur = tf_dropout(cur, st_keep, self.dropout_seed('state', layer_idx, step), self._node_uid())
             node_states_per_layer.append(cur)
@@ -383,7 +389,8 @@ class SparseGGNNChemModel(ChemModel):
                 comp = index._compact = ops.build_compact_sources(index)
         layers = [self._kernel_layer(l, False) for l in range(L)]
         edge_w = [lay[0].contiguous() for lay in layers]
-        edge_packed = [_PACKED.edge(w) for w in edge_w] if comp is not None else None
+        edge_fmts = list(self.last_edge_formats)
+        edge_packed = [_PACKED.edge(w, edge_fmts[l]) for l, w in enumerate(edge_w)] if comp is not None else None
         edge_bias = [lay[1] for lay in layers] if self.params['use_edge_bias'] else None
         cells = [lay[3] for lay in layers]
         residuals = [self.params['residual_connections'].get(str(l)) or [] for l in range(L)]
@@ -396,7 +403,7 @@ class SparseGGNNChemModel(ChemModel):
                                     edge_w, edge_packed, edge_bias,
                                     [c.gates_kernel for c in cells], [c.gates_bias for c in cells],
                                     [c.candidate_kernel for c in cells], [c.candidate_bias for c in cells],
-                                    gru_packed, act, gru_fmt=gru_fmts)
+                                    gru_packed, act, gru_fmt=gru_fmts, edge_fmt=edge_fmts)
         return outs[-1]
 
     def _graph_nodes_sorted(self) -> bool:

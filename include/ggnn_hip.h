@@ -35,7 +35,9 @@ extern "C" {
  *   3: (round 5) the operand format of the fused GRU forward is an ARGUMENT of every entry point that packs or consumes its weight
  *      images (`gru_fmt`, GGNN_GRU_FMT_*; see "Operand formats" below) instead of a process-wide environment setting:
  *      ggnn_gru_pack_weights_f32, ggnn_gru_packed_f32, ggnn_gru_packed_gather[_train]_f32, ggnn_sparse_propagate_f32,
- *      ggnn_sparse_train_prepare_f32, ggnn_sparse_train_forward_f32.  ggnn_gru_packed_bytes sizes a buffer for either format. */
+ *      ggnn_sparse_train_prepare_f32, ggnn_sparse_train_forward_f32.  ggnn_gru_packed_bytes sizes a buffer for either format.
+ *      The compacted message transform takes the format of its edge-weight images the same way: ggnn_edge_weights_pack_f32,
+ *      ggnn_msg_transform_compact_f32 (`fmt`), ggnn_sparse_propagate_f32 (`edge_fmt`). */
 #define GGNN_ABI_VERSION 3
 
 #define GGNN_OK 0
@@ -146,7 +148,7 @@ int ggnn_remap_gather_rows(const int32_t* gather_row, const int32_t* pair_id, in
                            ggnn_stream_t stream);
 size_t ggnn_msg_transform_compact_workspace_bytes(int D, int T);
 int ggnn_msg_transform_compact_f32(const float* h, const float* W, const int32_t* pair_node, const int64_t* type_row_off,
-                                   float* Hc, void* ws, size_t ws_bytes, int V, int D, int T, ggnn_stream_t stream);
+                                   float* Hc, void* ws, size_t ws_bytes, int V, int D, int T, int fmt, ggnn_stream_t stream);
 
 /* ---- (a-2,a-4..a-7) gather + segment sum + bias + mean: chem_tensorflow_sparse.py:160-162,168,
  *      198-209 ------------------------------------------------------------------------------------
@@ -282,7 +284,10 @@ int ggnn_gru_is_fused(int D);
  *                               operand format) in the format gru_fmt (GGNN_GRU_FMT_*, see "Operand formats" at the top)
  *   ggnn_gru_packed_f32         == ggnn_gru_f32 with the packed images instead of Wg / Wc (fused sizes only); gru_fmt = the format
  *                               the images were packed in.  (ggnn_gru_f32 itself, on raw weights, always multiplies in BF16X3.)
- *   ggnn_edge_weights_pack_f32  W [T,D,D] -> packed (ggnn_msg_transform_compact_workspace_bytes(D,T) bytes);
+ *   ggnn_edge_weights_pack_f32  W [T,D,D] -> packed (ggnn_msg_transform_compact_workspace_bytes(D,T) bytes: enough for either
+ *                               operand format), in the format `fmt` (GGNN_GRU_FMT_*; "Operand formats" at the top: BF16X3 is
+ *                               exact on every input; F16X2 needs |h| <= 65504 and |W| <= 255.875 PROVEN by the caller --
+ *                               forward transforms only; hidden sizes 32 / 64 / 100, ignored elsewhere);
  *                               then call ggnn_msg_transform_compact_f32 with W = NULL and ws = packed.
  * tile_counter (ggnn_gru_packed_f32, ggnn_gru_packed_gather_f32): NULL, or a DEVICE int32 that is 0 when the launch
  * starts (the kernel leaves it non-zero).  With a counter the 16-row tiles are handed to the workgroups dynamically:
@@ -292,7 +297,7 @@ int ggnn_gru_pack_weights_f32(const float* Wg, const float* Wc, int nx, int D, i
 int ggnn_gru_packed_f32(const float* const* x_segs, int nx, const float* h, const float* packed, const float* bg,
                         const float* bc, float* h_out, float* save_r, float* save_u, float* save_c, int V, int D, int act,
                         int gru_fmt, int32_t* tile_counter, ggnn_stream_t stream);
-int ggnn_edge_weights_pack_f32(const float* W, int T, int D, float* packed, ggnn_stream_t stream);
+int ggnn_edge_weights_pack_f32(const float* W, int T, int D, int fmt, float* packed, ggnn_stream_t stream);
 
 /* GRU with the segment sum fused in (chem_tensorflow_sparse.py:198-216 in one launch, no edge bias): the
  * aggregated-messages input -- the LAST of the nx concatenated inputs -- is gathered inside the kernel,
@@ -334,6 +339,7 @@ int ggnn_gru_candidate_f32(const float* const* x_segs, int nx, const float* rh, 
  *   Wg/Wc raw and/or gru_packed (ggnn_gru_pack_weights_f32); bg [2D], bc [D]
  *   gru_fmt                     HOST [num_layers] of GGNN_GRU_FMT_*: the format gru_packed[l] was packed in (NULL: BF16X3 for all;
  *                               layers that run on raw weights always multiply in BF16X3)
+ *   edge_fmt                    the same for edge_packed[l] (ggnn_edge_weights_pack_f32's fmt; NULL: BF16X3 for all)
  *   layer_out                   HOST [num_layers] of DEVICE [V,D]: node_states_per_layer[l+1]; the last one is
  *                               the function's return value (:218)
  *   fuse_gather                 k > 0: layers with at most k concatenated GRU inputs (residuals + messages; 1 = no
@@ -348,8 +354,8 @@ int ggnn_sparse_propagate_f32(const float* h0, int V, int D, int T,
                               int num_layers, const int32_t* layer_timesteps, const int32_t* res_ptr, const int32_t* res_idx,
                               const float* const* edge_w, const float* const* edge_packed, const float* const* edge_bias,
                               const float* const* Wg, const float* const* bg, const float* const* Wc, const float* const* bc,
-                              const float* const* gru_packed, const int32_t* gru_fmt, int act, int fuse_gather,
-                              float* const* layer_out, void* ws, size_t ws_bytes, ggnn_stream_t stream);
+                              const float* const* gru_packed, const int32_t* gru_fmt, const int32_t* edge_fmt, int act,
+                              int fuse_gather, float* const* layer_out, void* ws, size_t ws_bytes, ggnn_stream_t stream);
 
 /* ---- (a-B) element-wise stages of the GRU backward (TF autodiff of GRUCell, chem_tensorflow.py:184) -------
  * stage 1: dpc = g*(1-u)*act'(c) -> dpc [V,D];  g*(h-c)*u*(1-u) -> dpg[:, D:2D];  g*u -> dh [V,D];

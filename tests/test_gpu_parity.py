@@ -191,6 +191,10 @@ def test_sparse_model_matches_oracle(pkg, oracle, cuda, config, policy):
         provable = (policy == "auto" and p["graph_rnn_activation"].lower() == "tanh" and p["use_edge_msg_avg_aggregation"]
                     and p["graph_rnn_cell"].lower() == "gru" and not p["use_propagation_attention"])
         assert model.last_gru_formats == [f.F16X2 if provable else f.BF16X3] * len(p["layer_timesteps"])
+        # the message transform's operands (states, edge weights) do not depend on the aggregation: f16x2 whenever the states are bounded
+        e_provable = (policy == "auto" and p["graph_rnn_activation"].lower() == "tanh" and p["graph_rnn_cell"].lower() == "gru"
+                      and not p["use_propagation_attention"])
+        assert model.last_edge_formats == [f.F16X2 if e_provable else f.BF16X3] * len(p["layer_timesteps"])
 
 
 def _hub_molecules(pkg, n_hub, n_small=20, seed=5):
@@ -279,6 +283,10 @@ def test_default_path_is_f32_outside_the_f16x2_operand_range(pkg, oracle, cuda, 
         model.feed(feed)
         got = model.compute_final_node_representations().cpu().numpy()
     assert model.last_gru_formats == expect, (case, model.last_gru_formats, model.last_gru_format_bounds)
+    if case in ("huge-edge-weights", "h0-above-65504-small-weights", "nan-in-h0") or case.startswith("relu"):
+        assert model.last_edge_formats == [f.BF16X3] * L            # edge weights ~1e3 / states beyond f16 / unbounded: exact transform
+    elif case == "tanh-sum-hub":
+        assert model.last_edge_formats == [f.F16X2] * L             # bounded states, ordinary weights: only the GRU's aggregate is unbounded
     want = _oracle_states(oracle, feed, layers, model.params)
     if case == "nan-in-h0":
         # non-finite inputs stay non-finite exactly where the f64 evaluation has them
@@ -540,6 +548,20 @@ def test_compact_transform_equals_dense_form(pkg, oracle, cuda, V, M, D, T):
     b = pkg.ops.gather_segment_sum_compact(Hc, index, comp, nd, None, True)
     assert torch.equal(a[:, :full], b[:, :full])
     assert torch.allclose(a, b, atol=atol, rtol=1e-5)
+    # the two-piece f16 operand format of the same transform (per-launch argument; these operands are inside its range): against the
+    # f64 product both formats sit inside the bound of a K-term f32 product chain, 4e-7 * sum_k |h_k||w_k|
+    if pkg.formats.split_path() and D in (32, 64, 100):
+        Hc2 = pkg.ops.msg_transform_compact(hd, Wd, comp, fmt=pkg.formats.F16X2).cpu().numpy()
+        packed2 = pkg.ops.PackedWeights().edge(Wd, pkg.formats.F16X2)
+        assert np.array_equal(pkg.ops.msg_transform_compact_packed(hd, packed2, T, comp, fmt=pkg.formats.F16X2).cpu().numpy(), Hc2)
+        rows = np.arange(min(comp.num_rows, 4000))
+        for t in range(T):
+            sel = rows[(rows >= comp.type_row_off[t]) & (rows < comp.type_row_off[t + 1])]
+            if len(sel):
+                hs = h[pn[sel]].astype(np.float64)
+                want = hs @ W[t].astype(np.float64)
+                bound = 4e-7 * (np.abs(hs) @ np.abs(W[t]).astype(np.float64)) + 1e-12
+                assert (np.abs(Hc2[sel] - want) <= bound).all() and (np.abs(Hcn[sel] - want) <= bound).all()
 
 
 @pytest.mark.parametrize("M,K,N,strided", [(1000, 100, 100, False), (33333, 200, 200, False), (70001, 400, 100, True),
