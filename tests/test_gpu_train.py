@@ -215,9 +215,9 @@ def test_training_reduces_loss(pkg, oracle, cuda):
     {"use_propagation_attention": True, "hidden_size": 96, "layer_timesteps": [2, 1], "residual_connections": {"1": [0]}},
     {"graph_rnn_cell": "RNN", "hidden_size": 160, "use_edge_bias": True, "layer_timesteps": [2]},
     {"graph_rnn_cell": "CudnnCompatibleGRUCell", "hidden_size": 200, "layer_timesteps": [1, 1], "residual_connections": {"1": [0]}},
-    {"use_propagation_attention": True, "hidden_size": 300, "layer_timesteps": [1]},
+    {"graph_rnn_cell": "RNN", "graph_rnn_activation": "ReLU", "hidden_size": 300, "layer_timesteps": [1]},
 ], ids=["attention", "attention-bias-sum-h64", "rnn-relu", "rnn-bias-residual", "cudnn-gru", "cudnn-gru-attention-residual",
-        "attention-h128", "rnn-h192", "cudnn-gru-h256", "attention-h96", "rnn-bias-h160", "cudnn-gru-h200", "attention-h300"])
+        "attention-h128", "rnn-h192", "cudnn-gru-h256", "attention-h96", "rnn-bias-h160", "cudnn-gru-h200", "rnn-relu-h300"])
 def test_variant_hip_backward_equals_autograd_of_torch_restatement(pkg, oracle, cuda, config, monkeypatch):
     """The non-default switches (attention, BasicRNNCell, CudnnCompatibleGRUCell): the hand-written HIP backward against torch
     autograd of the timestep restated in differentiable torch ops (tests/variant_oracle.py)."""
