@@ -15,11 +15,11 @@ h = torch.rand(V, D, device=dev) * 2 - 1
 Wg = (torch.rand((nx + 1) * D, 2 * D, device=dev) - 0.5) * 0.3; bg = torch.ones(2 * D, device=dev)
 Wc = (torch.rand((nx + 1) * D, D, device=dev) - 0.5) * 0.3; bc = torch.zeros(D, device=dev)
 out = torch.empty_like(h); ws = pkg.ops.gru_workspace(V, D, dev)
-for _ in range(3): pkg.ops.gru(xs, h, Wg, bg, Wc, bc, "tanh", out=out, ws=ws)
+for _ in range(3): pkg.ops.gru(xs, h, Wg, bg, Wc, bc, "tanh", out=out, ws=ws, fmt=int(os.environ.get("GRU_FMT", "2")))
 torch.cuda.synchronize()
 os.environ["GGNN_GRU_TPTR"] = str(tbuf.data_ptr())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); pkg.ops.gru(xs, h, Wg, bg, Wc, bc, "tanh", out=out, ws=ws); e1.record()
+e0.record(); pkg.ops.gru(xs, h, Wg, bg, Wc, bc, "tanh", out=out, ws=ws, fmt=int(os.environ.get("GRU_FMT", "2"))); e1.record()
 torch.cuda.synchronize()
 print("launch (pack pre-pass + GRU) by events: %.1f us" % (e0.elapsed_time(e1) * 1e3))
 raw = tbuf.cpu().numpy().astype(np.float64)
