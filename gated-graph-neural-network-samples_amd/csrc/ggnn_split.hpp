@@ -48,9 +48,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 //     oracle.split3_f16_matmul, tests/test_oracle.py) -- the f32 chain rounds its running sum K times, this form once per 32 terms.
 //     Range and scaling: f16 reaches 65504 and its normals stop at 6.1e-5.  WEIGHTS are packed x 2^8 (exact; free: once per weight
 //     version), which lifts the lo pieces of everything above 2^-11 out of the subnormal range (the lo piece of an unscaled 0.1
-//     sits at 5e-5 and would keep 9 bits: 2 x the error) and bounds |w| to 255 (beyond: saturated at pack time); ACTIVATIONS are
-//     not scaled (numpy: scaling them too buys 1 %) and are clamped to +-65504 before the split (v_med3_f32: a finite,
-//     saturated operand instead of Inf - Inf = NaN; the gates are saturated long before).  The MFMA keeps f16 subnormal inputs
+//     sits at 5e-5 and would keep 9 bits: 2 x the error) and bounds |w| to 255.875; ACTIVATIONS are not scaled (numpy: scaling them
+//     too buys 1 %) and must stay within +-65504.  Neither bound is enforced in the kernel: it is the caller's precondition, and a
+//     value beyond it turns into Inf / NaN pieces, i.e. non-finite results (GGNN_F16_CLAMP below).  The MFMA keeps f16 subnormal inputs
 //     (tools/f16_mfma_denorm_probe.hip).  Accumulators hold 2^8 x the sums: the remainder weights (f32 MFMA) are packed x 2^8 and
 //     the consumer's epilogue scales by acc_scale, folded into a constant it multiplies by anyway.
 //     Used by the fused GRU FORWARD (kernel, both packers) when the CALL asks for it (GruFusedArgs::fmt == GGNN_GRU_FMT_F16X2, the
@@ -74,6 +74,14 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 // 0: left to hipcc (10: it converts each value twice)
 #ifndef GGNN_F16_SPLIT_ASM
 #define GGNN_F16_SPLIT_ASM 1
+#endif
+// 0 (round 5): NO clamp of the operands before the f16 split.  The format's operand range is the caller's PRECONDITION (formats.py
+// proves it per launch); a value beyond it becomes Inf in its hi piece and -Inf / NaN in its lo piece, so a precondition-violating call
+// yields non-finite results instead of plausible wrong ones, and a NaN operand stays NaN (round 4 clamped with v_med3_f32 -- 2 more
+// vector instructions per value pair -- which returned a finite, saturated operand for NaN / Inf: it could mask a diverged run).
+// 1: the round-4 clamp (experiments; profiles/r05_experiments/gru_valu_variants.txt: 66.8 vs 66.0 us).
+#ifndef GGNN_F16_CLAMP
+#define GGNN_F16_CLAMP 0
 #endif
 
 // Process default of the HOST policy (GGNN_GRU_FMT; 2 = f16x2 where proven safe, 3 = always bf16x3).  Kernels take the format per launch.
@@ -118,12 +126,15 @@ __device__ __forceinline__ float trunc_bf16_f(float x) { return __uint_as_float(
 
 // piece p (0 hi, 1 mid, 2 lo) of x as bf16 bits.  Truncation: every piece takes the next 8 significand bits, the three
 // together all 24 -- the split is exact and each residual subtraction is exact.
-// FMT = kSplitF16x2: piece p (0 hi, 1 lo) of the WEIGHT x as f16 bits: x 2^8 saturated at +-65504, round to nearest; the residual
-// subtraction is exact.
+// FMT = kSplitF16x2: piece p (0 hi, 1 lo) of the WEIGHT x as f16 bits: x 2^8, round to nearest; the residual subtraction is exact.
 template <int FMT = kSplitBf16x3>
 __device__ __forceinline__ unsigned split_piece_bits(float x, int p) {
     if constexpr (FMT == kSplitF16x2) {
+#if GGNN_F16_CLAMP
         const float xs = fminf(fmaxf(x * SplitFmt<FMT>::w_scale, -65504.0f), 65504.0f);
+#else
+        const float xs = x * SplitFmt<FMT>::w_scale;      // (|x| > 255.875: Inf / NaN pieces -- loud, see GGNN_F16_CLAMP)
+#endif
         const _Float16 h16 = (_Float16)xs;
         if (p == 0) return (unsigned)__builtin_bit_cast(unsigned short, h16);
         return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(xs - (float)h16));
@@ -213,11 +224,15 @@ struct SFrag {
 };
 
 // two floats -> one register of each plane (element 0 in the low half): 3 v_perm + 4 v_and + 4 v_sub
-// kSplitF16x2: h = the f16 hi pieces, m = the f16 lo pieces of the two values clamped to +-65504 (l unused)
+// kSplitF16x2: h = the f16 hi pieces, m = the f16 lo pieces of the two values (l unused)
 template <int FMT = kSplitBf16x3>
 __device__ __forceinline__ void split_pair(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
     if constexpr (FMT == kSplitF16x2) {
+#if GGNN_F16_CLAMP
         const float t0 = __builtin_amdgcn_fmed3f(a0, -65504.0f, 65504.0f), t1 = __builtin_amdgcn_fmed3f(a1, -65504.0f, 65504.0f);
+#else
+        const float t0 = a0, t1 = a1;
+#endif
 #if GGNN_F16_SPLIT_ASM
         // h = (RN_f16(t0), RN_f16(t1));  m = (RN_f16(t0 - h.lo), RN_f16(t1 - h.hi)): the mixed-precision FMA takes the f16 halves of h
         // as its third source (op_sel_hi marks a source as f16, op_sel picks the half), computes t - h exactly in f32 and rounds once

@@ -25,8 +25,8 @@ A NaN or Inf anywhere (h0 or a weight) makes its maximum non-finite, every `<=` 
 non-finite values stay non-finite.  Everything here is host arithmetic on a handful of floats; the only device work is the maxima.
 
 GGNN_GRU_FMT (process default of this policy, also ggnn_gru_forward_format()): unset / "auto" / "2" = as above; "3" / "exact" =
-BF16X3 always; "force2" = F16X2 without the proof (kernel experiments and the operand-range test only -- results outside the range
-are not the f32 results).  `with formats.forced(fmt):` overrides it for a block (the parity suite runs under both formats).
+BF16X3 always; "force2" = F16X2 without the proof (kernel experiments and the operand-range test only -- outside the range the f16
+pieces overflow and the results are non-finite: nothing is clamped).  `with formats.forced(fmt):` overrides it for a block (the parity suite runs under both formats).
 """
 from __future__ import annotations
 

@@ -69,10 +69,11 @@ int ggnn_matrix_path_is_split(void);
  *       products per f32 product, f32 accumulation; weights packed x 2^8, activations unscaled.  Half the MFMAs, 48 KiB stage
  *       images.  Measured against f64 its error is below the six-product form's and the f32 MFMA's (tests/test_gpu_split_precision.py)
  *       -- INSIDE ITS OPERAND RANGE, which is a PRECONDITION the caller must establish:
- *           every GRU weight   |w| <= GGNN_F16X2_MAX_WEIGHT      (255.875 = 65504 / 2^8: beyond, the packed piece saturates)
- *           every activation   |a| <= GGNN_F16X2_MAX_ACTIVATION  (65504: x segments, h, hence r*h; beyond, the operand is clamped)
+ *           every GRU weight   |w| <= GGNN_F16X2_MAX_WEIGHT      (255.875 = 65504 / 2^8: beyond, the packed f16 piece overflows)
+ *           every activation   |a| <= GGNN_F16X2_MAX_ACTIVATION  (65504: x segments, h, hence r*h; beyond, its f16 piece overflows)
  *           and all of them finite.
- *       Outside it the result is NOT the f32 result (saturated / clamped operands, NaN not propagated).  ggnn_absmax_f32 below
+ *       Outside it the result is NOT the f32 result: an operand beyond the range becomes Inf / NaN pieces and the output non-finite
+ *       (nothing is clamped or saturated silently).  ggnn_absmax_f32 below
  *       computes the maxima a caller needs; the Python host layer (formats.py) selects this format only when the bounds are PROVEN
  *       from max|h0|, the weights' maxima, the cell's activation and the aggregation -- and BF16X3 otherwise.
  * Under GGNN_MATRIX=f32 the argument is ignored (f32 MFMA kernels, f32 images).
