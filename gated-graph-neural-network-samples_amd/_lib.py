@@ -95,7 +95,7 @@ SYMBOLS = {
     "ggnn_dense_gru_packed_bytes": (c_size_t, [c_int]),
     "ggnn_dense_gru_pack_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "ggnn_dense_propagate_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                         c_int, c_int, c_int, c_void_p]),
+                                         c_int, c_int, c_int, c_int, c_void_p]),
     "ggnn_assemble_batch_backward": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, POINTER(c_int64), POINTER(c_int64), c_void_p,
                                              c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int64),
                                              POINTER(c_void_p), c_void_p]),

@@ -348,8 +348,9 @@ extern "C" int ggnn_dense_propagate_is_split(int v, int E, int D) {
 
 extern "C" int ggnn_dense_propagate_f32(const float* h0, const float* A, const float* edge_packed, const float* gru_packed,
                                         const float* edge_bias, const float* bg, const float* bc, float* out, int b, int v, int E,
-                                        int D, int steps, ggnn_stream_t stream) {
+                                        int D, int steps, int fmt, ggnn_stream_t stream) {
     GGNN_CHECK_ARG(b >= 0 && steps >= 1, "bad sizes b=%d steps=%d", b, steps);
+    GGNN_CHECK_ARG(fmt == 0 || fmt == GGNN_GRU_FMT_F16X2 || fmt == GGNN_GRU_FMT_BF16X3, "fmt %d is not a GGNN_GRU_FMT_* value", fmt);
     if (!ggnn_dense_propagate_supported(v, E, D))
         return fail(GGNN_E_UNSUPPORTED, "graph-resident dense forward: v <= 32, E in {2,4,6,8}, hidden size 32/64/100 (got v=%d E=%d D=%d)", v, E, D);
     if (b == 0) return GGNN_OK;
@@ -361,9 +362,9 @@ extern "C" int ggnn_dense_propagate_f32(const float* h0, const float* A, const f
     hipStream_t st = (hipStream_t)stream;
     if (ggnn_dense_propagate_is_split(v, E, D)) {
         DenseGraphArgs s = a;
-        s.eimg = edge_packed + dense_edge_f32_bytes(D, E) / sizeof(float);
-        s.gimg = gru_packed + dense_gru_f32_bytes(D) / sizeof(float);
-        return dense_split_launch(s, E, D, st);
+        s.eimg = edge_packed + (dense_edge_f32_bytes(D, E) + dense_split_images_offset(D, E, fmt)) / sizeof(float);
+        s.gimg = gru_packed + (dense_gru_f32_bytes(D) + dense_split_images_offset(D, 6, fmt)) / sizeof(float);
+        return dense_split_launch(s, E, D, fmt, st);
     }
 #define GGNN_DG_CASE(DD, EE) if (D == DD && E == EE) return launch_dense_graph<DD, EE>(a, st);
     GGNN_DG_CASE(100, 4) GGNN_DG_CASE(100, 8) GGNN_DG_CASE(100, 2) GGNN_DG_CASE(100, 6)

@@ -19,10 +19,11 @@ struct DenseGraphArgs {
 
 // split form (ggnn_dense_graph_split.hip): 1 when the kernel exists for the shape and its LDS blocks fit
 int dense_split_supported(int v, int E, int D);
-size_t dense_split_edge_bytes(int D, int T);      // bytes of the E split edge images
-size_t dense_split_gru_bytes(int D);              // bytes of the six split GRU images, in the split kernel's stage order
+size_t dense_split_edge_bytes(int D, int T);      // bytes of the split section of the edge images: T bf16x3 images, then T f16x2 images
+size_t dense_split_gru_bytes(int D);              // ... of the six GRU images, in the split kernel's stage order (both formats)
+size_t dense_split_images_offset(int D, int T, int fmt);   // byte offset of the images of format `fmt` inside a split section of T images
 int dense_split_pack_edge(const float* W, int T, int D, float* packed, hipStream_t st);
 int dense_split_pack_gru(const float* Wg, const float* Wc, int D, float* packed, hipStream_t st);
-int dense_split_launch(const DenseGraphArgs& a, int E, int D, hipStream_t st);
+int dense_split_launch(const DenseGraphArgs& a, int E, int D, int fmt, hipStream_t st);
 
 }  // namespace ggnn

@@ -82,6 +82,31 @@ class DenseGGNNChemModel(ChemModel):
             c.gates_kernel.copy_(as_t(gru['Wg'])); c.gates_bias.copy_(as_t(gru['bg']))
             c.candidate_kernel.copy_(as_t(gru['Wc'])); c.candidate_bias.copy_(as_t(gru['bc']))
 
+    def propagate_format(self, v: int) -> int:
+        """Operand format of the graph-resident dense forward for the fed batch (formats.py: the two-piece f16 format only where its
+        range is PROVEN, the exact bf16x3 split otherwise).  The dense cell is the tanh GRU (chem_tensorflow_dense.py:88), so every
+        state stays <= S = max(1, max|h0|); a vertex sums over at most v * E (source, type) pairs: |acts| <= v E (D max|W_e| S +
+        max|b_e|) (:103-112); the weights must lie within the x 2^8 packing's range.  Kept in self.last_format / last_format_bounds."""
+        from . import formats
+        pol = formats.policy()
+        if not formats.split_path() or pol == "exact":
+            fmt = formats.BF16X3
+        elif pol == "force2":
+            fmt = formats.F16X2
+        else:
+            cell = self.weights['node_gru']
+            ts = [self.weights['edge_weights'], cell.gates_kernel, cell.candidate_kernel]
+            if self.params['use_edge_bias']:
+                ts.append(self.weights['edge_biases'])
+            mx = formats.weight_absmax(ts)
+            S = formats.state_bound(formats.h0_absmax(self.placeholders), 'tanh')
+            acts = v * self.num_edge_types * (self.params['hidden_size'] * mx[0] * S + (mx[3] if len(mx) > 3 else 0.0))
+            fmt = formats.layer_format(S, acts, formats.nanmax(mx[0], mx[1], mx[2]))
+            self.last_format_bounds = {"proven": fmt == formats.F16X2, "state_bound": S, "acts_bound": acts,
+                                       "weight_absmax": formats.nanmax(mx[0], mx[1], mx[2])}
+        self.last_format = fmt
+        return fmt
+
     def compute_final_node_representations(self) -> torch.Tensor:
         """chem_tensorflow_dense.py:93-117."""
         if self.training and torch.is_grad_enabled():
@@ -105,7 +130,8 @@ class DenseGGNNChemModel(ChemModel):
             W = self.weights['edge_weights'].contiguous()
             return ops.dense_propagate(h.reshape(b, int(v), h_dim), A.contiguous(), _PACKED.dense_edge(W),
                                        _PACKED.dense_gru(cell.gates_kernel, cell.candidate_kernel, h_dim), bias,
-                                       cell.gates_bias, cell.candidate_bias, self.params['num_timesteps'])
+                                       cell.gates_bias, cell.candidate_bias, self.params['num_timesteps'],
+                                       fmt=self.propagate_format(int(v)))
         packed = _PACKED.gru(cell.gates_kernel, cell.candidate_kernel, 1, h_dim) if ops.gru_is_fused(h_dim) else None
         for i in range(self.params['num_timesteps']):                  # :100
             # :104 a fresh weight-dropout mask per (timestep, edge type)

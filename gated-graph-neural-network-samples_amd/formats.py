@@ -142,6 +142,7 @@ class _MaxCache:
 
 
 _WEIGHT_MAX = _MaxCache()
+_H0_MAX = _MaxCache()
 
 
 def weight_absmax(tensors: Sequence[torch.Tensor]) -> List[float]:
@@ -167,7 +168,7 @@ def h0_absmax(placeholders: Dict[str, Any], h0: Optional[torch.Tensor] = None) -
     v, of = placeholders.get('h0_absmax'), placeholders.get('_h0_absmax_of')
     if v is not None and of is not None and of[0]() is h0 and of[1] == h0._version:
         return float(v)
-    v = absmax([h0])[0]
+    v = _H0_MAX.get([h0])[0]                      # (per tensor object and version: a loop over a few resident feeds measures each once)
     placeholders['h0_absmax'] = v
     placeholders['_h0_absmax_of'] = (weakref.ref(h0), h0._version)
     return float(v)

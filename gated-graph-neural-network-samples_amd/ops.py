@@ -648,9 +648,11 @@ def dense_propagate_supported(v: int, E: int, D: int) -> bool:
 
 
 def dense_propagate(h0: torch.Tensor, adjacency: torch.Tensor, edge_packed: torch.Tensor, gru_packed: torch.Tensor,
-                    edge_biases: Optional[torch.Tensor], bg: torch.Tensor, bc: torch.Tensor, steps: int) -> torch.Tensor:
+                    edge_biases: Optional[torch.Tensor], bg: torch.Tensor, bc: torch.Tensor, steps: int,
+                    fmt: int = GRU_FMT_EXACT) -> torch.Tensor:
     """The whole dense forward (chem_tensorflow_dense.py:93-117) in one launch, graph-resident (ggnn_dense_propagate_f32).
-    h0 [b,v,D], adjacency [b,e,v,v]; edge_packed = PackedWeights.dense_edge(W [e,D,D]); gru_packed = PackedWeights.dense_gru(Wg, Wc)."""
+    h0 [b,v,D], adjacency [b,e,v,v]; edge_packed = PackedWeights.dense_edge(W [e,D,D]); gru_packed = PackedWeights.dense_gru(Wg, Wc).
+    fmt: operand format of the kernel's products (exact by default; formats.F16X2 when the caller has proven its range)."""
     lib = _lib.load()
     _req(h0, torch.float32, "h0"); _req(adjacency, torch.float32, "adjacency")
     b, v, D = h0.shape
@@ -668,7 +670,7 @@ def dense_propagate(h0: torch.Tensor, adjacency: torch.Tensor, edge_packed: torc
     out = torch.empty_like(h0)
     _launch("dense_propagate[steps=%d]" % steps, lambda: lib.ggnn_dense_propagate_f32(
         _ptr(h0), _ptr(adjacency), _ptr(edge_packed), _ptr(gru_packed), _ptr(edge_biases), _ptr(bg), _ptr(bc), _ptr(out), b, v, E, D,
-        int(steps), _stream()))
+        int(steps), int(fmt), _stream()))
     return out
 
 

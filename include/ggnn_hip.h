@@ -381,7 +381,11 @@ int ggnn_gru_bwd_stage2_f32(const float* drh, int ld_drh, const float* h, const 
  *   split ones);  gru_packed: ggnn_dense_gru_pack_f32 of Wg [2D,2D], Wc [2D,D] (ggnn_dense_gru_packed_bytes(D) bytes, likewise);
  *   edge_bias [E,D] or NULL;  h0, out [b,v,D];  A [b,E,v,v] (A[g,e,dst,src]).
  *   ggnn_dense_propagate_is_split(v, E, D): 1 when the launch runs the split-form kernel (bf16 matrix pipe, f32 arithmetic: the
- *   process's default matrix path, and the kernel's LDS blocks fit E edge types), 0 for the f32-MFMA kernel. */
+ *   process's default matrix path, and the kernel's LDS blocks fit E edge types), 0 for the f32-MFMA kernel.
+ *   fmt (split-form launches; ABI 3): operand format of every D x D product, GGNN_GRU_FMT_BF16X3 (exact; 0 means the same) or
+ *   GGNN_GRU_FMT_F16X2 under the precondition of "Operand formats" above -- here: every state, every aggregated message
+ *   (|acts| <= v E (D max|W_e| max|h| + max|b_e|)) and r*h within 65504, every weight within 255.875.  The packed buffers hold the
+ *   images of both formats (f32 | bf16x3 | f16x2 sections). */
 int ggnn_dense_propagate_supported(int v, int E, int D);
 int ggnn_dense_propagate_is_split(int v, int E, int D);
 size_t ggnn_dense_edge_packed_bytes(int D, int T);
@@ -389,7 +393,8 @@ int ggnn_dense_edge_pack_f32(const float* W, int T, int D, float* packed, ggnn_s
 size_t ggnn_dense_gru_packed_bytes(int D);
 int ggnn_dense_gru_pack_f32(const float* Wg, const float* Wc, int D, float* packed, ggnn_stream_t stream);
 int ggnn_dense_propagate_f32(const float* h0, const float* A, const float* edge_packed, const float* gru_packed, const float* edge_bias,
-                             const float* bg, const float* bc, float* out, int b, int v, int E, int D, int steps, ggnn_stream_t stream);
+                             const float* bg, const float* bc, float* out, int b, int v, int E, int D, int steps, int fmt,
+                             ggnn_stream_t stream);
 int ggnn_dense_aggregate_f32(const float* A, const float* Hm, const float* bias, float* acts, int b, int v,
                              int e, int D, ggnn_stream_t stream);
 

@@ -28,10 +28,14 @@ def test_dense_aggregate(pkg, cuda, b, v, E, D, bias):
 
 @pytest.mark.parametrize("b,v,E,D,bias,steps", [(7, 29, 4, 100, True, 4), (3, 32, 4, 100, False, 2), (5, 17, 8, 64, True, 3),
                                                  (4, 5, 2, 32, True, 4), (2, 16, 6, 100, True, 1), (256, 29, 4, 100, True, 4)])
-def test_graph_resident_dense_forward(pkg, oracle, cuda, b, v, E, D, bias, steps):
+@pytest.mark.parametrize("fmt", [3, 2])
+def test_graph_resident_dense_forward(pkg, oracle, cuda, b, v, E, D, bias, steps, fmt):
     """ggnn_dense_propagate_f32 -- all timesteps of a graph in one workgroup -- against the fp64 oracle of
     chem_tensorflow_dense.py:93-117 and against the three-launches-per-timestep path on the same inputs (both run fp32 MFMA
-    products in different summation orders: tolerance, not bit equality); repeatable bit for bit."""
+    products in different summation orders: tolerance, not bit equality); repeatable bit for bit.  fmt: the operand format of the
+    kernel's products, a per-launch argument (3 exact bf16x3; 2 two f16 pieces -- these operands are inside its range)."""
+    if fmt == 2 and not pkg._lib.load().ggnn_dense_propagate_is_split(v, E, D):
+        pytest.skip("the launch does not run the split-form kernel")
     rng = np.random.default_rng(b * v + E)
     A = (rng.random((b, E, v, v)) < 2.0 / v).astype(np.float32)
     h0 = rng.uniform(-1, 1, (b, v, D)).astype(np.float32)
@@ -44,7 +48,7 @@ def test_graph_resident_dense_forward(pkg, oracle, cuda, b, v, E, D, bias, steps
     dW, dWg, dWc = dev(W, cuda), dev(gru["Wg"], cuda), dev(gru["Wc"], cuda)
     dbias = None if eb is None else dev(eb.reshape(E, D), cuda)
     run = lambda: pkg.ops.dense_propagate(dev(h0, cuda), dev(A, cuda), P.dense_edge(dW), P.dense_gru(dWg, dWc, D), dbias,
-                                          dev(gru["bg"], cuda), dev(gru["bc"], cuda), steps)
+                                          dev(gru["bg"], cuda), dev(gru["bc"], cuda), steps, fmt=fmt)
     got = run()
     want = oracle.dense_propagate(h0, A, W, eb, gru, steps)
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=1e-5, rtol=1e-4)
@@ -83,6 +87,8 @@ def test_dense_model_matches_oracle(pkg, oracle, cuda):
         want = oracle.dense_propagate(feed["initial_node_representation"].cpu().numpy(), feed["adjacency_matrix"].cpu().numpy(),
                                       W, b, gru, model.params["num_timesteps"])
         np.testing.assert_allclose(got, want, atol=1e-5, rtol=1e-4)
+        if pkg.formats.split_path() and pkg._lib.load().ggnn_dense_propagate_is_split(int(feed["num_vertices"]), model.num_edge_types, 100):
+            assert model.last_format == pkg.formats.F16X2 and model.last_format_bounds["proven"]     # one-hot states, glorot weights
         g = model.weights['regression_gate_task0']; t = model.weights['regression_transform_task0']
         f = lambda x: x.cpu().numpy().astype(np.float64)
         pred = oracle.dense_gated_regression(want, f(feed["initial_node_representation"]), f(feed["node_mask"]),
@@ -115,3 +121,32 @@ def test_sparse_equals_dense_on_gpu(pkg, oracle, cuda):
         smodel.feed(sfeed)
         sparse = smodel.compute_final_node_representations().cpu().numpy()
     np.testing.assert_allclose(dense[mask], sparse, atol=2e-6, rtol=1e-5)
+
+
+def test_dense_model_runs_exact_outside_the_f16x2_range(pkg, oracle, cuda):
+    """The dense model's format policy (DenseGGNNChemModel.propagate_format): an edge weight beyond the x 2^8 packing's range, or edge
+    weights large enough that v E (D max|W| S + max|b|) leaves f16, select the exact format -- and the result matches the oracle."""
+    f = pkg.formats
+    if not f.split_path():
+        pytest.skip("f32 matrix path")
+    ms = pkg.synthetic_qm9(120, mean_nodes=10, seed=6)
+    for case in ("big-weight", "unbounded-acts"):
+        model, W, b, gru = _dense_model(pkg, oracle, ms)
+        W = W.copy()
+        if case == "big-weight":
+            W[1, 2, 3] = 400.0
+        else:
+            W *= 150.0                                          # v E D max|W| beyond 65504 for every bucket size (v >= 4: 4 * 4 * 100 * 26)
+        model.set_graph_weights(W, b, gru)
+        feed = next(iter(model.make_minibatch_iterator(model.valid_data, is_training=False)))
+        with torch.no_grad(), f.forced("auto"):
+            model.feed(feed)
+            got = model.compute_final_node_representations().cpu().numpy()
+        if pkg._lib.load().ggnn_dense_propagate_is_split(int(feed["num_vertices"]), model.num_edge_types, 100):
+            assert model.last_format == f.BF16X3, (case, model.last_format_bounds)
+        want = oracle.dense_propagate(feed["initial_node_representation"].cpu().numpy(), feed["adjacency_matrix"].cpu().numpy(),
+                                      W, b, gru, model.params["num_timesteps"])
+        if case == "big-weight":
+            np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-4)
+        else:       # pre-activations of O(100) that cancel: ill conditioned in any f32 evaluation -- an rms bound, not an entrywise one
+            assert np.isfinite(got).all() and float(np.sqrt(np.mean((got - want) ** 2))) < 1e-4
