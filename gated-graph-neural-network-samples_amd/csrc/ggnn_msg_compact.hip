@@ -203,7 +203,7 @@ static int launch_compact(const float* h, const float* W, const int* pair_node, 
 int gru_panel_supported(int D);      // ggnn_panel.hip: hidden sizes handled on column panels
 int transform_panel_image_floats(int D);
 int transform_panel_dispatch(const float* h, const float* W, const int* pair_node, const int* row_off, int T, int V, int D,
-                             float* packed, float* Hc, hipStream_t st);
+                             float* packed, float* Hc, int fmt, hipStream_t st);
 
 static int stage_img_floats(int D) {
     if (gru_panel_supported(D)) return (D / 64) * transform_panel_image_floats(D);      // NP panel images per type
@@ -281,7 +281,7 @@ extern "C" int ggnn_edge_weights_pack_f32(const float* W, int T, int D, int fmt,
     TypeRows tr{};
     tr.T = T;                                   // all row counts zero: pack only
     hipStream_t st = (hipStream_t)stream;
-    if (gru_panel_supported(D)) return transform_panel_dispatch(nullptr, W, nullptr, tr.row_off, T, 0, D, packed, nullptr, st);
+    if (gru_panel_supported(D)) return transform_panel_dispatch(nullptr, W, nullptr, tr.row_off, T, 0, D, packed, nullptr, fmt, st);
     switch (D) {
         case 100: return launch_compact<100>(nullptr, W, nullptr, tr, packed, nullptr, fmt, st);
         case 64: return launch_compact<64>(nullptr, W, nullptr, tr, packed, nullptr, fmt, st);
@@ -317,7 +317,7 @@ extern "C" int ggnn_msg_transform_compact_f32(const float* h, const float* W, co
         return fail(GGNN_E_WORKSPACE, "compact transform workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* packed = static_cast<float*>(ws);
-    if (gru_panel_supported(D)) return transform_panel_dispatch(h, W, pair_node, tr.row_off, T, V, D, packed, Hc, st);
+    if (gru_panel_supported(D)) return transform_panel_dispatch(h, W, pair_node, tr.row_off, T, V, D, packed, Hc, fmt, st);
     switch (D) {
         case 100: return launch_compact<100>(h, W, pair_node, tr, packed, Hc, fmt, st);
         case 64: return launch_compact<64>(h, W, pair_node, tr, packed, Hc, fmt, st);

@@ -839,11 +839,13 @@ __global__ __launch_bounds__(NW * 64) void msg_transform_panel_kernel(const floa
 // NP x 96 KiB of weights from L2 instead of (NP - 1) x 128 KiB of rows from HBM / Infinity Cache, and 352 instead of NP x 352
 // split instructions per tile.
 // pr.wg_off counts the workgroups of a type (NOT times NP); packed: [T][NP] images in pack_panel_gru_split_image's format
-template <int D, int NW>
+// FMT (round 5): operand format of the products and of the images, per launch (kSplitF16x2: two planes, whole images through the
+// ring -- no parts -- for a forward transform whose states and edge weights the caller has proven in range; formats.py).
+template <int D, int NW, int FMT = kSplitBf16x3>
 __global__ __launch_bounds__(NW * 64) void msg_transform_ring_kernel(const float* __restrict__ h, const int* __restrict__ pair_node,
                                                                      PanelRows pr, const float* __restrict__ packed, float* __restrict__ Hc) {
     using C = PanelCfg<D>;
-    using SC = PanelGruSplitCfg<D>;
+    using SC = PanelGruSplitCfg<D, FMT>;
     constexpr int NP = C::NP, PARTS = SC::PARTS, SLOTF = SC::PART, IMGF = SC::IMG, NC2 = SC::NC2;
     extern __shared__ __attribute__((aligned(16))) float ring[];     // [2][PART]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -895,8 +897,8 @@ __global__ __launch_bounds__(NW * 64) void msg_transform_ring_kernel(const float
             for (int c2 = 0; c2 < NC2; ++c2) {
                 const f32x4 x = a.v[2 * c2], y = a.v[2 * c2 + 1];
                 unsigned hh[4], mm[4], ll[4];
-                split_pair(x.x, x.y, hh[0], mm[0], ll[0]); split_pair(x.z, x.w, hh[1], mm[1], ll[1]);
-                split_pair(y.x, y.y, hh[2], mm[2], ll[2]); split_pair(y.z, y.w, hh[3], mm[3], ll[3]);
+                split_pair<FMT>(x.x, x.y, hh[0], mm[0], ll[0]); split_pair<FMT>(x.z, x.w, hh[1], mm[1], ll[1]);
+                split_pair<FMT>(y.x, y.y, hh[2], mm[2], ll[2]); split_pair<FMT>(y.z, y.w, hh[3], mm[3], ll[3]);
                 ph[c2] = u32x4{hh[0], hh[1], hh[2], hh[3]}; pm[c2] = u32x4{mm[0], mm[1], mm[2], mm[3]}; pl[c2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
             }
         }
@@ -918,13 +920,13 @@ __global__ __launch_bounds__(NW * 64) void msg_transform_ring_kernel(const float
                 if (more) dma(nsrc, ring + (cur ^ 1) * SLOTF);
                 if constexpr (ACT) { if (p == 0 && part == 0 && has_next) { load_frag<D>(a, h, node_next, kq); keep += C::NC; } }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (ACT) panel_part_mma_planes<D, part == 0, part>(acc, ph, pm, pl, ring + cur * SLOTF, li, kq);
+                if constexpr (ACT) panel_part_mma_planes<D, part == 0, part, FMT>(acc, ph, pm, pl, ring + cur * SLOTF, li, kq);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ACT && part == PARTS - 1) {
                     // (every tile has a valid first row: the four stores are issued by every wave with a tile)
                     if (r < row_end) {
 #pragma unroll
-                        for (int nt = 0; nt < 4; ++nt) st4_b(Hc, ((unsigned)r * (unsigned)D + p * 64 + nt * 16 + 4 * kq) * 4u, acc[nt]);
+                        for (int nt = 0; nt < 4; ++nt) st4_b(Hc, ((unsigned)r * (unsigned)D + p * 64 + nt * 16 + 4 * kq) * 4u, acc[nt] * SplitFmt<FMT>::acc_scale);
                     }
                     keep += 4;
                 }
@@ -950,13 +952,13 @@ static bool transform_ring() {
     return v && split_matrix_path();
 }
 
-template <int D, bool SPLIT>
+template <int D, bool SPLIT, int FMT = kSplitBf16x3>
 __global__ void edge_weight_panel_pack_kernel(const float* __restrict__ W, float* __restrict__ out, int ring_format) {
     using C = PanelCfg<D>;
     const int t = blockIdx.y / C::NP, p = blockIdx.y % C::NP;
     const int first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if constexpr (SPLIT) {
-        if (ring_format) pack_panel_gru_split_image<D>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * PanelGruSplitCfg<D>::IMG, first, stride);
+        if (ring_format) pack_panel_gru_split_image<D, FMT>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * PanelGruSplitCfg<D, FMT>::IMG, first, stride);
         else pack_panel_split_image<D>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * PanelSplitCfg<D>::IMG, first, stride);
     } else pack_panel_image<D>(W + (size_t)t * D * D, 0, p * C::BN, D, out + (size_t)blockIdx.y * C::IMG, first, stride);
 }
@@ -974,13 +976,14 @@ int transform_panel_image_floats(int D) {
     }
 }
 
-template <int D, bool SPLIT>
+// FMT: only the ring kernel (split path) has the two-piece f16 form; the stationary-image kernel and the f32 path ignore it
+template <int D, bool SPLIT, int FMT = kSplitBf16x3>
 static int launch_transform_panel_m(const float* h, const float* W, const int* pair_node, const int* row_off, int T, int V,
                                   float* packed, float* Hc, hipStream_t st) {
     using C = PanelCfg<D>;
     constexpr int NW = 8, NP = C::NP;
     if (W) {
-        hipLaunchKernelGGL((edge_weight_panel_pack_kernel<D, SPLIT>), dim3(8, T * NP), dim3(256), 0, st, W, packed, (int)(SPLIT && transform_ring()));
+        hipLaunchKernelGGL((edge_weight_panel_pack_kernel<D, SPLIT, FMT>), dim3(8, T * NP), dim3(256), 0, st, W, packed, (int)(SPLIT && transform_ring()));
         GGNN_CHECK_HIP(hipGetLastError());
     }
     const int R = row_off[T];
@@ -1019,9 +1022,9 @@ static int launch_transform_panel_m(const float* h, const float* W, const int* p
             }
             rr.row_off[T] = R;
             static std::atomic<unsigned long long> lds_ok_r{0};
-            constexpr size_t lds_r = (size_t)2 * PanelGruSplitCfg<D>::PART_BYTES;
-            if (lds_r > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&msg_transform_ring_kernel<D, NW>, lds_r, lds_ok_r));
-            hipLaunchKernelGGL((msg_transform_ring_kernel<D, NW>), dim3(rr.wg_off[T]), dim3(NW * 64), lds_r, st, h, pair_node, rr,
+            constexpr size_t lds_r = (size_t)2 * PanelGruSplitCfg<D, FMT>::PART_BYTES;
+            if (lds_r > 48 * 1024) GGNN_CHECK_HIP(allow_dynamic_lds(&msg_transform_ring_kernel<D, NW, FMT>, lds_r, lds_ok_r));
+            hipLaunchKernelGGL((msg_transform_ring_kernel<D, NW, FMT>), dim3(rr.wg_off[T]), dim3(NW * 64), lds_r, st, h, pair_node, rr,
                                (const float*)packed, Hc);
             GGNN_CHECK_HIP(hipGetLastError());
             return GGNN_OK;
@@ -1038,18 +1041,21 @@ static int launch_transform_panel_m(const float* h, const float* W, const int* p
 
 template <int D>
 static int launch_transform_panel(const float* h, const float* W, const int* pair_node, const int* row_off, int T, int V,
-                                  float* packed, float* Hc, hipStream_t st) {
-    if (split_matrix_path()) return launch_transform_panel_m<D, true>(h, W, pair_node, row_off, T, V, packed, Hc, st);
+                                  float* packed, float* Hc, int fmt, hipStream_t st) {
+    if (split_matrix_path())
+        return (gru_launch_fmt(fmt) == kSplitF16x2 && transform_ring())
+                   ? launch_transform_panel_m<D, true, kSplitF16x2>(h, W, pair_node, row_off, T, V, packed, Hc, st)
+                   : launch_transform_panel_m<D, true>(h, W, pair_node, row_off, T, V, packed, Hc, st);
     return launch_transform_panel_m<D, false>(h, W, pair_node, row_off, T, V, packed, Hc, st);
 }
 
 int transform_panel_dispatch(const float* h, const float* W, const int* pair_node, const int* row_off, int T, int V, int D,
-                             float* packed, float* Hc, hipStream_t st) {
+                             float* packed, float* Hc, int fmt, hipStream_t st) {
     if (T > kMaxTypesP) return fail(GGNN_E_UNSUPPORTED, "more than %d edge types", kMaxTypesP);
     switch (D) {
-        case 128: return launch_transform_panel<128>(h, W, pair_node, row_off, T, V, packed, Hc, st);
-        case 192: return launch_transform_panel<192>(h, W, pair_node, row_off, T, V, packed, Hc, st);
-        case 256: return launch_transform_panel<256>(h, W, pair_node, row_off, T, V, packed, Hc, st);
+        case 128: return launch_transform_panel<128>(h, W, pair_node, row_off, T, V, packed, Hc, fmt, st);
+        case 192: return launch_transform_panel<192>(h, W, pair_node, row_off, T, V, packed, Hc, fmt, st);
+        case 256: return launch_transform_panel<256>(h, W, pair_node, row_off, T, V, packed, Hc, fmt, st);
         default: return fail(GGNN_E_UNSUPPORTED, "no panel transform for hidden size %d", D);
     }
 }

@@ -288,7 +288,7 @@ int ggnn_gru_is_fused(int D);
  *   ggnn_edge_weights_pack_f32  W [T,D,D] -> packed (ggnn_msg_transform_compact_workspace_bytes(D,T) bytes: enough for either
  *                               operand format), in the format `fmt` (GGNN_GRU_FMT_*; "Operand formats" at the top: BF16X3 is
  *                               exact on every input; F16X2 needs |h| <= 65504 and |W| <= 255.875 PROVEN by the caller --
- *                               forward transforms only; hidden sizes 32 / 64 / 100, ignored elsewhere);
+ *                               forward transforms only; hidden sizes 32 / 64 / 100 and the ring kernel of 128 / 192 / 256);
  *                               then call ggnn_msg_transform_compact_f32 with W = NULL and ws = packed.
  * tile_counter (ggnn_gru_packed_f32, ggnn_gru_packed_gather_f32): NULL, or a DEVICE int32 that is 0 when the launch
  * starts (the kernel leaves it non-zero).  With a counter the 16-row tiles are handed to the workgroups dynamically:
