@@ -148,5 +148,8 @@ def test_dense_model_runs_exact_outside_the_f16x2_range(pkg, oracle, cuda):
                                       W, b, gru, model.params["num_timesteps"])
         if case == "big-weight":
             np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-4)
-        else:       # pre-activations of O(100) that cancel: ill conditioned in any f32 evaluation -- an rms bound, not an entrywise one
-            assert np.isfinite(got).all() and float(np.sqrt(np.mean((got - want) ** 2))) < 1e-4
+        else:       # pre-activations of O(1000) that cancel: ill conditioned in ANY f32 evaluation -- the measure is the oracle evaluated in f32
+            want32 = oracle.dense_propagate(feed["initial_node_representation"].cpu().numpy(), feed["adjacency_matrix"].cpu().numpy(),
+                                            W, b, gru, model.params["num_timesteps"], dtype=np.float32).astype(np.float64)
+            rms = lambda x: float(np.sqrt(np.mean(x * x)))
+            assert np.isfinite(got).all() and rms(got - want) <= 2.0 * rms(want32 - want) + 1e-6, (rms(got - want), rms(want32 - want))
