@@ -73,6 +73,7 @@ GRU_FWD_FORMAT = 3                 # set from ggnn_gru_forward_format() in main(
 EDGE_FORMAT = 3                    # operand format of the compacted message transform of the timed steps (model.last_edge_formats)
 F16X2_PRODUCTS = 3
 DENSE_SPLIT = False                # set from ggnn_dense_propagate_is_split() for the configs[2] shape in secondary_dense()
+DENSE_FORMAT = 3                   # operand format the dense model's policy chose for the configs[2] launches (model.last_format)
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 HBM_COPY_GBPS = 6290.0
 
@@ -191,7 +192,8 @@ def kernel_table(res, reps, V, M, D, T, R=None):
                                   "f32_mfma_peak": FP32_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                                   "matrix_path": "bf16x3 split: f32 operands as 3 bf16 pieces each, 6 bf16 MFMA products per f32 product, "
                                                  "f32 accumulation (error bound of an f32 FMA chain)"})
-            if (name.startswith("gru_fused") and GRU_FWD_FORMAT == 2) or (name == "msg_transform_compact" and EDGE_FORMAT == 2 and D in (32, 64, 100)):
+            if (name.startswith("gru_fused") and GRU_FWD_FORMAT == 2) or (name == "msg_transform_compact" and EDGE_FORMAT == 2) or \
+                    (name.startswith("dense_propagate") and DENSE_FORMAT == 2):
                 pipe = BF16_MFMA_PEAK_TFLOPS / F16X2_PRODUCTS
                 kernels[name].update({"peak": pipe, "frac": ach / pipe, "pipe": "f16 MFMA, 3 products per f32 product (2500 / 3 TF f32-equivalent)",
                                       "matrix_path": "f16x2 split: f32 operands as 2 f16 pieces each (22 of 24 significand bits, round to nearest; "
@@ -335,6 +337,10 @@ def secondary_large(pkg, dev):
             step(i)
     comp = getattr(index, "_compact", None)
     R = comp.num_rows if comp is not None else None
+    global GRU_FWD_FORMAT, EDGE_FORMAT             # (the formats THIS model's policy chose: the kernels' pipe ceilings follow them)
+    gf, ef = list(getattr(model, "last_gru_formats", None) or [3]), list(getattr(model, "last_edge_formats", None) or [3])
+    GRU_FWD_FORMAT = gf[0] if SPLIT_ACTIVE and all(x == gf[0] for x in gf) else (3 if SPLIT_ACTIVE else 0)
+    EDGE_FORMAT = ef[0] if SPLIT_ACTIVE and all(x == ef[0] for x in ef) else (3 if SPLIT_ACTIVE else 0)
     kernels, tot_ms = kernel_table(kt.results(), 3, V, M, D, T, R)
     err = attach_traffic(kernels, "large", D)
     out = {"workload": "configs[4]: sparse GGNN forward, ONE graph: %d nodes / %d edges / %d edge types, h=%d, 8 steps" % (V, M, T, D),
@@ -370,7 +376,8 @@ def secondary_dense(pkg, dev):
             step(i)
     b, v = feeds[0]["initial_node_representation"].shape[:2]
     D, T = model.params["hidden_size"], model.num_edge_types
-    global DENSE_SPLIT
+    global DENSE_SPLIT, DENSE_FORMAT
+    DENSE_FORMAT = int(getattr(model, "last_format", 3))
     DENSE_SPLIT = bool(pkg._lib.load().ggnn_dense_propagate_is_split(int(v), int(T), int(D)))
     kernels, tot_ms = kernel_table(kt.results(), 6, b * v, b * T * v * v, D, T)
     err = attach_traffic(kernels, "dense", D)
