@@ -410,10 +410,10 @@ def measure_sustained_mfma(pkg, dev, launches=60):
 
 
 def exact_format_reference(args, value, run=subprocess.run):
-    """The same timed forward with the fused GRU in the EXACT three-piece bf16 format (GGNN_GRU_FMT=3; the format is fixed per process: a
-    child process), so that the line carries both numbers of one box and one run -- `value` is with the two-piece f16 format (22-bit
-    operands, three products; error against f64 measured below the exact form's, tests/test_gpu_split_precision.py).  A reference leg
-    must never take the headline down: any failure comes back as {"error": ...}."""
+    """The same timed forward with EVERY product in the exact three-piece bf16 format (the host policy forced to `exact` by
+    GGNN_GRU_FMT=3 in a child process, so that the two legs share nothing but the box), so that the line carries both numbers of one
+    box and one run -- `value` is under the default policy (two-piece f16 operands where their range is proven, formats.py).  This
+    is the f32 number of record.  A reference leg must never take the headline down: any failure comes back as {"error": ...}."""
     try:
         env = dict(os.environ, GGNN_GRU_FMT="3", GGNN_BENCH_CHILD="1")
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
@@ -421,8 +421,8 @@ def exact_format_reference(args, value, run=subprocess.run):
                "--no-secondary", "--no-cpu-baseline", "--no-roofline"]
         r = run(cmd, env=env, capture_output=True, text=True, timeout=120)
         c = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        return {"what": "the same timed forward in a child process with GGNN_GRU_FMT=3: the fused GRU in the exact three-piece bf16 format, six "
-                        "products per f32 product (the format of every other split-form kernel)",
+        return {"what": "the same timed forward in a child process with GGNN_GRU_FMT=3 (policy `exact`): the fused GRU and the message transform in "
+                        "the exact three-piece bf16 format, six products per f32 product (the format of every backward kernel)",
                 "value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"], "ms_per_step_one_stream": c.get("ms_per_step_one_stream"),
                 "gru_forward_format": c.get("gru_forward_format"), "value_ratio_default_over_exact": value / c["value"]}
     except Exception as exc:

@@ -402,8 +402,8 @@ __device__ __forceinline__ void panel_part_mma_planes(f32x4 (&acc)[4], const u32
 }
 
 // SPLIT: the products on the bf16 pipe in 3-way split form; an image comes through the ring in PanelGruSplitCfg::PARTS parts.
-// FMT (SPLIT): operand format of the products and images (ggnn_split.hpp): kSplitF16x2 by default since the end of round 4 (two f16
-// pieces, three products, whole 64 KiB images through the ring), kSplitBf16x3 behind GGNN_GRU_FMT=3.
+// FMT (SPLIT): operand format of the products and images (ggnn_split.hpp), per launch (GruFusedArgs::fmt): kSplitF16x2 (two f16
+// pieces, three products, whole 64 KiB images through the ring; the caller's proven operand range) or the exact kSplitBf16x3.
 template <int FMT>
 __device__ __forceinline__ f32x4 panel_sigmoid4(f32x4 z, f32x4 b_scaled) {      // (sigmoid4_scaled on an accumulator of 1 / acc_scale x the sum)
     constexpr float k = -kLog2e * SplitFmt<FMT>::acc_scale;
