@@ -725,6 +725,9 @@ def main():
                    "graphs_per_batch": int(np.mean(graphs)), "mean_nodes_per_graph": args.mean_nodes,
                    "active_source_type_pairs_per_batch": None, "hip_streams": 1 if headline_train else max(args.streams, 1),
                    "resident_batches": len(feeds), "batch_size_param": params["batch_size"],
+                   # (data-parallel epochs of run_epoch are re-cut into equal-node batches by default, data.epoch_boundaries; the bench's
+                   #  ranks pack their own datasets with the reference's greedy batcher, so the headline's batches are the reference's)
+                   "dp_balance_nodes": bool(params.get("dp_balance_nodes", True)),
                    "parallelism": "dp%d (independent graph batches%s)" % (world, "; one flat fp32 gradient all-reduce per step" if headline_train else "")},
         "graphs_per_sec": total_graphs / elapsed,
     }
