@@ -20,6 +20,7 @@ SYMBOLS = {
     "ggnn_abi_version": (c_int, []),
     "ggnn_matrix_path_is_split": (c_int, []),
     "ggnn_gru_forward_format": (c_int, []),
+    "ggnn_gru_form_set": (c_int, [c_int]),
     "ggnn_absmax_f32": (c_int, [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_void_p]),
     "ggnn_last_error": (c_char_p, []),
     "ggnn_csr_workspace_bytes": (c_size_t, [c_int64, c_int]),

@@ -67,7 +67,7 @@ def _included_sources(src: str) -> list:
 # ... and with the AMDGPU register-pressure trackers in the machine scheduler: at the 256-register limit these kernels sit at, the
 # default scheduler's pressure estimate costs 8-70 B of scratch per lane more (split fused GRU R = 1: 8 -> 0 B; panel GRU 228 -> 156 B).
 NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
-PER_SOURCE_FLAGS = {"ggnn_gru_fused_split.hip": NO_PACKED_F32, "ggnn_dense_graph_split.hip": NO_PACKED_F32, "ggnn_gru_bwd_fused_split.hip": NO_PACKED_F32, "ggnn_msg_compact.hip": NO_PACKED_F32, "ggnn_panel.hip": NO_PACKED_F32, "ggnn_bwd_gemm.hip": NO_PACKED_F32}
+PER_SOURCE_FLAGS = {"ggnn_gru_fused_split.hip": NO_PACKED_F32, "ggnn_gru_wide.hip": NO_PACKED_F32, "ggnn_dense_graph_split.hip": NO_PACKED_F32, "ggnn_gru_bwd_fused_split.hip": NO_PACKED_F32, "ggnn_msg_compact.hip": NO_PACKED_F32, "ggnn_panel.hip": NO_PACKED_F32, "ggnn_bwd_gemm.hip": NO_PACKED_F32}
 
 
 def build(force: bool = False, verbose: bool = True) -> str:

@@ -45,8 +45,17 @@ int gru_fwd_fmt() {
     return v;
 }
 
+// Ring form of the gather-fused GRU launches (ggnn_gru_fused.hip: 0 / 1 / 2; 6 = the wide kernel of ggnn_gru_wide.hip): -1 = the
+// library's default per (fan-in, format).  GGNN_GRU_FORM sets the process default; ggnn_gru_form_set() overrides it at run time
+// (tests and experiments compare the forms -- bit-identical results -- inside one process).
+std::atomic<int>& gru_form_override() {
+    static std::atomic<int> v{[] { const char* e = getenv("GGNN_GRU_FORM"); return e ? atoi(e) : -1; }()};
+    return v;
+}
+
 }  // namespace ggnn
 
+extern "C" int ggnn_gru_form_set(int form) { return ggnn::gru_form_override().exchange(form); }
 extern "C" int ggnn_matrix_path_is_split(void) { return ggnn::split_matrix_path() ? 1 : 0; }
 extern "C" int ggnn_gru_forward_format(void) { return ggnn::split_matrix_path() ? ggnn::gru_fwd_fmt() : 0; }
 extern "C" int ggnn_abi_version(void) { return GGNN_ABI_VERSION; }

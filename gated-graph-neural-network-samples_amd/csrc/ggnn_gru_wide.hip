@@ -1,0 +1,617 @@
+// K3w: the gather-fused GRU launch (chem_tensorflow_sparse.py:198-216) in its WIDE form -- one wave per SIMD on the whole
+// 512-entry register file, NTW 16-row tiles per wave that share every weight-fragment read, gate-sequential stage order.
+//
+// Why (round 6).  The ring forms of ggnn_gru_fused.hip run two 256-register waves per SIMD, one 16-row tile each: every wave reads
+// every 48 KiB stage image for its own 16 rows (one ds_read_b128 per 1.5 MFMAs in the two-piece f16 format), a pass of a CU is 8
+// tiles -- three passes, i.e. 18 image DMAs and 18+ stage barriers per launch at the reference's batch size -- and all three
+// accumulator sets of a tile (84 registers) are live from the first stage to the last, which is what pins those kernels to the
+// 256-register wall (72 spilled SGPRs, 150 v_readlane / v_writelane per pass, no room to share a weight fragment between two tiles).
+// Here a workgroup is FOUR waves, one per SIMD, and a wave owns NTW tiles at once:
+//   * a weight fragment (the two / three operand planes of one (32-chunk, column tile) unit) is read from LDS ONCE and multiplies
+//     the NTW tiles' fragments: 3 NTW MFMAs per 2 ds_read_b128 instead of 3 -- the LDS weight traffic per row falls by NTW;
+//   * a pass of a CU is 4 NTW tiles (12 at NTW = 3): two passes per launch at the reference's batch size instead of three, a third
+//     fewer image DMAs and stage barriers per row, and a barrier is among four waves instead of eight;
+//   * the stages run GATE-SEQUENTIALLY -- every input segment -> r columns, then the r epilogue, every segment -> u columns, the u
+//     epilogue, every segment -> candidate columns -- so ONE accumulator set per tile is open at a time (28 registers instead of
+//     84): r leaves its set as the r*h planes, u stays as 28 values, and the NTW tiles fit the register file with the gather of the
+//     NEXT pass running beside the last stage.  Per accumulator the chain is the ring forms': segments in order, h / r*h last,
+//     chunks in order, remainder last, three (six) products per unit smallest first -- RESULTS ARE BIT-IDENTICAL to those kernels
+//     (tests/test_gpu_parity.py::test_wide_gru_equals_ring_forms), and the stage images are the ones ggnn_gru_pack_weights_f32
+//     writes: nothing is packed differently, only the ORDER in which a pass streams the 3 (NX + 1) images changes.
+// The r / u tail columns ride in the r images' padding columns exactly as there (StageCfg::TAILPACK / TAILPACK3).
+//
+// Work split: workgroup b owns the contiguous tile range [T b / nb, T (b + 1) / nb) and walks it in P = ceil(n_b / (4 NTW)) passes;
+// the n_b tiles are dealt evenly over the 4 P (pass, wave) slots, so no wave ever has more than one tile above another's and a
+// wave's count never grows from pass to pass.  The pass body is instantiated per tile count (NTA = 1 .. NTW): a wave with fewer
+// tiles issues fewer MFMAs, it does not multiply dummy rows.
+//
+// Gather (the aggregated-messages segment, :198-212): the 3-level chain row_ptr -> gather_row -> rows of the NEXT pass's tiles is
+// issued beside the last three stages of the current pass (slot range + in-degrees | first four source rows | rows of slots 0, 1)
+// and finished in the shadow of the candidate epilogue (slots 2, 3, any further ones synchronously, the mean); slot order, adds and
+// the one-division mean are those of ggnn_gather_segment_sum_f32.
+#include "ggnn_split.hpp"
+#include <type_traits>
+
+namespace ggnn {
+
+int gru_wide_launch(int D, int nx, int ntw_req, const GruFusedArgs& a, float* packed, hipStream_t st);
+int gru_wide_supported(int D, int nx);
+
+namespace {
+
+struct GruWideArgs {
+    const float* x[2];           // residual segments (NX - 1 of them)
+    const float* h; const float* bg; const float* bc; float* h_out;
+    float* save_r; float* save_u; float* save_c; float* save_x;
+    const float* g_H; const int* g_row_ptr; const int* g_idx; const float* g_nin;
+    const float* packed;
+    int V, act, g_T, g_use_avg;
+};
+
+template <int I0, int I1, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); sfor<I0 + 1, I1>(f); }
+}
+
+template <int D>
+__device__ __forceinline__ void frag_add_w(Frag<D>& f, const Frag<D>& t) {
+#pragma unroll
+    for (int c = 0; c < StageCfg<D>::NC; ++c) f.v[c] += t.v[c];
+#pragma unroll
+    for (int q = 0; q < StageCfg<D>::NR; ++q) f.r[q] += t.r[q];
+}
+
+// (the gate epilogues of ggnn_gru_fused.hip: same expressions)
+template <int FMT>
+__device__ __forceinline__ f32x4 w_sigmoid4_acc(f32x4 z, f32x4 b_scaled) {
+    constexpr float k = -kLog2e * SplitFmt<FMT>::acc_scale;
+    return rcp_4(exp2_4(z * k + b_scaled) + 1.0f);
+}
+template <int FMT>
+__device__ __forceinline__ f32x4 w_tanh4_acc(f32x4 z, f32x4 b_scaled) {
+    constexpr float k = 2.0f * kLog2e * SplitFmt<FMT>::acc_scale;
+    return 1.0f - 2.0f * rcp_4(exp2_4(z * k + b_scaled) + 1.0f);
+}
+
+// the operand planes of one 16-row activation fragment (p[0] = hi pieces, p[1] = mid / lo, p[2] = lo of the bf16 form)
+template <int D, int FMT>
+struct WPl { u32x4 p[SplitFmt<FMT>::NP][SplitCfg<D, FMT>::NC2 > 0 ? SplitCfg<D, FMT>::NC2 : 1]; };
+
+template <int D, int FMT>
+__device__ __forceinline__ void wsplit(WPl<D, FMT>& s, const Frag<D>& f) {
+#pragma unroll
+    for (int c2 = 0; c2 < SplitCfg<D, FMT>::NC2; ++c2) {
+        const f32x4 a = f.v[2 * c2], b = f.v[2 * c2 + 1];
+        unsigned h[4], m[4], l[4];
+        split_pair<FMT>(a.x, a.y, h[0], m[0], l[0]);
+        split_pair<FMT>(a.z, a.w, h[1], m[1], l[1]);
+        split_pair<FMT>(b.x, b.y, h[2], m[2], l[2]);
+        split_pair<FMT>(b.z, b.w, h[3], m[3], l[3]);
+        s.p[0][c2] = u32x4{h[0], h[1], h[2], h[3]};
+        s.p[1][c2] = u32x4{m[0], m[1], m[2], m[3]};
+        if constexpr (SplitFmt<FMT>::NP > 2) s.p[2][c2] = u32x4{l[0], l[1], l[2], l[3]};
+    }
+}
+
+// acc[t][nt] (+)= fragment t x split stage image for the wave's NTA tiles: stage_mma_split_at's products in its order per
+// accumulator (chunks in order, then the remainder on the f32 MFMA; per unit the products smallest first), every weight fragment
+// read once for all NTA tiles.  The planes of the NEXT unit are fetched at the start of the current one.
+template <int D, int NTW, int NTA, int NTILES, bool ZERO, int FMT>
+__device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT], const WPl<D, FMT> (&a)[NTW],
+                                               const float (&ar)[NTW][StageCfg<D>::NR > 0 ? StageCfg<D>::NR : 1],
+                                               const float* img, int li, int kq) {
+    using S = StageCfg<D>;
+    using C = SplitCfg<D, FMT>;
+    constexpr int NP = C::NP;
+    constexpr int NU = C::NC2 * NTILES;                               // units, chunk-major
+    const float* img_b = img + C::HA;
+    if constexpr (NU > 0) {
+        const u32x4* base_a = reinterpret_cast<const u32x4*>(img) + kq * (C::TA * 16) + li;
+        const u32x4* base_b = reinterpret_cast<const u32x4*>(img_b) + kq * ((S::NT - C::TA) * 16) + li;
+        auto slot = [&](int u, int p) {
+            const int nt = u % NTILES, c2 = u / NTILES;
+            const int nth = C::nth_of(nt);
+            const u32x4* b = C::half_of(nt) ? base_b : base_a;
+            return b[p * (C::plane_bytes(nth) / 16) + c2 * 4 * nth * 16 + C::tile_in_half(nt) * 16];
+        };
+        u32x4 w[NP], n[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { w[p] = slot(0, p); n[p] = w[p]; }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int c2 = u / NTILES, nt = u % NTILES;
+            if (u + 1 < NU) {
+#pragma unroll
+                for (int p = NP - 1; p >= 0; --p) n[p] = slot(u + 1, p);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 c[NTA];
+#pragma unroll
+            for (int t = 0; t < NTA; ++t) c[t] = (ZERO && c2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[t][nt];
+            if constexpr (FMT == kSplitF16x2) {
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) c[t] = mfma_f16(w[1], a[t].p[0][c2], c[t]);
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) c[t] = mfma_f16(w[0], a[t].p[1][c2], c[t]);
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) c[t] = mfma_f16(w[0], a[t].p[0][c2], c[t]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) c[t] = mfma_bf16(w[2], a[t].p[0][c2], c[t]);
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) c[t] = mfma_bf16(w[1], a[t].p[1][c2], c[t]);
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) c[t] = mfma_bf16(w[1], a[t].p[0][c2], c[t]);
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) c[t] = mfma_bf16(w[0], a[t].p[2][c2], c[t]);
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) c[t] = mfma_bf16(w[0], a[t].p[1][c2], c[t]);
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) c[t] = mfma_bf16(w[0], a[t].p[0][c2], c[t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NTA; ++t) acc[t][nt] = c[t];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) w[p] = n[p];
+        }
+    }
+    // the D % 16 remainder k values on the f32 MFMA (their weights one tile ahead)
+    if constexpr (S::NR > 0 && NTILES > 0) {
+        constexpr int NRM = S::NR * NTILES;
+        auto rw = [&](int i) {
+            const int nt = i % NTILES, q = i / NTILES;
+            const int nth = C::nth_of(nt);
+            const float* b = C::half_of(nt) ? img_b : img;
+            return b[C::main_bytes(nth) / 4 + (q * 4 + kq) * nth * 16 + li + C::tile_in_half(nt) * 16];
+        };
+        float w0 = rw(0), w1 = NRM > 1 ? rw(1) : 0.f;
+#pragma unroll
+        for (int i = 0; i < NRM; ++i) {
+            const int q = i / NTILES, nt = i % NTILES;
+#pragma unroll
+            for (int t = 0; t < NTA; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, ar[t][q], acc[t][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            w0 = w1;
+            if (i + 2 < NRM) w1 = rw(i + 2);
+        }
+    }
+}
+
+// Stage sequence of a pass (NSTAGE = 3 (NX + 1) images), position j -> (gate g: 0 r, 1 u, 2 candidate; segment s):
+//   residual segments s = 0 .. NX-2, SEGMENT-major: s -> r, s -> u, s -> c (a residual fragment is read once and dies after its third
+//   stage; all three accumulator sets are open from here on when NX > 1),
+//   then GATE-sequential over the gathered segment and the state: x -> r, h -> r | r epilogue | x -> u, h -> u | u epilogue |
+//   x -> c, r*h -> c.  Per accumulator: segments in order, h / r*h last -- the ring forms' chains.
+template <int NX> __host__ __device__ constexpr int wide_gate(int j) { return j < 3 * (NX - 1) ? j % 3 : (j - 3 * (NX - 1)) / 2; }
+template <int NX> __host__ __device__ constexpr int wide_seg(int j) { return j < 3 * (NX - 1) ? j / 3 : NX - 1 + (j - 3 * (NX - 1)) % 2; }
+
+template <int D, int NX, int NTW, int FMT>
+__global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
+    using C = StageCfg<D>;
+    using I = ImgCfg<D, true, FMT>;
+    constexpr int NT = C::NT, NC = C::NC, NR = C::NR, NRR = NR > 0 ? NR : 1;
+    constexpr int NW = 4, NSEG = NX + 1, NSTAGE = 3 * NSEG, KI = 4;
+    constexpr int JG = 3 * (NX - 1);                                 // first stage of the gate-sequential part
+    extern __shared__ __attribute__((aligned(16))) float lds_[];   // [biases | ring [2][IMG]]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+
+    constexpr int BIAS_FLOATS = (4 * D + 63) / 64 * 64;
+    float* bias_s = lds_;                             // [-log2e*bg (2D) | 2 log2e*bc (D) | bc (D)]
+    float* ring = lds_ + BIAS_FLOATS;
+    for (int i = tid; i < 4 * D; i += NW * 64)
+        bias_s[i] = i < 2 * D ? -kLog2e * a.bg[i] : (i < 3 * D ? 2.0f * kLog2e * a.bc[i - 2 * D] : a.bc[i - 3 * D]);
+
+    // ---- this workgroup's tiles and their deal over the (pass, wave) slots ---------------------------------------------------
+    const int wt_total = (a.V + 15) / 16;
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int t_lo = (int)((long long)wt_total * bid / nb), t_hi = (int)((long long)wt_total * (bid + 1) / nb);
+    const int n_b = t_hi - t_lo;
+    const int P = (n_b + NW * NTW - 1) / (NW * NTW);
+    if (P == 0) return;
+    const int nsl = NW * P;
+    const int sl_base = n_b / nsl, sl_extra = n_b % nsl;
+    auto slot_first = [&](int p) { const int s = p * NW + wave; return t_lo + s * sl_base + (s < sl_extra ? s : sl_extra); };
+    auto slot_count = [&](int p) { const int s = p * NW + wave; return p < P ? sl_base + (s < sl_extra ? 1 : 0) : 0; };
+
+    // stage position -> packed image (ggnn_gru_fused.hip's image order: gates (s = 0..NX) x {r, u}, then the candidate blocks)
+    auto img_of = [&](int j) -> const float* {
+        const int g = wide_gate<NX>(j), s = wide_seg<NX>(j);
+        return a.packed + (size_t)(g < 2 ? 2 * s + g : 2 * NSEG + s) * I::IMG;
+    };
+    int cur = 0;
+    auto dma = [&](const float* src, float* dst) { dma_image_asm<I::IMG_BYTES, NW>(src, dst, wave, lane); };
+    auto publish = [&]() { dma_wait(); __syncthreads(); };
+    dma(img_of(0), ring);
+
+    // ---- state that crosses a pass boundary: the gathered segment and the first residual segment of the pass to come -----------
+    WPl<D, FMT> xs[NTW];                              // operand planes of the gathered segment (aggregated messages)
+    float xr[NTW][NRR];                               // ... and its remainder values (f32 MFMA)
+    WPl<D, FMT> xq[NTW];                              // the residual segment being multiplied (NX > 1)
+    float xqr[NTW][NRR];
+    // gather of the aggregated-messages segment.  Its registers are LOCAL to a pass (GatherRegs below): declared outside the pass
+    // loop, a conditionally executed phase ("if this wave has a tile t in the pass to come") would keep the previous pass's values
+    // alive around the whole loop -- 200 registers that nothing reads.
+    struct GatherRegs {
+        int beg[NTW], end[NTW], i[NTW][KI];
+        f32x4 n[NTW];
+        float den[NTW], rcp[NTW];
+        Frag<D> x[NTW], t[NTW];
+        Frag<D> rf[NTW];                              // residual segment 0 of the pass to come, on its way in
+    };
+    auto g_ptrs = [&](GatherRegs& G, int t, int r) {  // level 1: slot range + in-degrees of row r
+        G.beg[t] = ldi_b(a.g_row_ptr, (unsigned)r * 4u); G.end[t] = ldi_b(a.g_row_ptr, (unsigned)r * 4u + 4u);
+        G.n[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.g_use_avg) {
+            if (a.g_T == 4) {
+                G.n[t] = ld4_b(a.g_nin, (unsigned)r * 16u);
+            } else {
+                float deg = 0.f;
+                for (int k = 0; k < a.g_T; ++k) deg += a.g_nin[(size_t)r * a.g_T + k];
+                G.n[t] = f32x4{deg, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto g_index = [&](GatherRegs& G, int t) {        // level 2: the first KI source rows (a slot beyond the degree -> row 0)
+        G.den[t] = (((G.n[t].x + G.n[t].y) + G.n[t].z) + G.n[t].w) + 1e-7f;
+        G.rcp[t] = 1.0f / G.den[t];
+#pragma unroll
+        for (int j = 0; j < KI; ++j) {
+            G.i[t][j] = 0;
+            if (G.beg[t] + j < G.end[t]) G.i[t][j] = ldi_b(a.g_idx, (unsigned)(G.beg[t] + j) * 4u);
+        }
+    };
+    auto g_rows0 = [&](GatherRegs& G, int t) {        // level 3: slot 0 straight into x, slot 1 into the temporary
+        load_frag<D>(G.x[t], a.g_H, G.i[t][0], kq);
+        load_frag<D>(G.t[t], a.g_H, G.i[t][1], kq);
+    };
+    auto g_rows = [&](GatherRegs& G, int t, int k) {  // add slot k-1 (landed), fetch slot k
+        if (G.beg[t] + k - 1 < G.end[t]) frag_add_w(G.x[t], G.t[t]);
+        load_frag<D>(G.t[t], a.g_H, G.i[t][k], kq);
+    };
+    auto g_finish = [&](GatherRegs& G, int t) {       // slot 3, any further slots (synchronously), mean
+        Frag<D>& f = G.x[t];
+        if (G.beg[t] + KI - 1 < G.end[t]) frag_add_w(f, G.t[t]);
+        for (int e = G.beg[t] + KI; e < G.end[t]; ++e) {
+            load_frag<D>(G.t[t], a.g_H, a.g_idx[e], kq);
+            frag_add_w(f, G.t[t]);
+        }
+        if (G.beg[t] >= G.end[t]) {                   // a node without incoming messages (slot 0 was row 0)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) f.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NR; ++q) f.r[q] = 0.f;
+        }
+        if (a.g_use_avg) {                            // :206-209, one division per row (Markstein: the correctly rounded quotient)
+            const float den = G.den[t], r = G.rcp[t];
+            auto dv = [&](float x) { const float q = x * r; return fmaf(fmaf(-den, q, x), r, q); };
+#pragma unroll
+            for (int c = 0; c < NC; ++c) f.v[c] = f32x4{dv(f.v[c].x), dv(f.v[c].y), dv(f.v[c].z), dv(f.v[c].w)};
+#pragma unroll
+            for (int q = 0; q < NR; ++q) f.r[q] = dv(f.r[q]);
+        }
+    };
+    auto store_x = [&](const Frag<D>& f, int row_) {  // (training) the gathered segment is an operand of the weight gradients
+        const unsigned ob = ((unsigned)row_ * (unsigned)D + 4u * (unsigned)kq) * 4u;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) st4_b(a.save_x, ob + 64u * c, f.v[c]);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.save_x) + ob - 16u * (unsigned)kq + (16u * NC + 4u * q + (unsigned)kq) * 4u) = f.r[q];
+    };
+    auto commit = [&](WPl<D, FMT>& pl, float (&rem)[NRR], const Frag<D>& f) {   // f32 fragment -> operand planes + remainder values
+        wsplit<D, FMT>(pl, f);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) rem[q] = f.r[q];
+    };
+    // gathered fragment of tile t complete -> planes of the pass to come; its first residual segment with it
+    auto x_commit = [&](GatherRegs& G, int t, int row_) {
+        if (a.save_x && row_ < a.V) store_x(G.x[t], row_);
+        commit(xs[t], xr[t], G.x[t]);
+        if constexpr (NX > 1) commit(xq[t], xqr[t], G.rf[t]);
+    };
+    auto clampv = [&](int r) { return r < a.V ? r : a.V - 1; };
+
+    // ---- first pass: its x segments, synchronously -----------------------------------------------------------------------------
+    {
+        GatherRegs G;
+        const int t0 = slot_first(0), n0 = slot_count(0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            if (t < n0) {
+                const int r = clampv((t0 + t) * 16 + li);
+                g_ptrs(G, t, r);
+                if constexpr (NX > 1) load_frag<D>(G.rf[t], a.x[0], r, kq);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) if (t < n0) g_index(G, t);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) if (t < n0) g_rows0(G, t);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) if (t < n0) g_rows(G, t, 2);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) if (t < n0) g_rows(G, t, 3);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            if (t < n0) { g_finish(G, t); x_commit(G, t, (t0 + t) * 16 + li); }
+        }
+    }
+    publish();
+
+    // ---- one pass with NTA tiles on this wave -----------------------------------------------------------------------------------
+    auto run_pass = [&](auto nta_c, const int p) {
+        constexpr int NTA = decltype(nta_c)::value;
+        const int t0 = slot_first(p);
+        const bool last = p + 1 >= P;
+        const int t0n = last ? 0 : slot_first(p + 1), nn = last ? 0 : slot_count(p + 1);     // the pass to come (nn <= NTA)
+        int row[NTW], rowc[NTW], rown[NTW];
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) { row[t] = (t0 + t) * 16 + li; rowc[t] = clampv(row[t]); rown[t] = clampv((t0n + t) * 16 + li); }
+
+        Frag<D> hf[NTW];
+        Frag<D> rq[NTW];                              // the next residual segment of this pass, on its way in (NX > 2)
+        WPl<D, FMT> hs[NTW], rhs[NTW];
+        float hr[NTW][NRR], rhr[NTW][NRR];
+        f32x4 acc_r[NTW][NT], acc_u[NTW][NT], acc_c[NTW][NT];
+        GatherRegs G;                                 // (the pass to come)
+
+        sfor<0, NSTAGE>([&](auto jc) {
+            constexpr int j = decltype(jc)::value, g = wide_gate<NX>(j), s = wide_seg<NX>(j);
+            // the next image of the sequence (or the first image of the pass to come) goes into the other slot
+            if (j + 1 < NSTAGE || !last) dma(img_of((j + 1) % NSTAGE), ring + (cur ^ 1) * I::IMG);
+            // ---- side work of the stage ----
+            if constexpr (j < JG && j % 3 == 0) {
+                // residual segment s: its planes (segment 0 crossed the pass boundary as planes); the next one is requested
+                if constexpr (s > 0) {
+#pragma unroll
+                    for (int t = 0; t < NTA; ++t) commit(xq[t], xqr[t], rq[t]);
+                }
+                if constexpr (s + 1 < NX - 1) {
+#pragma unroll
+                    for (int t = 0; t < NTA; ++t) load_frag<D>(rq[t], a.x[s + 1 < 2 ? s + 1 : 0], rowc[t], kq);
+                }
+            }
+            if constexpr (j == (JG > 0 ? JG - 1 : 0)) {               // the state, one stage before its first use (NX = 1: with the first stage)
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) load_frag<D>(hf[t], a.h, rowc[t], kq);
+            }
+            if constexpr (j == JG + 1) {                             // h -> r columns: the state's planes
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) commit(hs[t], hr[t], hf[t]);
+            }
+            if constexpr (j == JG + 2) {
+                // ---- r = sigmoid(.), r*h in activation-fragment layout -> planes; the u gate's tail tile leaves the r set ----
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) {
+                    if constexpr (C::TAILPACK) {
+                        // the u gate's last tile was accumulated in the padding columns of the r gate's last tile:
+                        // column D + j of that tile (lane kq + (D%16)/4) is u column 16*NC + j (lane kq)
+                        constexpr int SH = 16 * ((D % 16) / 4);
+                        f32x4 ut;
+                        ut.x = __shfl(acc_r[t][NT - 1].x, lane + SH); ut.y = __shfl(acc_r[t][NT - 1].y, lane + SH);
+                        ut.z = __shfl(acc_r[t][NT - 1].z, lane + SH); ut.w = __shfl(acc_r[t][NT - 1].w, lane + SH);
+                        acc_u[t][NT - 1] = ut;
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int col = nt * 16 + 4 * kq;
+                        if (col < D) {
+                            const f32x4 r = w_sigmoid4_acc<FMT>(acc_r[t][nt], ld4(bias_s + col));
+                            acc_r[t][nt] = r;
+                            if (a.save_r && row[t] < a.V) st4_b(a.save_r, ((unsigned)row[t] * D + col) * 4u, r);
+                        }
+                    }
+                    Frag<D> rh;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) rh.v[c] = acc_r[t][c] * hf[t].v[c];
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) {
+                        // remainder column 16NC + 4q + kq lives in tile NC of lane (li, kq' = q), element e = kq
+                        const float t0_ = __shfl(acc_r[t][NT - 1].x, li + 16 * q), t1_ = __shfl(acc_r[t][NT - 1].y, li + 16 * q);
+                        const float t2_ = __shfl(acc_r[t][NT - 1].z, li + 16 * q), t3_ = __shfl(acc_r[t][NT - 1].w, li + 16 * q);
+                        const float rr = kq == 0 ? t0_ : (kq == 1 ? t1_ : (kq == 2 ? t2_ : t3_));
+                        rh.r[q] = rr * hf[t].r[q];
+                    }
+                    commit(rhs[t], rhr[t], rh);
+                }
+            }
+            if constexpr (j == JG + 4) {
+                // ---- u = sigmoid(.) ----
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int col = nt * 16 + 4 * kq;
+                        if (col < D) {
+                            const f32x4 u = w_sigmoid4_acc<FMT>(acc_u[t][nt], ld4(bias_s + D + col));
+                            acc_u[t][nt] = u;
+                            if (a.save_u && row[t] < a.V) st4_b(a.save_u, ((unsigned)row[t] * D + col) * 4u, u);
+                        }
+                    }
+                }
+            }
+            if constexpr (j == (NX > 1 ? 2 : JG + 4)) {              // (before the first candidate stage: residual 0 -> c, or x -> c)
+                if constexpr (C::TAILPACK3) {
+#pragma unroll
+                    for (int t = 0; t < NTA; ++t) acc_c[t][NT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};   // (opened by the r*h stage only)
+                }
+            }
+            // the gather of the pass to come, beside the last three stages
+            if constexpr (j == NSTAGE - 3) {
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) if (t < nn) g_ptrs(G, t, rown[t]);
+            }
+            if constexpr (j == NSTAGE - 2) {
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) if (t < nn) g_index(G, t);
+            }
+            if constexpr (j == NSTAGE - 1) {
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) {
+                    if (t < nn) {
+                        g_rows0(G, t);
+                        if constexpr (NX > 1) load_frag<D>(G.rf[t], a.x[0], rown[t], kq);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- the stage's products ----
+            // u stages skip their last tile when it rides in the r image; so do the candidate stages of the x segments
+            constexpr int ntl = ((C::TAILPACK && g == 1) || (C::TAILPACK3 && g == 2 && s < NX)) ? NT - 1 : NT;
+            constexpr bool ZERO = (s == 0);
+            const float* img = ring + cur * I::IMG;
+            auto mma = [&](auto& acc, auto zc) {
+                constexpr bool Z = decltype(zc)::value;
+                if constexpr (s < NX - 1) wide_stage_mma<D, NTW, NTA, ntl, Z, FMT>(acc, xq, xqr, img, li, kq);
+                else if constexpr (s == NX - 1) wide_stage_mma<D, NTW, NTA, ntl, Z, FMT>(acc, xs, xr, img, li, kq);
+                else if constexpr (g < 2) wide_stage_mma<D, NTW, NTA, ntl, Z, FMT>(acc, hs, hr, img, li, kq);
+                else wide_stage_mma<D, NTW, NTA, ntl, false, FMT>(acc, rhs, rhr, img, li, kq);
+            };
+            if constexpr (g == 0) mma(acc_r, std::integral_constant<bool, ZERO>{});
+            else if constexpr (g == 1) mma(acc_u, std::integral_constant<bool, ZERO>{});
+            else mma(acc_c, std::integral_constant<bool, ZERO>{});
+            __builtin_amdgcn_sched_barrier(0);
+            publish();
+            cur ^= 1;
+        });
+
+        // ---- c = act(.), h' = u*h + (1-u)*c; the gather of the pass to come finishes in its shadow --------------------------------
+        // The state fragment is dead since the r epilogue (it would hold 25 registers per tile through four stages, beside the
+        // gather's two fragment sets): the blend reads the rows again, a tile ahead of its use.
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) if (t < nn) g_rows(G, t, 2);
+        Frag<D> hb[2];
+        load_frag<D>(hb[0], a.h, rowc[0], kq);
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) {
+            if (t + 1 < NTA) load_frag<D>(hb[(t + 1) & 1], a.h, rowc[t + 1 < NTA ? t + 1 : 0], kq);
+            __builtin_amdgcn_sched_barrier(0);
+            const Frag<D>& hq = hb[t & 1];
+            if constexpr (C::TAILPACK3) {
+                // the x segments' share of the candidate's last tile was accumulated two lane groups up in the r gate's last tile
+                // (which the r epilogue rewrote only in its own lanes); add it to the r*h share
+                constexpr int SH2 = 32 * ((D % 16) / 4);
+                f32x4 ct;
+                ct.x = __shfl(acc_r[t][NT - 1].x, lane + SH2); ct.y = __shfl(acc_r[t][NT - 1].y, lane + SH2);
+                ct.z = __shfl(acc_r[t][NT - 1].z, lane + SH2); ct.w = __shfl(acc_r[t][NT - 1].w, lane + SH2);
+                acc_c[t][NT - 1] = ct + acc_c[t][NT - 1];
+            }
+            f32x4 hrem = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const float h0 = __shfl(hq.r[q], li), h1 = __shfl(hq.r[q], li + 16);
+                const float h2 = __shfl(hq.r[q], li + 32), h3 = __shfl(hq.r[q], li + 48);
+                if (kq == q) hrem = f32x4{h0, h1, h2, h3};
+            }
+            if (row[t] < a.V) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = nt * 16 + 4 * kq;
+                    if (col < D) {
+                        f32x4 hv;
+                        if (nt < NC) hv = hq.v[nt < NC ? nt : 0];
+                        else hv = hrem;
+                        f32x4 c;
+                        if (a.act == GGNN_ACT_TANH) {
+                            c = w_tanh4_acc<FMT>(acc_c[t][nt], ld4(bias_s + 2 * D + col));           // (2 log2e * bc)
+                        } else {
+                            c = acc_c[t][nt] * SplitFmt<FMT>::acc_scale + ld4(bias_s + 3 * D + col);   // (bc itself)
+                            c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
+                        }
+                        const f32x4 u = acc_u[t][nt];
+                        st4_b(a.h_out, ((unsigned)row[t] * D + col) * 4u, u * hv + (1.0f - u) * c);
+                        if (a.save_c) st4_b(a.save_c, ((unsigned)row[t] * D + col) * 4u, c);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) if (t < nn) g_rows(G, t, 3);
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) {
+            if (t < nn) { g_finish(G, t); x_commit(G, t, (t0n + t) * 16 + li); }
+        }
+    };
+
+    // a pass of a wave without tiles: its share of the image DMAs and the barriers
+    auto idle_pass = [&](const int p) {
+        const bool last = p + 1 >= P;
+        for (int j = 0; j < NSTAGE; ++j) {
+            if (j + 1 < NSTAGE || !last) dma(img_of((j + 1) % NSTAGE), ring + (cur ^ 1) * I::IMG);
+            publish();
+            cur ^= 1;
+        }
+    };
+
+    for (int p = 0; p < P; ++p) {
+        const int n = slot_count(p);
+        if (NTW >= 4 && n == 4) run_pass(std::integral_constant<int, (NTW >= 4 ? 4 : 1)>{}, p);
+        else if (NTW >= 3 && n == 3) run_pass(std::integral_constant<int, (NTW >= 3 ? 3 : 1)>{}, p);
+        else if (NTW >= 2 && n == 2) run_pass(std::integral_constant<int, (NTW >= 2 ? 2 : 1)>{}, p);
+        else if (n == 1) run_pass(std::integral_constant<int, 1>{}, p);
+        else idle_pass(p);
+    }
+}
+
+template <int D, int NX, int NTW, int FMT>
+int launch_gru_wide(const GruFusedArgs& f, float* packed, hipStream_t st) {
+    using I = ImgCfg<D, true, FMT>;
+    if ((unsigned long long)f.V * D >= (1ULL << 30) || (unsigned long long)f.V * f.g_T * D >= (1ULL << 30))
+        return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit byte offsets: V*D and V*T*D must be < 2^30 (V=%d, D=%d)", f.V, D);
+    GruWideArgs a{};
+    for (int s = 0; s < 2; ++s) a.x[s] = s + 1 < NX ? f.x[s] : nullptr;
+    a.h = f.h; a.bg = f.bg; a.bc = f.bc; a.h_out = f.h_out;
+    a.save_r = f.save_r; a.save_u = f.save_u; a.save_c = f.save_c; a.save_x = f.save_x;
+    a.g_H = f.g_H; a.g_row_ptr = f.g_row_ptr; a.g_idx = f.g_idx; a.g_nin = f.g_nin;
+    a.packed = packed; a.V = f.V; a.act = f.act; a.g_T = f.g_T; a.g_use_avg = f.g_use_avg;
+    constexpr size_t lds = (size_t)2 * I::IMG_BYTES + (size_t)((4 * D + 63) / 64 * 64) * sizeof(float);
+    const int wt_total = (f.V + 15) / 16;
+    int nb = num_cus();
+    if (nb > wt_total) nb = wt_total;
+    static std::atomic<unsigned long long> lds_ok{0};        // (one per template instantiation)
+    GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_wide_kernel<D, NX, NTW, FMT>, lds, lds_ok));
+    hipLaunchKernelGGL((ggnn_gru_wide_kernel<D, NX, NTW, FMT>), dim3(nb), dim3(256), lds, st, a);
+    GGNN_CHECK_HIP(hipGetLastError());
+    return GGNN_OK;
+}
+
+}  // namespace
+
+// Tiles per wave by fan-in and format: what the 512-entry register file holds (kernel-resource-usage remarks of this file).
+// ntw_req (experiments: GGNN_GRU_FORM = 60 + NTW): 0 = these defaults.
+int gru_wide_supported(int D, int nx) { return D == 100 && nx >= 1 && nx <= 3; }
+
+int gru_wide_launch(int D, int nx, int ntw_req, const GruFusedArgs& a, float* packed, hipStream_t st) {
+    if (D != 100 || !a.g_H) return fail(GGNN_E_UNSUPPORTED, "the wide fused GRU is the gather-fused launch at hidden size 100");
+    const bool f2 = gru_launch_fmt(a.fmt) == kSplitF16x2;
+#ifdef GGNN_WIDE_PROBE_NTW   // register-allocation probe: one instantiation (-DGGNN_WIDE_PROBE_NTW=3 [-DGGNN_WIDE_PROBE_NX=1] [-DGGNN_WIDE_PROBE_FMT=2])
+#ifndef GGNN_WIDE_PROBE_NX
+#define GGNN_WIDE_PROBE_NX 1
+#endif
+#ifndef GGNN_WIDE_PROBE_FMT
+#define GGNN_WIDE_PROBE_FMT kSplitF16x2
+#endif
+    (void)f2; (void)ntw_req;
+    return launch_gru_wide<100, GGNN_WIDE_PROBE_NX, GGNN_WIDE_PROBE_NTW, GGNN_WIDE_PROBE_FMT>(a, packed, st);
+#else
+    if (f2) {
+        switch (nx) {
+            case 1: return ntw_req == 2 ? launch_gru_wide<100, 1, 2, kSplitF16x2>(a, packed, st) : launch_gru_wide<100, 1, 3, kSplitF16x2>(a, packed, st);
+            case 2: return launch_gru_wide<100, 2, 2, kSplitF16x2>(a, packed, st);
+            case 3: return launch_gru_wide<100, 3, 2, kSplitF16x2>(a, packed, st);
+        }
+    } else {
+        switch (nx) {
+            case 1: return launch_gru_wide<100, 1, 2, kSplitBf16x3>(a, packed, st);
+            case 2: return launch_gru_wide<100, 2, 2, kSplitBf16x3>(a, packed, st);
+            case 3: return launch_gru_wide<100, 3, 1, kSplitBf16x3>(a, packed, st);
+        }
+    }
+    return fail(GGNN_E_INVALID, "nx %d outside 1..3", nx);
+#endif
+}
+
+}  // namespace ggnn

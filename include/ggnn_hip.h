@@ -85,6 +85,14 @@ int ggnn_matrix_path_is_split(void);
 #define GGNN_F16X2_MAX_WEIGHT 255.875f
 #define GGNN_F16X2_MAX_ACTIVATION 65504.0f
 int ggnn_gru_forward_format(void);
+/* Ring form of the gather-fused GRU launches (ggnn_gru_packed_gather[_train]_f32 and the drivers built on them): every form computes
+ * the same products in the same order per accumulator -- results are bit-identical -- they differ in how a pass streams the stage
+ * images and how many 16-row tiles a wave owns.  -1: the library's default per (fan-in, operand format); 0 / 1 / 2: the ring forms of
+ * csrc/ggnn_gru_fused.hip (8 waves on whole images | two 4-wave workgroups per CU on half images | 8 waves, three half-image
+ * slots); 6: the wide form of csrc/ggnn_gru_wide.hip (one wave per SIMD, several tiles per wave, gate-sequential stages; hidden
+ * size 100).  Process default: environment GGNN_GRU_FORM.  Returns the previous setting.  (Tests and experiments: compare forms
+ * inside one process.) */
+int ggnn_gru_form_set(int form);
 /* out[i] = max |x| over the numel[i] floats at ptrs[i], i < n, in one launch per 32 tensors -- the operand-range check of
  * GGNN_GRU_FMT_F16X2.  A NaN anywhere in tensor i gives out[i] = NaN, an Inf gives Inf (the maximum is taken over the bit patterns
  * of |x|), so a host test `out[i] <= bound` fails on every non-finite input.  ptrs / numel: HOST arrays of n DEVICE pointers /

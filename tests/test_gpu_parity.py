@@ -649,6 +649,53 @@ def test_gru_with_gathered_segment_sum(pkg, oracle, cuda, V, M, D, T, R, avg, fm
     np.testing.assert_allclose(got.cpu().numpy(), ref, atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("V,M,R,avg", [(500, 1200, 0, True), (3001, 9000, 1, True), (777, 900, 2, False), (17, 60, 2, True), (100, 0, 0, True),
+                                       (16, 40, 0, True), (4097, 30000, 0, True),       # (one tile | hub rows: more than four slots per node)
+                                       # several passes per workgroup, waves with unequal tile counts, the gather of the pass to come
+                                       (70001, 150000, 0, True), (99990, 197571, 0, True), (98304, 190000, 0, False),
+                                       (70001, 150000, 1, True), (66000, 140000, 2, True)])
+@pytest.mark.parametrize("fmt", [2, 3])
+@pytest.mark.parametrize("form", [6, 62])
+def test_wide_gru_equals_ring_forms(pkg, cuda, V, M, R, avg, fmt, form):
+    """The wide form of the gather-fused GRU launch (csrc/ggnn_gru_wide.hip: one wave per SIMD, several tiles per wave sharing every
+    weight-fragment read, gate-sequential stages) == the ring forms of csrc/ggnn_gru_fused.hip, BIT FOR BIT: the same products in the
+    same order per accumulator, the same gather arithmetic, the same epilogues -- inference and training (r, u, c, incoming saved)."""
+    lib = pkg._lib.load()
+    D, T = 100, 4
+    rng = np.random.default_rng(V * 11 + M + R)
+    h, adj, nin = random_graph_batch(rng, V, M, T, D, sorted_src=False)
+    nx = R + 1
+    Wg = rng.uniform(-0.2, 0.2, ((nx + 1) * D, 2 * D)).astype(np.float32)
+    Wc = rng.uniform(-0.2, 0.2, ((nx + 1) * D, D)).astype(np.float32)
+    bg = rng.uniform(-0.5, 1.0, 2 * D).astype(np.float32)
+    bc = rng.uniform(-0.5, 0.5, D).astype(np.float32)
+    res = [dev(rng.uniform(-1, 1, (V, D)).astype(np.float32), cuda) for _ in range(R)]
+    H = dev(rng.uniform(-1, 1, (V * T, D)).astype(np.float32), cuda)
+    index = pkg.ops.build_message_index([dev(a, cuda) for a in adj], V)
+    nd = dev(nin, cuda) if avg else None
+    hd, Wgd, Wcd, bgd, bcd = (dev(x, cuda) for x in (h, Wg, Wc, bg, bc))
+    packed = pkg.ops.PackedWeights().gru(Wgd, Wcd, nx, D, fmt)
+    prev = lib.ggnn_gru_form_set(-1)
+    try:
+        want_s = {}
+        want = pkg.ops.gru_packed_gather(res, hd, packed, bgd, bcd, H, index, None, nd, fmt=fmt)
+        want_t = pkg.ops.gru_packed_gather(res, hd, packed, bgd, bcd, H, index, None, nd, fmt=fmt, save=want_s)
+        lib.ggnn_gru_form_set(form)
+        got_s = {}
+        got = pkg.ops.gru_packed_gather(res, hd, packed, bgd, bcd, H, index, None, nd, fmt=fmt)
+        got_t = pkg.ops.gru_packed_gather(res, hd, packed, bgd, bcd, H, index, None, nd, fmt=fmt, save=got_s)
+        relu = pkg.ops.gru_packed_gather(res, hd, packed, bgd, bcd, H, index, None, nd, activation="relu", fmt=fmt)
+        lib.ggnn_gru_form_set(-1)
+        relu_want = pkg.ops.gru_packed_gather(res, hd, packed, bgd, bcd, H, index, None, nd, activation="relu", fmt=fmt)
+    finally:
+        lib.ggnn_gru_form_set(prev)
+    assert torch.isfinite(want).all()
+    assert torch.equal(got, want) and torch.equal(got_t, want_t) and torch.equal(want_t, want)
+    assert torch.equal(relu, relu_want)
+    for k in ("r", "u", "c", "incoming"):
+        assert torch.equal(got_s[k], want_s[k]), k
+
+
 def test_sparse_model_compact_and_dense_transform_agree(pkg, oracle, cuda):
     ms = pkg.synthetic_qm9(300, mean_nodes=16, seed=8)
     model, layers, feeds = _model_and_feed(pkg, oracle, ms)
