@@ -815,7 +815,7 @@ static int launch_gru_fused_m(const GruFusedArgs& a_in, float* packed, hipStream
 // ahead of form 1 at R = 0 (round 4).
 std::atomic<int>& gru_form_override();     // ggnn_api.hip: GGNN_GRU_FORM / ggnn_gru_form_set()
 int gru_wide_launch(int D, int nx, int ntw_req, const GruFusedArgs& a, float* packed, hipStream_t st);   // ggnn_gru_wide.hip
-int gru_wide_supported(int D, int nx);
+int gru_wide_supported(int D, int nx, const GruFusedArgs& a);
 static int gru_form(int nx, int fmt) {
     const int v = gru_form_override().load(std::memory_order_relaxed);
     return v >= 0 ? v : ((nx >= 2 || fmt == kSplitF16x2) ? 1 : 0);
@@ -826,7 +826,7 @@ static int split_launch_d(int nx, bool gather, const GruFusedArgs& a, float* pac
     if constexpr (SplitCfg<D>::OK) {
         // form 6: the wide kernel (one wave per SIMD, several tiles per wave; ggnn_gru_wide.hip)
         // (60 + NTW: the same with NTW tiles per wave where the instantiation exists -- experiments)
-        if (const int f = gru_form(nx, FMT); gather && (f == 6 || (f >= 60 && f < 70)) && gru_wide_supported(D, nx))
+        if (const int f = gru_form(nx, FMT); gather && (f == 6 || (f >= 60 && f < 70)) && gru_wide_supported(D, nx, a))
             return gru_wide_launch(D, nx, f >= 60 ? f - 60 : 0, a, packed, st);
         if (gather && gru_form(nx, FMT) == 2) {
             switch (nx) {

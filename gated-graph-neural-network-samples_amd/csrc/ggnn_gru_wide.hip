@@ -35,7 +35,7 @@
 namespace ggnn {
 
 int gru_wide_launch(int D, int nx, int ntw_req, const GruFusedArgs& a, float* packed, hipStream_t st);
-int gru_wide_supported(int D, int nx);
+int gru_wide_supported(int D, int nx, const GruFusedArgs& a);
 
 namespace {
 
@@ -46,7 +46,19 @@ struct GruWideArgs {
     const float* g_H; const int* g_row_ptr; const int* g_idx; const float* g_nin;
     const float* packed;
     int V, act, g_T, g_use_avg;
+    unsigned long long* tdbg;    // (GGNN_WIDE_STAMPS builds) s_memtime stamps of workgroup 0: tools/wide_timeline.py
 };
+
+// -DGGNN_WIDE_STAMPS=1 (tools/variant_lib.sh): stamp [pass < 4][point < 32][wave] of workgroup 0; points 4 j + {0 stage start, 1 side
+// work done, 2 products done, 3 barrier passed}, 24 candidate epilogue done, 25 pass done
+#ifndef GGNN_WIDE_STAMPS
+#define GGNN_WIDE_STAMPS 0
+#endif
+#if GGNN_WIDE_STAMPS
+#define GGNN_WT(IDX) if (a.tdbg && blockIdx.x == 0 && lane == 0 && p < 4) a.tdbg[((p * 32) + (IDX)) * 4 + wave] = __builtin_amdgcn_s_memtime();
+#else
+#define GGNN_WT(IDX)
+#endif
 
 template <int I0, int I1, class F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -61,16 +73,40 @@ __device__ __forceinline__ void frag_add_w(Frag<D>& f, const Frag<D>& t) {
     for (int q = 0; q < StageCfg<D>::NR; ++q) f.r[q] += t.r[q];
 }
 
-// (the gate epilogues of ggnn_gru_fused.hip: same expressions)
+// (the gate epilogues of ggnn_gru_fused.hip with their fusions written out: z k + b is ONE fma there, and which fusion an expression
+// gets depends on the code around it -- the forms must agree bit for bit)
 template <int FMT>
 __device__ __forceinline__ f32x4 w_sigmoid4_acc(f32x4 z, f32x4 b_scaled) {
     constexpr float k = -kLog2e * SplitFmt<FMT>::acc_scale;
-    return rcp_4(exp2_4(z * k + b_scaled) + 1.0f);
+    const f32x4 e = {__builtin_fmaf(z.x, k, b_scaled.x), __builtin_fmaf(z.y, k, b_scaled.y), __builtin_fmaf(z.z, k, b_scaled.z), __builtin_fmaf(z.w, k, b_scaled.w)};
+    return rcp_4(exp2_4(e) + 1.0f);
 }
 template <int FMT>
 __device__ __forceinline__ f32x4 w_tanh4_acc(f32x4 z, f32x4 b_scaled) {
     constexpr float k = 2.0f * kLog2e * SplitFmt<FMT>::acc_scale;
-    return 1.0f - 2.0f * rcp_4(exp2_4(z * k + b_scaled) + 1.0f);
+    const f32x4 e = {__builtin_fmaf(z.x, k, b_scaled.x), __builtin_fmaf(z.y, k, b_scaled.y), __builtin_fmaf(z.z, k, b_scaled.z), __builtin_fmaf(z.w, k, b_scaled.w)};
+    return 1.0f - 2.0f * rcp_4(exp2_4(e) + 1.0f);
+}
+
+// h' = u h + (1 - u) c in the contraction hipcc gives the ring kernels' `u * hv + (1.0f - u) * c` (AMDGPU fuses aggressively:
+// (1 - u) c -> fma(-u, c, c), then the sum -> fma(u, h, .)); written out, because which fusion an expression gets depends on the
+// code around it and the forms must agree bit for bit.
+#ifndef GGNN_WIDE_BLEND
+#define GGNN_WIDE_BLEND 1
+#endif
+__device__ __forceinline__ float w_blend1(float u, float h, float c) {
+#if GGNN_WIDE_BLEND == 0
+    return __builtin_fmaf(u, h, __builtin_fmaf(-u, c, c));
+#elif GGNN_WIDE_BLEND == 1
+    float t = (1.0f - u) * c; asm volatile("" : "+v"(t)); return __builtin_fmaf(u, h, t);
+#elif GGNN_WIDE_BLEND == 2
+    float t = u * h; asm volatile("" : "+v"(t)); return __builtin_fmaf(1.0f - u, c, t);
+#else
+    float t = u * h; asm volatile("" : "+v"(t)); return __builtin_fmaf(-u, c, c) + t;
+#endif
+}
+__device__ __forceinline__ f32x4 w_blend4(f32x4 u, f32x4 h, f32x4 c) {
+    return f32x4{w_blend1(u.x, h.x, c.x), w_blend1(u.y, h.y, c.y), w_blend1(u.z, h.z, c.z), w_blend1(u.w, h.w, c.w)};
 }
 
 // the operand planes of one 16-row activation fragment (p[0] = hi pieces, p[1] = mid / lo, p[2] = lo of the bf16 form)
@@ -93,17 +129,61 @@ __device__ __forceinline__ void wsplit(WPl<D, FMT>& s, const Frag<D>& f) {
     }
 }
 
+// one 32-chunk of a fragment -> its operand planes
+template <int D, int FMT>
+__device__ __forceinline__ void wsplit_chunk(WPl<D, FMT>& s, int c2, f32x4 a, f32x4 b) {
+    unsigned h[4], m[4], l[4];
+    split_pair<FMT>(a.x, a.y, h[0], m[0], l[0]);
+    split_pair<FMT>(a.z, a.w, h[1], m[1], l[1]);
+    split_pair<FMT>(b.x, b.y, h[2], m[2], l[2]);
+    split_pair<FMT>(b.z, b.w, h[3], m[3], l[3]);
+    s.p[0][c2] = u32x4{h[0], h[1], h[2], h[3]};
+    s.p[1][c2] = u32x4{m[0], m[1], m[2], m[3]};
+    if constexpr (SplitFmt<FMT>::NP > 2) s.p[2][c2] = u32x4{l[0], l[1], l[2], l[3]};
+}
+
+// KiB piece K of this wave's share of an image DMA (dma_image_asm's transfer, one global_load_lds_dwordx4 at a time: the pieces
+// ride in the units of a stage's products instead of going out in one burst in front of them)
+template <int BYTES, int NW, int K>
+__device__ __forceinline__ void dma_piece_asm(const float* src, float* dst, int wave, int lane) {
+    constexpr int PER_WAVE = BYTES / (NW * 1024);
+    static_assert(BYTES % (NW * 1024) == 0 && K < PER_WAVE, "image must split into whole KiB per wave");
+    const unsigned voff = (unsigned)lane * 16u;
+    const unsigned long long sb = reinterpret_cast<unsigned long long>(src) + (unsigned long long)wave * PER_WAVE * 1024 + (unsigned long long)(K & ~3) * 1024;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+    const unsigned long long sa = ((unsigned long long)hi << 32) | lo;
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void*)dst + (unsigned)wave * (PER_WAVE * 1024) + (unsigned)(K & ~3) * 1024u);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" :: "s"(l), "v"(voff), "s"(sa), "n"((K & 3) * 1024) : "memory");
+}
+
+struct NoFill { template <class U> __device__ __forceinline__ void operator()(U) const {} };
+
+// units of a stage's product: NC2 * NTILES (32-chunk, column tile) units + NR * NTILES remainder units
+template <int D, int FMT> __host__ __device__ constexpr int wide_units(int ntiles) { return (SplitCfg<D, FMT>::NC2 + StageCfg<D>::NR) * ntiles; }
+
 // acc[t][nt] (+)= fragment t x split stage image for the wave's NTA tiles: stage_mma_split_at's products in its order per
 // accumulator (chunks in order, then the remainder on the f32 MFMA; per unit the products smallest first), every weight fragment
 // read once for all NTA tiles.  The planes of the NEXT unit are fetched at the start of the current one.
-template <int D, int NTW, int NTA, int NTILES, bool ZERO, int FMT>
+// fill(unit): a wave alone on its SIMD has no partner whose MFMAs would cover its vector work, and it issues in order -- so the side
+// work of a stage (an epilogue of the previous gate, a fragment split) is cut into PIECES and piece `unit` is emitted inside unit
+// `unit`'s scheduling region, where the scheduler deals its instructions between the unit's MFMAs (GGNN_WIDE_SGB: in a fixed
+// pattern, NTA MFMAs | FV vector instructions | ...).
+#ifndef GGNN_WIDE_SGB
+#define GGNN_WIDE_SGB 1
+#endif
+#ifndef GGNN_WIDE_FV
+#define GGNN_WIDE_FV 6
+#endif
+template <int D, int NTW, int NTA, int NTILES, bool ZERO, int FMT, class Fill = NoFill>
 __device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT], const WPl<D, FMT> (&a)[NTW],
                                                const float (&ar)[NTW][StageCfg<D>::NR > 0 ? StageCfg<D>::NR : 1],
-                                               const float* img, int li, int kq) {
+                                               const float* img, int li, int kq, const Fill& fill = Fill()) {
     using S = StageCfg<D>;
     using C = SplitCfg<D, FMT>;
     constexpr int NP = C::NP;
     constexpr int NU = C::NC2 * NTILES;                               // units, chunk-major
+    constexpr bool FILLED = !std::is_same<Fill, NoFill>::value;
     const float* img_b = img + C::HA;
     if constexpr (NU > 0) {
         const u32x4* base_a = reinterpret_cast<const u32x4*>(img) + kq * (C::TA * 16) + li;
@@ -117,14 +197,14 @@ __device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT
         u32x4 w[NP], n[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) { w[p] = slot(0, p); n[p] = w[p]; }
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int c2 = u / NTILES, nt = u % NTILES;
-            if (u + 1 < NU) {
+        sfor<0, NU>([&](auto uc) {
+            constexpr int u = decltype(uc)::value, c2 = u / NTILES, nt = u % NTILES;
+            if constexpr (u + 1 < NU) {
 #pragma unroll
                 for (int p = NP - 1; p >= 0; --p) n[p] = slot(u + 1, p);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!FILLED) __builtin_amdgcn_sched_barrier(0);
+            fill(uc);
             f32x4 c[NTA];
 #pragma unroll
             for (int t = 0; t < NTA; ++t) c[t] = (ZERO && c2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[t][nt];
@@ -149,12 +229,20 @@ __device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT
 #pragma unroll
                 for (int t = 0; t < NTA; ++t) c[t] = mfma_bf16(w[0], a[t].p[0][c2], c[t]);
             }
+            if constexpr (FILLED && GGNN_WIDE_SGB) {
+                if constexpr (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);       // the next unit's planes
+#pragma unroll
+                for (int m = 0; m < (FMT == kSplitF16x2 ? 3 : 6); ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, NTA, 0);                            // one product of every tile
+                    __builtin_amdgcn_sched_group_barrier(0x002, GGNN_WIDE_FV, 0);                   // ... then vector instructions of the piece
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NTA; ++t) acc[t][nt] = c[t];
 #pragma unroll
             for (int p = 0; p < NP; ++p) w[p] = n[p];
-        }
+        });
     }
     // the D % 16 remainder k values on the f32 MFMA (their weights one tile ahead)
     if constexpr (S::NR > 0 && NTILES > 0) {
@@ -166,15 +254,22 @@ __device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT
             return b[C::main_bytes(nth) / 4 + (q * 4 + kq) * nth * 16 + li + C::tile_in_half(nt) * 16];
         };
         float w0 = rw(0), w1 = NRM > 1 ? rw(1) : 0.f;
-#pragma unroll
-        for (int i = 0; i < NRM; ++i) {
-            const int q = i / NTILES, nt = i % NTILES;
+        sfor<0, NRM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, q = i / NTILES, nt = i % NTILES;
+            fill(std::integral_constant<int, NU + i>{});
 #pragma unroll
             for (int t = 0; t < NTA; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, ar[t][q], acc[t][nt], 0, 0, 0);
+            if constexpr (FILLED && GGNN_WIDE_SGB) {
+#pragma unroll
+                for (int m = 0; m < NTA; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, GGNN_WIDE_FV, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             w0 = w1;
-            if (i + 2 < NRM) w1 = rw(i + 2);
-        }
+            if constexpr (i + 2 < NRM) w1 = rw(i + 2);
+        });
     }
 }
 
@@ -186,7 +281,18 @@ __device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT
 template <int NX> __host__ __device__ constexpr int wide_gate(int j) { return j < 3 * (NX - 1) ? j % 3 : (j - 3 * (NX - 1)) / 2; }
 template <int NX> __host__ __device__ constexpr int wide_seg(int j) { return j < 3 * (NX - 1) ? j / 3 : NX - 1 + (j - 3 * (NX - 1)) % 2; }
 
-template <int D, int NX, int NTW, int FMT>
+// SAVE: r, u, c and the gathered segment are written for a backward pass (training).  TANH: the candidate's activation (else ReLU).
+// Both are compile-time: a run-time branch per float4 group cuts the epilogues into basic blocks of one group each, and a wave
+// alone on its SIMD then waits out every bias read and every exp -> rcp chain one after the other.
+// FILLS: 1 = the epilogues / splits are dealt into the MFMA stream of the stage they precede (wide_stage_mma's FILL), 0 = they
+// run in front of it.
+#ifndef GGNN_WIDE_DMA_PIECES
+#define GGNN_WIDE_DMA_PIECES 0   // 1: the image DMA goes out a KiB piece at a time inside the product units (0: in one burst in front of them)
+#endif
+#ifndef GGNN_WIDE_CARRY
+#define GGNN_WIDE_CARRY 0     // the candidate epilogue of a pass rides in the first stages of the next one (0: it runs behind its pass)
+#endif
+template <int D, int NX, int NTW, int FMT, bool SAVE, bool TANH>
 __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
     using C = StageCfg<D>;
     using I = ImgCfg<D, true, FMT>;
@@ -307,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
     };
     // gathered fragment of tile t complete -> planes of the pass to come; its first residual segment with it
     auto x_commit = [&](GatherRegs& G, int t, int row_) {
-        if (a.save_x && row_ < a.V) store_x(G.x[t], row_);
+        if constexpr (SAVE) store_x(G.x[t], row_);
         commit(xs[t], xr[t], G.x[t]);
         if constexpr (NX > 1) commit(xq[t], xqr[t], G.rf[t]);
     };
@@ -335,33 +441,243 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
         for (int t = 0; t < NTW; ++t) if (t < n0) g_rows(G, t, 3);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            if (t < n0) { g_finish(G, t); x_commit(G, t, (t0 + t) * 16 + li); }
+            if (t < n0) { g_finish(G, t); x_commit(G, t, clampv((t0 + t) * 16 + li)); }
         }
     }
     publish();
 
-    // ---- one pass with NTA tiles on this wave -----------------------------------------------------------------------------------
-    auto run_pass = [&](auto nta_c, const int p) {
+    // ---- the candidate epilogue of a pass runs INSIDE the next pass (its pieces ride in the units of that pass's first stages) ------
+    // what it needs crosses the pass boundary here; every path through the pass loop redefines all of it (no stale live ranges)
+    f32x4 pc[NTW][NT], pu[NTW][NT];                   // candidate accumulators and u of the tiles whose epilogue is pending
+    f32x4 ptl[NTW];                                   // their r-set tail tile (the x segments' share of the candidate's last tile)
+    int prow[NTW];                                    // their (clamped) rows
+    int npend = 0;                                    // tiles pending (wave-uniform)
+    auto pend_clear = [&](int from) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            if (t >= from) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { pc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; pu[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                ptl[t] = f32x4{0.f, 0.f, 0.f, 0.f}; prow[t] = 0;
+            }
+        }
+    };
+    pend_clear(0);
+    // c = act(.), h' = u*h + (1-u)*c for one float4 group (tile t, column tile nt) of the pending tiles; hq: the tile's state rows
+    // (read again: the fragment died with the r epilogue), bzc: the candidate biases.  Group 0 of a tile first folds the x
+    // segments' share of the last tile in (TAILPACK3) -- group NT - 1 reads it.
+    auto c_group = [&](auto tc, auto ntc, const Frag<D>& hq, const f32x4 (&bzc)[NT]) {
+        constexpr int t = decltype(tc)::value, nt = decltype(ntc)::value;
+        if constexpr (nt == 0 && C::TAILPACK3) {
+            // the x segments' share of the candidate's last tile was accumulated two lane groups up in the r gate's last tile
+            // (which the r epilogue rewrote only in its own lanes); add it to the r*h share
+            constexpr int SH2 = 32 * ((D % 16) / 4);
+            f32x4 ct;
+            ct.x = __shfl(ptl[t].x, lane + SH2); ct.y = __shfl(ptl[t].y, lane + SH2);
+            ct.z = __shfl(ptl[t].z, lane + SH2); ct.w = __shfl(ptl[t].w, lane + SH2);
+            pc[t][NT - 1] = ct + pc[t][NT - 1];
+        }
+        f32x4 hv;
+        if constexpr (nt < NC) hv = hq.v[nt < NC ? nt : 0];
+        else {
+            hv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const float h0 = __shfl(hq.r[q], li), h1 = __shfl(hq.r[q], li + 16);
+                const float h2 = __shfl(hq.r[q], li + 32), h3 = __shfl(hq.r[q], li + 48);
+                if (kq == q) hv = f32x4{h0, h1, h2, h3};
+            }
+        }
+        // (a row beyond V is the clamped row V - 1 computed again from the same inputs: its stores write the same values to the
+        // same addresses -- no predicate, no branch)
+        const int col = nt * 16 + 4 * kq;
+        if (col < D) {
+            f32x4 c;
+            if constexpr (TANH) {
+                c = w_tanh4_acc<FMT>(pc[t][nt], bzc[nt]);
+            } else {
+                c = pc[t][nt] * SplitFmt<FMT>::acc_scale + bzc[nt];
+                c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
+            }
+            st4_b(a.h_out, ((unsigned)prow[t] * D + col) * 4u, w_blend4(pu[t][nt], hv, c));
+            if constexpr (SAVE) st4_b(a.save_c, ((unsigned)prow[t] * D + col) * 4u, c);
+        }
+    };
+    auto load_cbias = [&](f32x4 (&bzc)[NT]) {
+        const float* b = TANH ? bias_s + 2 * D : bias_s + 3 * D;                     // (2 log2e * bc | bc itself)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bzc[nt] = (nt * 16 + 4 * kq < D) ? ld4(b + nt * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // the pending epilogue on its own (in front of a pass with another tile count, and behind the last pass)
+    auto flush = [&]() {
+        f32x4 bzc[NT];
+        load_cbias(bzc);
+        sfor<0, NTW>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if (t < npend) {
+                Frag<D> hq;
+                load_frag<D>(hq, a.h, prow[t], kq);
+                sfor<0, NT>([&](auto ntc) { c_group(tc, ntc, hq, bzc); });
+            }
+        });
+        npend = 0;
+    };
+
+    // ---- one pass with NTA tiles on this wave; CARRY: the NTA pending tiles' candidate epilogue rides in its first stages ---------
+    auto run_pass = [&](auto nta_c, auto carry_c, const int p) {
         constexpr int NTA = decltype(nta_c)::value;
+        constexpr bool CARRY = decltype(carry_c)::value;
         const int t0 = slot_first(p);
         const bool last = p + 1 >= P;
-        const int t0n = last ? 0 : slot_first(p + 1), nn = last ? 0 : slot_count(p + 1);     // the pass to come (nn <= NTA)
-        int row[NTW], rowc[NTW], rown[NTW];
+        const int t0n = last ? t0 : slot_first(p + 1), nn = last ? 0 : slot_count(p + 1);     // the pass to come (nn <= NTA)
+        int rowc[NTW], rown[NTW];
 #pragma unroll
-        for (int t = 0; t < NTA; ++t) { row[t] = (t0 + t) * 16 + li; rowc[t] = clampv(row[t]); rown[t] = clampv((t0n + t) * 16 + li); }
+        for (int t = 0; t < NTA; ++t) { rowc[t] = clampv((t0 + t) * 16 + li); rown[t] = clampv((t0n + t) * 16 + li); }
 
         Frag<D> hf[NTW];
+        Frag<D> hb[NTW];                              // (CARRY) the pending tiles' state rows, for their blend
         Frag<D> rq[NTW];                              // the next residual segment of this pass, on its way in (NX > 2)
         WPl<D, FMT> hs[NTW], rhs[NTW];
         float hr[NTW][NRR], rhr[NTW][NRR];
         f32x4 acc_r[NTW][NT], acc_u[NTW][NT], acc_c[NTW][NT];
         GatherRegs G;                                 // (the pass to come)
 
+        // the biases of the gate whose epilogue a stage carries, read from LDS ONCE in front of that stage's products: a read inside a
+        // piece is waited for inside the piece -- a full LDS round trip per unit with no other wave to cover it
+        f32x4 bz[NT], bzc[NT];
+        auto load_bias = [&](const float* b) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bz[nt] = (nt * 16 + 4 * kq < D) ? ld4(b + nt * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        // ---- the side work of a pass, in PIECES (wide_stage_mma's fill: the pieces of a unit are emitted inside its region) ------
+        auto touch4 = [](const f32x4& v) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); };   // "this value exists HERE" (no sinking)
+        constexpr int NC2 = SplitCfg<D, FMT>::NC2;
+        // the state's planes: piece k = (tile k / NC2, chunk k % NC2)
+        constexpr int H_PIECES = NC2 * NTA;
+        auto h_piece = [&](auto kc) {
+            constexpr int k = decltype(kc)::value, t = k / NC2, c2 = k % NC2;
+            wsplit_chunk<D, FMT>(hs[t], c2, hf[t].v[2 * c2], hf[t].v[2 * c2 + 1]);
+            if constexpr (c2 == 0) {
+#pragma unroll
+                for (int q = 0; q < NR; ++q) hr[t][q] = hf[t].r[q];
+            }
+        };
+        // r = sigmoid(.) group by group, then r*h -> planes chunk by chunk, then the remainder columns:
+        // pieces [0, NT NTA) | [NT NTA, (NT + NC2) NTA) | [(NT + NC2) NTA, (NT + NC2 + 1) NTA)
+        constexpr int R_PIECES = (NT + NC2 + 1) * NTA;
+        auto r_piece = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < NT * NTA) {
+                constexpr int t = k / NT, nt = k % NT;
+                if constexpr (nt == 0 && C::TAILPACK) {
+                    // the u gate's last tile was accumulated in the padding columns of the r gate's last tile:
+                    // column D + j of that tile (lane kq + (D%16)/4) is u column 16*NC + j (lane kq)
+                    constexpr int SH = 16 * ((D % 16) / 4);
+                    f32x4 ut;
+                    ut.x = __shfl(acc_r[t][NT - 1].x, lane + SH); ut.y = __shfl(acc_r[t][NT - 1].y, lane + SH);
+                    ut.z = __shfl(acc_r[t][NT - 1].z, lane + SH); ut.w = __shfl(acc_r[t][NT - 1].w, lane + SH);
+                    acc_u[t][NT - 1] = ut;
+                }
+                const int col = nt * 16 + 4 * kq;
+                if (col < D) {
+                    const f32x4 r = w_sigmoid4_acc<FMT>(acc_r[t][nt], bz[nt]);
+                    acc_r[t][nt] = r;
+                    if constexpr (SAVE) st4_b(a.save_r, ((unsigned)rowc[t] * D + col) * 4u, r);
+                }
+                touch4(acc_r[t][nt]);
+            } else if constexpr (k < (NT + NC2) * NTA) {
+                constexpr int kk = k - NT * NTA, t = kk / NC2, c2 = kk % NC2;
+                f32x4 ra = acc_r[t][2 * c2] * hf[t].v[2 * c2], rb = acc_r[t][2 * c2 + 1] * hf[t].v[2 * c2 + 1];
+                // (the product is ROUNDED before it is split: an fma of r, h and the hi piece would split the unrounded product)
+                asm volatile("" : "+v"(ra), "+v"(rb));
+                wsplit_chunk<D, FMT>(rhs[t], c2, ra, rb);
+            } else {
+                constexpr int t = k - (NT + NC2) * NTA;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    // remainder column 16NC + 4q + kq lives in tile NC of lane (li, kq' = q), element e = kq
+                    const float t0_ = __shfl(acc_r[t][NT - 1].x, li + 16 * q), t1_ = __shfl(acc_r[t][NT - 1].y, li + 16 * q);
+                    const float t2_ = __shfl(acc_r[t][NT - 1].z, li + 16 * q), t3_ = __shfl(acc_r[t][NT - 1].w, li + 16 * q);
+                    const float rr = kq == 0 ? t0_ : (kq == 1 ? t1_ : (kq == 2 ? t2_ : t3_));
+                    rhr[t][q] = rr * hf[t].r[q];
+                    asm volatile("" :: "v"(rhr[t][q]));
+                }
+            }
+        };
+        // u = sigmoid(.): piece k = (tile k / NT, group k % NT)
+        constexpr int U_PIECES = NT * NTA;
+        auto u_piece = [&](auto kc) {
+            constexpr int k = decltype(kc)::value, t = k / NT, nt = k % NT;
+            const int col = nt * 16 + 4 * kq;
+            if (col < D) {
+                const f32x4 u = w_sigmoid4_acc<FMT>(acc_u[t][nt], bz[nt]);
+                acc_u[t][nt] = u;
+                if constexpr (SAVE) st4_b(a.save_u, ((unsigned)rowc[t] * D + col) * 4u, u);
+            }
+            touch4(acc_u[t][nt]);
+        };
+        // the pending candidate epilogue: piece k = (tile k / NT, group k % NT)
+        constexpr int C_PIECES = CARRY ? NT * NTA : 0;
+        auto c_piece = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            c_group(std::integral_constant<int, k / NT>{}, std::integral_constant<int, k % NT>{}, hb[k / NT], bzc);
+        };
+        // the gathered segment of the pass to come, tile t: [0] the last pipelined slot, any further ones, an empty row;
+        // [1 .. NC2] the mean of a 32-chunk -> its planes; [NC2 + 1] the remainder columns (and the residual segment's planes)
+        constexpr int G_PER = NC2 + 2, G_PIECES = G_PER * NTA;
+        auto dvq = [&](int t, float x) { const float q = x * G.rcp[t]; return fmaf(fmaf(-G.den[t], q, x), G.rcp[t], q); };   // x / den, one division per row (Markstein)
+        auto dv4 = [&](int t, f32x4 v) { return a.g_use_avg ? f32x4{dvq(t, v.x), dvq(t, v.y), dvq(t, v.z), dvq(t, v.w)} : v; };
+        auto g_piece = [&](auto kc) {
+            constexpr int k = decltype(kc)::value, t = k / G_PER, w = k % G_PER;
+            Frag<D>& f = G.x[t];
+            if constexpr (w == 0) {
+                if (G.beg[t] + KI - 1 < G.end[t]) frag_add_w(f, G.t[t]);
+                for (int e = G.beg[t] + KI; e < G.end[t]; ++e) {
+                    load_frag<D>(G.t[t], a.g_H, a.g_idx[e], kq);
+                    frag_add_w(f, G.t[t]);
+                }
+                if (G.beg[t] >= G.end[t]) {                   // a node without incoming messages (slot 0 was row 0)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) f.v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) f.r[q] = 0.f;
+                }
+            } else if constexpr (w <= NC2) {
+                constexpr int c2 = w - 1;
+                const f32x4 va = dv4(t, f.v[2 * c2]), vb = dv4(t, f.v[2 * c2 + 1]);
+                if constexpr (SAVE) {
+                    if (t < nn) {
+                        const unsigned ob = ((unsigned)rown[t] * (unsigned)D + 4u * (unsigned)kq) * 4u;
+                        st4_b(a.save_x, ob + 64u * (2 * c2), va); st4_b(a.save_x, ob + 64u * (2 * c2 + 1), vb);
+                    }
+                }
+                wsplit_chunk<D, FMT>(xs[t], c2, va, vb);
+            } else {
+#pragma unroll
+                for (int c = 2 * NC2; c < NC; ++c) f.v[c] = dv4(t, f.v[c]);       // (no odd 16-chunk at the supported sizes)
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const float v = a.g_use_avg ? dvq(t, f.r[q]) : f.r[q];
+                    if constexpr (SAVE) {
+                        if (t < nn) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.save_x) + ((unsigned)rown[t] * (unsigned)D + 16u * NC + 4u * q + (unsigned)kq) * 4u) = v;
+                    }
+                    xr[t][q] = v;
+                }
+                if constexpr (NX > 1) commit(xq[t], xqr[t], G.rf[t]);
+            }
+        };
+        static_assert(NC % 2 == 0, "whole 32-chunks");
+
+        if constexpr (CARRY) {
+            load_cbias(bzc);
+#pragma unroll
+            for (int t = 0; t < NTA; ++t) load_frag<D>(hb[t], a.h, prow[t], kq);
+        }
+
         sfor<0, NSTAGE>([&](auto jc) {
             constexpr int j = decltype(jc)::value, g = wide_gate<NX>(j), s = wide_seg<NX>(j);
-            // the next image of the sequence (or the first image of the pass to come) goes into the other slot
-            if (j + 1 < NSTAGE || !last) dma(img_of((j + 1) % NSTAGE), ring + (cur ^ 1) * I::IMG);
-            // ---- side work of the stage ----
+            GGNN_WT(4 * (j < 6 ? j : 5) + 0)
+            // ---- side work in front of the stage's products: loads (they land under the products) ----
             if constexpr (j < JG && j % 3 == 0) {
                 // residual segment s: its planes (segment 0 crossed the pass boundary as planes); the next one is requested
                 if constexpr (s > 0) {
@@ -373,64 +689,9 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
                     for (int t = 0; t < NTA; ++t) load_frag<D>(rq[t], a.x[s + 1 < 2 ? s + 1 : 0], rowc[t], kq);
                 }
             }
-            if constexpr (j == (JG > 0 ? JG - 1 : 0)) {               // the state, one stage before its first use (NX = 1: with the first stage)
+            if constexpr (j == (JG > 0 ? JG - 1 : 0)) {               // the state, a stage before its planes are made (NX = 1: with the first stage)
 #pragma unroll
                 for (int t = 0; t < NTA; ++t) load_frag<D>(hf[t], a.h, rowc[t], kq);
-            }
-            if constexpr (j == JG + 1) {                             // h -> r columns: the state's planes
-#pragma unroll
-                for (int t = 0; t < NTA; ++t) commit(hs[t], hr[t], hf[t]);
-            }
-            if constexpr (j == JG + 2) {
-                // ---- r = sigmoid(.), r*h in activation-fragment layout -> planes; the u gate's tail tile leaves the r set ----
-#pragma unroll
-                for (int t = 0; t < NTA; ++t) {
-                    if constexpr (C::TAILPACK) {
-                        // the u gate's last tile was accumulated in the padding columns of the r gate's last tile:
-                        // column D + j of that tile (lane kq + (D%16)/4) is u column 16*NC + j (lane kq)
-                        constexpr int SH = 16 * ((D % 16) / 4);
-                        f32x4 ut;
-                        ut.x = __shfl(acc_r[t][NT - 1].x, lane + SH); ut.y = __shfl(acc_r[t][NT - 1].y, lane + SH);
-                        ut.z = __shfl(acc_r[t][NT - 1].z, lane + SH); ut.w = __shfl(acc_r[t][NT - 1].w, lane + SH);
-                        acc_u[t][NT - 1] = ut;
-                    }
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int col = nt * 16 + 4 * kq;
-                        if (col < D) {
-                            const f32x4 r = w_sigmoid4_acc<FMT>(acc_r[t][nt], ld4(bias_s + col));
-                            acc_r[t][nt] = r;
-                            if (a.save_r && row[t] < a.V) st4_b(a.save_r, ((unsigned)row[t] * D + col) * 4u, r);
-                        }
-                    }
-                    Frag<D> rh;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) rh.v[c] = acc_r[t][c] * hf[t].v[c];
-#pragma unroll
-                    for (int q = 0; q < NR; ++q) {
-                        // remainder column 16NC + 4q + kq lives in tile NC of lane (li, kq' = q), element e = kq
-                        const float t0_ = __shfl(acc_r[t][NT - 1].x, li + 16 * q), t1_ = __shfl(acc_r[t][NT - 1].y, li + 16 * q);
-                        const float t2_ = __shfl(acc_r[t][NT - 1].z, li + 16 * q), t3_ = __shfl(acc_r[t][NT - 1].w, li + 16 * q);
-                        const float rr = kq == 0 ? t0_ : (kq == 1 ? t1_ : (kq == 2 ? t2_ : t3_));
-                        rh.r[q] = rr * hf[t].r[q];
-                    }
-                    commit(rhs[t], rhr[t], rh);
-                }
-            }
-            if constexpr (j == JG + 4) {
-                // ---- u = sigmoid(.) ----
-#pragma unroll
-                for (int t = 0; t < NTA; ++t) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int col = nt * 16 + 4 * kq;
-                        if (col < D) {
-                            const f32x4 u = w_sigmoid4_acc<FMT>(acc_u[t][nt], ld4(bias_s + D + col));
-                            acc_u[t][nt] = u;
-                            if (a.save_u && row[t] < a.V) st4_b(a.save_u, ((unsigned)row[t] * D + col) * 4u, u);
-                        }
-                    }
-                }
             }
             if constexpr (j == (NX > 1 ? 2 : JG + 4)) {              // (before the first candidate stage: residual 0 -> c, or x -> c)
                 if constexpr (C::TAILPACK3) {
@@ -438,109 +699,109 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
                     for (int t = 0; t < NTA; ++t) acc_c[t][NT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};   // (opened by the r*h stage only)
                 }
             }
-            // the gather of the pass to come, beside the last three stages
-            if constexpr (j == NSTAGE - 3) {
+            if constexpr (j == JG + 2) load_bias(bias_s);            // r gate
+            if constexpr (j == JG + 4) load_bias(bias_s + D);        // u gate
+            // the gather of the pass to come: one level of its dependent chain per stage, for every tile (a tile the pass to come
+            // does not have gathers a valid row for nothing -- no branches in the product stream)
+            if constexpr (j == JG + 1) {
 #pragma unroll
-                for (int t = 0; t < NTA; ++t) if (t < nn) g_ptrs(G, t, rown[t]);
+                for (int t = 0; t < NTA; ++t) g_ptrs(G, t, rown[t]);
             }
-            if constexpr (j == NSTAGE - 2) {
+            if constexpr (j == JG + 2) {
 #pragma unroll
-                for (int t = 0; t < NTA; ++t) if (t < nn) g_index(G, t);
+                for (int t = 0; t < NTA; ++t) g_index(G, t);
             }
-            if constexpr (j == NSTAGE - 1) {
+            if constexpr (j == JG + 3) {
 #pragma unroll
                 for (int t = 0; t < NTA; ++t) {
-                    if (t < nn) {
-                        g_rows0(G, t);
-                        if constexpr (NX > 1) load_frag<D>(G.rf[t], a.x[0], rown[t], kq);
-                    }
+                    g_rows0(G, t);
+                    if constexpr (NX > 1) load_frag<D>(G.rf[t], a.x[0], rown[t], kq);
                 }
             }
+            if constexpr (j == JG + 4) {
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) g_rows(G, t, 2);
+            }
+            if constexpr (j == JG + 5) {
+#pragma unroll
+                for (int t = 0; t < NTA; ++t) g_rows(G, t, 3);
+            }
+            if constexpr (!GGNN_WIDE_DMA_PIECES) dma(img_of((j + 1) % NSTAGE), ring + (cur ^ 1) * I::IMG);
             __builtin_amdgcn_sched_barrier(0);
-            // ---- the stage's products ----
+            GGNN_WT(4 * (j < 6 ? j : 5) + 1)
+            // ---- the stage's products, with the pieces of the pass's side work in their units ----
             // u stages skip their last tile when it rides in the r image; so do the candidate stages of the x segments
             constexpr int ntl = ((C::TAILPACK && g == 1) || (C::TAILPACK3 && g == 2 && s < NX)) ? NT - 1 : NT;
             constexpr bool ZERO = (s == 0);
+            constexpr int UN = wide_units<D, FMT>(ntl);              // units of this stage
+            constexpr int UNF = wide_units<D, FMT>(NT);              // units of a full stage (x -> r, h -> r, r*h -> c)
+            constexpr int UN2 = wide_units<D, FMT>(C::TAILPACK ? NT - 1 : NT);   // units of stage JG + 2 (x -> u)
+            constexpr int PW = I::IMG_BYTES / (NW * 1024);           // this wave's KiB pieces of an image DMA
+            constexpr int C0 = 6;                                    // first unit of the pending epilogue (its state rows land first)
+            constexpr int H0 = UNF - H_PIECES;                       // first unit of the state's planes in stage JG
+            constexpr int G0 = UNF - G_PIECES - 1;                   // first unit of the gathered segment's pieces in the last stage
+            static_assert(C0 + C_PIECES <= H0 + UNF && R_PIECES <= 2 * UN2 && U_PIECES <= wide_units<D, FMT>(C::TAILPACK3 ? NT - 1 : NT) &&
+                          G0 >= 4 && PW <= wide_units<D, FMT>(NT - 1), "the side work must fit the units of its stages");
             const float* img = ring + cur * I::IMG;
+            const float* nsrc = img_of((j + 1) % NSTAGE);            // the next image of the sequence (behind the last stage of the last
+            float* ndst = ring + (cur ^ 1) * I::IMG;                 // pass: an image nobody reads -- no branch in the product stream)
+            auto fill = [&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                // the image DMA, a KiB piece at a time: piece k in unit k UN / PW
+                if constexpr (GGNN_WIDE_DMA_PIECES) {
+                    sfor<0, PW>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if constexpr ((k * UN) / PW == u) dma_piece_asm<I::IMG_BYTES, NW, k>(nsrc, ndst, wave, lane);
+                    });
+                }
+                if constexpr (j == JG) {                             // x -> r: the pending epilogue, then the state's planes in the LAST units
+                    if constexpr (u >= C0 && u < H0 && u - C0 < C_PIECES) c_piece(std::integral_constant<int, u - C0>{});
+                    if constexpr (u >= H0) h_piece(std::integral_constant<int, u - H0>{});
+                } else if constexpr (j == JG + 1) {                  // h -> r: the rest of the pending epilogue
+                    if constexpr (u + (H0 - C0) < C_PIECES) c_piece(std::integral_constant<int, u + (H0 - C0)>{});
+                } else if constexpr (j == JG + 2) {                  // x -> u, h -> u: the r epilogue
+                    if constexpr (u < R_PIECES) r_piece(uc);
+                } else if constexpr (j == JG + 3) {
+                    if constexpr (u + UN2 < R_PIECES) r_piece(std::integral_constant<int, u + UN2>{});
+                } else if constexpr (j == JG + 4) {                  // x -> c: the u epilogue
+                    if constexpr (u < U_PIECES) u_piece(uc);
+                } else if constexpr (j == JG + 5) {                  // r*h -> c: the gathered segment of the pass to come
+                    if constexpr (u >= G0 && u - G0 < G_PIECES) g_piece(std::integral_constant<int, u - G0>{});
+                }
+            };
             auto mma = [&](auto& acc, auto zc) {
                 constexpr bool Z = decltype(zc)::value;
-                if constexpr (s < NX - 1) wide_stage_mma<D, NTW, NTA, ntl, Z, FMT>(acc, xq, xqr, img, li, kq);
-                else if constexpr (s == NX - 1) wide_stage_mma<D, NTW, NTA, ntl, Z, FMT>(acc, xs, xr, img, li, kq);
-                else if constexpr (g < 2) wide_stage_mma<D, NTW, NTA, ntl, Z, FMT>(acc, hs, hr, img, li, kq);
-                else wide_stage_mma<D, NTW, NTA, ntl, false, FMT>(acc, rhs, rhr, img, li, kq);
+                if constexpr (s < NX - 1) wide_stage_mma<D, NTW, NTA, ntl, Z, FMT>(acc, xq, xqr, img, li, kq, fill);
+                else if constexpr (s == NX - 1) wide_stage_mma<D, NTW, NTA, ntl, Z, FMT>(acc, xs, xr, img, li, kq, fill);
+                else if constexpr (g < 2) wide_stage_mma<D, NTW, NTA, ntl, Z, FMT>(acc, hs, hr, img, li, kq, fill);
+                else wide_stage_mma<D, NTW, NTA, ntl, false, FMT>(acc, rhs, rhr, img, li, kq, fill);
             };
             if constexpr (g == 0) mma(acc_r, std::integral_constant<bool, ZERO>{});
             else if constexpr (g == 1) mma(acc_u, std::integral_constant<bool, ZERO>{});
             else mma(acc_c, std::integral_constant<bool, ZERO>{});
             __builtin_amdgcn_sched_barrier(0);
+            GGNN_WT(4 * (j < 6 ? j : 5) + 2)
             publish();
+            GGNN_WT(4 * (j < 6 ? j : 5) + 3)
             cur ^= 1;
         });
 
-        // ---- c = act(.), h' = u*h + (1-u)*c; the gather of the pass to come finishes in its shadow --------------------------------
-        // The state fragment is dead since the r epilogue (it would hold 25 registers per tile through four stages, beside the
-        // gather's two fragment sets): the blend reads the rows again, a tile ahead of its use.
-#pragma unroll
-        for (int t = 0; t < NTA; ++t) if (t < nn) g_rows(G, t, 2);
-        Frag<D> hb[2];
-        load_frag<D>(hb[0], a.h, rowc[0], kq);
+        // this pass's candidate epilogue is now pending
 #pragma unroll
         for (int t = 0; t < NTA; ++t) {
-            if (t + 1 < NTA) load_frag<D>(hb[(t + 1) & 1], a.h, rowc[t + 1 < NTA ? t + 1 : 0], kq);
-            __builtin_amdgcn_sched_barrier(0);
-            const Frag<D>& hq = hb[t & 1];
-            if constexpr (C::TAILPACK3) {
-                // the x segments' share of the candidate's last tile was accumulated two lane groups up in the r gate's last tile
-                // (which the r epilogue rewrote only in its own lanes); add it to the r*h share
-                constexpr int SH2 = 32 * ((D % 16) / 4);
-                f32x4 ct;
-                ct.x = __shfl(acc_r[t][NT - 1].x, lane + SH2); ct.y = __shfl(acc_r[t][NT - 1].y, lane + SH2);
-                ct.z = __shfl(acc_r[t][NT - 1].z, lane + SH2); ct.w = __shfl(acc_r[t][NT - 1].w, lane + SH2);
-                acc_c[t][NT - 1] = ct + acc_c[t][NT - 1];
-            }
-            f32x4 hrem = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < NR; ++q) {
-                const float h0 = __shfl(hq.r[q], li), h1 = __shfl(hq.r[q], li + 16);
-                const float h2 = __shfl(hq.r[q], li + 32), h3 = __shfl(hq.r[q], li + 48);
-                if (kq == q) hrem = f32x4{h0, h1, h2, h3};
-            }
-            if (row[t] < a.V) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int col = nt * 16 + 4 * kq;
-                    if (col < D) {
-                        f32x4 hv;
-                        if (nt < NC) hv = hq.v[nt < NC ? nt : 0];
-                        else hv = hrem;
-                        f32x4 c;
-                        if (a.act == GGNN_ACT_TANH) {
-                            c = w_tanh4_acc<FMT>(acc_c[t][nt], ld4(bias_s + 2 * D + col));           // (2 log2e * bc)
-                        } else {
-                            c = acc_c[t][nt] * SplitFmt<FMT>::acc_scale + ld4(bias_s + 3 * D + col);   // (bc itself)
-                            c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
-                        }
-                        const f32x4 u = acc_u[t][nt];
-                        st4_b(a.h_out, ((unsigned)row[t] * D + col) * 4u, u * hv + (1.0f - u) * c);
-                        if (a.save_c) st4_b(a.save_c, ((unsigned)row[t] * D + col) * 4u, c);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int nt = 0; nt < NT; ++nt) { pc[t][nt] = acc_c[t][nt]; pu[t][nt] = acc_u[t][nt]; }
+            ptl[t] = acc_r[t][NT - 1]; prow[t] = rowc[t];
         }
-#pragma unroll
-        for (int t = 0; t < NTA; ++t) if (t < nn) g_rows(G, t, 3);
-#pragma unroll
-        for (int t = 0; t < NTA; ++t) {
-            if (t < nn) { g_finish(G, t); x_commit(G, t, (t0n + t) * 16 + li); }
-        }
+        pend_clear(NTA);
+        npend = NTA;
+        GGNN_WT(25)
     };
 
     // a pass of a wave without tiles: its share of the image DMAs and the barriers
     auto idle_pass = [&](const int p) {
-        const bool last = p + 1 >= P;
         for (int j = 0; j < NSTAGE; ++j) {
-            if (j + 1 < NSTAGE || !last) dma(img_of((j + 1) % NSTAGE), ring + (cur ^ 1) * I::IMG);
+            dma(img_of((j + 1) % NSTAGE), ring + (cur ^ 1) * I::IMG);
             publish();
             cur ^= 1;
         }
@@ -548,16 +809,21 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
 
     for (int p = 0; p < P; ++p) {
         const int n = slot_count(p);
-        if (NTW >= 4 && n == 4) run_pass(std::integral_constant<int, (NTW >= 4 ? 4 : 1)>{}, p);
-        else if (NTW >= 3 && n == 3) run_pass(std::integral_constant<int, (NTW >= 3 ? 3 : 1)>{}, p);
-        else if (NTW >= 2 && n == 2) run_pass(std::integral_constant<int, (NTW >= 2 ? 2 : 1)>{}, p);
-        else if (n == 1) run_pass(std::integral_constant<int, 1>{}, p);
-        else idle_pass(p);
+        const bool carry = GGNN_WIDE_CARRY && n > 0 && npend == n;
+        if (!carry && npend > 0) flush();
+        if (n == 0) { pend_clear(0); idle_pass(p); continue; }
+        sfor<1, NTW + 1>([&](auto nc) {
+            if (n == decltype(nc)::value) {
+                if (carry) run_pass(nc, std::true_type{}, p);
+                else run_pass(nc, std::false_type{}, p);
+            }
+        });
     }
+    flush();
 }
 
-template <int D, int NX, int NTW, int FMT>
-int launch_gru_wide(const GruFusedArgs& f, float* packed, hipStream_t st) {
+template <int D, int NX, int NTW, int FMT, bool SAVE, bool TANH>
+int launch_gru_wide_m(const GruFusedArgs& f, float* packed, hipStream_t st) {
     using I = ImgCfg<D, true, FMT>;
     if ((unsigned long long)f.V * D >= (1ULL << 30) || (unsigned long long)f.V * f.g_T * D >= (1ULL << 30))
         return fail(GGNN_E_UNSUPPORTED, "fused GRU indexes with 32-bit byte offsets: V*D and V*T*D must be < 2^30 (V=%d, D=%d)", f.V, D);
@@ -567,26 +833,47 @@ int launch_gru_wide(const GruFusedArgs& f, float* packed, hipStream_t st) {
     a.save_r = f.save_r; a.save_u = f.save_u; a.save_c = f.save_c; a.save_x = f.save_x;
     a.g_H = f.g_H; a.g_row_ptr = f.g_row_ptr; a.g_idx = f.g_idx; a.g_nin = f.g_nin;
     a.packed = packed; a.V = f.V; a.act = f.act; a.g_T = f.g_T; a.g_use_avg = f.g_use_avg;
+#if GGNN_WIDE_STAMPS
+    { const char* e = getenv("GGNN_GRU_TPTR"); a.tdbg = (e && NX == 1) ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
+#endif
     constexpr size_t lds = (size_t)2 * I::IMG_BYTES + (size_t)((4 * D + 63) / 64 * 64) * sizeof(float);
     const int wt_total = (f.V + 15) / 16;
     int nb = num_cus();
     if (nb > wt_total) nb = wt_total;
     static std::atomic<unsigned long long> lds_ok{0};        // (one per template instantiation)
-    GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_wide_kernel<D, NX, NTW, FMT>, lds, lds_ok));
-    hipLaunchKernelGGL((ggnn_gru_wide_kernel<D, NX, NTW, FMT>), dim3(nb), dim3(256), lds, st, a);
+    GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_wide_kernel<D, NX, NTW, FMT, SAVE, TANH>, lds, lds_ok));
+    hipLaunchKernelGGL((ggnn_gru_wide_kernel<D, NX, NTW, FMT, SAVE, TANH>), dim3(nb), dim3(256), lds, st, a);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
 
+template <int D, int NX, int NTW, int FMT>
+int launch_gru_wide(const GruFusedArgs& f, float* packed, hipStream_t st) {
+    return launch_gru_wide_m<D, NX, NTW, FMT, false, true>(f, packed, st);
+}
+
 }  // namespace
 
-// Tiles per wave by fan-in and format: what the 512-entry register file holds (kernel-resource-usage remarks of this file).
-// ntw_req (experiments: GGNN_GRU_FORM = 60 + NTW): 0 = these defaults.
-int gru_wide_supported(int D, int nx) { return D == 100 && nx >= 1 && nx <= 3; }
-
-int gru_wide_launch(int D, int nx, int ntw_req, const GruFusedArgs& a, float* packed, hipStream_t st) {
-    if (D != 100 || !a.g_H) return fail(GGNN_E_UNSUPPORTED, "the wide fused GRU is the gather-fused launch at hidden size 100");
+// What the wide form is instantiated for: the inference launch (no r / u / c stores) of the tanh cell at hidden size 100 -- the
+// benchmark's launches; training launches, ReLU cells and the other fused sizes stay on the ring forms (each instantiation of
+// this kernel is 2 NTW unrolled pass bodies: minutes of compile time apiece).
+// GGNN_WIDE_SET: 1 = nx 1 in the two-piece f16 format only (kernel experiments), 2 = + the residual fan-ins, 3 = + bf16x3.
+#ifndef GGNN_WIDE_SET
+#define GGNN_WIDE_SET 1
+#endif
+int gru_wide_supported(int D, int nx, const GruFusedArgs& a) {
+    if (D != 100 || !a.g_H || a.save_r || a.act != GGNN_ACT_TANH || nx < 1 || nx > 3) return 0;
     const bool f2 = gru_launch_fmt(a.fmt) == kSplitF16x2;
+    if (GGNN_WIDE_SET < 3 && !f2) return 0;
+    if (GGNN_WIDE_SET < 2 && nx > 1) return 0;
+    return 1;
+}
+
+// ntw_req (experiments: GGNN_GRU_FORM = 60 + NTW): 0 = the default tiles per wave
+int gru_wide_launch(int D, int nx, int ntw_req, const GruFusedArgs& a, float* packed, hipStream_t st) {
+    if (!gru_wide_supported(D, nx, a)) return fail(GGNN_E_UNSUPPORTED, "no wide fused GRU for this launch");
+    const bool f2 = gru_launch_fmt(a.fmt) == kSplitF16x2;
+    (void)ntw_req;
 #ifdef GGNN_WIDE_PROBE_NTW   // register-allocation probe: one instantiation (-DGGNN_WIDE_PROBE_NTW=3 [-DGGNN_WIDE_PROBE_NX=1] [-DGGNN_WIDE_PROBE_FMT=2])
 #ifndef GGNN_WIDE_PROBE_NX
 #define GGNN_WIDE_PROBE_NX 1
@@ -594,22 +881,27 @@ int gru_wide_launch(int D, int nx, int ntw_req, const GruFusedArgs& a, float* pa
 #ifndef GGNN_WIDE_PROBE_FMT
 #define GGNN_WIDE_PROBE_FMT kSplitF16x2
 #endif
-    (void)f2; (void)ntw_req;
+    (void)f2;
     return launch_gru_wide<100, GGNN_WIDE_PROBE_NX, GGNN_WIDE_PROBE_NTW, GGNN_WIDE_PROBE_FMT>(a, packed, st);
 #else
     if (f2) {
         switch (nx) {
-            case 1: return ntw_req == 2 ? launch_gru_wide<100, 1, 2, kSplitF16x2>(a, packed, st) : launch_gru_wide<100, 1, 3, kSplitF16x2>(a, packed, st);
+            case 1: return launch_gru_wide<100, 1, 2, kSplitF16x2>(a, packed, st);
+#if GGNN_WIDE_SET >= 2
             case 2: return launch_gru_wide<100, 2, 2, kSplitF16x2>(a, packed, st);
             case 3: return launch_gru_wide<100, 3, 2, kSplitF16x2>(a, packed, st);
+#endif
         }
-    } else {
+    }
+#if GGNN_WIDE_SET >= 3
+    else {
         switch (nx) {
             case 1: return launch_gru_wide<100, 1, 2, kSplitBf16x3>(a, packed, st);
             case 2: return launch_gru_wide<100, 2, 2, kSplitBf16x3>(a, packed, st);
             case 3: return launch_gru_wide<100, 3, 1, kSplitBf16x3>(a, packed, st);
         }
     }
+#endif
     return fail(GGNN_E_INVALID, "nx %d outside 1..3", nx);
 #endif
 }

@@ -12,7 +12,7 @@ for src in ${srcs//,/ }; do
     base=$(basename "$src" .hip)
     extra=""
     case $base in   # the translation units build.py compiles without packed-f32 vector instructions
-        *_split|ggnn_msg_compact|ggnn_panel|ggnn_bwd_gemm) extra="-Xclang -target-feature -Xclang -packed-fp32-ops -mllvm -amdgpu-use-amdgpu-trackers=1" ;;
+        *_split|ggnn_msg_compact|ggnn_panel|ggnn_bwd_gemm|ggnn_gru_wide) extra="-Xclang -target-feature -Xclang -packed-fp32-ops -mllvm -amdgpu-use-amdgpu-trackers=1" ;;
     esac
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -I "$ROOT/include" $extra "$@" -c "$P/csrc/$base.hip" -o "/tmp/${base}_$tag.o"
     objs=$(echo "$objs" | grep -v "/$base.o")
