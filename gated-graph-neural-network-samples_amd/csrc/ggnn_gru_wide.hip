@@ -157,6 +157,16 @@ __device__ __forceinline__ void dma_piece_asm(const float* src, float* dst, int 
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" :: "s"(l), "v"(voff), "s"(sa), "n"((K & 3) * 1024) : "memory");
 }
 
+// one of the NC + NR loads of load_frag<D>: PART < NC the float4 of 16-chunk PART, PART = NC + q the remainder float q
+template <int D, int PART>
+__device__ __forceinline__ void load_frag_part(Frag<D>& f, const float* base, int row, int kq) {
+    constexpr int NC = StageCfg<D>::NC;
+    const unsigned ob = ((unsigned)row * (unsigned)D + 4u * (unsigned)kq) * 4u;
+    __builtin_assume(ob < 0xF0000000u);
+    if constexpr (PART < NC) f.v[PART] = ld4_b(base, ob + 64u * PART);
+    else f.r[PART - NC] = ld1_b(base, ob - 16u * (unsigned)kq + 4u * (unsigned)(16 * NC + 4 * (PART - NC)) + 4u * (unsigned)kq);
+}
+
 struct NoFill { template <class U> __device__ __forceinline__ void operator()(U) const {} };
 
 // units of a stage's product: NC2 * NTILES (32-chunk, column tile) units + NR * NTILES remainder units
@@ -182,6 +192,9 @@ __device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT
     using S = StageCfg<D>;
     using C = SplitCfg<D, FMT>;
     constexpr int NP = C::NP;
+    // (REMAT, as in stage_mma_split_at: the lane parts of the LDS addresses are recomputed per stage instead of living -- and being
+    // spilled -- across the pass: a scratch reload here waits, in order, behind every DMA piece and gathered row in flight)
+    asm volatile("" : "+v"(li), "+v"(kq));
     constexpr int NU = C::NC2 * NTILES;                               // units, chunk-major
     constexpr bool FILLED = !std::is_same<Fill, NoFill>::value;
     const float* img_b = img + C::HA;
@@ -287,22 +300,24 @@ template <int NX> __host__ __device__ constexpr int wide_seg(int j) { return j <
 // FILLS: 1 = the epilogues / splits are dealt into the MFMA stream of the stage they precede (wide_stage_mma's FILL), 0 = they
 // run in front of it.
 #ifndef GGNN_WIDE_DMA_PIECES
-#define GGNN_WIDE_DMA_PIECES 0   // 1: the image DMA goes out a KiB piece at a time inside the product units (0: in one burst in front of them)
+#define GGNN_WIDE_DMA_PIECES 1   // 1: the image DMA goes out a KiB piece at a time inside the product units (0: in one burst in front of them)
 #endif
 #ifndef GGNN_WIDE_CARRY
 #define GGNN_WIDE_CARRY 0     // the candidate epilogue of a pass rides in the first stages of the next one (0: it runs behind its pass)
 #endif
-template <int D, int NX, int NTW, int FMT, bool SAVE, bool TANH>
-__global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
+// NW: waves per workgroup -- 4 (one per SIMD, the whole register file each) or 8 (two per SIMD on 256 registers each: NTW = 1).
+template <int D, int NX, int NTW, int FMT, bool SAVE, bool TANH, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW / 4) void ggnn_gru_wide_kernel(GruWideArgs a) {
     using C = StageCfg<D>;
     using I = ImgCfg<D, true, FMT>;
     constexpr int NT = C::NT, NC = C::NC, NR = C::NR, NRR = NR > 0 ? NR : 1;
-    constexpr int NW = 4, NSEG = NX + 1, NSTAGE = 3 * NSEG, KI = 4;
+    constexpr int NSEG = NX + 1, NSTAGE = 3 * NSEG, KI = 4;
     constexpr int JG = 3 * (NX - 1);                                 // first stage of the gate-sequential part
     extern __shared__ __attribute__((aligned(16))) float lds_[];   // [biases | ring [2][IMG]]
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, kq = lane >> 4;
+    int li = lane & 15, kq = lane >> 4;               // (not const: re-made opaque per stage, see the stage loop)
 
     constexpr int BIAS_FLOATS = (4 * D + 63) / 64 * 64;
     float* bias_s = lds_;                             // [-log2e*bg (2D) | 2 log2e*bc (D) | bc (D)]
@@ -466,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
     // c = act(.), h' = u*h + (1-u)*c for one float4 group (tile t, column tile nt) of the pending tiles; hq: the tile's state rows
     // (read again: the fragment died with the r epilogue), bzc: the candidate biases.  Group 0 of a tile first folds the x
     // segments' share of the last tile in (TAILPACK3) -- group NT - 1 reads it.
-    auto c_group = [&](auto tc, auto ntc, const Frag<D>& hq, const f32x4 (&bzc)[NT]) {
+    auto c_group = [&](auto tc, auto ntc, const Frag<D>& hq, const f32x4 bcv) {
         constexpr int t = decltype(tc)::value, nt = decltype(ntc)::value;
         if constexpr (nt == 0 && C::TAILPACK3) {
             // the x segments' share of the candidate's last tile was accumulated two lane groups up in the r gate's last tile
@@ -494,9 +509,9 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
         if (col < D) {
             f32x4 c;
             if constexpr (TANH) {
-                c = w_tanh4_acc<FMT>(pc[t][nt], bzc[nt]);
+                c = w_tanh4_acc<FMT>(pc[t][nt], bcv);
             } else {
-                c = pc[t][nt] * SplitFmt<FMT>::acc_scale + bzc[nt];
+                c = pc[t][nt] * SplitFmt<FMT>::acc_scale + bcv;
                 c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
             }
             st4_b(a.h_out, ((unsigned)prow[t] * D + col) * 4u, w_blend4(pu[t][nt], hv, c));
@@ -517,7 +532,7 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
             if (t < npend) {
                 Frag<D> hq;
                 load_frag<D>(hq, a.h, prow[t], kq);
-                sfor<0, NT>([&](auto ntc) { c_group(tc, ntc, hq, bzc); });
+                sfor<0, NT>([&](auto ntc) { c_group(tc, ntc, hq, bzc[decltype(ntc)::value]); });
             }
         });
         npend = 0;
@@ -544,10 +559,16 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
 
         // the biases of the gate whose epilogue a stage carries, read from LDS ONCE in front of that stage's products: a read inside a
         // piece is waited for inside the piece -- a full LDS round trip per unit with no other wave to cover it
-        f32x4 bz[NT], bzc[NT];
+        f32x4 bz[NT];
         auto load_bias = [&](const float* b) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bz[nt] = (nt * 16 + 4 * kq < D) ? ld4(b + nt * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        // ... or, inside the product units, a PIECE ahead of its use (one float4 in flight instead of NT of them held for a stage)
+        f32x4 bq[NT * NTW + 1];                       // bq[k]: the bias of the epilogue piece k of the running gate
+        auto bias_ahead = [&](const float* b, auto kc, auto nkc) {   // the bias of piece k (group k % NT) if k < nk
+            constexpr int k = decltype(kc)::value, nk = decltype(nkc)::value, nt = k % NT;
+            if constexpr (k < nk) bq[k] = (nt * 16 + 4 * kq < D) ? ld4(b + nt * 16 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
         };
         // ---- the side work of a pass, in PIECES (wide_stage_mma's fill: the pieces of a unit are emitted inside its region) ------
         auto touch4 = [](const f32x4& v) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); };   // "this value exists HERE" (no sinking)
@@ -578,9 +599,10 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
                     ut.z = __shfl(acc_r[t][NT - 1].z, lane + SH); ut.w = __shfl(acc_r[t][NT - 1].w, lane + SH);
                     acc_u[t][NT - 1] = ut;
                 }
+                bias_ahead(bias_s, std::integral_constant<int, k + 1>{}, std::integral_constant<int, NT * NTA>{});
                 const int col = nt * 16 + 4 * kq;
                 if (col < D) {
-                    const f32x4 r = w_sigmoid4_acc<FMT>(acc_r[t][nt], bz[nt]);
+                    const f32x4 r = w_sigmoid4_acc<FMT>(acc_r[t][nt], bq[k]);
                     acc_r[t][nt] = r;
                     if constexpr (SAVE) st4_b(a.save_r, ((unsigned)rowc[t] * D + col) * 4u, r);
                 }
@@ -608,9 +630,10 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
         constexpr int U_PIECES = NT * NTA;
         auto u_piece = [&](auto kc) {
             constexpr int k = decltype(kc)::value, t = k / NT, nt = k % NT;
+            bias_ahead(bias_s + D, std::integral_constant<int, k + 1>{}, std::integral_constant<int, U_PIECES>{});
             const int col = nt * 16 + 4 * kq;
             if (col < D) {
-                const f32x4 u = w_sigmoid4_acc<FMT>(acc_u[t][nt], bz[nt]);
+                const f32x4 u = w_sigmoid4_acc<FMT>(acc_u[t][nt], bq[k]);
                 acc_u[t][nt] = u;
                 if constexpr (SAVE) st4_b(a.save_u, ((unsigned)rowc[t] * D + col) * 4u, u);
             }
@@ -618,9 +641,20 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
         };
         // the pending candidate epilogue: piece k = (tile k / NT, group k % NT)
         constexpr int C_PIECES = CARRY ? NT * NTA : 0;
+        // (its state rows are read again a piece ahead of their use, one load per piece: hb as a whole would hold 25 registers per
+        // tile through the stage -- the registers whose spills a wave alone on its SIMD cannot afford: a scratch reload waits, in
+        // order, behind every DMA piece and gathered row in flight)
+        auto hb_load = [&](auto kc) {
+            constexpr int k = decltype(kc)::value, t = k / NT, nt = k % NT;
+            if constexpr (k < C_PIECES) {
+                if constexpr (nt < NC) load_frag_part<D, nt < NC ? nt : 0>(hb[t], a.h, prow[t], kq);
+                else sfor<0, NR>([&](auto qc) { load_frag_part<D, NC + decltype(qc)::value>(hb[t], a.h, prow[t], kq); });
+            }
+        };
         auto c_piece = [&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            c_group(std::integral_constant<int, k / NT>{}, std::integral_constant<int, k % NT>{}, hb[k / NT], bzc);
+            bias_ahead(TANH ? bias_s + 2 * D : bias_s + 3 * D, std::integral_constant<int, k + 1>{}, std::integral_constant<int, C_PIECES>{});
+            c_group(std::integral_constant<int, k / NT>{}, std::integral_constant<int, k % NT>{}, hb[k / NT], bq[k]);
         };
         // the gathered segment of the pass to come, tile t: [0] the last pipelined slot, any further ones, an empty row;
         // [1 .. NC2] the mean of a 32-chunk -> its planes; [NC2 + 1] the remainder columns (and the residual segment's planes)
@@ -667,16 +701,27 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
             }
         };
         static_assert(NC % 2 == 0, "whole 32-chunks");
+        // the source rows of the pass to come, ONE LOAD per piece (a load rides in a product unit for free; in front of the products
+        // a wave alone on its SIMD pays ~100 clocks of issue for each): piece m = (slot m / RL, tile, part of the row); slot 0 lands
+        // in the sum itself, slots 1 .. 3 in the temporary, whose previous slot is added first (slot order = the reference's)
+        constexpr int RLP = NC + NR, RL = RLP * NTA;
+        auto gl_piece = [&](auto mc) {
+            constexpr int m = decltype(mc)::value, slot = m / RL, t = (m % RL) / RLP, part = m % RLP;
+            if constexpr (slot == 0) load_frag_part<D, part>(G.x[t], a.g_H, G.i[t][0], kq);
+            else {
+                if constexpr (part == 0 && slot >= 2) { if (G.beg[t] + slot - 1 < G.end[t]) frag_add_w(G.x[t], G.t[t]); }
+                load_frag_part<D, part>(G.t[t], a.g_H, G.i[t][slot < KI ? slot : 0], kq);
+            }
+        };
 
-        if constexpr (CARRY) {
-            load_cbias(bzc);
-#pragma unroll
-            for (int t = 0; t < NTA; ++t) load_frag<D>(hb[t], a.h, prow[t], kq);
-        }
 
         sfor<0, NSTAGE>([&](auto jc) {
             constexpr int j = decltype(jc)::value, g = wide_gate<NX>(j), s = wide_seg<NX>(j);
             GGNN_WT(4 * (j < 6 ? j : 5) + 0)
+            // REMAT: everything derived from the lane coordinates (LDS and row addresses) is recomputed per stage instead of living --
+            // and, in this kernel at the edge of the register file, being spilled -- across the pass: a scratch reload waits, in
+            // order, behind every DMA piece and gathered row in flight
+            asm volatile("" : "+v"(li), "+v"(kq), "+v"(lane));
             // ---- side work in front of the stage's products: loads (they land under the products) ----
             if constexpr (j < JG && j % 3 == 0) {
                 // residual segment s: its planes (segment 0 crossed the pass boundary as planes); the next one is requested
@@ -699,8 +744,8 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
                     for (int t = 0; t < NTA; ++t) acc_c[t][NT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};   // (opened by the r*h stage only)
                 }
             }
-            if constexpr (j == JG + 2) load_bias(bias_s);            // r gate
-            if constexpr (j == JG + 4) load_bias(bias_s + D);        // u gate
+            if constexpr (j == JG + 2) bias_ahead(bias_s, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});       // r gate
+            if constexpr (j == JG + 4) bias_ahead(bias_s + D, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});   // u gate
             // the gather of the pass to come: one level of its dependent chain per stage, for every tile (a tile the pass to come
             // does not have gathers a valid row for nothing -- no branches in the product stream)
             if constexpr (j == JG + 1) {
@@ -711,20 +756,9 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
 #pragma unroll
                 for (int t = 0; t < NTA; ++t) g_index(G, t);
             }
-            if constexpr (j == JG + 3) {
+            if constexpr (j == JG + 3 && NX > 1) {
 #pragma unroll
-                for (int t = 0; t < NTA; ++t) {
-                    g_rows0(G, t);
-                    if constexpr (NX > 1) load_frag<D>(G.rf[t], a.x[0], rown[t], kq);
-                }
-            }
-            if constexpr (j == JG + 4) {
-#pragma unroll
-                for (int t = 0; t < NTA; ++t) g_rows(G, t, 2);
-            }
-            if constexpr (j == JG + 5) {
-#pragma unroll
-                for (int t = 0; t < NTA; ++t) g_rows(G, t, 3);
+                for (int t = 0; t < NTA; ++t) load_frag<D>(G.rf[t], a.x[0], rown[t], kq);
             }
             if constexpr (!GGNN_WIDE_DMA_PIECES) dma(img_of((j + 1) % NSTAGE), ring + (cur ^ 1) * I::IMG);
             __builtin_amdgcn_sched_barrier(0);
@@ -737,11 +771,12 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
             constexpr int UNF = wide_units<D, FMT>(NT);              // units of a full stage (x -> r, h -> r, r*h -> c)
             constexpr int UN2 = wide_units<D, FMT>(C::TAILPACK ? NT - 1 : NT);   // units of stage JG + 2 (x -> u)
             constexpr int PW = I::IMG_BYTES / (NW * 1024);           // this wave's KiB pieces of an image DMA
-            constexpr int C0 = 6;                                    // first unit of the pending epilogue (its state rows land first)
+            constexpr int C0 = 2;                                    // first unit of the pending epilogue
             constexpr int H0 = UNF - H_PIECES;                       // first unit of the state's planes in stage JG
             constexpr int G0 = UNF - G_PIECES - 1;                   // first unit of the gathered segment's pieces in the last stage
             static_assert(C0 + C_PIECES <= H0 + UNF && R_PIECES <= 2 * UN2 && U_PIECES <= wide_units<D, FMT>(C::TAILPACK3 ? NT - 1 : NT) &&
-                          G0 >= 4 && PW <= wide_units<D, FMT>(NT - 1), "the side work must fit the units of its stages");
+                          G0 >= RL + 2 && RL <= wide_units<D, FMT>(C::TAILPACK3 ? NT - 1 : NT) && PW <= wide_units<D, FMT>(NT - 1),
+                          "the side work must fit the units of its stages");
             const float* img = ring + cur * I::IMG;
             const float* nsrc = img_of((j + 1) % NSTAGE);            // the next image of the sequence (behind the last stage of the last
             float* ndst = ring + (cur ^ 1) * I::IMG;                 // pass: an image nobody reads -- no branch in the product stream)
@@ -755,17 +790,26 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
                     });
                 }
                 if constexpr (j == JG) {                             // x -> r: the pending epilogue, then the state's planes in the LAST units
+                    // (ALL the pending tiles' state rows before the first h' store: the load counter retires in order and stores count
+                    // in it -- a row load issued behind a store is waited for behind that store's write acknowledgement)
+                    if constexpr (CARRY && u < C0) sfor<0, C_PIECES>([&](auto kc) { if constexpr ((decltype(kc)::value * C0) / (C_PIECES > 0 ? C_PIECES : 1) == u) hb_load(kc); });
+                    if constexpr (CARRY && u == C0 - 1) {
+                        bias_ahead(TANH ? bias_s + 2 * D : bias_s + 3 * D, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                    }
                     if constexpr (u >= C0 && u < H0 && u - C0 < C_PIECES) c_piece(std::integral_constant<int, u - C0>{});
                     if constexpr (u >= H0) h_piece(std::integral_constant<int, u - H0>{});
                 } else if constexpr (j == JG + 1) {                  // h -> r: the rest of the pending epilogue
                     if constexpr (u + (H0 - C0) < C_PIECES) c_piece(std::integral_constant<int, u + (H0 - C0)>{});
                 } else if constexpr (j == JG + 2) {                  // x -> u, h -> u: the r epilogue
                     if constexpr (u < R_PIECES) r_piece(uc);
-                } else if constexpr (j == JG + 3) {
+                } else if constexpr (j == JG + 3) {                  // h -> u: ... and the rows of slots 0, 1 of the pass to come
                     if constexpr (u + UN2 < R_PIECES) r_piece(std::integral_constant<int, u + UN2>{});
-                } else if constexpr (j == JG + 4) {                  // x -> c: the u epilogue
+                    sfor<0, 2 * RL>([&](auto mc) { if constexpr ((decltype(mc)::value * UN) / (2 * RL) == u) gl_piece(mc); });
+                } else if constexpr (j == JG + 4) {                  // x -> c: the u epilogue; slot 1 added, the rows of slot 2
                     if constexpr (u < U_PIECES) u_piece(uc);
-                } else if constexpr (j == JG + 5) {                  // r*h -> c: the gathered segment of the pass to come
+                    if constexpr (u >= UN - RL) gl_piece(std::integral_constant<int, 2 * RL + (u - (UN - RL))>{});
+                } else if constexpr (j == JG + 5) {                  // r*h -> c: slot 2 added, the rows of slot 3; then the gathered segment
+                    if constexpr (u >= 1 && u - 1 < RL) gl_piece(std::integral_constant<int, 3 * RL + (u - 1)>{});
                     if constexpr (u >= G0 && u - G0 < G_PIECES) g_piece(std::integral_constant<int, u - G0>{});
                 }
             };
@@ -822,7 +866,7 @@ __global__ __launch_bounds__(256, 1) void ggnn_gru_wide_kernel(GruWideArgs a) {
     flush();
 }
 
-template <int D, int NX, int NTW, int FMT, bool SAVE, bool TANH>
+template <int D, int NX, int NTW, int FMT, bool SAVE, bool TANH, int NW = 4>
 int launch_gru_wide_m(const GruFusedArgs& f, float* packed, hipStream_t st) {
     using I = ImgCfg<D, true, FMT>;
     if ((unsigned long long)f.V * D >= (1ULL << 30) || (unsigned long long)f.V * f.g_T * D >= (1ULL << 30))
@@ -841,15 +885,15 @@ int launch_gru_wide_m(const GruFusedArgs& f, float* packed, hipStream_t st) {
     int nb = num_cus();
     if (nb > wt_total) nb = wt_total;
     static std::atomic<unsigned long long> lds_ok{0};        // (one per template instantiation)
-    GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_wide_kernel<D, NX, NTW, FMT, SAVE, TANH>, lds, lds_ok));
-    hipLaunchKernelGGL((ggnn_gru_wide_kernel<D, NX, NTW, FMT, SAVE, TANH>), dim3(nb), dim3(256), lds, st, a);
+    GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_wide_kernel<D, NX, NTW, FMT, SAVE, TANH, NW>, lds, lds_ok));
+    hipLaunchKernelGGL((ggnn_gru_wide_kernel<D, NX, NTW, FMT, SAVE, TANH, NW>), dim3(nb), dim3(NW * 64), lds, st, a);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
 
-template <int D, int NX, int NTW, int FMT>
+template <int D, int NX, int NTW, int FMT, int NW = 4>
 int launch_gru_wide(const GruFusedArgs& f, float* packed, hipStream_t st) {
-    return launch_gru_wide_m<D, NX, NTW, FMT, false, true>(f, packed, st);
+    return launch_gru_wide_m<D, NX, NTW, FMT, false, true, NW>(f, packed, st);
 }
 
 }  // namespace
@@ -873,7 +917,6 @@ int gru_wide_supported(int D, int nx, const GruFusedArgs& a) {
 int gru_wide_launch(int D, int nx, int ntw_req, const GruFusedArgs& a, float* packed, hipStream_t st) {
     if (!gru_wide_supported(D, nx, a)) return fail(GGNN_E_UNSUPPORTED, "no wide fused GRU for this launch");
     const bool f2 = gru_launch_fmt(a.fmt) == kSplitF16x2;
-    (void)ntw_req;
 #ifdef GGNN_WIDE_PROBE_NTW   // register-allocation probe: one instantiation (-DGGNN_WIDE_PROBE_NTW=3 [-DGGNN_WIDE_PROBE_NX=1] [-DGGNN_WIDE_PROBE_FMT=2])
 #ifndef GGNN_WIDE_PROBE_NX
 #define GGNN_WIDE_PROBE_NX 1
@@ -881,12 +924,12 @@ int gru_wide_launch(int D, int nx, int ntw_req, const GruFusedArgs& a, float* pa
 #ifndef GGNN_WIDE_PROBE_FMT
 #define GGNN_WIDE_PROBE_FMT kSplitF16x2
 #endif
-    (void)f2;
+    (void)f2; (void)ntw_req;
     return launch_gru_wide<100, GGNN_WIDE_PROBE_NX, GGNN_WIDE_PROBE_NTW, GGNN_WIDE_PROBE_FMT>(a, packed, st);
 #else
     if (f2) {
         switch (nx) {
-            case 1: return launch_gru_wide<100, 1, 2, kSplitF16x2>(a, packed, st);
+            case 1: return ntw_req == 1 ? launch_gru_wide<100, 1, 1, kSplitF16x2, 8>(a, packed, st) : launch_gru_wide<100, 1, 2, kSplitF16x2>(a, packed, st);
 #if GGNN_WIDE_SET >= 2
             case 2: return launch_gru_wide<100, 2, 2, kSplitF16x2>(a, packed, st);
             case 3: return launch_gru_wide<100, 3, 2, kSplitF16x2>(a, packed, st);
