@@ -94,6 +94,9 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] / train legs")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--batch-size", type=int, default=0, help="override the reference's batch_size (100000 nodes); experiments only")
+    ap.add_argument("--n1-value", type=float, default=0.0,
+                    help="N > 1 runs: the `value` a --gpus 1 run of this script printed on the same node; the line then carries "
+                         "weak_scaling_efficiency = value / (N * n1_value) (per-GPU work is fixed: scaling 'weak')")
     ap.add_argument("--dry-run", action="store_true",
                     help="no kernels: rendezvous, per-rank data sharding, the flat gradient all-reduce and the timing bracket only "
                          "(runs on CPU over gloo; exercises the N-rank launch path where there is no GPU)")
@@ -409,22 +412,43 @@ def measure_sustained_mfma(pkg, dev, launches=60):
     return res
 
 
+def child_line(args, env_extra, argv_extra, run=subprocess.run, timeout=180):
+    """The compact line of this script run again in a child process (another operand-format policy, another molecule size): the two
+    legs then share nothing but the box."""
+    env = dict(os.environ, GGNN_BENCH_CHILD="1", **env_extra)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--min-time", "0.3", "--streams", str(args.streams), "--batches", str(args.batches), "--no-secondary", "--no-cpu-baseline"] + argv_extra
+    r = run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
 def exact_format_reference(args, value, run=subprocess.run):
     """The same timed forward with EVERY product in the exact three-piece bf16 format (the host policy forced to `exact` by
     GGNN_GRU_FMT=3 in a child process, so that the two legs share nothing but the box), so that the line carries both numbers of one
     box and one run -- `value` is under the default policy (two-piece f16 operands where their range is proven, formats.py).  This
-    is the f32 number of record.  A reference leg must never take the headline down: any failure comes back as {"error": ...}."""
+    is the f32 number of record; the child also times its kernels, so the exact leg has a `roofline` of its own (its dominant
+    launch against the six-product pipe).  A reference leg must never take the headline down: any failure comes back as {"error": ...}."""
     try:
-        env = dict(os.environ, GGNN_GRU_FMT="3", GGNN_BENCH_CHILD="1")
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--min-time", "0.3", "--streams", str(args.streams), "--batches", str(args.batches), "--mean-nodes", str(args.mean_nodes),
-               "--no-secondary", "--no-cpu-baseline", "--no-roofline"]
-        r = run(cmd, env=env, capture_output=True, text=True, timeout=120)
-        c = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        c = child_line(args, {"GGNN_GRU_FMT": "3"}, ["--mean-nodes", str(args.mean_nodes)], run=run)
         return {"what": "the same timed forward in a child process with GGNN_GRU_FMT=3 (policy `exact`): the fused GRU and the message transform in "
                         "the exact three-piece bf16 format, six products per f32 product (the format of every backward kernel)",
                 "value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"], "ms_per_step_one_stream": c.get("ms_per_step_one_stream"),
-                "gru_forward_format": c.get("gru_forward_format"), "value_ratio_default_over_exact": value / c["value"]}
+                "gru_forward_format": c.get("gru_forward_format"), "value_ratio_default_over_exact": value / c["value"],
+                "roofline": c.get("roofline")}
+    except Exception as exc:
+        return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+
+
+def small_molecule_reference(args, run=subprocess.run):
+    """BASELINE.json words its workload "~9 nodes" (heavy atoms); the reference's data has hydrogens (mean 18) and the
+    headline follows the data.  This leg is the same timed forward on batches of mean-9 molecules (same node cap: twice the
+    graphs per batch), in a child process."""
+    try:
+        c = child_line(args, {}, ["--mean-nodes", "9", "--no-roofline"], run=run)
+        cfg = c.get("config") or {}
+        return {"value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"], "mean_nodes_per_graph": 9.0,
+                "nodes_per_batch": cfg.get("nodes_per_batch"), "messages_per_batch": cfg.get("messages_per_batch"),
+                "graphs_per_batch": cfg.get("graphs_per_batch"), "graphs_per_sec": c.get("graphs_per_sec")}
     except Exception as exc:
         return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
@@ -439,13 +463,16 @@ def compact_line(out, detail_file):
                                     "vs_baseline", "dtype", "data")}
     cfg = out.get("config") or {}
     line["config"] = pick(cfg, ("workload", "mode", "hidden_size", "num_edge_types", "propagation_steps", "nodes_per_batch",
-                                "messages_per_batch", "graphs_per_batch", "batch_size_param", "hip_streams", "parallelism"))
+                                "messages_per_batch", "graphs_per_batch", "mean_nodes_per_graph", "batch_size_param", "hip_streams", "parallelism"))
     of = out.get("operand_format") or {}
     line["operand_format"] = pick(of, ("gru_forward", "gru_forward_per_layer", "message_transform", "policy", "every_other_kernel"))
     if isinstance(of.get("bounds"), dict):
         line["operand_format"]["proven"] = of["bounds"].get("proven")
     ex = out.get("exact_bf16x3_gru_reference")
     line["exact_format_value"] = None if not isinstance(ex, dict) else ex.get("value", ex.get("error"))
+    if isinstance(ex, dict) and isinstance(ex.get("roofline"), dict):
+        line["roofline_exact"] = pick(ex["roofline"], ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "mfma_achieved", "mfma_peak",
+                                                         "mfma_frac", "arithmetic_intensity", "ridge_point"))
     rf = out.get("roofline")
     if isinstance(rf, dict):
         line["roofline"] = pick(rf, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_us",
@@ -461,9 +488,12 @@ def compact_line(out, detail_file):
     tr = out.get("train")
     line["train"] = pick(tr, ("ms_per_step", "value", "n_gpus", "allreduce_ms", "allreduce_share", "error"))
     e2e = out.get("end_to_end_fresh_batch")
-    line["end_to_end_fresh_batch"] = pick(e2e, ("value", "one_stream_value"))
+    line["end_to_end_fresh_batch"] = pick(e2e, ("value", "one_stream_value", "value_measured_h0", "one_stream_value_measured_h0"))
     sec = out.get("secondary") or {}
-    line["secondary"] = {k: pick(v, ("ms_per_step", "node_state_updates_per_sec", "graphs_per_sec", "error")) for k, v in sec.items()}
+    line["secondary"] = {k: pick(v, ("ms_per_step", "node_state_updates_per_sec", "graphs_per_sec", "value", "mean_nodes_per_graph",
+                                     "nodes_per_batch", "messages_per_batch", "graphs_per_batch", "error")) for k, v in sec.items()}
+    if out.get("weak_scaling_efficiency") is not None:
+        line["weak_scaling_efficiency"] = out["weak_scaling_efficiency"]
     line["allreduce_us"] = out.get("allreduce_us")
     line["ranks_seen"] = out.get("ranks_seen")
     line["graphs_per_sec"] = out.get("graphs_per_sec")
@@ -718,6 +748,8 @@ def main():
         "ranks_seen": ranks_seen(dist_ctx), "allreduce_us": None,
         "steps_timed": steps_timed, "timed_repeats": repeats, "timed_seconds": elapsed,
         "ms_per_step_one_stream": one_stream,
+        # (N > 1 with --n1-value: the curve's point without a second run of arithmetic elsewhere)
+        "weak_scaling_efficiency": (value / (world * args.n1_value)) if (world > 1 and args.n1_value > 0) else None,
         "config": {"workload": what + ", full-QM9-sized synthetic batches (configs[%d])" % (3 if world > 1 else 1),
                    "mode": args.mode, "hidden_size": D, "num_edge_types": T, "propagation_steps": n_prop,
                    "layer_timesteps": params["layer_timesteps"], "residual_connections": params["residual_connections"],
@@ -768,7 +800,11 @@ def main():
             fb["initial_node_representation"] = pool[:fb["initial_node_representation"].shape[0]]
             pkg.formats.declare_h0_absmax(fb, 1.0)                                  # (uniform in (-1, 1) by construction, see above)
 
-        def fresh_epochs(reps, pipelined):
+        def dense_states_measured(fb):                                              # ... and NOT declared: formats.h0_absmax measures it
+            fb["initial_node_representation"] = pool[:fb["initial_node_representation"].shape[0]]
+
+        def fresh_epochs(reps, pipelined, hook=None):
+            hook = hook or dense_states
             """`reps` passes over the dataset, every batch packed fresh.  pipelined: SparseGGNNChemModel.forward_dataset -- batch
             i+1.. assembled on side streams while batch i's forward runs, forwards alternating over the compute streams
             (utils.StreamPrefetcher); else: packing and forward in sequence on one stream."""
@@ -777,12 +813,12 @@ def main():
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 for rep in range(reps):
                     if pipelined:
-                        for fb, states, st in model.forward_dataset(e2e_data, num_streams=max(args.streams, 1), feed_hook=dense_states,
+                        for fb, states, st in model.forward_dataset(e2e_data, num_streams=max(args.streams, 1), feed_hook=hook,
                                                                    consumer_streams=streams):
                             nn += states.shape[0]
                     else:
                         for fb in dd.pack_batches_device(dms_e2e, params, T, None):
-                            dense_states(fb)
+                            hook(fb)
                             model.feed(fb)
                             nn += model.compute_final_node_representations().shape[0]
                     if dbg_steps:
@@ -797,6 +833,9 @@ def main():
         nn1, e2e1 = fresh_epochs(1, False)
         reps = max(2, int(np.ceil(0.25 / max(e2e1, 1e-3))))
         nn, e2e = fresh_epochs(reps, True)
+        # the same with max |h0| MEASURED per fresh batch (ggnn_absmax_f32 + one read-back: a foreign feed that declares nothing)
+        nnm1, e2em1 = fresh_epochs(1, False, dense_states_measured)
+        nnm, e2em = fresh_epochs(reps, True, dense_states_measured)
         gc.enable()
         del dms_e2e, e2e_data, pool
         out["index_build_ms_per_batch"] = idx_ms
@@ -805,6 +844,9 @@ def main():
             "value": nn * n_prop / e2e, "unit": "node-state updates/s", "hip_streams": "%d compute + %d packing" % (len(e2e_streams), len(e2e_packs)),
             "epochs_timed": reps, "batches_per_epoch": e2e_batches, "molecules": ms_full.num_graphs, "seconds": e2e,
             "one_stream_value": nn1 * n_prop / e2e1,
+            "value_measured_h0": nnm * n_prop / e2em, "one_stream_value_measured_h0": nnm1 * n_prop / e2em1,
+            "h0_bound": "value / one_stream_value: max |h0| declared by the packer (formats.declare_h0_absmax); *_measured_h0: measured per "
+                        "fresh batch (one 9 us launch + a read-back that waits for the stream)",
             "what": "whole epochs over a full-QM9-sized synthetic dataset; every step assembles a fresh ~100k-node batch on the GPU from graph ids (chem_tensorflow_sparse.py:278-350: h0, "
                     "adjacency lists, in-degree table, graph_nodes_list, plus the message index of :120-129 and the source-pair "
                     "compaction) and runs the 8-step forward on it; batch i+1 is assembled on a side stream under batch i's forward, "
@@ -930,6 +972,8 @@ def main():
         out["secondary"] = sec
         if SPLIT_ACTIVE and GRU_FWD_FORMAT == 2 and not os.environ.get("GGNN_BENCH_CHILD"):
             out["exact_bf16x3_gru_reference"] = exact_format_reference(args, value)
+        if not os.environ.get("GGNN_BENCH_CHILD") and abs(args.mean_nodes - 9.0) > 0.5:
+            out["secondary"]["config1_mean9_molecules"] = small_molecule_reference(args)
 
     # ---- CPU baseline leg: torch-CPU port of the reference op order, bounded sample (rank 0, N=1) ---------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

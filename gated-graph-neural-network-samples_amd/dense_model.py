@@ -100,9 +100,13 @@ class DenseGGNNChemModel(ChemModel):
                 ts.append(self.weights['edge_biases'])
             mx = formats.weight_absmax(ts)
             S = formats.state_bound(formats.h0_absmax(self.placeholders), 'tanh')
-            acts = v * self.num_edge_types * (self.params['hidden_size'] * mx[0] * S + (mx[3] if len(mx) > 3 else 0.0))
+            # (|A| <= 1 for the reference's 0 / 1 adjacency; a weighted or multi-edge feed scales the sum: measured, cached per tensor)
+            a_max = formats.adjacency_absmax(self.placeholders['adjacency_matrix'])
+            acts = max(1.0, a_max) * v * self.num_edge_types * (self.params['hidden_size'] * mx[0] * S + (mx[3] if len(mx) > 3 else 0.0))
+            if a_max != a_max:
+                acts = float("nan")
             fmt = formats.layer_format(S, acts, formats.nanmax(mx[0], mx[1], mx[2]))
-            self.last_format_bounds = {"proven": fmt == formats.F16X2, "state_bound": S, "acts_bound": acts,
+            self.last_format_bounds = {"proven": fmt == formats.F16X2, "state_bound": S, "acts_bound": acts, "adjacency_absmax": a_max,
                                        "weight_absmax": formats.nanmax(mx[0], mx[1], mx[2])}
         self.last_format = fmt
         return fmt

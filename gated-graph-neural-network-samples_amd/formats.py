@@ -157,7 +157,55 @@ def declare_h0_absmax(feed: Dict[str, Any], value: float) -> Dict[str, Any]:
     h0 = feed['initial_node_representation']
     feed['h0_absmax'] = float(value)
     feed['_h0_absmax_of'] = (weakref.ref(h0), h0._version)
+    # ... and, with it, the packer's second statement: the in-degree table of this feed was counted from the very adjacency lists its
+    # message index was built from (nin_consistent below), tied to the table's identity and version the same way
+    nin = feed.get('num_incoming_edges_per_type')
+    if isinstance(nin, torch.Tensor):
+        feed['_nin_consistent_of'] = (weakref.ref(nin), nin._version)
     return feed
+
+
+_NIN_OK: Dict[Any, Any] = {}
+
+
+def nin_consistent(placeholders: Dict[str, Any], row_ptr: Optional[torch.Tensor]) -> bool:
+    """Mean aggregation divides by sum_t nin[v, t] + 1e-7 (chem_tensorflow_sparse.py:206-209), and the bound on the aggregated messages
+    (incoming_bound) holds only if that divisor is at least the number of messages summed into v.  `num_incoming_edges_per_type` is a
+    fed placeholder: a foreign feed may hold anything (zeros, fractions), and sum / 1e-7 then leaves the two-piece f16 format's range
+    where the reference's f32 stays finite.  True iff the packer declared the table (declare_h0_absmax) and it is still that tensor,
+    or -- measured once per (table, version, index) with one read-back -- every entry is finite and >= 0 and every node's row sum
+    reaches its in-degree in the message index."""
+    nin = placeholders.get('num_incoming_edges_per_type')
+    if not isinstance(nin, torch.Tensor):
+        return False
+    of = placeholders.get('_nin_consistent_of')
+    if of is not None and of[0]() is nin and of[1] == nin._version:
+        return True
+    if row_ptr is None or nin.dim() != 2 or row_ptr.numel() != nin.shape[0] + 1:
+        return False
+    key = (id(nin), nin._version, id(row_ptr), row_ptr._version)
+    hit = _NIN_OK.get(key)
+    if hit is not None and hit[0]() is nin and hit[1]() is row_ptr:
+        return hit[2]
+    deg = (row_ptr[1:] - row_ptr[:-1]).to(torch.float32)
+    ok = bool((torch.isfinite(nin).all() & (nin >= 0).all() & ((nin.sum(1) + 1e-3) >= deg).all()).item()) if nin.shape[0] else True
+    if len(_NIN_OK) > 1024:
+        _NIN_OK.clear()
+    _NIN_OK[key] = (weakref.ref(nin), weakref.ref(row_ptr), ok)
+    return ok
+
+
+_ADJ_MAX = _MaxCache()
+
+
+def adjacency_absmax(A: torch.Tensor) -> float:
+    """max |A| of a dense model's fed adjacency tensor (cached per tensor and version): the bound on the aggregated activations
+    assumes entries of magnitude <= 1 -- the reference's 0 / 1 matrices; a foreign feed may weight its edges."""
+    if A.numel() == 0:
+        return 0.0
+    if A.dtype != torch.float32:
+        return float(A.abs().max())                   # (not the reference's feed dtype: measured outright)
+    return float(_ADJ_MAX.get([A])[0])
 
 
 def h0_absmax(placeholders: Dict[str, Any], h0: Optional[torch.Tensor] = None) -> float:

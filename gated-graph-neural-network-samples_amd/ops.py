@@ -268,8 +268,8 @@ def gru(x_segs: Sequence[torch.Tensor], h: torch.Tensor, Wg: torch.Tensor, bg: t
     if fmt is not None and int(fmt) != GRU_FMT_EXACT and not two_launch and lib.ggnn_gru_is_fused(h.shape[1]) \
             and len(x_segs) <= GRU_FUSED_MAX_INPUTS:
         _req(Wg, torch.float32, "Wg"); _req(Wc, torch.float32, "Wc")
-        packed = torch.empty(lib.ggnn_gru_packed_bytes(h.shape[1], len(x_segs)) // 4, dtype=torch.float32, device=h.device)
-        check(lib.ggnn_gru_pack_weights_f32(_ptr(Wg), _ptr(Wc), len(x_segs), h.shape[1], int(fmt), _ptr(packed), _stream()))
+        # (the images are cached per weight version and format: this branch runs once per timestep on the non-gather training path)
+        packed = _gru_images().gru(Wg, Wc, len(x_segs), h.shape[1], int(fmt))
         return gru_packed(x_segs, h, packed, bg, bc, activation, out=out, fmt=int(fmt), save=save)
     _req(h, torch.float32, "h")
     V, D = h.shape
@@ -347,6 +347,13 @@ def gemm_tn(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
         raise ValueError("x and dy must have the same number of rows")
     if M == 0:
         return torch.zeros((K, N), dtype=torch.float32, device=x.device)
+    if M > 1 and (dy.stride(0) % 4 != 0 or dy.data_ptr() % 16 != 0):
+        # the kernel reads dy in float4s: a row stride that is no multiple of 4 floats (a contiguous [M, 6] or [M, 513]) or a
+        # misaligned view goes through ONE copy whose rows are padded to a multiple of 4 (zero columns add nothing to the product)
+        n_pad = (N + 3) // 4 * 4
+        buf = torch.zeros((M, n_pad), dtype=torch.float32, device=dy.device)
+        buf[:, :N] = dy
+        return gemm_tn(x, buf)[:, :N].contiguous() if n_pad != N else gemm_tn(x, buf)
     if N > 512 or N % 4 != 0:
         # the kernel takes N <= 512, N % 4 == 0: wider products go through in 512-column views (it takes any row stride), a ragged
         # tail (N % 4 columns: readout widths like 1 or 2) through a zero-padded copy of those columns
@@ -852,6 +859,17 @@ def gather_segment_sum_compact(Hc: torch.Tensor, index: MessageIndex, comp: Comp
 
 
 # ---- pre-packed weights (inference) ---------------------------------------------------------------------
+_GRU_IMAGES_CACHE = None
+
+
+def _gru_images():
+    """ops.gru's own image cache (raw-weight callers that ask for a packed operand format)."""
+    global _GRU_IMAGES_CACHE
+    if _GRU_IMAGES_CACHE is None:
+        _GRU_IMAGES_CACHE = PackedWeights()
+    return _GRU_IMAGES_CACHE
+
+
 class PackedWeights:
     """Cache of the kernels' LDS stage images of weight tensors, keyed by (storage pointer, version counter):
     during inference the weights do not change between batches, so the pack pre-pass runs once per weight

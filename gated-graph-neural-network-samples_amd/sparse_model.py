@@ -254,7 +254,9 @@ class SparseGGNNChemModel(ChemModel):
                 maxima = formats.weight_absmax(flat)
             h0_max = formats.h0_absmax(self.placeholders)            # (of the FED tensor; `h0` may be its zero-padded copy)
             S = formats.state_bound(h0_max, 'tanh', int(sum(p['layer_timesteps'])), st_keep)
-            use_avg = bool(p['use_edge_msg_avg_aggregation'])
+            # (the mean's divisor bounds the sum only if the fed in-degree table covers the messages: declared by the packers, else checked)
+            mi = self.placeholders.get('message_index')
+            use_avg = bool(p['use_edge_msg_avg_aggregation']) and formats.nin_consistent(self.placeholders, getattr(mi, 'row_ptr', None))
             fm, em, i, inc_max, w_max = [], [], 0, 0.0, 0.0
             for l in range(L):
                 ew, wg, wc = maxima[i], maxima[i + 1], maxima[i + 2]

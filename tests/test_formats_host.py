@@ -128,6 +128,11 @@ def test_model_selects_f16x2_only_with_a_proof(pkg):
     h0 = torch.zeros(V, 100); h0[:, :5] = torch.eye(5).repeat(3, 1)[:V]
     m.placeholders["initial_node_representation"] = h0
     with f.forced("auto"):
+        # (mean aggregation bounds the aggregate only with an in-degree table that covers the message index: none fed yet)
+        assert m.gru_formats(h0) == [f.BF16X3, f.BF16X3]
+        import types
+        m.placeholders["num_incoming_edges_per_type"] = torch.ones(V, 4)
+        m.placeholders["message_index"] = types.SimpleNamespace(row_ptr=torch.arange(V + 1, dtype=torch.int32) * 3)   # in-degree 3 <= 4
         assert m.gru_formats(h0) == [f.F16X2, f.F16X2] and m.last_gru_format_bounds["proven"]
         m.gnn_weights.rnn_cells[1].gates_kernel[3, 7] = 400.0                # one weight outside the x 2^8 range: that layer only
         assert m.gru_formats(h0) == [f.F16X2, f.BF16X3] and not m.last_gru_format_bounds["proven"]
@@ -147,3 +152,38 @@ def test_model_selects_f16x2_only_with_a_proof(pkg):
     m.params["graph_rnn_activation"] = "tanh"
     with f.forced(f.BF16X3):
         assert m.gru_formats(h0) == [f.BF16X3, f.BF16X3]
+
+
+def test_nin_consistency_is_declared_or_checked(pkg):
+    """Advisor (round 5): the bound on the aggregated messages under mean aggregation needs sum_t nin[v, t] >= in-degree(v).  The
+    packers declare their table with the batch (tied to the tensor's identity and version); any other table is checked against the
+    message index once -- zeros, fractions, negative or non-finite entries fail, and the GRU then runs in the exact format."""
+    f = pkg.formats
+    row_ptr = torch.tensor([0, 2, 2, 5], dtype=torch.int32)                 # in-degrees 2, 0, 3
+    good = torch.tensor([[1., 1.], [0., 0.], [3., 0.]])
+    feed = {"initial_node_representation": torch.zeros(3, 4), "num_incoming_edges_per_type": good}
+    assert f.nin_consistent(feed, row_ptr)                                   # checked: consistent
+    for bad in (torch.zeros(3, 2), torch.tensor([[1., 1.], [0., 0.], [1.5, 1.]]), torch.tensor([[3., -1.], [0., 0.], [3., 0.]]),
+                torch.tensor([[1., 1.], [0., float("nan")], [3., 0.]])):
+        assert not f.nin_consistent({"num_incoming_edges_per_type": bad}, row_ptr)
+    assert not f.nin_consistent({"num_incoming_edges_per_type": good}, None)             # nothing to check against
+    assert not f.nin_consistent({"num_incoming_edges_per_type": good}, row_ptr[:-1])     # another batch's index
+    # a declaration holds while it is about THIS tensor at THIS version
+    z = torch.zeros(3, 2)
+    feed = f.declare_h0_absmax({"initial_node_representation": torch.zeros(3, 4), "num_incoming_edges_per_type": z}, 1.0)
+    assert f.nin_consistent(feed, row_ptr)                                   # (the packer's word, not the contents)
+    z.add_(0.0)                                                              # an in-place write bumps the version
+    assert not f.nin_consistent(feed, row_ptr)
+    feed["num_incoming_edges_per_type"] = torch.zeros(3, 2)                  # a replaced table
+    assert not f.nin_consistent(feed, row_ptr)
+
+
+def test_adjacency_absmax_follows_the_fed_tensor(pkg):
+    f = pkg.formats
+    A = torch.zeros(2, 4, 5, 5); A[0, 1, 2, 3] = 1.0
+    assert f.adjacency_absmax(A) == 1.0
+    A[1, 0, 0, 0] = -50.0                                                    # a weighted edge: new version, measured again
+    assert f.adjacency_absmax(A) == 50.0
+    A[0, 0, 1, 1] = float("nan")
+    assert f.adjacency_absmax(A) != f.adjacency_absmax(A)                    # NaN stays NaN (fails every <= of the policy)
+    assert f.adjacency_absmax(torch.zeros(0, 4, 5, 5)) == 0.0

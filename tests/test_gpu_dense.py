@@ -153,3 +153,34 @@ def test_dense_model_runs_exact_outside_the_f16x2_range(pkg, oracle, cuda):
                                             W, b, gru, model.params["num_timesteps"], dtype=np.float32).astype(np.float64)
             rms = lambda x: float(np.sqrt(np.mean(x * x)))
             assert np.isfinite(got).all() and rms(got - want) <= 2.0 * rms(want32 - want) + 1e-6, (rms(got - want), rms(want32 - want))
+
+
+def test_dense_model_weighted_adjacency_leaves_the_f16x2_proof(pkg, oracle, cuda):
+    """Advisor (round 5): the bound |acts| <= v E (D max|W| S + max|b|) assumes |A| <= 1 (the reference's 0 / 1 matrices,
+    chem_tensorflow_dense.py:30-36).  A foreign feed with weighted edges scales the sum: max|A| is measured (cached per tensor and
+    version) and multiplies the bound; beyond the format's range the exact format runs and the result matches the oracle (finite,
+    where the unchecked fast format returns Inf / NaN)."""
+    f = pkg.formats
+    if not f.split_path():
+        pytest.skip("f32 matrix path")
+    ms = pkg.synthetic_qm9(120, mean_nodes=10, seed=7)
+    model, W, b, gru = _dense_model(pkg, oracle, ms)
+    feed = next(iter(model.make_minibatch_iterator(model.valid_data, is_training=False)))
+    v = int(feed["num_vertices"])
+    split = bool(pkg._lib.load().ggnn_dense_propagate_is_split(v, model.num_edge_types, 100))
+    with torch.no_grad(), f.forced("auto"):
+        model.feed(feed)
+        model.compute_final_node_representations()
+        if split:
+            assert model.last_format == f.F16X2 and model.last_format_bounds["adjacency_absmax"] == 1.0
+        feed["adjacency_matrix"] = feed["adjacency_matrix"] * 4000.0          # weighted edges: v E D max|W| * 4000 > 65504
+        model.feed(feed)
+        got = model.compute_final_node_representations().cpu().numpy()
+    if split:
+        assert model.last_format == f.BF16X3 and model.last_format_bounds["adjacency_absmax"] == 4000.0, model.last_format_bounds
+    want = oracle.dense_propagate(feed["initial_node_representation"].cpu().numpy(), feed["adjacency_matrix"].cpu().numpy(),
+                                  W, b, gru, model.params["num_timesteps"])
+    want32 = oracle.dense_propagate(feed["initial_node_representation"].cpu().numpy(), feed["adjacency_matrix"].cpu().numpy(),
+                                    W, b, gru, model.params["num_timesteps"], dtype=np.float32).astype(np.float64)
+    rms = lambda x: float(np.sqrt(np.mean(x * x)))
+    assert np.isfinite(got).all() and rms(got - want) <= 2.0 * rms(want32 - want) + 1e-6, (rms(got - want), rms(want32 - want))

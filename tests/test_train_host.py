@@ -469,12 +469,19 @@ def test_bench_exact_format_reference_leg_never_raises():
 
     def ok_run(cmd, env=None, **kw):
         seen["cmd"], seen["env"] = cmd, env
-        line = {"value": 9.5e8, "unit": "node-state updates/s", "ms_per_step": 0.84, "ms_per_step_one_stream": 0.97, "gru_forward_format": "bf16x3"}
+        line = {"value": 9.5e8, "unit": "node-state updates/s", "ms_per_step": 0.84, "ms_per_step_one_stream": 0.97, "gru_forward_format": "bf16x3",
+                "roofline": {"kernel": "gru_fused_gather[nx=1]", "bound": "mfma", "frac": 0.33}, "config": {"nodes_per_batch": 99990, "graphs_per_batch": 11000}}
         return types.SimpleNamespace(returncode=0, stdout="noise\n" + json.dumps(line) + "\n", stderr="")
     rec = bench.exact_format_reference(args, 1.2e9, run=ok_run)
     assert rec["value"] == 9.5e8 and rec["gru_forward_format"] == "bf16x3" and abs(rec["value_ratio_default_over_exact"] - 1.2e9 / 9.5e8) < 1e-12
     assert seen["env"]["GGNN_GRU_FMT"] == "3" and seen["env"]["GGNN_BENCH_CHILD"] == "1"          # (the child must not spawn a child)
-    assert "--no-secondary" in seen["cmd"] and "--no-roofline" in seen["cmd"] and "--no-cpu-baseline" in seen["cmd"]
+    # (the exact leg times its kernels too: its own roofline rides on the line as `roofline_exact`)
+    assert "--no-secondary" in seen["cmd"] and "--no-roofline" not in seen["cmd"] and "--no-cpu-baseline" in seen["cmd"]
+    assert rec["roofline"]["frac"] == 0.33
+    small = bench.small_molecule_reference(args, run=ok_run)        # BASELINE.json's "~9 nodes" wording, as a secondary leg
+    assert small["value"] == 9.5e8 and small["mean_nodes_per_graph"] == 9.0 and small["graphs_per_batch"] == 11000
+    assert seen["cmd"][seen["cmd"].index("--mean-nodes") + 1] == "9" and "--no-roofline" in seen["cmd"]
+    assert "error" in bench.small_molecule_reference(args, run=lambda cmd, **kw: types.SimpleNamespace(returncode=1, stdout="", stderr="x"))
 
     def dead_run(cmd, **kw):
         return types.SimpleNamespace(returncode=1, stdout="", stderr="boom")
