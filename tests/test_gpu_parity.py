@@ -294,11 +294,11 @@ def test_default_path_is_f32_outside_the_f16x2_operand_range(pkg, oracle, cuda, 
         feed = dict(feed, initial_node_representation=h0)
     elif case == "foreign-in-degree-table":
         # (advisor, round 5) the mean's divisor is a FED placeholder: a table that undercounts the messages (fractions here) makes
-        # incoming = sum / (nin + 1e-7) ~1e4 x the bound the proof assumes -- with edge weights x 30, beyond 65504.  The table is not
+        # incoming = sum / (nin + 1e-7) ~1e4 x the bound the proof assumes -- with edge weights x 100, beyond 65504.  The table is not
         # the packer's any more (replaced tensor): it is checked against the message index, fails, and the GRU runs exact.
         feed = dict(feed, num_incoming_edges_per_type=feed["num_incoming_edges_per_type"] * 1e-4)
         for l in range(L):
-            layers[l]["edge_weights"] *= 30.0
+            layers[l]["edge_weights"] *= 100.0
     model.set_graph_weights(layers)
     with torch.no_grad(), f.forced("auto"):
         model.feed(feed)
