@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- node-state updates/sec of the sparse GGNN propagation hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode forward|train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode forward|train] [--n1-value V1]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -553,6 +553,8 @@ def dry_run(args, pkg, dist_ctx):
         print(json.dumps({"metric": "node-state updates/sec on QM9-shaped graphs, h=100, 4 edge types", "value": None, "dry_run": True,
                           "unit": "node-state updates/s", "n_gpus": world, "ranks_seen": ranks_seen(dist_ctx), "steps": args.steps,
                           "warmup": args.warmup, "scaling": "weak", "data": "synthetic",
+                          # (a real run divides its value by world * n1_value: weak_scaling_efficiency; nothing is measured here)
+                          "n1_value": args.n1_value, "weak_scaling_efficiency": None,
                           "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
                           "allreduce_us": float(np.min(ar)) if world > 1 else None,
                           "allreduce_bytes": int(sum(v.numel() for v in variables) * 4),

@@ -404,11 +404,12 @@ def test_bench_gpus_8_dry_run():
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2"], env=env,
-                       capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2", "--n1-value", "1.25e9"],
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["dry_run"] is True
+    assert line["n1_value"] == 1.25e9                 # (the N = 1 value reaches every rank: the real line carries weak_scaling_efficiency)
     assert line["sharded_graphs_total"] == line["dataset_graphs"]
     assert line["allreduce_us"] > 0 and line["allreduce_bytes"] == 591802 * 4
     assert line["batches_total_incl_padding"] % 8 == 0 and line["rank_nodes_max_over_min"] < 1.05
