@@ -1,34 +1,49 @@
 // K3w: the gather-fused GRU launch (chem_tensorflow_sparse.py:198-216) in its WIDE form -- one wave per SIMD on the whole
-// 512-entry register file, NTW 16-row tiles per wave that share every weight-fragment read, gate-sequential stage order.
+// 512-entry register file, NTW 16-row tiles per wave that share every weight-fragment read, gate-sequential stage order, every
+// piece of side work riding inside the product units (GGNN_GRU_FORM = 6 / 62; 61: the same pass body as 8 waves x one tile).
 //
-// Why (round 6).  The ring forms of ggnn_gru_fused.hip run two 256-register waves per SIMD, one 16-row tile each: every wave reads
-// every 48 KiB stage image for its own 16 rows (one ds_read_b128 per 1.5 MFMAs in the two-piece f16 format), a pass of a CU is 8
-// tiles -- three passes, i.e. 18 image DMAs and 18+ stage barriers per launch at the reference's batch size -- and all three
-// accumulator sets of a tile (84 registers) are live from the first stage to the last, which is what pins those kernels to the
-// 256-register wall (72 spilled SGPRs, 150 v_readlane / v_writelane per pass, no room to share a weight fragment between two tiles).
-// Here a workgroup is FOUR waves, one per SIMD, and a wave owns NTW tiles at once:
+// STATUS (round 6; profiles/r06_experiments/wide_gru.md): bit-identical to the ring forms of ggnn_gru_fused.hip, and NOT faster --
+// 82-84 us (form 62) / 71-73 us (form 61) against 67 us for ring form 1 at the headline shape.  A pass is bound by instruction
+// ISSUE (~2700 instructions per tile at 6-8 clocks each), and one wave on a SIMD issues slower than two; what this form saves (LDS
+// weight reads, image DMAs and barriers per row, SGPR spills, branches) is not what bounds the launch.  The default dispatch is
+// unchanged; the form stays selectable (ggnn_gru_form_set) as the measured record of that design.
+//
+// Why it was built.  The ring forms run two 256-register waves per SIMD, one 16-row tile each: every wave reads every 48 KiB stage
+// image for its own 16 rows (one ds_read_b128 per 1.5 MFMAs in the two-piece f16 format), a pass of a CU is 8 tiles -- three passes,
+// i.e. 18 image DMAs and 18+ stage barriers per launch at the reference's batch size -- and all three accumulator sets of a tile (84
+// registers) are live from the first stage to the last, which pins those kernels to the 256-register wall (72 spilled SGPRs, 150
+// v_readlane / v_writelane per pass).  Here a workgroup is FOUR waves, one per SIMD, and a wave owns NTW tiles at once:
 //   * a weight fragment (the two / three operand planes of one (32-chunk, column tile) unit) is read from LDS ONCE and multiplies
-//     the NTW tiles' fragments: 3 NTW MFMAs per 2 ds_read_b128 instead of 3 -- the LDS weight traffic per row falls by NTW;
-//   * a pass of a CU is 4 NTW tiles (12 at NTW = 3): two passes per launch at the reference's batch size instead of three, a third
-//     fewer image DMAs and stage barriers per row, and a barrier is among four waves instead of eight;
-//   * the stages run GATE-SEQUENTIALLY -- every input segment -> r columns, then the r epilogue, every segment -> u columns, the u
-//     epilogue, every segment -> candidate columns -- so ONE accumulator set per tile is open at a time (28 registers instead of
-//     84): r leaves its set as the r*h planes, u stays as 28 values, and the NTW tiles fit the register file with the gather of the
-//     NEXT pass running beside the last stage.  Per accumulator the chain is the ring forms': segments in order, h / r*h last,
-//     chunks in order, remainder last, three (six) products per unit smallest first -- RESULTS ARE BIT-IDENTICAL to those kernels
-//     (tests/test_gpu_parity.py::test_wide_gru_equals_ring_forms), and the stage images are the ones ggnn_gru_pack_weights_f32
-//     writes: nothing is packed differently, only the ORDER in which a pass streams the 3 (NX + 1) images changes.
-// The r / u tail columns ride in the r images' padding columns exactly as there (StageCfg::TAILPACK / TAILPACK3).
+//     the NTW tiles' fragments: 3 NTW MFMAs per 2 ds_read_b128 instead of 3;
+//   * a pass of a CU is 4 NTW tiles: fewer image DMAs and stage barriers per row, and a barrier is among four waves instead of eight;
+//   * the stages run GATE-SEQUENTIALLY -- (residual segments segment-major, then) x -> r, h -> r | r epilogue | x -> u, h -> u | u
+//     epilogue | x -> c, r*h -> c -- so ONE accumulator set per tile is open at a time in the gate-sequential part (28 registers
+//     instead of 84).  Per accumulator the chain is the ring forms': segments in order, h / r*h last, chunks in order, remainder
+//     last, three (six) products per unit smallest first -- RESULTS ARE BIT-IDENTICAL to those kernels
+//     (tests/test_gpu_parity.py::test_wide_gru_equals_ring_forms); the fusions hipcc applies to the ring kernels' epilogue
+//     expressions are written out here (w_sigmoid4_acc, w_tanh4_acc, w_blend4): which contraction an expression gets depends on the
+//     code around it.  The stage images are the ones ggnn_gru_pack_weights_f32 writes: only the ORDER in which a pass streams them changes.
+//   * a wave alone on its SIMD has no partner whose MFMAs would cover its vector work, and it issues in order: the side work of a
+//     pass is cut into PIECES and each piece is emitted inside the scheduling region of one product unit (wide_stage_mma's fill):
+//     r / u epilogues a float4 group at a time, the state's planes a chunk at a time, the gathered rows of the pass to come ONE LOAD
+//     per unit, the mean + split of the gathered segment, the image DMA a KiB piece at a time (GGNN_WIDE_DMA_PIECES), optionally the
+//     candidate epilogue of the previous pass (GGNN_WIDE_CARRY, off: it spills).
+// Two rules the measurements taught (both fatal for a lone wave when broken):
+//   1. the load counter retires IN ORDER and everything counts in it -- a scratch reload, a state row, a gathered row is waited for
+//      behind every older DMA piece (inline assembly: invisible to the compiler's count) and every older global_store's write
+//      acknowledgement: no spills in the hot loop, loads before stores;
+//   2. a run-time branch per float4 group (optional stores, activation) cuts an epilogue into one basic block per group, each
+//      waiting out its own bias read and exp -> rcp chain: SAVE and the activation are compile-time, stores go to clamped rows.
+// The r / u tail columns ride in the r images' padding columns exactly as in the ring forms (StageCfg::TAILPACK / TAILPACK3).
 //
-// Work split: workgroup b owns the contiguous tile range [T b / nb, T (b + 1) / nb) and walks it in P = ceil(n_b / (4 NTW)) passes;
-// the n_b tiles are dealt evenly over the 4 P (pass, wave) slots, so no wave ever has more than one tile above another's and a
-// wave's count never grows from pass to pass.  The pass body is instantiated per tile count (NTA = 1 .. NTW): a wave with fewer
-// tiles issues fewer MFMAs, it does not multiply dummy rows.
+// Work split: workgroup b owns the contiguous tile range [T b / nb, T (b + 1) / nb) and walks it in P = ceil(n_b / (NW NTW)) passes;
+// the n_b tiles are dealt evenly over the NW P (pass, wave) slots, so no wave ever has more than one tile above another's and a
+// wave's count never grows from pass to pass.  The pass body is instantiated per tile count (NTA = 1 .. NTW).
 //
-// Gather (the aggregated-messages segment, :198-212): the 3-level chain row_ptr -> gather_row -> rows of the NEXT pass's tiles is
-// issued beside the last three stages of the current pass (slot range + in-degrees | first four source rows | rows of slots 0, 1)
-// and finished in the shadow of the candidate epilogue (slots 2, 3, any further ones synchronously, the mean); slot order, adds and
-// the one-division mean are those of ggnn_gather_segment_sum_f32.
+// Gather (the aggregated-messages segment, :198-212) of the pass to come: slot range + in-degrees beside h -> r, the first four
+// source-row indices beside x -> u, the rows of slots 0, 1 inside h -> u, slot 2 inside x -> c, slot 3 inside r*h -> c, where the sum
+// is finished (any further slots synchronously), divided (one division per row) and split into the next pass's operand planes;
+// slot order and adds are those of ggnn_gather_segment_sum_f32.
 #include "ggnn_split.hpp"
 #include <type_traits>
 
