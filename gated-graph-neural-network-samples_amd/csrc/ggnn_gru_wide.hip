@@ -920,10 +920,13 @@ int launch_gru_wide(const GruFusedArgs& f, float* packed, hipStream_t st) {
 #ifndef GGNN_WIDE_SET
 #define GGNN_WIDE_SET 1
 #endif
+#ifndef GGNN_WIDE_BF16
+#define GGNN_WIDE_BF16 0      // 1: also nx 1 in the exact bf16x3 format (experiments)
+#endif
 int gru_wide_supported(int D, int nx, const GruFusedArgs& a) {
     if (D != 100 || !a.g_H || a.save_r || a.act != GGNN_ACT_TANH || nx < 1 || nx > 3) return 0;
     const bool f2 = gru_launch_fmt(a.fmt) == kSplitF16x2;
-    if (GGNN_WIDE_SET < 3 && !f2) return 0;
+    if (GGNN_WIDE_SET < 3 && !f2 && !(GGNN_WIDE_BF16 && nx == 1)) return 0;
     if (GGNN_WIDE_SET < 2 && nx > 1) return 0;
     return 1;
 }
@@ -951,6 +954,9 @@ int gru_wide_launch(int D, int nx, int ntw_req, const GruFusedArgs& a, float* pa
 #endif
         }
     }
+#if GGNN_WIDE_BF16 && GGNN_WIDE_SET < 3
+    else if (nx == 1) return ntw_req == 1 ? launch_gru_wide<100, 1, 1, kSplitBf16x3, 8>(a, packed, st) : launch_gru_wide<100, 1, 2, kSplitBf16x3>(a, packed, st);
+#endif
 #if GGNN_WIDE_SET >= 3
     else {
         switch (nx) {
