@@ -61,6 +61,7 @@ struct GruWideArgs {
     const float* g_H; const int* g_row_ptr; const int* g_idx; const float* g_nin;
     const float* packed;
     int V, act, g_T, g_use_avg;
+    int* tickets;                // the ABI's tile counter (0 at launch, left non-zero): this form deals its tiles statically and only marks it
     unsigned long long* tdbg;    // (GGNN_WIDE_STAMPS builds) s_memtime stamps of workgroup 0: tools/wide_timeline.py
 };
 
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ggnn_gru_wide_kernel(GruWideA
     for (int i = tid; i < 4 * D; i += NW * 64)
         bias_s[i] = i < 2 * D ? -kLog2e * a.bg[i] : (i < 3 * D ? 2.0f * kLog2e * a.bc[i - 2 * D] : a.bc[i - 3 * D]);
 
+    if (a.tickets && blockIdx.x == 0 && tid == 0) atomicAdd(a.tickets, (int)gridDim.x);   // (the counter's contract: non-zero after the launch)
     // ---- this workgroup's tiles and their deal over the (pass, wave) slots ---------------------------------------------------
     const int wt_total = (a.V + 15) / 16;
     const int nb = gridDim.x, bid = blockIdx.x;
@@ -891,7 +893,7 @@ int launch_gru_wide_m(const GruFusedArgs& f, float* packed, hipStream_t st) {
     a.h = f.h; a.bg = f.bg; a.bc = f.bc; a.h_out = f.h_out;
     a.save_r = f.save_r; a.save_u = f.save_u; a.save_c = f.save_c; a.save_x = f.save_x;
     a.g_H = f.g_H; a.g_row_ptr = f.g_row_ptr; a.g_idx = f.g_idx; a.g_nin = f.g_nin;
-    a.packed = packed; a.V = f.V; a.act = f.act; a.g_T = f.g_T; a.g_use_avg = f.g_use_avg;
+    a.packed = packed; a.V = f.V; a.act = f.act; a.g_T = f.g_T; a.g_use_avg = f.g_use_avg; a.tickets = f.tickets;
 #if GGNN_WIDE_STAMPS
     { const char* e = getenv("GGNN_GRU_TPTR"); a.tdbg = (e && NX == 1) ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
 #endif
