@@ -16,13 +16,19 @@ def test_mfma_rate_probe_reports_sane_numbers(pkg):
     got = {}
     for mode in (0, 1, 2):
         tf, mhz = ctypes.c_double(0.0), ctypes.c_double(0.0)
-        pkg._lib.check(lib.ggnn_probe_mfma_rate(mode, 3, ws.data_ptr(), ws.numel() * 4, ctypes.byref(tf), ctypes.byref(mhz), st))
-        got[mode] = (tf.value, mhz.value)
-        assert 1000.0 < mhz.value < 2600.0, got
-        assert 500.0 < tf.value < 2600.0, got                  # never above the data-sheet peak (2.5 PF at 2.4 GHz)
-        # the stream is MFMA-bound: TFLOP/s == clock x 256 CUs x 4 SIMDs x 16384 flops / 16 clocks (within the launch's ramp)
-        # (3 launches of ~30 ms: on a box that is throttling -- round 5 met one sustaining 1.80 GHz on random operands instead of
-        #  1.95 -- the clock moves inside the probe and the two readings, taken over slightly different windows, part by up to ~8 %)
-        assert abs(tf.value - mhz.value * 1e6 * 256 * 4 * 1024 / 1e12) / tf.value < 0.12, got
+
+        def sane():
+            # never above the data-sheet peak (2.5 PF at 2.4 GHz); and the stream is MFMA-bound: TFLOP/s == clock x 256 CUs x 4 SIMDs
+            # x 16384 flops / 16 clocks (within the launch's ramp).  (3 launches of ~30 ms: on a box that is throttling -- round 5 met
+            # one sustaining 1.80 GHz on random operands instead of 1.95 -- the clock moves inside the probe and the two readings,
+            # taken over slightly different windows, part by up to ~8 %)
+            return (1000.0 < mhz.value < 2600.0 and 500.0 < tf.value < 2600.0 and
+                    abs(tf.value - mhz.value * 1e6 * 256 * 4 * 1024 / 1e12) / tf.value < 0.12)
+        for attempt in range(3):          # (a clock transient -- the probe right behind minutes of other tests -- gets a second look)
+            pkg._lib.check(lib.ggnn_probe_mfma_rate(mode, 3, ws.data_ptr(), ws.numel() * 4, ctypes.byref(tf), ctypes.byref(mhz), st))
+            got.setdefault(mode, []).append((tf.value, mhz.value))
+            if sane():
+                break
+        assert sane(), got
     with pytest.raises(pkg._lib.GGNNError):
         pkg._lib.check(lib.ggnn_probe_mfma_rate(7, 1, ws.data_ptr(), ws.numel() * 4, ctypes.byref(tf), ctypes.byref(mhz), st))
