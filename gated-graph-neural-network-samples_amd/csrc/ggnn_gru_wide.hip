@@ -1,9 +1,10 @@
 // K3w: the gather-fused GRU launch (chem_tensorflow_sparse.py:198-216) in its WIDE form -- one wave per SIMD on the whole
 // 512-entry register file, NTW 16-row tiles per wave that share every weight-fragment read, gate-sequential stage order, every
-// piece of side work riding inside the product units (GGNN_GRU_FORM = 6 / 62; 61: the same pass body as 8 waves x one tile).
+// piece of side work riding inside the product units (GGNN_GRU_FORM = 6 / 62; 61: the same pass body as 8 waves x one tile; 64: as
+// two 4-wave one-tile workgroups per CU on half-image rings).
 //
 // STATUS (round 6; profiles/r06_experiments/wide_gru.md): bit-identical to the ring forms of ggnn_gru_fused.hip, and NOT faster --
-// 82-84 us (form 62) / 71-73 us (form 61) against 67 us for ring form 1 at the headline shape.  A pass is bound by instruction
+// 82-84 us (form 62) / 71-75 us (form 61) / 73 us (form 64) against 67 us for ring form 1 at the headline shape.  A pass is bound by instruction
 // ISSUE (~2700 instructions per tile at 6-8 clocks each), and one wave on a SIMD issues slower than two; what this form saves (LDS
 // weight reads, image DMAs and barriers per row, SGPR spills, branches) is not what bounds the launch.  The default dispatch is
 // unchanged; the form stays selectable (ggnn_gru_form_set) as the measured record of that design.
@@ -201,10 +202,13 @@ template <int D, int FMT> __host__ __device__ constexpr int wide_units(int ntile
 #ifndef GGNN_WIDE_FV
 #define GGNN_WIDE_FV 6
 #endif
-template <int D, int NTW, int NTA, int NTILES, bool ZERO, int FMT, class Fill = NoFill>
-__device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT], const WPl<D, FMT> (&a)[NTW],
-                                               const float (&ar)[NTW][StageCfg<D>::NR > 0 ? StageCfg<D>::NR : 1],
-                                               const float* img, int li, int kq, const Fill& fill = Fill()) {
+// (tiles [T0, T1) of the stage; half A of the image at img, half B at img_b -- one image, or two ring slots of the half-image form;
+// U0: the number this call's first unit has for `fill`)
+template <int D, int NTW, int NTA, int T0, int T1, bool ZERO, int FMT, int U0, class Fill = NoFill>
+__device__ __forceinline__ void wide_stage_mma_at(f32x4 (&acc)[NTW][StageCfg<D>::NT], const WPl<D, FMT> (&a)[NTW],
+                                                  const float (&ar)[NTW][StageCfg<D>::NR > 0 ? StageCfg<D>::NR : 1],
+                                                  const float* img, const float* img_b, int li, int kq, const Fill& fill = Fill()) {
+    constexpr int NTILES = T1 - T0;
     using S = StageCfg<D>;
     using C = SplitCfg<D, FMT>;
     constexpr int NP = C::NP;
@@ -213,12 +217,11 @@ __device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT
     asm volatile("" : "+v"(li), "+v"(kq));
     constexpr int NU = C::NC2 * NTILES;                               // units, chunk-major
     constexpr bool FILLED = !std::is_same<Fill, NoFill>::value;
-    const float* img_b = img + C::HA;
     if constexpr (NU > 0) {
         const u32x4* base_a = reinterpret_cast<const u32x4*>(img) + kq * (C::TA * 16) + li;
         const u32x4* base_b = reinterpret_cast<const u32x4*>(img_b) + kq * ((S::NT - C::TA) * 16) + li;
         auto slot = [&](int u, int p) {
-            const int nt = u % NTILES, c2 = u / NTILES;
+            const int nt = T0 + u % NTILES, c2 = u / NTILES;
             const int nth = C::nth_of(nt);
             const u32x4* b = C::half_of(nt) ? base_b : base_a;
             return b[p * (C::plane_bytes(nth) / 16) + c2 * 4 * nth * 16 + C::tile_in_half(nt) * 16];
@@ -227,13 +230,13 @@ __device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT
 #pragma unroll
         for (int p = 0; p < NP; ++p) { w[p] = slot(0, p); n[p] = w[p]; }
         sfor<0, NU>([&](auto uc) {
-            constexpr int u = decltype(uc)::value, c2 = u / NTILES, nt = u % NTILES;
+            constexpr int u = decltype(uc)::value, c2 = u / NTILES, nt = T0 + u % NTILES;
             if constexpr (u + 1 < NU) {
 #pragma unroll
                 for (int p = NP - 1; p >= 0; --p) n[p] = slot(u + 1, p);
             }
             if constexpr (!FILLED) __builtin_amdgcn_sched_barrier(0);
-            fill(uc);
+            fill(std::integral_constant<int, U0 + u>{});
             f32x4 c[NTA];
 #pragma unroll
             for (int t = 0; t < NTA; ++t) c[t] = (ZERO && c2 == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[t][nt];
@@ -277,15 +280,15 @@ __device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT
     if constexpr (S::NR > 0 && NTILES > 0) {
         constexpr int NRM = S::NR * NTILES;
         auto rw = [&](int i) {
-            const int nt = i % NTILES, q = i / NTILES;
+            const int nt = T0 + i % NTILES, q = i / NTILES;
             const int nth = C::nth_of(nt);
             const float* b = C::half_of(nt) ? img_b : img;
             return b[C::main_bytes(nth) / 4 + (q * 4 + kq) * nth * 16 + li + C::tile_in_half(nt) * 16];
         };
         float w0 = rw(0), w1 = NRM > 1 ? rw(1) : 0.f;
         sfor<0, NRM>([&](auto ic) {
-            constexpr int i = decltype(ic)::value, q = i / NTILES, nt = i % NTILES;
-            fill(std::integral_constant<int, NU + i>{});
+            constexpr int i = decltype(ic)::value, q = i / NTILES, nt = T0 + i % NTILES;
+            fill(std::integral_constant<int, U0 + NU + i>{});
 #pragma unroll
             for (int t = 0; t < NTA; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, ar[t][q], acc[t][nt], 0, 0, 0);
             if constexpr (FILLED && GGNN_WIDE_SGB) {
@@ -300,6 +303,13 @@ __device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT
             if constexpr (i + 2 < NRM) w1 = rw(i + 2);
         });
     }
+}
+
+template <int D, int NTW, int NTA, int NTILES, bool ZERO, int FMT, class Fill = NoFill>
+__device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT], const WPl<D, FMT> (&a)[NTW],
+                                               const float (&ar)[NTW][StageCfg<D>::NR > 0 ? StageCfg<D>::NR : 1],
+                                               const float* img, int li, int kq, const Fill& fill = Fill()) {
+    wide_stage_mma_at<D, NTW, NTA, 0, NTILES, ZERO, FMT, 0>(acc, a, ar, img, img + SplitCfg<D, FMT>::HA, li, kq, fill);
 }
 
 // Stage sequence of a pass (NSTAGE = 3 (NX + 1) images), position j -> (gate g: 0 r, 1 u, 2 candidate; segment s):
@@ -322,8 +332,11 @@ template <int NX> __host__ __device__ constexpr int wide_seg(int j) { return j <
 #define GGNN_WIDE_CARRY 0     // the candidate epilogue of a pass rides in the first stages of the next one (0: it runs behind its pass)
 #endif
 // NW: waves per workgroup -- 4 (one per SIMD, the whole register file each) or 8 (two per SIMD on 256 registers each: NTW = 1).
-template <int D, int NX, int NTW, int FMT, bool SAVE, bool TANH, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW / 4) void ggnn_gru_wide_kernel(GruWideArgs a) {
+// HALF (form 64): TWO 4-wave workgroups per CU (256 registers a wave, NTW = 1), each on a two-slot ring of HALF images (slot 0:
+// tiles [0, TA), slot 1: the rest; a stage = two sub-stages with a barrier each) -- ring form 1's arrangement: the two waves of a
+// SIMD belong to different workgroups and meet at no barrier.
+template <int D, int NX, int NTW, int FMT, bool SAVE, bool TANH, int NW = 4, bool HALF = false>
+__global__ __launch_bounds__(NW * 64, HALF ? 2 : NW / 4) void ggnn_gru_wide_kernel(GruWideArgs a) {
     using C = StageCfg<D>;
     using I = ImgCfg<D, true, FMT>;
     constexpr int NT = C::NT, NC = C::NC, NR = C::NR, NRR = NR > 0 ? NR : 1;
@@ -360,9 +373,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ggnn_gru_wide_kernel(GruWideA
         return a.packed + (size_t)(g < 2 ? 2 * s + g : 2 * NSEG + s) * I::IMG;
     };
     int cur = 0;
+    using SCH = SplitCfg<D, FMT>;
+    static_assert(!HALF || (NW == 4 && NTW == 1), "the half-image form is four waves x one tile");
+    constexpr int SLOT = HALF ? SCH::HA : I::IMG;                    // floats per ring slot
     auto dma = [&](const float* src, float* dst) { dma_image_asm<I::IMG_BYTES, NW>(src, dst, wave, lane); };
+    auto dma_ha = [&](const float* src, float* dst) { dma_kib_asm<SCH::HA_BYTES / 1024, NW>(src, dst, wave, lane); };
+    auto dma_hb = [&](const float* src, float* dst) { dma_kib_asm<SCH::HB_BYTES / 1024, NW>(src, dst, wave, lane); };
     auto publish = [&]() { dma_wait(); __syncthreads(); };
-    dma(img_of(0), ring);
+    if constexpr (HALF) dma_ha(img_of(0), ring);
+    else dma(img_of(0), ring);
 
     // ---- state that crosses a pass boundary: the gathered segment and the first residual segment of the pass to come -----------
     WPl<D, FMT> xs[NTW];                              // operand planes of the gathered segment (aggregated messages)
@@ -777,7 +796,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ggnn_gru_wide_kernel(GruWideA
 #pragma unroll
                 for (int t = 0; t < NTA; ++t) load_frag<D>(G.rf[t], a.x[0], rown[t], kq);
             }
-            if constexpr (!GGNN_WIDE_DMA_PIECES) dma(img_of((j + 1) % NSTAGE), ring + (cur ^ 1) * I::IMG);
+            if constexpr (HALF) dma_hb(img_of(j) + SCH::HA, ring + SLOT);          // (this image's other half, under sub-stage A)
+            else if constexpr (!GGNN_WIDE_DMA_PIECES) dma(img_of((j + 1) % NSTAGE), ring + (cur ^ 1) * I::IMG);
             __builtin_amdgcn_sched_barrier(0);
             GGNN_WT(4 * (j < 6 ? j : 5) + 1)
             // ---- the stage's products, with the pieces of the pass's side work in their units ----
@@ -794,13 +814,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ggnn_gru_wide_kernel(GruWideA
             static_assert(C0 + C_PIECES <= H0 + UNF && R_PIECES <= 2 * UN2 && U_PIECES <= wide_units<D, FMT>(C::TAILPACK3 ? NT - 1 : NT) &&
                           G0 >= RL + 2 && RL <= wide_units<D, FMT>(C::TAILPACK3 ? NT - 1 : NT) && PW <= wide_units<D, FMT>(NT - 1),
                           "the side work must fit the units of its stages");
-            const float* img = ring + cur * I::IMG;
+            const float* img = ring + cur * SLOT;
             const float* nsrc = img_of((j + 1) % NSTAGE);            // the next image of the sequence (behind the last stage of the last
             float* ndst = ring + (cur ^ 1) * I::IMG;                 // pass: an image nobody reads -- no branch in the product stream)
             auto fill = [&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 // the image DMA, a KiB piece at a time: piece k in unit k UN / PW
-                if constexpr (GGNN_WIDE_DMA_PIECES) {
+                if constexpr (GGNN_WIDE_DMA_PIECES && !HALF) {
                     sfor<0, PW>([&](auto kc) {
                         constexpr int k = decltype(kc)::value;
                         if constexpr ((k * UN) / PW == u) dma_piece_asm<I::IMG_BYTES, NW, k>(nsrc, ndst, wave, lane);
@@ -830,21 +850,41 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ggnn_gru_wide_kernel(GruWideA
                     if constexpr (u >= G0 && u - G0 < G_PIECES) g_piece(std::integral_constant<int, u - G0>{});
                 }
             };
-            auto mma = [&](auto& acc, auto zc) {
+            // tiles [t0, t1) of the stage from the image halves at ia / ib, the first unit numbered u0
+            auto mma = [&](auto& acc, auto zc, auto t0c, auto t1c, auto u0c, const float* ia, const float* ib) {
                 constexpr bool Z = decltype(zc)::value;
-                if constexpr (s < NX - 1) wide_stage_mma<D, NTW, NTA, ntl, Z, FMT>(acc, xq, xqr, img, li, kq, fill);
-                else if constexpr (s == NX - 1) wide_stage_mma<D, NTW, NTA, ntl, Z, FMT>(acc, xs, xr, img, li, kq, fill);
-                else if constexpr (g < 2) wide_stage_mma<D, NTW, NTA, ntl, Z, FMT>(acc, hs, hr, img, li, kq, fill);
-                else wide_stage_mma<D, NTW, NTA, ntl, false, FMT>(acc, rhs, rhr, img, li, kq, fill);
+                constexpr int t0 = decltype(t0c)::value, t1 = decltype(t1c)::value, u0 = decltype(u0c)::value;
+                if constexpr (s < NX - 1) wide_stage_mma_at<D, NTW, NTA, t0, t1, Z, FMT, u0>(acc, xq, xqr, ia, ib, li, kq, fill);
+                else if constexpr (s == NX - 1) wide_stage_mma_at<D, NTW, NTA, t0, t1, Z, FMT, u0>(acc, xs, xr, ia, ib, li, kq, fill);
+                else if constexpr (g < 2) wide_stage_mma_at<D, NTW, NTA, t0, t1, Z, FMT, u0>(acc, hs, hr, ia, ib, li, kq, fill);
+                else wide_stage_mma_at<D, NTW, NTA, t0, t1, false, FMT, u0>(acc, rhs, rhr, ia, ib, li, kq, fill);
             };
-            if constexpr (g == 0) mma(acc_r, std::integral_constant<bool, ZERO>{});
-            else if constexpr (g == 1) mma(acc_u, std::integral_constant<bool, ZERO>{});
-            else mma(acc_c, std::integral_constant<bool, ZERO>{});
-            __builtin_amdgcn_sched_barrier(0);
-            GGNN_WT(4 * (j < 6 ? j : 5) + 2)
-            publish();
-            GGNN_WT(4 * (j < 6 ? j : 5) + 3)
-            cur ^= 1;
+            auto mma_g = [&](auto t0c, auto t1c, auto u0c, const float* ia, const float* ib) {
+                if constexpr (g == 0) mma(acc_r, std::integral_constant<bool, ZERO>{}, t0c, t1c, u0c, ia, ib);
+                else if constexpr (g == 1) mma(acc_u, std::integral_constant<bool, ZERO>{}, t0c, t1c, u0c, ia, ib);
+                else mma(acc_c, std::integral_constant<bool, ZERO>{}, t0c, t1c, u0c, ia, ib);
+            };
+            using ic0 = std::integral_constant<int, 0>;
+            if constexpr (!HALF) {
+                mma_g(ic0{}, std::integral_constant<int, ntl>{}, ic0{}, img, img + SCH::HA);
+                __builtin_amdgcn_sched_barrier(0);
+                GGNN_WT(4 * (j < 6 ? j : 5) + 2)
+                publish();
+                GGNN_WT(4 * (j < 6 ? j : 5) + 3)
+                cur ^= 1;
+            } else {
+                constexpr int ta = ntl < SCH::TA ? ntl : SCH::TA;                   // tiles of sub-stage A
+                mma_g(ic0{}, std::integral_constant<int, ta>{}, ic0{}, ring, ring);
+                __builtin_amdgcn_sched_barrier(0);
+                publish();                                                            // (half B has landed; slot 0 is free)
+                dma_ha(img_of((j + 1) % NSTAGE), ring);                              // the next image's first half, under sub-stage B
+                __builtin_amdgcn_sched_barrier(0);
+                mma_g(std::integral_constant<int, ta>{}, std::integral_constant<int, ntl>{}, std::integral_constant<int, wide_units<D, FMT>(ta)>{}, ring, ring + SLOT);
+                __builtin_amdgcn_sched_barrier(0);
+                GGNN_WT(4 * (j < 6 ? j : 5) + 2)
+                publish();
+                GGNN_WT(4 * (j < 6 ? j : 5) + 3)
+            }
         });
 
         // this pass's candidate epilogue is now pending
@@ -862,9 +902,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ggnn_gru_wide_kernel(GruWideA
     // a pass of a wave without tiles: its share of the image DMAs and the barriers
     auto idle_pass = [&](const int p) {
         for (int j = 0; j < NSTAGE; ++j) {
-            dma(img_of((j + 1) % NSTAGE), ring + (cur ^ 1) * I::IMG);
-            publish();
-            cur ^= 1;
+            if constexpr (HALF) {
+                dma_hb(img_of(j) + SCH::HA, ring + SLOT);
+                publish();
+                dma_ha(img_of((j + 1) % NSTAGE), ring);
+                publish();
+            } else {
+                dma(img_of((j + 1) % NSTAGE), ring + (cur ^ 1) * I::IMG);
+                publish();
+                cur ^= 1;
+            }
         }
     };
 
@@ -883,7 +930,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void ggnn_gru_wide_kernel(GruWideA
     flush();
 }
 
-template <int D, int NX, int NTW, int FMT, bool SAVE, bool TANH, int NW = 4>
+template <int D, int NX, int NTW, int FMT, bool SAVE, bool TANH, int NW = 4, bool HALF = false>
 int launch_gru_wide_m(const GruFusedArgs& f, float* packed, hipStream_t st) {
     using I = ImgCfg<D, true, FMT>;
     if ((unsigned long long)f.V * D >= (1ULL << 30) || (unsigned long long)f.V * f.g_T * D >= (1ULL << 30))
@@ -897,20 +944,20 @@ int launch_gru_wide_m(const GruFusedArgs& f, float* packed, hipStream_t st) {
 #if GGNN_WIDE_STAMPS
     { const char* e = getenv("GGNN_GRU_TPTR"); a.tdbg = (e && NX == 1) ? (unsigned long long*)strtoull(e, nullptr, 10) : nullptr; }
 #endif
-    constexpr size_t lds = (size_t)2 * I::IMG_BYTES + (size_t)((4 * D + 63) / 64 * 64) * sizeof(float);
+    constexpr size_t lds = (size_t)2 * (HALF ? SplitCfg<D, FMT>::HA_BYTES : I::IMG_BYTES) + (size_t)((4 * D + 63) / 64 * 64) * sizeof(float);
     const int wt_total = (f.V + 15) / 16;
-    int nb = num_cus();
+    int nb = HALF ? 2 * num_cus() : num_cus();
     if (nb > wt_total) nb = wt_total;
     static std::atomic<unsigned long long> lds_ok{0};        // (one per template instantiation)
-    GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_wide_kernel<D, NX, NTW, FMT, SAVE, TANH, NW>, lds, lds_ok));
-    hipLaunchKernelGGL((ggnn_gru_wide_kernel<D, NX, NTW, FMT, SAVE, TANH, NW>), dim3(nb), dim3(NW * 64), lds, st, a);
+    GGNN_CHECK_HIP(allow_dynamic_lds(&ggnn_gru_wide_kernel<D, NX, NTW, FMT, SAVE, TANH, NW, HALF>, lds, lds_ok));
+    hipLaunchKernelGGL((ggnn_gru_wide_kernel<D, NX, NTW, FMT, SAVE, TANH, NW, HALF>), dim3(nb), dim3(NW * 64), lds, st, a);
     GGNN_CHECK_HIP(hipGetLastError());
     return GGNN_OK;
 }
 
-template <int D, int NX, int NTW, int FMT, int NW = 4>
+template <int D, int NX, int NTW, int FMT, int NW = 4, bool HALF = false>
 int launch_gru_wide(const GruFusedArgs& f, float* packed, hipStream_t st) {
-    return launch_gru_wide_m<D, NX, NTW, FMT, false, true, NW>(f, packed, st);
+    return launch_gru_wide_m<D, NX, NTW, FMT, false, true, NW, HALF>(f, packed, st);
 }
 
 }  // namespace
@@ -949,7 +996,9 @@ int gru_wide_launch(int D, int nx, int ntw_req, const GruFusedArgs& a, float* pa
 #else
     if (f2) {
         switch (nx) {
-            case 1: return ntw_req == 1 ? launch_gru_wide<100, 1, 1, kSplitF16x2, 8>(a, packed, st) : launch_gru_wide<100, 1, 2, kSplitF16x2>(a, packed, st);
+            case 1: return ntw_req == 1 ? launch_gru_wide<100, 1, 1, kSplitF16x2, 8>(a, packed, st)
+                         : ntw_req == 4 ? launch_gru_wide<100, 1, 1, kSplitF16x2, 4, true>(a, packed, st)      // (form 64: the half-image form)
+                                        : launch_gru_wide<100, 1, 2, kSplitF16x2>(a, packed, st);
 #if GGNN_WIDE_SET >= 2
             case 2: return launch_gru_wide<100, 2, 2, kSplitF16x2>(a, packed, st);
             case 3: return launch_gru_wide<100, 3, 2, kSplitF16x2>(a, packed, st);

@@ -89,8 +89,9 @@ int ggnn_gru_forward_format(void);
  * the same products in the same order per accumulator -- results are bit-identical -- they differ in how a pass streams the stage
  * images and how many 16-row tiles a wave owns.  -1: the library's default per (fan-in, operand format); 0 / 1 / 2: the ring forms of
  * csrc/ggnn_gru_fused.hip (8 waves on whole images | two 4-wave workgroups per CU on half images | 8 waves, three half-image
- * slots); 6: the wide form of csrc/ggnn_gru_wide.hip (one wave per SIMD, several tiles per wave, gate-sequential stages; hidden
- * size 100).  Process default: environment GGNN_GRU_FORM.  Returns the previous setting.  (Tests and experiments: compare forms
+ * slots); 6 / 62: the wide form of csrc/ggnn_gru_wide.hip (one wave per SIMD, two tiles per wave, gate-sequential stages; hidden
+ * size 100, inference launch of the tanh cell in the two-piece f16 format -- other launches keep the ring forms), 61 / 64: the same
+ * pass body as 8 waves x one tile / as two 4-wave workgroups per CU on half-image rings.  Process default: environment GGNN_GRU_FORM.  Returns the previous setting.  (Tests and experiments: compare forms
  * inside one process.) */
 int ggnn_gru_form_set(int form);
 /* out[i] = max |x| over the numel[i] floats at ptrs[i], i < n, in one launch per 32 tensors -- the operand-range check of

@@ -681,7 +681,7 @@ def test_gru_with_gathered_segment_sum(pkg, oracle, cuda, V, M, D, T, R, avg, fm
                                        (70001, 150000, 0, True), (99990, 197571, 0, True), (98304, 190000, 0, False),
                                        (70001, 150000, 1, True), (66000, 140000, 2, True)])
 @pytest.mark.parametrize("fmt", [2, 3])
-@pytest.mark.parametrize("form", [6, 61])
+@pytest.mark.parametrize("form", [6, 61, 64])
 def test_wide_gru_equals_ring_forms(pkg, cuda, V, M, R, avg, fmt, form):
     """The wide form of the gather-fused GRU launch (csrc/ggnn_gru_wide.hip: one wave per SIMD, several tiles per wave sharing every
     weight-fragment read, gate-sequential stages) == the ring forms of csrc/ggnn_gru_fused.hip, BIT FOR BIT: the same products in the
