@@ -317,8 +317,21 @@ __device__ __forceinline__ void wide_stage_mma(f32x4 (&acc)[NTW][StageCfg<D>::NT
 //   stage; all three accumulator sets are open from here on when NX > 1),
 //   then GATE-sequential over the gathered segment and the state: x -> r, h -> r | r epilogue | x -> u, h -> u | u epilogue |
 //   x -> c, r*h -> c.  Per accumulator: segments in order, h / r*h last -- the ring forms' chains.
-template <int NX> __host__ __device__ constexpr int wide_gate(int j) { return j < 3 * (NX - 1) ? j % 3 : (j - 3 * (NX - 1)) / 2; }
-template <int NX> __host__ __device__ constexpr int wide_seg(int j) { return j < 3 * (NX - 1) ? j / 3 : NX - 1 + (j - 3 * (NX - 1)) % 2; }
+// GGNN_WIDE_ORDER (experiment): 1 = the last part SEGMENT-major like the ring forms -- x -> r, x -> u, x -> c | h -> r, h -> u | r*h -> c
+// (all three accumulator sets open throughout; the r epilogue rides in h -> u, the u epilogue in r*h -> c).
+#ifndef GGNN_WIDE_ORDER
+#define GGNN_WIDE_ORDER 0
+#endif
+template <int NX> __host__ __device__ constexpr int wide_gate(int j) {
+    if (j < 3 * (NX - 1)) return j % 3;
+    const int jj = j - 3 * (NX - 1);
+    return GGNN_WIDE_ORDER ? (jj < 3 ? jj : (jj == 5 ? 2 : jj - 3)) : jj / 2;
+}
+template <int NX> __host__ __device__ constexpr int wide_seg(int j) {
+    if (j < 3 * (NX - 1)) return j / 3;
+    const int jj = j - 3 * (NX - 1);
+    return NX - 1 + (GGNN_WIDE_ORDER ? (jj < 3 ? 0 : 1) : jj % 2);
+}
 
 // SAVE: r, u, c and the gathered segment are written for a backward pass (training).  TANH: the candidate's activation (else ReLU).
 // Both are compile-time: a run-time branch per float4 group cuts the epilogues into basic blocks of one group each, and a wave
@@ -753,6 +766,13 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : NW / 4) void ggnn_gru_wide_kern
 
         sfor<0, NSTAGE>([&](auto jc) {
             constexpr int j = decltype(jc)::value, g = wide_gate<NX>(j), s = wide_seg<NX>(j);
+            // where the side work rides, by the order of the last part: the state's planes in the stage BEFORE h -> r, the r epilogue
+            // behind h -> r (two stages | one), the u epilogue behind h -> u, the tail tile of the candidate set zeroed before its first stage
+            constexpr int J_HP = GGNN_WIDE_ORDER ? JG + 2 : JG;      // h pieces (last units of this stage)
+            constexpr int J_R0 = GGNN_WIDE_ORDER ? JG + 4 : JG + 2;  // r pieces, first stage
+            constexpr int J_R1 = GGNN_WIDE_ORDER ? -1 : JG + 3;      // ... second stage (none in order 1)
+            constexpr int J_U = GGNN_WIDE_ORDER ? JG + 5 : JG + 4;   // u pieces
+            constexpr int J_C0 = GGNN_WIDE_ORDER ? JG + 2 : JG + 4;  // first candidate stage of the last part
             GGNN_WT(4 * (j < 6 ? j : 5) + 0)
             // REMAT: everything derived from the lane coordinates (LDS and row addresses) is recomputed per stage instead of living --
             // and, in this kernel at the edge of the register file, being spilled -- across the pass: a scratch reload waits, in
@@ -774,14 +794,14 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : NW / 4) void ggnn_gru_wide_kern
 #pragma unroll
                 for (int t = 0; t < NTA; ++t) load_frag<D>(hf[t], a.h, rowc[t], kq);
             }
-            if constexpr (j == (NX > 1 ? 2 : JG + 4)) {              // (before the first candidate stage: residual 0 -> c, or x -> c)
+            if constexpr (j == (NX > 1 ? 2 : J_C0)) {                // (before the first candidate stage: residual 0 -> c, or x -> c)
                 if constexpr (C::TAILPACK3) {
 #pragma unroll
                     for (int t = 0; t < NTA; ++t) acc_c[t][NT - 1] = f32x4{0.f, 0.f, 0.f, 0.f};   // (opened by the r*h stage only)
                 }
             }
-            if constexpr (j == JG + 2) bias_ahead(bias_s, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});       // r gate
-            if constexpr (j == JG + 4) bias_ahead(bias_s + D, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});   // u gate
+            if constexpr (j == J_R0) bias_ahead(bias_s, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});       // r gate
+            if constexpr (j == J_U) bias_ahead(bias_s + D, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});    // u gate
             // the gather of the pass to come: one level of its dependent chain per stage, for every tile (a tile the pass to come
             // does not have gathers a valid row for nothing -- no branches in the product stream)
             if constexpr (j == JG + 1) {
@@ -811,7 +831,7 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : NW / 4) void ggnn_gru_wide_kern
             constexpr int C0 = 2;                                    // first unit of the pending epilogue
             constexpr int H0 = UNF - H_PIECES;                       // first unit of the state's planes in stage JG
             constexpr int G0 = UNF - G_PIECES - 1;                   // first unit of the gathered segment's pieces in the last stage
-            static_assert(C0 + C_PIECES <= H0 + UNF && R_PIECES <= 2 * UN2 && U_PIECES <= wide_units<D, FMT>(C::TAILPACK3 ? NT - 1 : NT) &&
+            static_assert(C0 + C_PIECES <= H0 + UNF && R_PIECES <= (GGNN_WIDE_ORDER ? 1 : 2) * UN2 && U_PIECES <= wide_units<D, FMT>(C::TAILPACK3 ? NT - 1 : NT) &&
                           G0 >= RL + 2 && RL <= wide_units<D, FMT>(C::TAILPACK3 ? NT - 1 : NT) && PW <= wide_units<D, FMT>(NT - 1),
                           "the side work must fit the units of its stages");
             const float* img = ring + cur * SLOT;
@@ -826,7 +846,7 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : NW / 4) void ggnn_gru_wide_kern
                         if constexpr ((k * UN) / PW == u) dma_piece_asm<I::IMG_BYTES, NW, k>(nsrc, ndst, wave, lane);
                     });
                 }
-                if constexpr (j == JG) {                             // x -> r: the pending epilogue, then the state's planes in the LAST units
+                if constexpr (j == JG) {                             // first stage of the last part: the pending epilogue (CARRY)
                     // (ALL the pending tiles' state rows before the first h' store: the load counter retires in order and stores count
                     // in it -- a row load issued behind a store is waited for behind that store's write acknowledgement)
                     if constexpr (CARRY && u < C0) sfor<0, C_PIECES>([&](auto kc) { if constexpr ((decltype(kc)::value * C0) / (C_PIECES > 0 ? C_PIECES : 1) == u) hb_load(kc); });
@@ -834,18 +854,29 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : NW / 4) void ggnn_gru_wide_kern
                         bias_ahead(TANH ? bias_s + 2 * D : bias_s + 3 * D, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
                     }
                     if constexpr (u >= C0 && u < H0 && u - C0 < C_PIECES) c_piece(std::integral_constant<int, u - C0>{});
-                    if constexpr (u >= H0) h_piece(std::integral_constant<int, u - H0>{});
-                } else if constexpr (j == JG + 1) {                  // h -> r: the rest of the pending epilogue
+                }
+                if constexpr (j == JG + 1) {                         // ... the rest of it
                     if constexpr (u + (H0 - C0) < C_PIECES) c_piece(std::integral_constant<int, u + (H0 - C0)>{});
-                } else if constexpr (j == JG + 2) {                  // x -> u, h -> u: the r epilogue
+                }
+                if constexpr (j == J_HP) {                           // the state's planes in the LAST units of the stage before h -> r (the rows have landed)
+                    if constexpr (u >= UN - H_PIECES) h_piece(std::integral_constant<int, u - (UN - H_PIECES)>{});
+                }
+                if constexpr (j == J_R0) {                           // the r epilogue behind h -> r
                     if constexpr (u < R_PIECES) r_piece(uc);
-                } else if constexpr (j == JG + 3) {                  // h -> u: ... and the rows of slots 0, 1 of the pass to come
+                }
+                if constexpr (j == J_R1) {
                     if constexpr (u + UN2 < R_PIECES) r_piece(std::integral_constant<int, u + UN2>{});
-                    sfor<0, 2 * RL>([&](auto mc) { if constexpr ((decltype(mc)::value * UN) / (2 * RL) == u) gl_piece(mc); });
-                } else if constexpr (j == JG + 4) {                  // x -> c: the u epilogue; slot 1 added, the rows of slot 2
+                }
+                if constexpr (j == J_U) {                            // the u epilogue behind h -> u
                     if constexpr (u < U_PIECES) u_piece(uc);
+                }
+                // the gathered segment of the pass to come: the rows of slots 0, 1 | slot 1 added, the rows of slot 2 | slot 2 added, the
+                // rows of slot 3, then the finished sum -> planes
+                if constexpr (j == JG + 3) {
+                    sfor<0, 2 * RL>([&](auto mc) { if constexpr ((decltype(mc)::value * UN) / (2 * RL) == u) gl_piece(mc); });
+                } else if constexpr (j == JG + 4) {
                     if constexpr (u >= UN - RL) gl_piece(std::integral_constant<int, 2 * RL + (u - (UN - RL))>{});
-                } else if constexpr (j == JG + 5) {                  // r*h -> c: slot 2 added, the rows of slot 3; then the gathered segment
+                } else if constexpr (j == JG + 5) {
                     if constexpr (u >= 1 && u - 1 < RL) gl_piece(std::integral_constant<int, 3 * RL + (u - 1)>{});
                     if constexpr (u >= G0 && u - G0 < G_PIECES) g_piece(std::integral_constant<int, u - G0>{});
                 }
